@@ -1,0 +1,159 @@
+"""ctypes binding of libcara_hip.so (the C ABI declared in include/cara_hip.h).
+
+There is no fallback: if the library cannot be loaded, or a call returns a non-zero status,
+an exception is raised.  Tensors are handed over as raw device pointers; torch only owns the
+memory and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcara_hip.so")
+
+# every symbol include/cara_hip.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "cara_abi_version", "cara_build_arch", "cara_gemm_bf16", "cara_skinny_xu",
+    "cara_tskinny_scratch_bytes", "cara_tskinny_xtg", "cara_layernorm_fwd", "cara_layernorm_bwd",
+    "cara_attention_fwd", "cara_attention_bwd", "cara_im2col_patches", "cara_assemble_tokens",
+    "cara_cross_entropy", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_pack_offsets",
+    "cara_factor_prep", "cara_factor_grad_reduce", "cara_vit_workspace_bytes", "cara_vit_forward",
+    "cara_vit_backward", "cara_head_backward",
+)
+
+EPI_BF16, EPI_F32, EPI_GELU, EPI_RESID, EPI_DGELU = range(5)
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int),
+                ("A2", C.c_void_p), ("B2", C.c_void_p), ("Rp", C.c_int),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("bias", C.c_void_p), ("epi", C.c_int),
+                ("C", C.c_void_p), ("ldc", C.c_int), ("C2", C.c_void_p), ("aux", C.c_void_p),
+                ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int)]
+
+
+class Geom(C.Structure):
+    _fields_ = [("depth", C.c_int), ("dim", C.c_int), ("heads", C.c_int), ("rank", C.c_int),
+                ("Rp", C.c_int), ("scale", C.c_float)]
+
+
+CP_FIELDS = ("A1", "A2", "A3", "A4", "P1", "P2", "P3", "R1", "R2", "bias1", "bias2", "bias3")
+
+
+class CpPtrs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in CP_FIELDS]
+
+
+class PackLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in (
+        "Ut_qkv", "U_qkv", "Vs_qkv", "Vst_qkv", "Ut_proj", "U_proj", "Vs_proj", "Vst_proj",
+        "Ut_fc1", "U_fc1", "Vs_fc1", "Vst_fc1", "Ut_fc2", "U_fc2", "Vs_fc2", "Vst_fc2",
+        "bias_proj", "bias_fc1", "bias_fc2", "layer_stride", "total")]
+
+
+class LayerGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "dU_qkv", "dVs_qkv", "dU_proj", "dVs_proj", "dU_fc1", "dVs_fc1", "dU_fc2", "dVs_fc2",
+        "dc_proj", "dc_fc1", "dc_fc2")]
+
+
+class VitWeights(C.Structure):
+    """Frozen backbone, device pointers.  [depth, ...] tensors are contiguous over layers."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "patch_w", "patch_b", "cls", "pos",
+        "ln1_g", "ln1_b", "ln2_g", "ln2_b",
+        "qkv_w", "qkv_wt", "qkv_b", "proj_w", "proj_wt", "proj_b",
+        "fc1_w", "fc1_wt", "fc1_b", "fc2_w", "fc2_wt", "fc2_b",
+        "norm_g", "norm_b")]
+
+
+class VitShape(C.Structure):
+    _fields_ = [("B", C.c_int), ("img", C.c_int), ("patch", C.c_int), ("chans", C.c_int),
+                ("tokens", C.c_int), ("num_classes", C.c_int), ("eps", C.c_float)]
+
+
+class CaraError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libcara_hip.so or raise.  Never falls back to another implementation."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CaraError(
+                f"{LIB_PATH} not found: build it with cara_amd/csrc/build.sh (or __graft_entry__.build()). "
+                "cara_amd has no CPU or eager fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.cara_build_arch.restype = C.c_char_p
+        _lib.cara_tskinny_scratch_bytes.restype = C.c_size_t
+        if hasattr(_lib, "cara_vit_workspace_bytes"):
+            _lib.cara_vit_workspace_bytes.restype = C.c_size_t
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise CaraError(f"{what} failed with status {status} "
+                        f"({ {1: 'CARA_E_ARG', 2: 'CARA_E_LAUNCH'}.get(status, '?') })")
+
+
+def ptr(t) -> C.c_void_p:
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise CaraError("cara_amd kernels need device tensors (no CPU path)")
+    if not t.is_contiguous():
+        raise CaraError("cara_amd kernels need contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---- thin per-op wrappers (used by tests and by the module-level drop-in) ---------------------
+
+def gemm(A, B, out, *, epi, bias=None, A2=None, B2=None, C2=None, aux=None, rowscale=None,
+         rows_per_sample=0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None):
+    a = GemmArgs()
+    a.M = M if M is not None else A.shape[0]
+    a.K = K if K is not None else A.shape[1]
+    a.N = N if N is not None else B.shape[0]
+    a.A, a.lda = ptr(A), lda or A.shape[1]
+    a.B, a.ldb = ptr(B), ldb or B.shape[1]
+    a.A2, a.B2 = ptr(A2), ptr(B2)
+    a.Rp = A2.shape[1] if A2 is not None else 0
+    a.bias, a.epi = ptr(bias), epi
+    a.C, a.ldc = ptr(out), ldc or out.shape[-1]
+    a.C2, a.aux, a.rowscale = ptr(C2), ptr(aux), ptr(rowscale)
+    a.rows_per_sample = rows_per_sample
+    check(lib().cara_gemm_bf16(C.byref(a), stream()), "cara_gemm_bf16")
+    return out
+
+
+def skinny_xu(X, Ut, T, Tt=None):
+    M, K = X.shape
+    Rp = Ut.shape[0]
+    ldt = Tt.shape[1] if Tt is not None else 0
+    check(lib().cara_skinny_xu(ptr(X), K, ptr(Ut), ptr(T), ptr(Tt), ldt, M, K, Rp, stream()), "cara_skinny_xu")
+    return T
+
+
+def tskinny_xtg(X, Gt, D, colsum=None, M=None):
+    M = M if M is not None else X.shape[0]
+    K1 = X.shape[1]
+    Rp = Gt.shape[0]
+    nbytes = lib().cara_tskinny_scratch_bytes(M, K1, Rp)
+    if nbytes == 0:
+        raise CaraError("cara_tskinny_scratch_bytes: unsupported shape")
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
+    check(lib().cara_tskinny_xtg(ptr(X), K1, ptr(Gt), Gt.shape[1], ptr(D), ptr(colsum), ptr(scratch),
+                                 M, K1, Rp, stream()), "cara_tskinny_xtg")
+    return D

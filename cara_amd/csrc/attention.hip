@@ -1,0 +1,356 @@
+// Fused attention forward / backward for the ViT token counts (N <= 224, head dim 64) on gfx950.
+// Reference semantics: /root/reference/src/cara/cara.py:43-48
+//     attn = softmax((q @ k^T) * scale); x = (attn @ v).transpose(1, 2).reshape(B, N, C)
+// with q, k, v the three [B,H,N,64] views of the qkv activation laid out exactly as cara.py:39
+// reshapes it ([B*N, 3*H*64], column k*H*64 + h*64 + d).  attn_drop has p = 0 in the reference
+// configuration (timm attn_drop_rate = 0), so no dropout on the probabilities.
+//
+// Forward: the whole K/V of one head sits in LDS (28 KiB + 33 KiB), each wave owns 32 query rows
+// and, because N is small, the whole score row block in registers (7 tiles of 32x32): exact
+// two-pass softmax, no online rescaling.  Scores are computed TRANSPOSED (S^T = K Q^T) with
+// v_mfma_f32_32x32x16_bf16 so that a query's row lives in ONE lane (max / sum = in-lane reduction
+// + one cross-half shuffle) and the probability accumulators are already the A operand of P.V
+// (no LDS round trip).  V is staged transposed so that its B fragments are two 8-byte LDS reads.
+//
+// Backward: one workgroup of 7 waves per (batch, head); wave w owns keys 32w..32w+31 and keeps
+// dK^T, dV^T of them in accumulators while sweeping the query tiles; S and dP are computed with the
+// key on the lane, so P and dS feed dV^T += dO^T P and dK^T += Q^T dS straight from the
+// accumulators; only dS crosses LDS (wave-private scratch) for dQ += dS K, which is summed across
+// the waves by LDS float adds.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;        // head dim
+constexpr int NMAX = 224;     // 7 tiles of 32
+constexpr int KP = 260;       // padded key stride of the transposed images (bank-conflict free b64 reads)
+
+__device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// row of the 32x32 C/D layout held in register r of lane half h
+__device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)v[8 * s + j];
+  return o;
+}
+
+// 8 bf16 of row `d` of a transposed image at positions base+4h..+3 and base+8+4h..+3
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* img, int d, int base, int h) {
+  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(img + d * KP + base + 4 * h);
+  const bf16x4 hi = *reinterpret_cast<const bf16x4*>(img + d * KP + base + 8 + 4 * h);
+  bf16x8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return o;
+}
+
+// stage rows [0, NMAX) (clamped to N-1) of a [N, 64] bf16 matrix with row stride ld, transposed:
+// img[d][n]
+__device__ __forceinline__ void stage_transposed(const bf16* __restrict__ src, int ld, int N, bf16* img,
+                                                 int tid, int nthreads) {
+  for (int idx = tid; idx < NMAX * 8; idx += nthreads) {
+    const int n = idx >> 3, c = idx & 7;
+    const int nn = n < N ? n : N - 1;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (size_t)nn * ld + c * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) img[(c * 8 + j) * KP + n] = v[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+constexpr int FWD_LDS = NMAX * 128 + HD * KP * 2;  // K (swizzled rows) + V^T
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                          float* __restrict__ lse, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  bf16* Vt = reinterpret_cast<bf16*>(smem + NMAX * 128);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x, b = bh / H, head = bh - b * H;
+  const int ld = 3 * H * HD;
+  const bf16* qb = qkv + (size_t)b * N * ld + head * HD;
+  const bf16* kb = qb + H * HD;
+  const bf16* vb = qb + 2 * H * HD;
+
+  for (int idx = tid; idx < NMAX * 8; idx += 256) {
+    const int n = idx >> 3, c = idx & 7;
+    const int nn = n < N ? n : N - 1;
+    *reinterpret_cast<uint4*>(Ks + swz128(n, c)) = *reinterpret_cast<const uint4*>(kb + (size_t)nn * ld + c * 8);
+  }
+  stage_transposed(vb, ld, N, Vt, tid, 256);
+  __syncthreads();
+
+  const int q0 = (blockIdx.y * 4 + wave) * 32;
+  if (q0 >= N) return;
+  const int ql = lane & 31, h = lane >> 5;
+  const int qrow = (q0 + ql) < N ? (q0 + ql) : N - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qb + (size_t)qrow * ld + ks * 16 + h * 8);
+
+  const int nkt = (N + 31) >> 5;
+  f32x16 s[7];
+#pragma unroll
+  for (int kt = 0; kt < 7; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+    if (kt < nkt) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + swz128(kt * 32 + ql, ks * 2 + h));
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kt], 0, 0, 0);
+      }
+    }
+  }
+  // S^T layout: column (lane & 31) = query, row = key kt*32 + crow(r, h)
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + crow(r, h);
+      s[kt][r] = key < N ? s[kt][r] : -3.0e38f;
+      mx = fmaxf(mx, s[kt][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float c2 = scale * 1.4426950408889634f;
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = exp2f((s[kt][r] - mx) * c2);
+      s[kt][r] = p;
+      sum += p;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 7; ++kt) {
+    if (kt < nkt) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const bf16x8 pa = pack8(s[kt], st);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 vf = tr_frag(Vt, dt * 32 + ql, kt * 32 + st * 16, h);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vf, o[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // O layout: column (lane & 31) = d, row = query q0 + crow(r, h); 1/sum of that query sits in
+  // lane crow(r, h)
+  const float inv = 1.0f / sum;
+  bf16* ob = out + (size_t)b * N * (H * HD) + head * HD;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int qq = crow(r, h);
+    const float iv = __shfl(inv, qq, 64);
+    if (q0 + qq < N) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) ob[(size_t)(q0 + qq) * (H * HD) + dt * 32 + ql] = (bf16)(o[dt][r] * iv);
+    }
+  }
+  if (h == 0 && q0 + ql < N) lse[(size_t)bh * N + q0 + ql] = mx * scale + __logf(sum);
+}
+
+// ------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------
+constexpr int BWD_WAVES = 7;
+constexpr int DS_STRIDE = 40;  // bf16 per row of the wave-private dS scratch (80 B: 16-B aligned)
+constexpr int BWD_OFF_QT = 0;
+constexpr int BWD_OFF_DOT = BWD_OFF_QT + HD * KP * 2;
+constexpr int BWD_OFF_DQ = BWD_OFF_DOT + HD * KP * 2;
+constexpr int BWD_OFF_DS = BWD_OFF_DQ + NMAX * HD * 4;
+constexpr int BWD_OFF_ROW = BWD_OFF_DS + BWD_WAVES * 32 * DS_STRIDE * 2;
+constexpr int BWD_LDS = BWD_OFF_ROW + 2 * NMAX * 4;
+
+__global__ __launch_bounds__(448, 2) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                          bf16* __restrict__ dqkv, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* Qt = reinterpret_cast<bf16*>(smem + BWD_OFF_QT);
+  bf16* dOt = reinterpret_cast<bf16*>(smem + BWD_OFF_DOT);
+  float* dQ = reinterpret_cast<float*>(smem + BWD_OFF_DQ);
+  float* lse_s = reinterpret_cast<float*>(smem + BWD_OFF_ROW);
+  float* del_s = lse_s + NMAX;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  bf16* dSw = reinterpret_cast<bf16*>(smem + BWD_OFF_DS) + wave * 32 * DS_STRIDE;
+  const int bh = blockIdx.x, b = bh / H, head = bh - b * H;
+  const int ld = 3 * H * HD, ldo = H * HD;
+  const bf16* qb = qkv + (size_t)b * N * ld + head * HD;
+  const bf16* kb = qb + H * HD;
+  const bf16* vb = qb + 2 * H * HD;
+  const bf16* ob = out + (size_t)b * N * ldo + head * HD;
+  const bf16* dob = dout + (size_t)b * N * ldo + head * HD;
+
+  stage_transposed(qb, ld, N, Qt, tid, 448);
+  stage_transposed(dob, ldo, N, dOt, tid, 448);
+  for (int i = tid; i < NMAX * HD; i += 448) dQ[i] = 0.f;
+  if (tid < NMAX) {
+    const int n = tid < N ? tid : N - 1;
+    float dl = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(ob + (size_t)n * ldo + c * 8);
+      const bf16x8 g = *reinterpret_cast<const bf16x8*>(dob + (size_t)n * ldo + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl += (float)a[j] * (float)g[j];
+    }
+    del_s[tid] = dl;
+    lse_s[tid] = lse[(size_t)bh * N + n];
+  }
+  __syncthreads();
+
+  const int key0 = wave * 32;
+  const int kl = lane & 31, h = lane >> 5;
+  const float c2 = scale * 1.4426950408889634f;
+  const float l2e = 1.4426950408889634f;
+  if (key0 < N) {
+    const int key = key0 + kl;
+    const int keyc = key < N ? key : N - 1;
+    const bool kvalid = key < N;
+    // B operands with the key on the lane: K[key][16ks + 8h + j], V likewise
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = *reinterpret_cast<const bf16x8*>(kb + (size_t)keyc * ld + ks * 16 + h * 8);
+      vf[ks] = *reinterpret_cast<const bf16x8*>(vb + (size_t)keyc * ld + ks * 16 + h * 8);
+    }
+    // B operand of dQ += dS K: lane = d (dt*32 + kl), element j = K[key0 + 16 st + 8h + j][d]
+    bf16x8 ktf[2][2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          int kk = key0 + 16 * st + 8 * h + j;
+          kk = kk < N ? kk : N - 1;
+          ktf[dt][st][j] = kb[(size_t)kk * ld + dt * 32 + kl];
+        }
+    f32x16 dkt[2], dvt[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dkt[dt][r] = 0.f; dvt[dt][r] = 0.f; }
+
+    const int nqt = (N + 31) >> 5;
+    for (int qt = 0; qt < nqt; ++qt) {
+      const int q0 = qt * 32;
+      const int qrow = (q0 + kl) < N ? (q0 + kl) : N - 1;  // A-operand row of this lane
+      f32x16 sacc, pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qb + (size_t)qrow * ld + ks * 16 + h * 8);
+        const bf16x8 da = *reinterpret_cast<const bf16x8*>(dob + (size_t)qrow * ldo + ks * 16 + h * 8);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], pacc, 0, 0, 0);
+      }
+      // layout: column (lane & 31) = key, row = query q0 + crow(r, h)
+      f32x16 p, ds;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = q0 + crow(r, h);
+        const bool ok = kvalid && (q < N);
+        const float pv = ok ? exp2f(sacc[r] * c2 - lse_s[q] * l2e) : 0.f;
+        p[r] = pv;
+        ds[r] = pv * (pacc[r] - del_s[q]);
+      }
+      // dV^T += dO^T P ; dK^T += Q^T dS   (sum over the 32 queries = the accumulators' row index)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const bf16x8 pb = pack8(p, st), dsb = pack8(ds, st);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 doa = tr_frag(dOt, dt * 32 + kl, q0 + st * 16, h);
+          const bf16x8 qta = tr_frag(Qt, dt * 32 + kl, q0 + st * 16, h);
+          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa, pb, dvt[dt], 0, 0, 0);
+          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsb, dkt[dt], 0, 0, 0);
+        }
+      }
+      // dQ[q, d] += sum_key dS[q, key] K[key, d]: dS through the wave-private scratch
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dSw[crow(r, h) * DS_STRIDE + kl] = (bf16)ds[r];
+      f32x16 dq[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(dSw + kl * DS_STRIDE + st * 16 + h * 8);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ktf[dt][st], dq[dt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(&dQ[(q0 + crow(r, h)) * HD + dt * 32 + kl], dq[dt][r]);
+    }
+    // dK[key][d] = scale * dK^T[d][key]; registers 4g..4g+3 hold d = dt*32 + 8g + 4h + (0..3)
+    if (kvalid) {
+      bf16* dk = dqkv + (size_t)(b * N + key) * ld + H * HD + head * HD;
+      bf16* dv = dk + H * HD;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = dt * 32 + 8 * g + 4 * h;
+          bf16x4 a = {(bf16)(dkt[dt][4 * g] * scale), (bf16)(dkt[dt][4 * g + 1] * scale),
+                      (bf16)(dkt[dt][4 * g + 2] * scale), (bf16)(dkt[dt][4 * g + 3] * scale)};
+          bf16x4 c = {(bf16)dvt[dt][4 * g], (bf16)dvt[dt][4 * g + 1], (bf16)dvt[dt][4 * g + 2], (bf16)dvt[dt][4 * g + 3]};
+          *reinterpret_cast<bf16x4*>(dk + d) = a;
+          *reinterpret_cast<bf16x4*>(dv + d) = c;
+        }
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < N * 16; idx += 448) {
+    const int q = idx >> 4, c = idx & 15;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(dQ + q * HD + c * 4);
+    bf16x4 o = {(bf16)(v[0] * scale), (bf16)(v[1] * scale), (bf16)(v[2] * scale), (bf16)(v[3] * scale)};
+    *reinterpret_cast<bf16x4*>(dqkv + (size_t)(b * N + q) * ld + head * HD + c * 4) = o;
+  }
+}
+
+}  // namespace
+
+extern "C" int cara_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, void* stream) {
+  if (!qkv || !out || !lse || B <= 0 || H <= 0 || N <= 0 || N > NMAX) return CARA_E_ARG;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
+    attr_set = true;
+  }
+  const dim3 grid(B * H, (N + 127) / 128);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), FWD_LDS, static_cast<hipStream_t>(stream), (const bf16*)qkv,
+                     (bf16*)out, lse, N, H, scale);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
+extern "C" int cara_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                  int B, int N, int H, float scale, void* stream) {
+  if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || H <= 0 || N <= 0 || N > NMAX) return CARA_E_ARG;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(448), BWD_LDS, static_cast<hipStream_t>(stream),
+                     (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}

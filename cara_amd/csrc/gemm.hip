@@ -1,0 +1,186 @@
+// bf16 MFMA GEMM with a rank-R K-extension and fused epilogues (gfx950 / MI355X only).
+//
+//   C = A[M,K] . B[N,K]^T  (+ A2[M,Rp] . B2[N,Rp]^T)  -> epilogue
+//
+// This one template serves every dense product of the adapted ViT block
+// (/root/reference/src/cara/cara.py:25 qkv, :50 proj, :75 fc1, :87 fc2 and their dX backward):
+// the CaRA delta  s * ((X U) (.) g) V^T  rides along as Rp extra columns of K
+// ([X | T] . [W | Vs]^T), i.e. Rp/K extra MFMA work instead of the reference's
+// second dense GEMM on a materialised dW.
+//
+// Structure: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 =
+// 4x4 v_mfma_f32_16x16x32_bf16 accumulators), BK = 64, two LDS buffers (64 KiB -> 2 blocks/CU),
+// tiles staged by 16-byte global_load_lds (LDS-DMA, no VGPR round trip) issued one K-step ahead
+// of the MFMAs that consume them; one barrier per K-step.  LDS image is [row][64 bf16] with the
+// 16-byte chunk index XOR-swizzled by (row>>1)&7, applied on the global SOURCE address (the DMA
+// destination is lane-linear) and again on the ds_read_b128 address: conflict-free fragment reads.
+// 1-D grid remapped so that each XCD's L2 sees a contiguous run of tiles.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
+constexpr int LDS_BYTES = 4 * TILE_BYTES;      // [buf0: A,B][buf1: A,B]
+
+__device__ __forceinline__ int swz_off(int row, int chunk) {
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+// Stage rows r0..r0+127 (clamped to rmax), columns k0..k0+63 of row-major P into a swizzled tile.
+// 16 one-KiB pieces (8 rows each); wave w issues pieces 4w..4w+3.
+__device__ __forceinline__ void stage_tile(const bf16* __restrict__ P, int ld, int r0, int rmax,
+                                           int k0, char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int q = wave * 4 + t;
+    const int r = q * 8 + (lane >> 3);
+    const int cg = (lane & 7) ^ ((r >> 1) & 7);
+    int gr = r0 + r;
+    gr = gr < rmax ? gr : rmax;
+    glds16(P + (size_t)gr * ld + k0 + cg * 8, lds_tile + q * 1024);
+  }
+}
+
+// The K-extension operands are [rows, Rp] with Rp in {32, 64}: too narrow for lane-linear 1-KiB
+// pieces, so this single step per tile goes through registers.
+__device__ __forceinline__ void stage_ext(const bf16* __restrict__ P, int Rp, int r0, int rmax,
+                                          char* lds_tile, int tid) {
+  const int cpr = Rp >> 3;
+  for (int idx = tid; idx < 128 * cpr; idx += 256) {
+    const int r = idx / cpr, c = idx - r * cpr;
+    int gr = r0 + r;
+    gr = gr < rmax ? gr : rmax;
+    const uint4 v = *reinterpret_cast<const uint4*>(P + (size_t)gr * Rp + c * 8);
+    *reinterpret_cast<uint4*>(lds_tile + swz_off(r, c)) = v;
+  }
+}
+
+__device__ __forceinline__ void mma_tile(const char* sA, const char* sB, f32x4 (&acc)[4][4],
+                                         int wr, int wc, int lane, int ksub) {
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kk = 0; kk < ksub; ++kk) {
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a[i] = *reinterpret_cast<const bf16x8*>(sA + swz_off(wr * 64 + i * 16 + fr, kk * 4 + fq));
+      b[i] = *reinterpret_cast<const bf16x8*>(sB + swz_off(wc * 64 + i * 16 + fr, kk * 4 + fq));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const cara_gemm_args p, const int tiles_n,
+                                                      const int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const bf16* __restrict__ A = static_cast<const bf16*>(p.A);
+  const bf16* __restrict__ B = static_cast<const bf16*>(p.B);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  stage_tile(A, p.lda, m0, p.M - 1, 0, smem, wave, lane);
+  stage_tile(B, p.ldb, n0, p.N - 1, 0, smem + TILE_BYTES, wave, lane);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed (own DMA: vmcnt; other waves': barrier) and every wave has finished
+    // reading the other buffer (its MFMAs of step kt-1 are issued), so it may be refilled.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    char* sA = smem + cur * (2 * TILE_BYTES);
+    if (kt + 1 < nk) {
+      char* nA = smem + (cur ^ 1) * (2 * TILE_BYTES);
+      stage_tile(A, p.lda, m0, p.M - 1, (kt + 1) * BK, nA, wave, lane);
+      stage_tile(B, p.ldb, n0, p.N - 1, (kt + 1) * BK, nA + TILE_BYTES, wave, lane);
+    }
+    mma_tile(sA, sA + TILE_BYTES, acc, wr, wc, lane, BK / 32);
+    cur ^= 1;
+  }
+  if (p.Rp > 0) {
+    __syncthreads();
+    stage_ext(static_cast<const bf16*>(p.A2), p.Rp, m0, p.M - 1, smem, tid);
+    stage_ext(static_cast<const bf16*>(p.B2), p.Rp, n0, p.N - 1, smem + TILE_BYTES, tid);
+    __syncthreads();
+    mma_tile(smem, smem + TILE_BYTES, acc, wr, wc, lane, p.Rp >> 5);
+  }
+
+  // ---- epilogue: C/D layout of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg ----
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wc * 64 + j * 16 + fr;
+    if (n >= p.N) continue;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wr * 64 + i * 16 + fq * 4 + r;
+        if (m >= p.M) continue;
+        const size_t o = (size_t)m * p.ldc + n;
+        const float v = acc[i][j][r] + bv;
+        if constexpr (EPI == CARA_EPI_BF16) {
+          static_cast<bf16*>(p.C)[o] = (bf16)v;
+        } else if constexpr (EPI == CARA_EPI_F32) {
+          static_cast<float*>(p.C)[o] = v;
+        } else if constexpr (EPI == CARA_EPI_GELU) {
+          // the stored pre-activation is the bf16 value; GELU is taken of that same rounded value
+          // so that forward h and backward gelu'(u) see one consistent u
+          const bf16 ub = (bf16)v;
+          static_cast<bf16*>(p.C2)[o] = ub;
+          static_cast<bf16*>(p.C)[o] = (bf16)gelu_erf((float)ub);
+        } else if constexpr (EPI == CARA_EPI_RESID) {
+          const float rs = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.f;
+          static_cast<float*>(p.C)[o] = static_cast<const float*>(p.aux)[o] + rs * v;
+        } else if constexpr (EPI == CARA_EPI_DGELU) {
+          const float u = (float)static_cast<const bf16*>(p.aux)[o];
+          static_cast<bf16*>(p.C)[o] = (bf16)(v * gelu_erf_grad(u));
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch(const cara_gemm_args* a, hipStream_t st) {
+  const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  hipLaunchKernelGGL(gemm_kernel<EPI>, dim3(nwg), dim3(256), LDS_BYTES, st, *a, tiles_n, nwg);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
+}  // namespace
+
+extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
+  if (!a || !a->A || !a->B || !a->C) return CARA_E_ARG;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % BK) != 0) return CARA_E_ARG;
+  if (a->lda < a->K || a->ldb < a->K || (a->lda & 7) || (a->ldb & 7) || a->ldc < a->N) return CARA_E_ARG;
+  if (!(a->Rp == 0 || a->Rp == 32 || a->Rp == 64)) return CARA_E_ARG;
+  if (a->Rp && (!a->A2 || !a->B2)) return CARA_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (a->epi) {
+    case CARA_EPI_BF16: return launch<CARA_EPI_BF16>(a, st);
+    case CARA_EPI_F32: return launch<CARA_EPI_F32>(a, st);
+    case CARA_EPI_GELU: return a->C2 ? launch<CARA_EPI_GELU>(a, st) : CARA_E_ARG;
+    case CARA_EPI_RESID:
+      if (!a->aux || (a->rowscale && a->rows_per_sample <= 0)) return CARA_E_ARG;
+      return launch<CARA_EPI_RESID>(a, st);
+    case CARA_EPI_DGELU: return a->aux ? launch<CARA_EPI_DGELU>(a, st) : CARA_E_ARG;
+    default: return CARA_E_ARG;
+  }
+}

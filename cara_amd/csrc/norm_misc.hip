@@ -1,0 +1,270 @@
+// LayerNorm forward/backward and the small pieces of the ViT around the blocks (gfx950 only).
+// timm 0.4.12 Block: x = x + drop_path(attn(norm1(x))); x = x + drop_path(mlp(norm2(x)))
+// (restated in oracle/cara_oracle.py).  The residual stream stays fp32; normalised activations
+// leave as bf16 GEMM operands.  All kernels are HBM-bound streaming passes: one wave per row,
+// 16-byte accesses, wave shuffles for the two row reductions.
+#include "common.h"
+
+namespace {
+
+template <int V4>  // C / 256 : float4 per lane
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta,
+                                                     bf16* __restrict__ y, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int M, float eps) {
+  constexpr int C = V4 * 256;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * ldx;
+  float4 v[V4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < V4; ++i) {
+    v[i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mu = wave_sum(s) * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < V4; ++i) {
+    const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+  const float rs = rsqrtf(wave_sum(q) * (1.0f / C) + eps);
+  bf16* yr = y + (size_t)row * C;
+#pragma unroll
+  for (int i = 0; i < V4; ++i) {
+    const int c0 = i * 256 + lane * 4;
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c0);
+    const float4 b = *reinterpret_cast<const float4*>(beta + c0);
+    bf16x4 o = {(bf16)((v[i].x - mu) * rs * g.x + b.x), (bf16)((v[i].y - mu) * rs * g.y + b.y),
+                (bf16)((v[i].z - mu) * rs * g.z + b.z), (bf16)((v[i].w - mu) * rs * g.w + b.w)};
+    *reinterpret_cast<bf16x4*>(yr + c0) = o;
+  }
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mu) * rstd
+template <int V4>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
+                                                     long ldx, const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd,
+                                                     const float* __restrict__ dx_in,
+                                                     float* __restrict__ dx_out, bf16* __restrict__ dyb,
+                                                     const float* __restrict__ rowscale,
+                                                     int rows_per_sample, int M) {
+  constexpr int C = V4 * 256;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float mu = mean[row], rs = rstd[row];
+  const float* xr = x + (size_t)row * ldx;
+  const bf16* dr = dy + (size_t)row * C;
+  float4 g[V4], xh[V4];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < V4; ++i) {
+    const int c0 = i * 256 + lane * 4;
+    const float4 xv = *reinterpret_cast<const float4*>(xr + c0);
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + c0);
+    const bf16x4 d = *reinterpret_cast<const bf16x4*>(dr + c0);
+    xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+    g[i] = make_float4((float)d[0] * gm.x, (float)d[1] * gm.y, (float)d[2] * gm.z, (float)d[3] * gm.w);
+    s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+    s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+  }
+  const float c1 = wave_sum(s1) * (1.0f / C), c2 = wave_sum(s2) * (1.0f / C);
+  const float sc = rowscale ? rowscale[row / rows_per_sample] : 1.f;
+  const float* di = dx_in ? dx_in + (size_t)row * ldx : nullptr;
+  float* dor = dx_out + (size_t)row * ldx;
+  bf16* db = dyb ? dyb + (size_t)row * ldx : nullptr;
+#pragma unroll
+  for (int i = 0; i < V4; ++i) {
+    const int c0 = i * 256 + lane * 4;
+    float4 o = make_float4(rs * (g[i].x - c1 - xh[i].x * c2), rs * (g[i].y - c1 - xh[i].y * c2),
+                           rs * (g[i].z - c1 - xh[i].z * c2), rs * (g[i].w - c1 - xh[i].w * c2));
+    if (di) {
+      const float4 p = *reinterpret_cast<const float4*>(di + c0);
+      o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+    }
+    *reinterpret_cast<float4*>(dor + c0) = o;
+    if (db) {
+      bf16x4 b = {(bf16)(o.x * sc), (bf16)(o.y * sc), (bf16)(o.z * sc), (bf16)(o.w * sc)};
+      *reinterpret_cast<bf16x4*>(db + c0) = b;
+    }
+  }
+}
+
+// images fp32 [B,C,Hi,Wi] -> patch rows bf16 [B*gh*gw, C*p*p], column = (c*p + py)*p + px
+// (the flattening of Conv2d weight [D, C, p, p]); p == 16: one 16-float image row segment per
+// 4 lanes.
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16* __restrict__ out,
+                                                     int B, int C, int Hi, int Wi, int p, long total4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of a patch row
+  if (idx >= total4) return;
+  const int gw = Wi / p, gh = Hi / p;
+  const int kcols = C * p * p;
+  const long e = idx * 4;
+  const long row = e / kcols;
+  const int col = (int)(e - row * kcols);
+  const int c = col / (p * p), py = (col / p) % p, px = col % p;
+  const int b = (int)(row / (gh * gw)), pr = (int)(row % (gh * gw));
+  const int gy = pr / gw, gx = pr % gw;
+  const float4 v = *reinterpret_cast<const float4*>(img + (((size_t)b * C + c) * Hi + gy * p + py) * Wi + gx * p + px);
+  bf16x4 o = {(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w};
+  *reinterpret_cast<bf16x4*>(out + e) = o;
+}
+
+__global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__ emb, const float* __restrict__ cls,
+                                                       const float* __restrict__ pos, float* __restrict__ x,
+                                                       int B, int P, int D, long total4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const long e = idx * 4;
+  const int d = (int)(e % D);
+  const long tok = e / D;
+  const int t = (int)(tok % (P + 1)), b = (int)(tok / (P + 1));
+  const float4 pv = *reinterpret_cast<const float4*>(pos + (size_t)t * D + d);
+  float4 s = (t == 0) ? *reinterpret_cast<const float4*>(cls + d)
+                      : *reinterpret_cast<const float4*>(emb + ((size_t)b * P + (t - 1)) * D + d);
+  s.x += pv.x; s.y += pv.y; s.z += pv.z; s.w += pv.w;
+  *reinterpret_cast<float4*>(x + e) = s;
+}
+
+// one wave per sample; loss = mean_b (lse_b - logit_b[y_b]); dlogits = (softmax - onehot) / B
+__global__ __launch_bounds__(64) void xent_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                  float* __restrict__ loss_per, float* __restrict__ dlogits,
+                                                  int B, int C) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* lr = logits + (size_t)b * C;
+  float m = -3.0e38f;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, lr[c]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += __expf(lr[c] - m);
+  s = wave_sum(s);
+  const float lse = m + __logf(s);
+  const int y = (int)labels[b];
+  const float invB = 1.0f / B;
+  if (dlogits)
+    for (int c = lane; c < C; c += 64)
+      dlogits[(size_t)b * C + c] = (__expf(lr[c] - lse) - (c == y ? 1.f : 0.f)) * invB;
+  if (lane == 0) loss_per[b] = (lse - lr[y]) * invB;
+}
+__global__ __launch_bounds__(64) void xent_sum_kernel(const float* __restrict__ loss_per, float* __restrict__ loss, int B) {
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += 64) s += loss_per[b];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) *loss = s;
+}
+
+__global__ __launch_bounds__(256) void cvt_kernel(const float* __restrict__ src, bf16* __restrict__ dst, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const float4 v = *reinterpret_cast<const float4*>(src + i);
+    bf16x4 o = {(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w};
+    *reinterpret_cast<bf16x4*>(dst + i) = o;
+  } else {
+    for (size_t k = i; k < n; ++k) dst[k] = (bf16)src[k];
+  }
+}
+
+// dst[c][r] = src[r][c], 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
+                                                        int rows, int cols) {
+  __shared__ bf16 tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int k = ty; k < 32; k += 8)
+    if (r0 + k < rows && c0 + tx < cols) tile[k][tx] = src[(size_t)(r0 + k) * cols + c0 + tx];
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8)
+    if (c0 + k < cols && r0 + tx < rows) dst[(size_t)(c0 + k) * rows + r0 + tx] = tile[tx][k];
+}
+
+}  // namespace
+
+extern "C" int cara_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, void* y,
+                                  float* mean, float* rstd, int M, int C, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0 || ldx < C || (ldx & 3)) return CARA_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((M + 3) / 4), block(256);
+  if (C == 768) hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, st, x, ldx, gamma, beta, (bf16*)y, mean, rstd, M, eps);
+  else if (C == 1024) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, st, x, ldx, gamma, beta, (bf16*)y, mean, rstd, M, eps);
+  else if (C == 256) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, st, x, ldx, gamma, beta, (bf16*)y, mean, rstd, M, eps);
+  else return CARA_E_ARG;
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
+extern "C" int cara_layernorm_bwd(const void* dy, const float* x, long ldx, const float* gamma, const float* mean,
+                                  const float* rstd, const float* dx_in, float* dx_out, void* dyb,
+                                  const float* rowscale, int rows_per_sample, int M, int C, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx_out || M <= 0 || ldx < C || (ldx & 3)) return CARA_E_ARG;
+  if (rowscale && rows_per_sample <= 0) return CARA_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((M + 3) / 4), block(256);
+#define LNB(V) hipLaunchKernelGGL(ln_bwd_kernel<V>, grid, block, 0, st, (const bf16*)dy, x, ldx, gamma, mean, rstd, \
+                                  dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M)
+  if (C == 768) LNB(3);
+  else if (C == 1024) LNB(4);
+  else if (C == 256) LNB(1);
+  else return CARA_E_ARG;
+#undef LNB
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
+extern "C" int cara_im2col_patches(const float* img, void* patches, int B, int C, int Hi, int Wi, int p, void* stream) {
+  if (!img || !patches || B <= 0 || C <= 0 || p <= 0 || (p & 3) || Hi % p || Wi % p || (Wi & 3)) return CARA_E_ARG;
+  const long total4 = (long)B * C * Hi * Wi / 4;
+  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     img, (bf16*)patches, B, C, Hi, Wi, p, total4);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
+extern "C" int cara_assemble_tokens(const float* emb, const float* cls, const float* pos, float* x, int B, int P,
+                                    int D, void* stream) {
+  if (!emb || !cls || !pos || !x || B <= 0 || P <= 0 || D <= 0 || (D & 3)) return CARA_E_ARG;
+  const long total4 = (long)B * (P + 1) * D / 4;
+  hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     emb, cls, pos, x, B, P, D, total4);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
+extern "C" int cara_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits, int B,
+                                  int C, void* stream) {
+  // loss doubles as scratch: needs room for 1 + B floats (loss[0] = mean loss, loss[1..B] per-sample terms)
+  if (!logits || !labels || !loss || B <= 0 || C <= 0) return CARA_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(xent_kernel, dim3(B), dim3(64), 0, st, logits, labels, loss + 1, dlogits, B, C);
+  CARA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(xent_sum_kernel, dim3(1), dim3(64), 0, st, loss + 1, loss, B);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
+extern "C" int cara_f32_to_bf16(const float* src, void* dst, size_t n, void* stream) {
+  if (!src || !dst || n == 0) return CARA_E_ARG;
+  const size_t nthreads = (n + 3) / 4;
+  hipLaunchKernelGGL(cvt_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     src, (bf16*)dst, n);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
+extern "C" int cara_transpose_bf16(const void* src, void* dst, int rows, int cols, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0) return CARA_E_ARG;
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), (const bf16*)src, (bf16*)dst, rows, cols);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}

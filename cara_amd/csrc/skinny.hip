@@ -1,0 +1,318 @@
+// HBM-bound rank-R adapter contractions (gfx950 / MI355X only).
+//
+//  cara_skinny_xu  : T[M,Rp]   = X[M,K] . U[K,Rp]        forward T = X U ; backward G' = dY Vs
+//  cara_tskinny_xtg: D[K1,Rp]  = X[M,K1]^T . G[M,Rp]      dU = X^T G'  and  dVs = dY^T T  (A.4)
+//
+// Together with the K-extension of gemm.hip these replace the reference's materialise-dW +
+// second dense GEMM + dense d(dW) (/root/reference/src/cara/cara.py:26-35,51-57,76-81,88-92 and
+// their autograd) by products whose cost is one streaming read of X (algorithmic bytes:
+// M*K*2 in, tiny out).  Both use MFMA so the VALU never bounds them.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// T = X . Ut^T.  Block = 32 rows x all Rp columns; the 4 waves split K (k-step w, w+4, ...:
+// adjacent waves read adjacent 64-B pieces of a row) and reduce through LDS.
+// ------------------------------------------------------------------------------------------
+template <int NT>  // Rp / 16
+__global__ __launch_bounds__(256) void skinny_xu_kernel(const bf16* __restrict__ X, int ldx,
+                                                        const bf16* __restrict__ Ut,
+                                                        bf16* __restrict__ T, bf16* __restrict__ Tt,
+                                                        int ldt, int M, int K) {
+  __shared__ f32x4 red[4][2 * NT][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.x * 32;
+  constexpr int Rp = NT * 16;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int r0 = m0 + fr, r1 = m0 + 16 + fr;
+  r0 = r0 < M ? r0 : M - 1;
+  r1 = r1 < M ? r1 : M - 1;
+  const bf16* xa0 = X + (size_t)r0 * ldx + fq * 8;
+  const bf16* xa1 = X + (size_t)r1 * ldx + fq * 8;
+  const bf16* ub = Ut + (size_t)fr * K + fq * 8;
+  const int nks = K >> 5;
+#pragma unroll 4
+  for (int ks = wave; ks < nks; ks += 4) {
+    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(xa0 + ks * 32);
+    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(xa1 + ks * 32);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(ub + (size_t)j * 16 * K + ks * 32);
+      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][j], 0, 0, 0);
+      acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) red[wave][i * NT + j][lane] = acc[i][j];
+  __syncthreads();
+  for (int t = wave; t < 2 * NT; t += 4) {
+    f32x4 s = red[0][t][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const f32x4 v = red[w][t][lane];
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    const int mt = t / NT, nt = t - mt * NT;
+    const int n = nt * 16 + fr;
+    const int mb = m0 + mt * 16 + fq * 4;  // rows mb..mb+3, column n
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (mb + r < M) T[(size_t)(mb + r) * Rp + n] = (bf16)s[r];
+    if (Tt) {
+      if (mb + 3 < M) {
+        bf16x4 pk = {(bf16)s[0], (bf16)s[1], (bf16)s[2], (bf16)s[3]};
+        *reinterpret_cast<bf16x4*>(Tt + (size_t)n * ldt + mb) = pk;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (mb + r < M) Tt[(size_t)n * ldt + mb + r] = (bf16)s[r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// D[i, r] = sum_m X[m, i] * G[m, r]   with Gt[r, m] given.
+// MFMA orientation: rows = r (A operand = Gt, m-contiguous), cols = i (B operand = X, taken
+// from an LDS image of the [32 m][64 i] tile by 2-byte reads: k = m is the slow index of X).
+// Grid = (K1/64 column blocks) x (m-chunks); inside a block the 4 waves take alternate 32-row
+// steps, each with a PRIVATE 3-deep LDS ring filled by LDS-DMA (no block barrier in the loop,
+// only counted vmcnt), and combine through LDS at the end.  Each block writes one fp32 slab
+// [64, Rp]; a second tiny kernel sums the slabs in a fixed order (bitwise reproducible, no
+// float atomics).
+// ------------------------------------------------------------------------------------------
+constexpr int TS_COLS = 64;
+
+__host__ __device__ inline int ts_chunks(int M, int K1) {
+  const int colblocks = K1 / TS_COLS;
+  int c = (256 + colblocks - 1) / colblocks;  // ~1 block per CU
+  const int steps = (M + 31) / 32;
+  const int maxc = (steps + 7) / 8;  // at least 8 steps (2 per wave) per block
+  if (c > maxc) c = maxc;
+  if (c < 1) c = 1;
+  return c;
+}
+
+template <int NT>
+struct TsRing {
+  static constexpr int X_BYTES = 32 * TS_COLS * 2;   // 4 KiB : 4 pieces of 8 rows x 128 B
+  static constexpr int G_BYTES = NT * 16 * 32 * 2;   // Rp rows x 64 B : NT pieces of 16 rows
+  static constexpr int STAGE = X_BYTES + G_BYTES;
+  static constexpr int PIECES = 4 + NT;
+  static constexpr int WAVE_BYTES = 3 * STAGE;
+};
+
+template <int NT>
+__device__ __forceinline__ void ts_issue(const bf16* __restrict__ X, int ldx, const bf16* __restrict__ Gt,
+                                         int ldg, int i0, int m0, int M, char* stage, int lane) {
+  // X tile: piece q = rows 8q..8q+7; lane -> row 8q + lane/8, 16-B slot lane%8 holding global
+  // chunk (lane%8) ^ q  (reader of row group fq = q reads chunk c ^ fq: bank-conflict free)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int m = m0 + q * 8 + (lane >> 3);
+    m = m < M ? m : M - 1;
+    const int cg = (lane & 7) ^ q;
+    glds16(X + (size_t)m * ldx + i0 + cg * 8, stage + q * 1024);
+  }
+  // Gt tile: [Rp][32 m] bf16, 64-B rows; piece p = rows 16p..16p+15, lane -> row lane/4, chunk lane%4
+#pragma unroll
+  for (int p = 0; p < NT; ++p) {
+    const int r = p * 16 + (lane >> 2);
+    glds16(Gt + (size_t)r * ldg + m0 + (lane & 3) * 8, stage + TsRing<NT>::X_BYTES + p * 1024);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else static_assert(N == 0, "unsupported vmcnt");
+}
+
+template <int NT, bool COLSUM>
+__global__ __launch_bounds__(256) void tskinny_kernel(const bf16* __restrict__ X, int ldx,
+                                                      const bf16* __restrict__ Gt, int ldg,
+                                                      float* __restrict__ slabs,
+                                                      float* __restrict__ cs_slabs, int M, int K1,
+                                                      int nchunks) {
+  using R = TsRing<NT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int colblocks = K1 / TS_COLS;
+  const int cb = blockIdx.x % colblocks, chunk = blockIdx.x / colblocks;
+  const int i0 = cb * TS_COLS;
+  const int steps = (M + 31) / 32;
+  const int s_begin = (int)((long)steps * chunk / nchunks), s_end = (int)((long)steps * (chunk + 1) / nchunks);
+  char* ring = smem + wave * R::WAVE_BYTES;
+
+  f32x4 acc[NT][4];  // [r-tile][i-tile]
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // this wave's steps: s_begin + wave, +4, ...
+  const int first = s_begin + wave;
+  const int nmine = first < s_end ? (s_end - first + 3) / 4 : 0;
+  if (nmine > 0) ts_issue<NT>(X, ldx, Gt, ldg, i0, first * 32, M, ring, lane);
+  if (nmine > 1) ts_issue<NT>(X, ldx, Gt, ldg, i0, (first + 4) * 32, M, ring + R::STAGE, lane);
+  for (int t = 0; t < nmine; ++t) {
+    const int slot = t % 3;
+    if (t + 2 < nmine) {
+      ts_issue<NT>(X, ldx, Gt, ldg, i0, (first + 4 * (t + 2)) * 32, M, ring + ((t + 2) % 3) * R::STAGE, lane);
+      wait_vmcnt<2 * R::PIECES>();
+    } else if (t + 1 < nmine) {
+      wait_vmcnt<R::PIECES>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    const char* sx = ring + slot * R::STAGE;
+    const char* sg = sx + R::X_BYTES;
+    bf16x8 a[NT];
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt)
+      a[rt] = *reinterpret_cast<const bf16x8*>(sg + (rt * 16 + fr) * 64 + fq * 16);
+    const int mrow = (first + 4 * t) * 32 + fq * 8;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      // B fragment: X[m = 8 fq + j][i = it*16 + fr], j = 0..7
+      const int col = it * 16 + fr;
+      const int off = ((((col >> 3) ^ fq) << 4) | ((col & 7) << 1));
+      bf16x8 b;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[j] = *reinterpret_cast<const bf16*>(sx + (fq * 8 + j) * 128 + off);
+      if constexpr (COLSUM) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) csum[it] += (mrow + j < M) ? (float)b[j] : 0.f;
+      }
+#pragma unroll
+      for (int rt = 0; rt < NT; ++rt)
+        acc[rt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt], b, acc[rt][it], 0, 0, 0);
+    }
+  }
+  // ---- combine the 4 waves through LDS (ring memory is dead now) ----
+  __syncthreads();
+  f32x4* red = reinterpret_cast<f32x4*>(smem);  // [wave][NT*4][64]
+#pragma unroll
+  for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) red[(wave * NT * 4 + rt * 4 + it) * 64 + lane] = acc[rt][it];
+  float* cred = reinterpret_cast<float*>(smem + 4 * NT * 4 * 64 * 16);  // [wave][4 it][64 lanes]
+  if constexpr (COLSUM) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) cred[(wave * 4 + it) * 64 + lane] = csum[it];
+  }
+  __syncthreads();
+  float* slab = slabs + (size_t)blockIdx.x * TS_COLS * (NT * 16);
+  for (int t = wave; t < NT * 4; t += 4) {
+    f32x4 s = red[t * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const f32x4 v = red[(w * NT * 4 + t) * 64 + lane];
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    const int rt = t >> 2, it = t & 3;
+    // C layout: row (= r) = rt*16 + fq*4 + reg, col (= i) = it*16 + fr  ->  slab[i][r..r+3]
+    *reinterpret_cast<f32x4*>(slab + (size_t)(it * 16 + fr) * (NT * 16) + rt * 16 + fq * 4) = s;
+  }
+  if constexpr (COLSUM) {
+    if (tid < TS_COLS) {
+      const int it = tid >> 4, f = tid & 15;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s += cred[(w * 4 + it) * 64 + q * 16 + f];
+      cs_slabs[(size_t)blockIdx.x * TS_COLS + tid] = s;
+    }
+  }
+}
+
+// D[i][r] = sum_chunk slab[chunk*colblocks + i/64][i%64][r]   (fixed order)
+__global__ void tskinny_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ cs_slabs,
+                                      float* __restrict__ D, float* __restrict__ colsum, int K1, int Rp,
+                                      int nchunks) {
+  const int colblocks = K1 / TS_COLS;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = K1 * Rp;
+  if (idx < total) {
+    const int i = idx / Rp, r = idx - i * Rp;
+    const int cb = i / TS_COLS, il = i - cb * TS_COLS;
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += slabs[((size_t)(c * colblocks + cb) * TS_COLS + il) * Rp + r];
+    D[idx] = s;
+  }
+  if (colsum && idx < K1) {
+    const int cb = idx / TS_COLS, il = idx - cb * TS_COLS;
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += cs_slabs[(size_t)(c * colblocks + cb) * TS_COLS + il];
+    colsum[idx] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" int cara_skinny_xu(const void* X, int ldx, const void* Ut, void* T, void* Tt, int ldt,
+                              int M, int K, int Rp, void* stream) {
+  if (!X || !Ut || !T || M <= 0 || K <= 0 || (K & 31) || (ldx & 7) || ldx < K) return CARA_E_ARG;
+  if (Tt && (ldt < M || (ldt & 7))) return CARA_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((M + 31) / 32), block(256);
+  if (Rp == 32)
+    hipLaunchKernelGGL(skinny_xu_kernel<2>, grid, block, 0, st, (const bf16*)X, ldx, (const bf16*)Ut, (bf16*)T, (bf16*)Tt, ldt, M, K);
+  else if (Rp == 64)
+    hipLaunchKernelGGL(skinny_xu_kernel<4>, grid, block, 0, st, (const bf16*)X, ldx, (const bf16*)Ut, (bf16*)T, (bf16*)Tt, ldt, M, K);
+  else
+    return CARA_E_ARG;
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
+extern "C" size_t cara_tskinny_scratch_bytes(int M, int K1, int Rp) {
+  if (M <= 0 || K1 <= 0 || (K1 % TS_COLS) || !(Rp == 32 || Rp == 64)) return 0;
+  const size_t nblk = (size_t)(K1 / TS_COLS) * ts_chunks(M, K1);
+  return nblk * TS_COLS * Rp * sizeof(float) + nblk * TS_COLS * sizeof(float);
+}
+
+extern "C" int cara_tskinny_xtg(const void* X, int ldx, const void* Gt, int ldg, float* D, float* colsum,
+                                void* slabs, int M, int K1, int Rp, void* stream) {
+  if (!X || !Gt || !D || !slabs || M <= 0 || K1 <= 0 || (K1 % TS_COLS) || (ldx & 7) || ldx < K1) return CARA_E_ARG;
+  // Gt rows must be readable (and zero) up to the next multiple of 32 rows of M
+  if ((ldg & 7) || ldg < ((M + 31) / 32) * 32) return CARA_E_ARG;
+  if (!(Rp == 32 || Rp == 64)) return CARA_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nchunks = ts_chunks(M, K1);
+  const int nblk = (K1 / TS_COLS) * nchunks;
+  float* sl = static_cast<float*>(slabs);
+  float* cs = sl + (size_t)nblk * TS_COLS * Rp;
+  const bf16* x = (const bf16*)X;
+  const bf16* g = (const bf16*)Gt;
+  if (Rp == 32) {
+    const size_t lds = 4 * TsRing<2>::WAVE_BYTES;
+    if (colsum) hipLaunchKernelGGL((tskinny_kernel<2, true>), dim3(nblk), dim3(256), lds, st, x, ldx, g, ldg, sl, cs, M, K1, nchunks);
+    else hipLaunchKernelGGL((tskinny_kernel<2, false>), dim3(nblk), dim3(256), lds, st, x, ldx, g, ldg, sl, cs, M, K1, nchunks);
+  } else {
+    const size_t lds = 4 * TsRing<4>::WAVE_BYTES;
+    if (colsum) hipLaunchKernelGGL((tskinny_kernel<4, true>), dim3(nblk), dim3(256), lds, st, x, ldx, g, ldg, sl, cs, M, K1, nchunks);
+    else hipLaunchKernelGGL((tskinny_kernel<4, false>), dim3(nblk), dim3(256), lds, st, x, ldx, g, ldg, sl, cs, M, K1, nchunks);
+  }
+  CARA_CHECK_LAUNCH();
+  const int total = K1 * Rp;
+  hipLaunchKernelGGL(tskinny_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sl, cs, D, colsum, K1, Rp, nchunks);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}

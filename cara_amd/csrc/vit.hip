@@ -1,0 +1,321 @@
+// Whole adapted ViT forward / backward as stream-ordered sequences of the kernels in this
+// library (gfx950).  What `model(x)` and `loss.backward()` of
+// /root/reference/image_classification/vit_cp.py:46-49 execute, with the patched forwards of
+// /root/reference/src/cara/cara.py:15-95 in factored form: no dW is ever
+// materialised and no dense weight gradient exists; the frozen backbone only propagates dX.
+// Host side is plain C++ in the library so a train step costs two FFI calls and the whole
+// sequence can be captured in a hipGraph (nothing here allocates or synchronises).
+#include "common.h"
+
+namespace {
+
+struct Carver {
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off = (off + bytes + 255) & ~(size_t)255;
+    return o;
+  }
+};
+
+struct LayerWs {
+  size_t x_in, x_mid, mean1, rstd1, mean2, rstd2;
+  size_t xn1, qkv, lse, ao, xn2, u, h;
+  size_t T[4], Tt[4];   // qkv, proj, fc1, fc2
+};
+
+struct Ws {
+  size_t pack, patches, emb, head_wb, clsn, meanF, rstdF, x_last;
+  LayerWs layer[64];
+  // backward
+  size_t dx, dyb, dH, dXn, dAO, dQKV, G, Gt, slabs, dclsn;
+  size_t dU[4], dVs[4], dc[4];
+  size_t total;
+  int M, ldt;
+};
+
+size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
+bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
+  if (!g || !s || g->depth <= 0 || g->depth > 64 || g->dim % g->heads || g->dim / g->heads != 64) return false;
+  if (!(g->Rp == 32 || g->Rp == 64) || g->rank > g->Rp || s->B <= 0 || s->tokens <= 1 || s->tokens > 224) return false;
+  if (s->img % s->patch || (s->img / s->patch) * (s->img / s->patch) + 1 != s->tokens) return false;
+  if ((s->chans * s->patch * s->patch) % 64 || g->dim % 256) return false;
+  const size_t D = g->dim, M = (size_t)s->B * s->tokens, Rp = g->Rp;
+  const size_t ldt = (M + 31) / 32 * 32;
+  w->M = (int)M;
+  w->ldt = (int)ldt;
+  Carver c;
+  cara_pack_layout pl;
+  if (cara_pack_offsets(g, &pl) != CARA_OK) return false;
+  w->pack = c.take(pl.total);
+  const size_t P = s->tokens - 1, kp = (size_t)s->chans * s->patch * s->patch;
+  w->patches = c.take((size_t)s->B * P * kp * 2);
+  w->emb = c.take((size_t)s->B * P * D * 4);
+  w->head_wb = c.take((size_t)s->num_classes * D * 2);
+  w->clsn = c.take((size_t)s->B * D * 2);
+  w->meanF = c.take((size_t)s->B * 4);
+  w->rstdF = c.take((size_t)s->B * 4);
+  w->x_last = c.take(M * D * 4);
+  for (int l = 0; l < g->depth; ++l) {
+    LayerWs& L = w->layer[l];
+    L.x_in = c.take(M * D * 4);
+    L.x_mid = c.take(M * D * 4);
+    L.mean1 = c.take(M * 4); L.rstd1 = c.take(M * 4); L.mean2 = c.take(M * 4); L.rstd2 = c.take(M * 4);
+    L.xn1 = c.take(M * D * 2);
+    L.qkv = c.take(M * 3 * D * 2);
+    L.lse = c.take((size_t)s->B * g->heads * s->tokens * 4);
+    L.ao = c.take(M * D * 2);
+    L.xn2 = c.take(M * D * 2);
+    L.u = c.take(M * 4 * D * 2);
+    L.h = c.take(M * 4 * D * 2);
+    for (int i = 0; i < 4; ++i) {
+      L.T[i] = c.take(M * Rp * 2);
+      L.Tt[i] = c.take(Rp * ldt * 2);
+    }
+  }
+  w->dx = c.take(M * D * 4);
+  w->dyb = c.take(M * D * 2);
+  w->dH = c.take(M * 4 * D * 2);
+  w->dXn = c.take(M * D * 2);
+  w->dAO = c.take(M * D * 2);
+  w->dQKV = c.take(M * 3 * D * 2);
+  w->G = c.take(M * Rp * 2);
+  w->Gt = c.take(Rp * ldt * 2);
+  size_t sl = 0;
+  const int k1s[3] = {(int)D, (int)(3 * D), (int)(4 * D)};
+  for (int i = 0; i < 3; ++i) sl = max_sz(sl, cara_tskinny_scratch_bytes((int)M, k1s[i], (int)Rp));
+  w->slabs = c.take(sl);
+  w->dclsn = c.take((size_t)s->B * D * 2);
+  const size_t ins[4] = {D, D, D, 4 * D}, outs[4] = {3 * D, D, 4 * D, D};
+  for (int i = 0; i < 4; ++i) {
+    w->dU[i] = c.take((size_t)g->depth * ins[i] * Rp * 4);
+    w->dVs[i] = c.take((size_t)g->depth * outs[i] * Rp * 4);
+    w->dc[i] = c.take((size_t)g->depth * outs[i] * 4);
+  }
+  w->total = c.off;
+  return true;
+}
+
+#define TRY(expr)                 \
+  do {                            \
+    const int _st = (expr);       \
+    if (_st != CARA_OK) return _st; \
+  } while (0)
+
+struct Lin {  // one adapted linear of one layer
+  const bf16 *W, *Wt;
+  const bf16 *Ut, *U, *Vs, *Vst;
+  const float* bias;
+  int in, out, slot;
+};
+
+// forward of one adapted linear: T = X U ; C = [X | T] [W | Vs]^T + bias -> epilogue
+int lin_fwd(const Lin& L, const bf16* X, int M, int Rp, int ldt, char* ws, const LayerWs& lw, cara_gemm_args a, void* st) {
+  bf16* T = reinterpret_cast<bf16*>(ws + lw.T[L.slot]);
+  bf16* Tt = reinterpret_cast<bf16*>(ws + lw.Tt[L.slot]);
+  TRY(cara_skinny_xu(X, L.in, L.Ut, T, Tt, ldt, M, L.in, Rp, st));
+  a.A = X; a.lda = L.in; a.B = L.W; a.ldb = L.in; a.A2 = T; a.B2 = L.Vs; a.Rp = Rp;
+  a.M = M; a.N = L.out; a.K = L.in; a.bias = L.bias; a.ldc = L.out;
+  return cara_gemm_bf16(&a, st);
+}
+
+// backward of one adapted linear given dY (bf16 [M,out]) and its saved input X:
+//   G' = dY Vs ; dX = [dY | G'] [W^T | U]^T (optional) ; dU = X^T G' ; dVs = dY^T T ; dc = colsum dY
+int lin_bwd(const Lin& L, const bf16* dY, const bf16* X, int M, int Rp, int ldt, char* ws, const Ws& W, const LayerWs& lw,
+            int layer, bool want_dx, cara_gemm_args a, bool want_dc, void* st) {
+  bf16* G = reinterpret_cast<bf16*>(ws + W.G);
+  bf16* Gt = reinterpret_cast<bf16*>(ws + W.Gt);
+  TRY(cara_skinny_xu(dY, L.out, L.Vst, G, Gt, ldt, M, L.out, Rp, st));
+  if (want_dx) {
+    a.A = dY; a.lda = L.out; a.B = L.Wt; a.ldb = L.out; a.A2 = G; a.B2 = L.U; a.Rp = Rp;
+    a.M = M; a.N = L.in; a.K = L.out; a.bias = nullptr; a.ldc = L.in;
+    TRY(cara_gemm_bf16(&a, st));
+  }
+  float* dU = reinterpret_cast<float*>(ws + W.dU[L.slot]) + (size_t)layer * L.in * Rp;
+  float* dVs = reinterpret_cast<float*>(ws + W.dVs[L.slot]) + (size_t)layer * L.out * Rp;
+  float* dc = want_dc ? reinterpret_cast<float*>(ws + W.dc[L.slot]) + (size_t)layer * L.out : nullptr;
+  TRY(cara_tskinny_xtg(X, L.in, Gt, ldt, dU, nullptr, ws + W.slabs, M, L.in, Rp, st));
+  TRY(cara_tskinny_xtg(dY, L.out, ws + lw.Tt[L.slot], ldt, dVs, dc, ws + W.slabs, M, L.out, Rp, st));
+  return CARA_OK;
+}
+
+void make_lins(const cara_geom* g, const cara_vit_weights* w, const char* pack, const cara_pack_layout& pl, int l, Lin* out) {
+  const size_t D = g->dim;
+  const char* pk = pack + (size_t)l * pl.layer_stride;
+  auto B = [](const void* p, size_t elems) { return static_cast<const bf16*>(p) + elems; };
+  auto P = [&](size_t off) { return reinterpret_cast<const bf16*>(pk + off); };
+  out[0] = Lin{B(w->qkv_w, l * 3 * D * D), B(w->qkv_wt, l * 3 * D * D), P(pl.Ut_qkv), P(pl.U_qkv), P(pl.Vs_qkv), P(pl.Vst_qkv),
+               w->qkv_b + (size_t)l * 3 * D, (int)D, (int)(3 * D), 0};
+  out[1] = Lin{B(w->proj_w, l * D * D), B(w->proj_wt, l * D * D), P(pl.Ut_proj), P(pl.U_proj), P(pl.Vs_proj), P(pl.Vst_proj),
+               reinterpret_cast<const float*>(pk + pl.bias_proj), (int)D, (int)D, 1};
+  out[2] = Lin{B(w->fc1_w, l * 4 * D * D), B(w->fc1_wt, l * 4 * D * D), P(pl.Ut_fc1), P(pl.U_fc1), P(pl.Vs_fc1), P(pl.Vst_fc1),
+               reinterpret_cast<const float*>(pk + pl.bias_fc1), (int)D, (int)(4 * D), 2};
+  out[3] = Lin{B(w->fc2_w, l * 4 * D * D), B(w->fc2_wt, l * 4 * D * D), P(pl.Ut_fc2), P(pl.U_fc2), P(pl.Vs_fc2), P(pl.Vst_fc2),
+               reinterpret_cast<const float*>(pk + pl.bias_fc2), (int)(4 * D), (int)D, 3};
+}
+
+// tiny classifier-head backward (B x classes x D, fp32 VALU)
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl, const bf16* __restrict__ xn,
+                                                       const float* __restrict__ W, float* __restrict__ dW,
+                                                       float* __restrict__ db, bf16* __restrict__ dxn, int B, int Cn, int D) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < Cn * D) {
+    const int c = e / D, d = e - c * D;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dl[b * Cn + c] * (float)xn[b * D + d];
+    dW[e] = s;
+  }
+  if (e < B * D) {
+    const int b = e / D, d = e - b * D;
+    float s = 0.f;
+    for (int c = 0; c < Cn; ++c) s += dl[b * Cn + c] * W[c * D + d];
+    dxn[e] = (bf16)s;
+  }
+  if (e < Cn) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dl[b * Cn + e];
+    db[e] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t cara_vit_workspace_bytes(const cara_geom* g, const cara_vit_shape* s) {
+  Ws w;
+  return layout(g, s, &w) ? w.total : 0;
+}
+
+extern "C" int cara_head_backward(const float* dlogits, const void* xn, const float* head_w, float* dhead_w,
+                                  float* dhead_b, void* dxn, int B, int classes, int D, void* stream) {
+  if (!dlogits || !xn || !head_w || !dhead_w || !dhead_b || !dxn || B <= 0 || classes <= 0 || D <= 0) return CARA_E_ARG;
+  int n = classes * D;
+  if (B * D > n) n = B * D;
+  hipLaunchKernelGGL(head_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), dlogits,
+                     (const bf16*)xn, head_w, dhead_w, dhead_b, (bf16*)dxn, B, classes, D);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
+extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, const cara_vit_weights* w,
+                                const cara_cp* cp, const float* head_w, const float* head_b, const float* images,
+                                const float* droppath, void* workspace, float* logits, void* stream) {
+  Ws W;
+  if (!layout(g, s, &W) || !w || !cp || !head_w || !head_b || !images || !workspace || !logits) return CARA_E_ARG;
+  char* ws = static_cast<char*>(workspace);
+  const int D = g->dim, M = W.M, Rp = g->Rp, B = s->B, N = s->tokens, P = N - 1;
+  const float att_scale = 1.0f / sqrtf((float)(D / g->heads));
+  cara_pack_layout pl;
+  TRY(cara_pack_offsets(g, &pl));
+  TRY(cara_factor_prep(g, cp, w->proj_b, w->fc1_b, w->fc2_b, ws + W.pack, stream));
+  TRY(cara_f32_to_bf16(head_w, ws + W.head_wb, (size_t)s->num_classes * D, stream));
+  // patch embedding: Conv2d(k = s = patch) as a GEMM over im2col rows, then cls + pos_embed
+  const int kp = s->chans * s->patch * s->patch;
+  TRY(cara_im2col_patches(images, ws + W.patches, B, s->chans, s->img, s->img, s->patch, stream));
+  cara_gemm_args a = {};
+  a.A = ws + W.patches; a.lda = kp; a.B = w->patch_w; a.ldb = kp; a.M = B * P; a.N = D; a.K = kp;
+  a.bias = w->patch_b; a.epi = CARA_EPI_F32; a.C = ws + W.emb; a.ldc = D;
+  TRY(cara_gemm_bf16(&a, stream));
+  TRY(cara_assemble_tokens(reinterpret_cast<float*>(ws + W.emb), w->cls, w->pos,
+                           reinterpret_cast<float*>(ws + W.layer[0].x_in), B, P, D, stream));
+  for (int l = 0; l < g->depth; ++l) {
+    const LayerWs& lw = W.layer[l];
+    Lin lin[4];
+    make_lins(g, w, ws + W.pack, pl, l, lin);
+    float* x_in = reinterpret_cast<float*>(ws + lw.x_in);
+    float* x_mid = reinterpret_cast<float*>(ws + lw.x_mid);
+    float* x_out = reinterpret_cast<float*>(ws + (l + 1 < g->depth ? W.layer[l + 1].x_in : W.x_last));
+    const float* dp1 = droppath ? droppath + (size_t)(2 * l) * B : nullptr;
+    const float* dp2 = droppath ? droppath + (size_t)(2 * l + 1) * B : nullptr;
+    // x = x + drop_path(attn(norm1(x)))
+    TRY(cara_layernorm_fwd(x_in, D, w->ln1_g + (size_t)l * D, w->ln1_b + (size_t)l * D, ws + lw.xn1,
+                           reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), M, D, s->eps, stream));
+    cara_gemm_args e = {};
+    e.epi = CARA_EPI_BF16; e.C = ws + lw.qkv;
+    TRY(lin_fwd(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), M, Rp, W.ldt, ws, lw, e, stream));
+    TRY(cara_attention_fwd(ws + lw.qkv, ws + lw.ao, reinterpret_cast<float*>(ws + lw.lse), B, N, g->heads, att_scale, stream));
+    e = {};
+    e.epi = CARA_EPI_RESID; e.C = x_mid; e.aux = x_in; e.rowscale = dp1; e.rows_per_sample = N;
+    TRY(lin_fwd(lin[1], reinterpret_cast<bf16*>(ws + lw.ao), M, Rp, W.ldt, ws, lw, e, stream));
+    // x = x + drop_path(mlp(norm2(x)))
+    TRY(cara_layernorm_fwd(x_mid, D, w->ln2_g + (size_t)l * D, w->ln2_b + (size_t)l * D, ws + lw.xn2,
+                           reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), M, D, s->eps, stream));
+    e = {};
+    e.epi = CARA_EPI_GELU; e.C = ws + lw.h; e.C2 = ws + lw.u;
+    TRY(lin_fwd(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), M, Rp, W.ldt, ws, lw, e, stream));
+    e = {};
+    e.epi = CARA_EPI_RESID; e.C = x_out; e.aux = x_mid; e.rowscale = dp2; e.rows_per_sample = N;
+    TRY(lin_fwd(lin[3], reinterpret_cast<bf16*>(ws + lw.h), M, Rp, W.ldt, ws, lw, e, stream));
+  }
+  // norm -> cls token -> head  (LayerNorm is per token, so only the cls rows are normalised)
+  TRY(cara_layernorm_fwd(reinterpret_cast<float*>(ws + W.x_last), (long)N * D, w->norm_g, w->norm_b, ws + W.clsn,
+                         reinterpret_cast<float*>(ws + W.meanF), reinterpret_cast<float*>(ws + W.rstdF), B, D, s->eps, stream));
+  a = {};
+  a.A = ws + W.clsn; a.lda = D; a.B = ws + W.head_wb; a.ldb = D; a.M = B; a.N = s->num_classes; a.K = D;
+  a.bias = head_b; a.epi = CARA_EPI_F32; a.C = logits; a.ldc = s->num_classes;
+  return cara_gemm_bf16(&a, stream);
+}
+
+extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, const cara_vit_weights* w,
+                                 const cara_cp* cp, const float* head_w, const float* dlogits, const float* droppath,
+                                 void* workspace, const cara_cp* grads, float* dhead_w, float* dhead_b, void* stream) {
+  Ws W;
+  if (!layout(g, s, &W) || !w || !cp || !head_w || !dlogits || !workspace || !grads || !dhead_w || !dhead_b) return CARA_E_ARG;
+  char* ws = static_cast<char*>(workspace);
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  const int D = g->dim, M = W.M, Rp = g->Rp, B = s->B, N = s->tokens;
+  const float att_scale = 1.0f / sqrtf((float)(D / g->heads));
+  cara_pack_layout pl;
+  TRY(cara_pack_offsets(g, &pl));
+  float* dx = reinterpret_cast<float*>(ws + W.dx);
+  bf16* dyb = reinterpret_cast<bf16*>(ws + W.dyb);
+  TRY(cara_head_backward(dlogits, ws + W.clsn, head_w, dhead_w, dhead_b, ws + W.dclsn, B, s->num_classes, D, stream));
+  // gradient enters the token stream only through the cls rows
+  if (hipMemsetAsync(dx, 0, (size_t)M * D * 4, hs) != hipSuccess) return CARA_E_LAUNCH;
+  if (hipMemsetAsync(dyb, 0, (size_t)M * D * 2, hs) != hipSuccess) return CARA_E_LAUNCH;
+  const float* dp_last = droppath ? droppath + (size_t)(2 * (g->depth - 1) + 1) * B : nullptr;
+  TRY(cara_layernorm_bwd(ws + W.dclsn, reinterpret_cast<float*>(ws + W.x_last), (long)N * D, w->norm_g,
+                         reinterpret_cast<float*>(ws + W.meanF), reinterpret_cast<float*>(ws + W.rstdF), nullptr, dx, dyb,
+                         dp_last, 1, B, D, stream));
+  for (int l = g->depth - 1; l >= 0; --l) {
+    const LayerWs& lw = W.layer[l];
+    Lin lin[4];
+    make_lins(g, w, ws + W.pack, pl, l, lin);
+    const float* dp1 = droppath ? droppath + (size_t)(2 * l) * B : nullptr;
+    const float* dp_prev = (droppath && l > 0) ? droppath + (size_t)(2 * (l - 1) + 1) * B : nullptr;
+    // ---- mlp branch: dY = drop_path scale * dx (already in dyb) ----
+    cara_gemm_args e = {};
+    e.epi = CARA_EPI_DGELU; e.C = ws + W.dH; e.aux = ws + lw.u;
+    TRY(lin_bwd(lin[3], dyb, reinterpret_cast<bf16*>(ws + lw.h), M, Rp, W.ldt, ws, W, lw, l, true, e, true, stream));
+    e = {};
+    e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
+    TRY(lin_bwd(lin[2], reinterpret_cast<bf16*>(ws + W.dH), reinterpret_cast<bf16*>(ws + lw.xn2), M, Rp, W.ldt, ws, W, lw, l,
+                true, e, true, stream));
+    TRY(cara_layernorm_bwd(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_mid), D, w->ln2_g + (size_t)l * D,
+                           reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyb, dp1, N,
+                           M, D, stream));
+    // ---- attention branch ----
+    e = {};
+    e.epi = CARA_EPI_BF16; e.C = ws + W.dAO;
+    TRY(lin_bwd(lin[1], dyb, reinterpret_cast<bf16*>(ws + lw.ao), M, Rp, W.ldt, ws, W, lw, l, true, e, true, stream));
+    TRY(cara_attention_bwd(ws + lw.qkv, ws + lw.ao, ws + W.dAO, reinterpret_cast<float*>(ws + lw.lse), ws + W.dQKV, B, N,
+                           g->heads, att_scale, stream));
+    e = {};
+    e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
+    // block 0 has nothing trainable upstream of it: its dX GEMM and LayerNorm backward are skipped
+    TRY(lin_bwd(lin[0], reinterpret_cast<bf16*>(ws + W.dQKV), reinterpret_cast<bf16*>(ws + lw.xn1), M, Rp, W.ldt, ws, W, lw, l,
+                l > 0, e, false, stream));
+    if (l > 0)
+      TRY(cara_layernorm_bwd(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_in), D, w->ln1_g + (size_t)l * D,
+                             reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), dx, dx, dyb,
+                             dp_prev, N, M, D, stream));
+  }
+  cara_layer_grads lg;
+  lg.dU_qkv = reinterpret_cast<float*>(ws + W.dU[0]); lg.dVs_qkv = reinterpret_cast<float*>(ws + W.dVs[0]);
+  lg.dU_proj = reinterpret_cast<float*>(ws + W.dU[1]); lg.dVs_proj = reinterpret_cast<float*>(ws + W.dVs[1]);
+  lg.dU_fc1 = reinterpret_cast<float*>(ws + W.dU[2]); lg.dVs_fc1 = reinterpret_cast<float*>(ws + W.dVs[2]);
+  lg.dU_fc2 = reinterpret_cast<float*>(ws + W.dU[3]); lg.dVs_fc2 = reinterpret_cast<float*>(ws + W.dVs[3]);
+  lg.dc_proj = reinterpret_cast<float*>(ws + W.dc[1]); lg.dc_fc1 = reinterpret_cast<float*>(ws + W.dc[2]);
+  lg.dc_fc2 = reinterpret_cast<float*>(ws + W.dc[3]);
+  return cara_factor_grad_reduce(g, cp, &lg, grads, stream);
+}

@@ -1,0 +1,186 @@
+/* cara_hip.h -- C ABI of libcara_hip.so, the MI355X (gfx950) CaRA hot path.
+ *
+ * The reference (BonnBytes/CaRA) is pure Python on PyTorch and has no FFI of its own: the
+ * functions below are what a maintainer's ctypes binding replaces inside the two patched
+ * forwards of /root/reference/src/cara/cara.py (cp_attn :15-60, cp_mlp :63-95) and around the
+ * train step of image_classification/vit_cp.py:45-50.  INTEGRATION.md shows that binding.
+ *
+ * Conventions: plain pointers and sizes only (device pointers unless a comment says host);
+ * every entry point enqueues work on `stream` (a hipStream_t passed as void*) and returns an
+ * int status: 0 = ok, >0 = CARA_E_* below.  Nothing allocates, frees, synchronises or keeps
+ * state, so every call is re-entrant and hipGraph-capturable.  bf16 tensors are raw uint16
+ * (round-to-nearest-even of fp32).  All matrices are row-major and dense unless an ld* is given.
+ */
+#ifndef CARA_HIP_H
+#define CARA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CARA_OK 0
+#define CARA_E_ARG 1     /* bad shape / null pointer / unsupported size */
+#define CARA_E_LAUNCH 2  /* hipGetLastError() != hipSuccess after a launch */
+
+/* ---- library info ------------------------------------------------------------------------ */
+int cara_abi_version(void);              /* bumped on any signature change */
+const char* cara_build_arch(void);       /* "gfx950" */
+
+/* ---- GEMM with rank-R K-extension -------------------------------------------------------- */
+/* C = A[M,K] * B[N,K]^T  (+ A2[M,Rp] * B2[N,Rp]^T)  then an epilogue.  bf16 in, fp32 accumulate.
+ * This is the adapter linear of cara.py:25-42,50-58,75-82,87-93 in factored form:
+ * A2 = T = X U (cara_skinny_xu), B2 = Vs = s * g (.) V (cara_factor_prep), so that
+ * y = X W^T + b + s((X U) (.) g) V^T + s c  costs Rp/K extra MFMA work instead of a second GEMM.
+ * Requirements: K % 64 == 0, Rp in {0, 32, 64}; M, N arbitrary (edges are clamped/masked).   */
+enum {
+  CARA_EPI_BF16 = 0,   /* C bf16 [M,ldc]          = acc + bias                                  */
+  CARA_EPI_F32 = 1,    /* C fp32 [M,ldc]          = acc + bias                                  */
+  CARA_EPI_GELU = 2,   /* C2 bf16 = u = acc+bias ; C bf16 = gelu_erf(u)           (fc1 forward) */
+  CARA_EPI_RESID = 3,  /* C fp32 = aux_f32 + rowscale[m / rows_per_sample] * (acc + bias)       */
+  CARA_EPI_DGELU = 4,  /* C bf16 = acc * gelu_erf'(aux_bf16[m,n])                (fc2 backward) */
+};
+typedef struct {
+  const void* A;  int lda;      /* bf16 [M,K]  */
+  const void* B;  int ldb;      /* bf16 [N,K]  */
+  const void* A2; const void* B2; int Rp;   /* bf16 [M,Rp], [N,Rp]; Rp = 0 => none */
+  int M, N, K;
+  const float* bias;            /* fp32 [N] or NULL */
+  int epi;
+  void* C;  int ldc;
+  void* C2;                     /* CARA_EPI_GELU only (same ldc) */
+  const void* aux;              /* CARA_EPI_RESID: fp32 [M,ldc]; CARA_EPI_DGELU: bf16 [M,ldc] */
+  const float* rowscale;        /* CARA_EPI_RESID: fp32 [M / rows_per_sample] or NULL (=1) */
+  int rows_per_sample;
+} cara_gemm_args;
+int cara_gemm_bf16(const cara_gemm_args* a, void* stream);
+
+/* ---- skinny adapter contractions (HBM-bound) --------------------------------------------- */
+/* T[M,Rp] = X[M,K] * Ut[Rp,K]^T, bf16 out, also written transposed Tt[Rp,ldt] when Tt != NULL
+ * (ldt >= M, multiple of 8).  Forward: T = X U; backward: G' = dY Vs.  K % 32 == 0.            */
+int cara_skinny_xu(const void* X, int ldx, const void* Ut, void* T, void* Tt, int ldt,
+                   int M, int K, int Rp, void* stream);
+/* D[K1,Rp] (fp32) = sum_m X[m,K1] * G[m,Rp]  given Gt[Rp,ldg] (= G transposed, bf16); optional
+ * colsum[K1] (fp32) = sum_m X[m,:].  Outputs are OVERWRITTEN.  `slabs` is caller scratch of
+ * cara_tskinny_scratch_bytes(M, K1, Rp) bytes.  Gives dU = X^T G' and dVs = dY^T T (A.4).      */
+size_t cara_tskinny_scratch_bytes(int M, int K1, int Rp);
+int cara_tskinny_xtg(const void* X, int ldx, const void* Gt, int ldg, float* D, float* colsum,
+                     void* slabs, int M, int K1, int Rp, void* stream);
+
+/* ---- LayerNorm (eps inside the sqrt, biased variance; timm Block norm1/norm2/norm) ------- */
+/* y bf16 [M,C] = (x - mean) * rstd * gamma + beta; saves mean, rstd fp32 [M].  x fp32 rows with
+ * stride ldx elements (ldx = tokens*C picks the cls rows for the final norm).  C % 256 == 0.   */
+int cara_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, void* y,
+                       float* mean, float* rstd, int M, int C, float eps, void* stream);
+/* dx_out fp32 = dx_in + LN'(dy) ; optional dyb bf16 = rowscale[m / rows_per_sample] * dx_out.
+ * dy is bf16 [M,C]; x/dx rows strided by ldx like the forward.  dx_in may be NULL (= 0) and may
+ * alias dx_out.                                                                               */
+int cara_layernorm_bwd(const void* dy, const float* x, long ldx, const float* gamma,
+                       const float* mean, const float* rstd, const float* dx_in, float* dx_out,
+                       void* dyb, const float* rowscale, int rows_per_sample, int M, int C,
+                       void* stream);
+
+/* ---- attention (cara.py:43-48; softmax(q k^T * scale) v per head) ------------------------- */
+/* qkv bf16 [B*N, 3*H*64] with column k*H*64 + h*64 + d (k = q,k,v): exactly the layout
+ * cara.py:39 reshapes.  out bf16 [B*N, H*64]; lse fp32 [B,H,N].  N <= 224, head dim 64.        */
+int cara_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale,
+                       void* stream);
+int cara_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                       void* dqkv, int B, int N, int H, float scale, void* stream);
+
+/* ---- small pieces of the ViT around the blocks -------------------------------------------- */
+/* patches bf16 [B*gh*gw, C*p*p] <- images fp32 [B,C,Hi,Wi]  (Conv2d k=s=p as a GEMM operand)  */
+int cara_im2col_patches(const float* img, void* patches, int B, int C, int Hi, int Wi, int p,
+                        void* stream);
+/* x fp32 [B,1+P,D]: row 0 = cls + pos[0]; row 1+i = emb[b*P+i] + pos[1+i]                      */
+int cara_assemble_tokens(const float* emb, const float* cls, const float* pos, float* x, int B,
+                         int P, int D, void* stream);
+/* loss[0] = mean cross-entropy over B (loss must hold 1 + B floats: [1..B] is scratch);
+ * dlogits (optional) = (softmax - onehot)/B ; logits fp32 [B,C]   (vit_cp.py:47)              */
+int cara_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits,
+                       int B, int C, void* stream);
+/* bf16 <-> fp32 helpers (weight ingest)                                                        */
+int cara_f32_to_bf16(const float* src, void* dst, size_t n, void* stream);
+int cara_transpose_bf16(const void* src, void* dst, int rows, int cols, void* stream);
+
+/* ---- CP factor preparation / gradient scatter --------------------- */
+/* Geometry of one adapted ViT.  The reference hard-codes dim 768 / heads 12 / depth 12
+ * (cara.py:112-125); the same formulas are kept general.                                      */
+typedef struct {
+  int depth, dim, heads, rank, Rp;
+  float scale;                       /* child.s, cara.py:149,159 */
+} cara_geom;
+/* Pointers to the 12 CP tensors (fp32, shapes of cara.py:112-125) or to their gradients.      */
+typedef struct {
+  float *A1, *A2, *A3, *A4, *P1, *P2, *P3, *R1, *R2, *bias1, *bias2, *bias3;
+} cara_cp;
+/* Per-layer operand pack written by cara_factor_prep (bf16 unless noted), l = 0..depth-1:
+ *   Ut_* [Rp,in] (U transposed, K-contiguous), U_* [in,Rp], Vs_* [out,Rp], Vst_* [Rp,out]
+ * laid out back to back; offsets via cara_pack_offsets().  Row padding rank..Rp-1 is zero.     */
+typedef struct {
+  size_t Ut_qkv, U_qkv, Vs_qkv, Vst_qkv;
+  size_t Ut_proj, U_proj, Vs_proj, Vst_proj;
+  size_t Ut_fc1, U_fc1, Vs_fc1, Vst_fc1;
+  size_t Ut_fc2, U_fc2, Vs_fc2, Vst_fc2;
+  size_t bias_proj, bias_fc1, bias_fc2;      /* fp32: b + s*CP_bias (needs backbone bias)      */
+  size_t layer_stride;                       /* bytes between consecutive layers               */
+  size_t total;                              /* bytes for all layers                           */
+} cara_pack_layout;
+int cara_pack_offsets(const cara_geom* g, cara_pack_layout* out);            /* host only */
+/* Build every layer's operand pack from the CP tensors in one launch.  base_bias_* are the
+ * frozen fp32 biases of proj/fc1/fc2, [depth, out] contiguous.                                 */
+int cara_factor_prep(const cara_geom* g, const cara_cp* cp, const float* base_bias_proj,
+                     const float* base_bias_fc1, const float* base_bias_fc2, void* pack,
+                     void* stream);
+/* Scatter per-layer skinny gradients onto the 12 shared tensors (A.4).  dU_x / dVs_x are fp32
+ * [depth, in|out, Rp]; dc_x fp32 [depth, out] (column sums of dY of proj/fc1/fc2).  grads are
+ * OVERWRITTEN.                                                                                */
+typedef struct {
+  const float *dU_qkv, *dVs_qkv, *dU_proj, *dVs_proj, *dU_fc1, *dVs_fc1, *dU_fc2, *dVs_fc2;
+  const float *dc_proj, *dc_fc1, *dc_fc2;
+} cara_layer_grads;
+int cara_factor_grad_reduce(const cara_geom* g, const cara_cp* cp, const cara_layer_grads* lg,
+                            const cara_cp* grads, void* stream);
+
+/* ---- whole adapted ViT: forward and backward as stream-ordered kernel sequences ------------ */
+/* What model(x) / loss.backward() of vit_cp.py:46-49 run, for the factored adapters.  Both calls
+ * only enqueue kernels on `stream` (no allocation, no sync): capturable in a hipGraph.         */
+typedef struct {           /* frozen backbone (timm 0.4.12 VisionTransformer), device pointers  */
+  const void* patch_w;     /* bf16 [dim, chans*patch*patch]   (patch_embed.proj.weight)         */
+  const float* patch_b;    /* fp32 [dim]                                                        */
+  const float* cls;        /* fp32 [dim]                      (cls_token)                       */
+  const float* pos;        /* fp32 [tokens, dim]              (pos_embed)                       */
+  const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;   /* fp32 [depth, dim]                            */
+  const void *qkv_w, *qkv_wt;   const float* qkv_b;    /* bf16 [depth,3dim,dim], [depth,dim,3dim] */
+  const void *proj_w, *proj_wt; const float* proj_b;   /* bf16 [depth,dim,dim] both              */
+  const void *fc1_w, *fc1_wt;   const float* fc1_b;    /* bf16 [depth,4dim,dim], [depth,dim,4dim] */
+  const void *fc2_w, *fc2_wt;   const float* fc2_b;    /* bf16 [depth,dim,4dim], [depth,4dim,dim] */
+  const float *norm_g, *norm_b; /* fp32 [dim]                                                    */
+} cara_vit_weights;
+typedef struct {
+  int B, img, patch, chans, tokens, num_classes;
+  float eps;
+} cara_vit_shape;
+size_t cara_vit_workspace_bytes(const cara_geom* g, const cara_vit_shape* s);
+/* images fp32 [B,chans,img,img]; droppath fp32 [depth,2,B] per-sample branch multipliers
+ * (mask/keep_prob of timm DropPath) or NULL; head_w fp32 [classes,dim], head_b fp32 [classes];
+ * logits fp32 [B,classes].  The workspace must be zero-filled once before its first use and
+ * must not be touched between a forward and its backward.                                      */
+int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, const cara_vit_weights* w,
+                     const cara_cp* cp, const float* head_w, const float* head_b, const float* images,
+                     const float* droppath, void* workspace, float* logits, void* stream);
+/* dlogits fp32 [B,classes] -> grads of the 12 CP tensors (overwritten), dhead_w, dhead_b.       */
+int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, const cara_vit_weights* w,
+                      const cara_cp* cp, const float* head_w, const float* dlogits, const float* droppath,
+                      void* workspace, const cara_cp* grads, float* dhead_w, float* dhead_b, void* stream);
+/* classifier head backward on its own (used by the two above):
+ * dW[c,d] = sum_b dl[b,c] xn[b,d]; db[c] = sum_b dl[b,c]; dxn bf16 [B,D] = dl W               */
+int cara_head_backward(const float* dlogits, const void* xn_bf16, const float* head_w, float* dhead_w,
+                       float* dhead_b, void* dxn_bf16, int B, int classes, int D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CARA_HIP_H */

@@ -1,0 +1,329 @@
+"""GPU parity tests of every C-ABI kernel against fp32/fp64 torch restatements of the same op on
+the same seeded inputs.  Tolerances are stated per test: inputs are bf16-representable, products
+are accumulated in fp32 on the device and in fp64 here, so differences come only from the output
+rounding (bf16: 2^-9 relative) and fp32 summation order."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def L():
+    from cara_amd import _lib
+    return _lib
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.bfloat16):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def close(got, ref, rtol, atol, what=""):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    bad = err > bound
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max err {err.max():.3e} (ref max {ref.abs().max():.3e})"
+
+
+# ------------------------------------------------------------------------------------------
+# MFMA layout check with exact integer data (asymmetric operands): catches swapped maps
+# ------------------------------------------------------------------------------------------
+def test_gemm_exact_small_integers():
+    _ = L()
+    M, N, K = 128, 128, 64
+    A = (torch.arange(M * K).reshape(M, K) % 7 - 3).float()
+    B = (torch.arange(N * K).reshape(N, K) % 5 - 2).float() + (torch.arange(N).reshape(N, 1) % 3).float()
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    L().gemm(A.bfloat16().to(DEV), B.bfloat16().to(DEV), out, epi=L().EPI_F32)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), A @ B.t())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (12608, 768, 768), (333, 100, 768), (64, 2304, 128), (197, 3072, 192)])
+def test_gemm_shapes_f32(M, N, K):
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    bias = rnd(N, seed=3, dtype=torch.float32)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    L().gemm(A, B, out, epi=L().EPI_F32, bias=bias)
+    ref = A.double() @ B.double().t() + bias.double()
+    close(out, ref, 1e-4, 1e-3 * math.sqrt(K / 64), f"gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("Rp", [32, 64])
+def test_gemm_k_extension(Rp):
+    M, N, K = 777, 640, 768
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    A2, B2 = rnd(M, Rp, seed=3), rnd(N, Rp, seed=4)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    L().gemm(A, B, out, epi=L().EPI_F32, A2=A2, B2=B2)
+    ref = A.double() @ B.double().t() + A2.double() @ B2.double().t()
+    close(out, ref, 1e-4, 5e-3, "gemm+ext")
+
+
+def test_gemm_epilogues():
+    M, N, K = 400, 256, 128
+    A, B = rnd(M, K, seed=1, scale=0.3), rnd(N, K, seed=2, scale=0.3)
+    bias = rnd(N, seed=3, dtype=torch.float32)
+    acc = A.double() @ B.double().t() + bias.double()
+    # bf16 out
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L().gemm(A, B, out, epi=L().EPI_BF16, bias=bias)
+    close(out, acc, 2 ** -8, 1e-3, "epi bf16")
+    # gelu: u (bf16) and gelu(u)
+    h = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L().gemm(A, B, h, epi=L().EPI_GELU, bias=bias, C2=u)
+    close(u, acc, 2 ** -8, 1e-3, "epi gelu u")
+    close(h, torch.nn.functional.gelu(u.double()), 2 ** -8, 1e-3, "epi gelu h")
+    # residual with per-sample scale: rows_per_sample = 50 -> 8 samples
+    xin = rnd(M, N, seed=5, dtype=torch.float32)
+    rs = torch.tensor([1.0, 0.0, 1.1, 1.1, 0.0, 1.1, 1.0, 1.1], device=DEV)
+    xo = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    L().gemm(A, B, xo, epi=L().EPI_RESID, bias=bias, aux=xin, rowscale=rs, rows_per_sample=50)
+    ref = xin.double() + rs.double().repeat_interleave(50)[:, None] * acc
+    close(xo, ref, 1e-5, 1e-4, "epi resid")
+    # dgelu
+    dg = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L().gemm(A, B, dg, epi=L().EPI_DGELU, aux=u)
+    ud = u.double().requires_grad_(True)
+    torch.nn.functional.gelu(ud).sum().backward()
+    close(dg, (A.double() @ B.double().t()) * ud.grad, 2 ** -8, 2e-3, "epi dgelu")
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,Rp", [(12608, 768, 32), (12608, 3072, 32), (197, 768, 64), (45, 2304, 32)])
+def test_skinny_xu(M, K, Rp):
+    X, Ut = rnd(M, K, seed=1), rnd(Rp, K, seed=2, scale=0.1)
+    ldt = (M + 31) // 32 * 32
+    T = torch.empty(M, Rp, dtype=torch.bfloat16, device=DEV)
+    Tt = torch.zeros(Rp, ldt, dtype=torch.bfloat16, device=DEV)
+    L().skinny_xu(X, Ut, T, Tt)
+    ref = X.double() @ Ut.double().t()
+    close(T, ref, 2 ** -8, 1e-3, "skinny T")
+    close(Tt[:, :M], ref.t(), 2 ** -8, 1e-3, "skinny Tt")
+    assert torch.count_nonzero(Tt[:, M:]) == 0
+
+
+@pytest.mark.parametrize("M,K1,Rp", [(12608, 768, 32), (12608, 3072, 32), (12608, 2304, 64), (197, 768, 32), (70, 128, 32)])
+def test_tskinny(M, K1, Rp):
+    X = rnd(M, K1, seed=1)
+    ldg = (M + 31) // 32 * 32
+    G = rnd(M, Rp, seed=2, scale=0.5)
+    Gt = torch.zeros(Rp, ldg, dtype=torch.bfloat16, device=DEV)
+    Gt[:, :M] = G.t()
+    D = torch.full((K1, Rp), float("nan"), dtype=torch.float32, device=DEV)
+    cs = torch.full((K1,), float("nan"), dtype=torch.float32, device=DEV)
+    L().tskinny_xtg(X, Gt, D, cs)
+    close(D, X.double().t() @ G.double(), 1e-4, 2e-3 * math.sqrt(M / 100), "tskinny D")
+    close(cs, X.double().sum(0), 1e-4, 2e-3 * math.sqrt(M / 100), "tskinny colsum")
+    D2 = torch.empty_like(D)
+    L().tskinny_xtg(X, Gt, D2, None)
+    assert torch.equal(D, D2), "tskinny must be bitwise reproducible (fixed-order slab sum)"
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,C_", [(12608, 768), (64, 768), (33, 1024)])
+def test_layernorm_fwd_bwd(M, C_):
+    lib = L().lib()
+    x = rnd(M, C_, seed=1, scale=2.0, dtype=torch.float32) + 0.5
+    g = 1 + 0.1 * rnd(C_, seed=2, dtype=torch.float32)
+    b = 0.1 * rnd(C_, seed=3, dtype=torch.float32)
+    y = torch.empty(M, C_, dtype=torch.bfloat16, device=DEV)
+    mean = torch.empty(M, device=DEV)
+    rstd = torch.empty(M, device=DEV)
+    p, st = L().ptr, L().stream
+    L().check(lib.cara_layernorm_fwd(p(x), C.c_long(C_), p(g), p(b), p(y), p(mean), p(rstd), M, C_, C.c_float(1e-6), st()), "ln fwd")
+    xd = x.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (C_,), g.double(), b.double(), 1e-6)
+    close(y, ref, 2 ** -8, 1e-3, "ln fwd")
+    close(mean, x.double().mean(1), 1e-5, 1e-5, "ln mean")
+    dy = rnd(M, C_, seed=4)
+    ref.backward(dy.double())
+    dx_in = rnd(M, C_, seed=5, dtype=torch.float32)
+    dx = torch.empty(M, C_, device=DEV)
+    dyb = torch.empty(M, C_, dtype=torch.bfloat16, device=DEV)
+    rps = 7
+    rs = (torch.arange((M + rps - 1) // rps, device=DEV) % 3).float() * 0.5
+    L().check(lib.cara_layernorm_bwd(p(dy), p(x), C.c_long(C_), p(g), p(mean), p(rstd), p(dx_in), p(dx), p(dyb), p(rs),
+                                     rps, M, C_, st()), "ln bwd")
+    refdx = dx_in.double() + xd.grad
+    close(dx, refdx, 1e-4, 1e-4, "ln bwd dx")
+    close(dyb, refdx * rs.double().repeat_interleave(rps)[:M, None], 2 ** -8, 1e-3, "ln bwd dyb")
+
+
+def test_layernorm_strided_cls_rows():
+    """Final norm: only the cls row of each sample (row stride tokens*C)."""
+    lib = L().lib()
+    B, T, C_ = 5, 7, 768
+    x = rnd(B * T, C_, seed=1, dtype=torch.float32)
+    g, b = 1 + 0.1 * rnd(C_, seed=2, dtype=torch.float32), 0.1 * rnd(C_, seed=3, dtype=torch.float32)
+    y = torch.empty(B, C_, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(B, device=DEV), torch.empty(B, device=DEV)
+    p, st = L().ptr, L().stream
+    L().check(lib.cara_layernorm_fwd(p(x), C.c_long(T * C_), p(g), p(b), p(y), p(mean), p(rstd), B, C_, C.c_float(1e-6), st()), "ln")
+    ref = torch.nn.functional.layer_norm(x.double().reshape(B, T, C_)[:, 0], (C_,), g.double(), b.double(), 1e-6)
+    close(y, ref, 2 ** -8, 1e-3, "ln strided")
+
+
+# ------------------------------------------------------------------------------------------
+def attn_ref(qkv, B, N, H, scale):
+    q, k, v = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-2, -1)) * scale
+    p = s.softmax(-1)
+    o = (p @ v).transpose(1, 2).reshape(B * N, H * 64)
+    return o, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 5, 2), (1, 64, 1), (2, 224, 3), (1, 33, 2)])
+def test_attention_fwd_bwd(B, N, H):
+    lib = L().lib()
+    scale = 64 ** -0.5
+    qkv = rnd(B * N, 3 * H * 64, seed=1, scale=1.0)
+    out = torch.full((B * N, H * 64), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, H, N, device=DEV)
+    p, st = L().ptr, L().stream
+    L().check(lib.cara_attention_fwd(p(qkv), p(out), p(lse), B, N, H, C.c_float(scale), st()), "attn fwd")
+    qd = qkv.double().requires_grad_(True)
+    ref, ref_lse = attn_ref(qd, B, N, H, scale)
+    # P is rounded to bf16 before P.V (2^-9 relative on each weight), output rounded to bf16
+    close(out, ref, 2 ** -7, 4e-3, "attn out")
+    close(lse, ref_lse, 1e-4, 1e-4, "attn lse")
+    dout = rnd(B * N, H * 64, seed=2)
+    ref.backward(dout.double())
+    dqkv = torch.full_like(qkv, float("nan"))
+    L().check(lib.cara_attention_bwd(p(qkv), p(out), p(dout), p(lse), p(dqkv), B, N, H, C.c_float(scale), st()), "attn bwd")
+    g = qd.grad
+    err = (dqkv.double() - g).abs()
+    tol = 2 ** -6 * g.abs() + 0.02 * g.abs().max()
+    assert not torch.isnan(dqkv).any()
+    assert (err <= tol).all(), f"attn bwd max err {err.max():.3e} vs grad max {g.abs().max():.3e}"
+    rel = (dqkv.double() - g).norm() / g.norm()
+    assert rel < 8e-3, f"attn bwd rel-L2 {rel:.3e}"
+
+
+def test_attention_softmax_extremes():
+    """Large-magnitude scores: exact two-pass softmax must not overflow."""
+    lib = L().lib()
+    B, N, H = 1, 197, 1
+    qkv = rnd(B * N, 3 * 64, seed=3, scale=6.0)
+    out = torch.empty(B * N, 64, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, H, N, device=DEV)
+    L().check(lib.cara_attention_fwd(L().ptr(qkv), L().ptr(out), L().ptr(lse), B, N, H, C.c_float(0.125), L().stream()), "attn")
+    ref, _ = attn_ref(qkv, B, N, H, 0.125)
+    assert torch.isfinite(out).all()
+    close(out, ref, 2 ** -6, 0.05, "attn extreme")
+
+
+# ------------------------------------------------------------------------------------------
+def test_im2col_assemble_xent_transpose():
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+    B, Cc, Hi, P = 3, 3, 64, 16
+    img = rnd(B, Cc, Hi, Hi, seed=1, dtype=torch.float32)
+    gh = Hi // P
+    patches = torch.empty(B * gh * gh, Cc * P * P, dtype=torch.bfloat16, device=DEV)
+    L().check(lib.cara_im2col_patches(p(img), p(patches), B, Cc, Hi, Hi, P, st()), "im2col")
+    ref = img.reshape(B, Cc, gh, P, gh, P).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gh, -1).bfloat16()
+    assert torch.equal(patches, ref)
+    D = 768
+    emb = rnd(B * gh * gh, D, seed=2, dtype=torch.float32)
+    cls = rnd(D, seed=3, dtype=torch.float32)
+    pos = rnd(gh * gh + 1, D, seed=4, dtype=torch.float32)
+    x = torch.empty(B, gh * gh + 1, D, device=DEV)
+    L().check(lib.cara_assemble_tokens(p(emb), p(cls), p(pos), p(x), B, gh * gh, D, st()), "assemble")
+    refx = torch.cat((cls.expand(B, 1, D), emb.reshape(B, gh * gh, D)), 1) + pos
+    assert torch.equal(x, refx)
+    Bc, Cn = 64, 100
+    logits = rnd(Bc, Cn, seed=5, scale=3.0, dtype=torch.float32)
+    labels = torch.randint(0, Cn, (Bc,), generator=torch.Generator().manual_seed(6)).to(DEV)
+    loss = torch.empty(1 + Bc, device=DEV)
+    dl = torch.empty(Bc, Cn, device=DEV)
+    L().check(lib.cara_cross_entropy(p(logits), p(labels), p(loss), p(dl), Bc, Cn, st()), "xent")
+    ld = logits.double().requires_grad_(True)
+    rl = torch.nn.functional.cross_entropy(ld, labels)
+    rl.backward()
+    close(loss[0], rl.detach(), 1e-5, 1e-6, "xent loss")
+    close(dl, ld.grad, 1e-4, 1e-7, "xent grad")
+    src = rnd(100, 70, seed=7)
+    dst = torch.empty(70, 100, dtype=torch.bfloat16, device=DEV)
+    L().check(lib.cara_transpose_bf16(p(src), p(dst), 100, 70, st()), "transpose")
+    assert torch.equal(dst, src.t().contiguous())
+    f = rnd(1001, seed=8, dtype=torch.float32)
+    o = torch.empty(1001, dtype=torch.bfloat16, device=DEV)
+    L().check(lib.cara_f32_to_bf16(p(f), p(o), C.c_size_t(1001), st()), "cvt")
+    assert torch.equal(o, f.bfloat16())
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rank,Rp", [(16, 32), (8, 32), (32, 32), (64, 64)])
+def test_factor_prep_and_grad_reduce(rank, Rp):
+    """cara_factor_prep vs the oracle's A.3 table; cara_factor_grad_reduce vs autograd through it."""
+    from oracle import cara_oracle as O
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+    depth, dim, heads, s = 12, 768, 12, 0.1
+    cp = O.synthetic_cp(rank=rank)
+    cpd = {k: v.to(DEV).contiguous() for k, v in cp.items()}
+    geom = L().Geom(depth, dim, heads, rank, Rp, s)
+    lay = L().PackLayout()
+    L().check(lib.cara_pack_offsets(C.byref(geom), C.byref(lay)), "offsets")
+    pack = torch.zeros(lay.total, dtype=torch.uint8, device=DEV)
+    cps = L().CpPtrs(*[p(cpd["CP_" + n]) for n in L().CP_FIELDS])
+    bb = [rnd(depth, n, seed=i, dtype=torch.float32) for i, n in ((1, dim), (2, 4 * dim), (3, dim))]
+    L().check(lib.cara_factor_prep(C.byref(geom), C.byref(cps), p(bb[0]), p(bb[1]), p(bb[2]), p(pack), st()), "prep")
+    torch.cuda.synchronize()
+    fac = O.build_factored(cp, s)
+
+    def view(l, off, rows, cols, dt=torch.bfloat16):
+        n = rows * cols * (2 if dt == torch.bfloat16 else 4)
+        return pack[l * lay.layer_stride + off: l * lay.layer_stride + off + n].view(dt).reshape(rows, cols).cpu()
+
+    for l in (0, 5, 11):
+        for name, din, dout in (("qkv", dim, 3 * dim), ("proj", dim, dim), ("fc1", dim, 4 * dim), ("fc2", 4 * dim, dim)):
+            U, Vs, cs = fac[l][name]
+            Upad = torch.zeros(din, Rp); Upad[:, :rank] = U
+            Vpad = torch.zeros(dout, Rp); Vpad[:, :rank] = Vs
+            assert torch.equal(view(l, getattr(lay, "U_" + name), din, Rp), Upad.bfloat16()), (l, name, "U")
+            assert torch.equal(view(l, getattr(lay, "Ut_" + name), Rp, din), Upad.t().bfloat16()), (l, name, "Ut")
+            got = view(l, getattr(lay, "Vs_" + name), dout, Rp).float()
+            assert torch.allclose(got, Vpad.bfloat16().float(), rtol=2 ** -7, atol=1e-8), (l, name, "Vs")
+            assert torch.equal(view(l, getattr(lay, "Vst_" + name), Rp, dout).float(), got.t()), (l, name, "Vst")
+        for i, (nm, key) in enumerate((("bias_proj", "CP_bias1"), ("bias_fc1", "CP_bias2"), ("bias_fc2", "CP_bias3"))):
+            n = cp[key].numel()
+            ref = bb[i][l].cpu() + s * cp[key]
+            assert torch.allclose(view(l, getattr(lay, nm), 1, n, torch.float32)[0], ref, rtol=1e-6, atol=1e-7)
+
+    # gradient scatter: random per-layer dU/dVs/dc, compare with autograd through build_factored
+    g = torch.Generator().manual_seed(9)
+    names = (("qkv", dim, 3 * dim), ("proj", dim, dim), ("fc1", dim, 4 * dim), ("fc2", 4 * dim, dim))
+    dU = {n: torch.randn(depth, di, Rp, generator=g) for n, di, do in names}
+    dV = {n: torch.randn(depth, do, Rp, generator=g) for n, di, do in names}
+    dc = {n: torch.randn(depth, do, generator=g) for n, di, do in names if n != "qkv"}
+    cpv = {k: v.double().clone().requires_grad_(True) for k, v in cp.items()}
+    facv = O.build_factored(cpv, s)
+    tot = 0
+    for l in range(depth):
+        for n, di, do in names:
+            U, Vs, cs = facv[l][n]
+            tot = tot + (U * dU[n][l, :, :rank].double()).sum() + (Vs * dV[n][l, :, :rank].double()).sum()
+            if cs is not None:
+                tot = tot + (cs * dc[n][l].double()).sum()
+    tot.backward()
+    dev = lambda t: t.to(DEV).contiguous()  # noqa: E731
+    keep = [dev(dU["qkv"]), dev(dV["qkv"]), dev(dU["proj"]), dev(dV["proj"]), dev(dU["fc1"]), dev(dV["fc1"]),
+            dev(dU["fc2"]), dev(dV["fc2"]), dev(dc["proj"]), dev(dc["fc1"]), dev(dc["fc2"])]
+    lg = L().LayerGrads(*[p(t) for t in keep])
+    gout = {n: torch.full_like(cpd["CP_" + n], float("nan")) for n in L().CP_FIELDS}
+    gp = L().CpPtrs(*[p(gout[n]) for n in L().CP_FIELDS])
+    L().check(lib.cara_factor_grad_reduce(C.byref(geom), C.byref(cps), C.byref(lg), C.byref(gp), st()), "grad reduce")
+    torch.cuda.synchronize()
+    for n in L().CP_FIELDS:
+        ref = cpv["CP_" + n].grad
+        scale_ = max(ref.abs().max().item(), 1e-6)
+        close(gout[n], ref, 1e-4, 1e-4 * scale_, "grad " + n)
