@@ -1,0 +1,137 @@
+"""``cara(config)`` -- the reference's adapter-installation API on the MI355X-native path.
+
+Mirrors ``/root/reference/src/cara/cara.py``:
+
+* ``cara(config)`` (``cara.py:169-188``): same five dict keys (``model, rank, scale, l_mu, l_std``;
+  a missing key raises ``KeyError`` exactly like the reference), returns the SAME module, mutated.
+* ``set_cara`` (``cara.py:98-166``): same 12 top-level ``nn.Parameter`` names / shapes / inits /
+  RNG consumption order, same index walk (``attn.idx = 9l``, ``attn.attn_idx = 3l``,
+  ``mlp.idx = 9l+1``; ``model.idx == 108``, ``model.attn_idx == 36`` for depth 12), same child
+  attributes ``dp, s, dim, idx, attn_idx`` and a rebound ``forward`` on every Attention / Mlp.
+
+Differences, all deliberate:
+
+* the arithmetic runs in libcara_hip.so (factored form) instead of
+  ``tensorly.cp_to_tensor`` + a second dense GEMM; there is no CPU path;
+* the shared factors are bound per model instance instead of through the module-level singleton
+  ``global_model`` (``cara.py:12,185-186``), so several adapted models can live in one process
+  (``global_model`` is still set, for scripts that read it);
+* dims are taken from the model (ViT-B = the reference's hard-coded 768/12/12, ``cara.py:112-125``).
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Any, Dict
+
+import torch as th
+import torch.nn as nn
+
+from . import vit as _vit
+from ._lib import CaraError
+
+global_model: th.nn.Module = None  # kept for API compatibility with cara.py:12
+
+
+def _owner(child):
+    ref = child.__dict__.get("_cara_owner")
+    model = ref() if ref is not None else None
+    if model is None:
+        raise CaraError("adapter owner model is gone")
+    return model
+
+
+def cp_attn(self, x: th.Tensor) -> th.Tensor:
+    """Attention with CP parameters (counterpart of ``cara.py:15-60``), module-level entry."""
+    return _owner(self)._cara_engine.attn_forward(self, x)
+
+
+def cp_mlp(self, x: th.Tensor) -> th.Tensor:
+    """Mlp with CP parameters (counterpart of ``cara.py:63-95``), module-level entry."""
+    return _owner(self)._cara_engine.mlp_forward(self, x)
+
+
+def _is(obj, *classes) -> bool:
+    return any(type(obj) is c for c in classes)  # exact-type dispatch, like cara.py:110,147,157
+
+
+def set_cara(model: nn.Module, rank: int, scale: float, l_mu: float, l_std: float, _root=None) -> None:
+    """Declare + initialise the CP tensors on the ViT and walk its children (``cara.py:98-166``)."""
+    root = _root
+    if _is(model, _vit.VisionTransformer):
+        root = model
+        dim, heads, depth = model.embed_dim, model.blocks[0].attn.num_heads, len(model.blocks)
+        model.CP_A1 = nn.Parameter(th.empty([3 * depth, rank]), requires_grad=True)
+        model.CP_A2 = nn.Parameter(th.empty([dim, rank]), requires_grad=True)
+        model.CP_A3 = nn.Parameter(th.empty([heads, rank]), requires_grad=True)
+        model.CP_A4 = nn.Parameter(th.empty([dim // heads, rank]), requires_grad=True)
+        model.CP_P1 = nn.Parameter(th.empty([9 * depth, rank]), requires_grad=True)
+        model.CP_P2 = nn.Parameter(th.empty([dim, rank]), requires_grad=True)
+        model.CP_P3 = nn.Parameter(th.empty([dim, rank]), requires_grad=True)
+        model.CP_R1 = nn.Parameter(th.empty([rank]), requires_grad=True)
+        model.CP_R2 = nn.Parameter(th.empty([rank]), requires_grad=True)
+        model.CP_bias1 = nn.Parameter(th.empty([dim]), requires_grad=True)
+        model.CP_bias2 = nn.Parameter(th.empty([dim * 4]), requires_grad=True)
+        model.CP_bias3 = nn.Parameter(th.empty([dim]), requires_grad=True)
+        # same initialisers in the same order => same draws from the global RNG (A1, A3, A4, P1, P3, R1, R2)
+        nn.init.xavier_normal_(model.CP_A1)
+        nn.init.zeros_(model.CP_A2)
+        nn.init.orthogonal_(model.CP_A3)
+        nn.init.orthogonal_(model.CP_A4)
+        nn.init.xavier_normal_(model.CP_P1)
+        nn.init.zeros_(model.CP_P2)
+        nn.init.orthogonal_(model.CP_P3)
+        if l_std != 0.0:
+            nn.init.normal_(model.CP_R1, mean=l_mu, std=l_std)
+            nn.init.normal_(model.CP_R2, mean=l_mu, std=l_std)
+        elif l_mu == 1.0 and l_std == 0.0:
+            nn.init.ones_(model.CP_R1)
+            nn.init.ones_(model.CP_R2)
+        # (else: left as allocated, like the reference)
+        nn.init.zeros_(model.CP_bias1)
+        nn.init.zeros_(model.CP_bias2)
+        nn.init.zeros_(model.CP_bias3)
+        model.idx = 0
+        model.attn_idx = 0
+    if root is None:
+        return
+    for child in model.children():
+        if _is(child, _vit.Attention):
+            child.dp = nn.Dropout(0.1)
+            child.s = scale
+            child.dim = rank
+            child.idx = root.idx
+            child.attn_idx = root.attn_idx
+            root.idx += 1
+            root.attn_idx += 3
+            child.__dict__["_cara_owner"] = weakref.ref(root)
+            setattr(child, "forward", cp_attn.__get__(child, child.__class__))  # noqa: B010
+        elif _is(child, _vit.Mlp):
+            child.dp = nn.Dropout(0.1)
+            child.s = scale
+            child.dim = rank
+            child.idx = root.idx
+            root.idx += 8
+            child.__dict__["_cara_owner"] = weakref.ref(root)
+            setattr(child, "forward", cp_mlp.__get__(child, child.__class__))  # noqa: B010
+        elif len(list(child.children())) != 0:
+            set_cara(child, rank, scale, l_mu, l_std, _root=root)
+
+
+def cara(config: Dict[str, Any]) -> th.nn.Module:
+    """Install CaRA on ``config["model"]`` and return it (``cara.py:169-188``)."""
+    model = config["model"]
+    rank = config["rank"]
+    scale = config["scale"]
+    l_mu = config["l_mu"]
+    l_std = config["l_std"]
+    if not _is(model, _vit.VisionTransformer):
+        raise CaraError("cara_amd.cara() needs a cara_amd.vit.VisionTransformer (timm-named container); "
+                        "build one with cara_amd.create_model(...)")
+    if not (1 <= int(rank) <= 64):
+        raise CaraError("rank must be in 1..64 (the K-extension is padded to 32 or 64 columns)")
+    global global_model
+    global_model = model
+    set_cara(model, rank, scale, l_mu, l_std)
+    from .engine import CaraEngine
+    model.__dict__["_cara_engine"] = CaraEngine(model, rank=int(rank), scale=float(scale))
+    return model

@@ -1,0 +1,246 @@
+"""Engine: binds an adapted VisionTransformer to the whole-model entry points of libcara_hip.so.
+
+torch owns device memory, the stream and autograd bookkeeping; every FLOP of the forward and
+backward is issued by ``cara_vit_forward`` / ``cara_vit_backward`` (include/cara_hip.h).
+Reference call sites this replaces: ``out = model(x)`` and ``loss.backward()`` of
+``/root/reference/image_classification/vit_cp.py:46-49`` with the patched forwards of
+``/root/reference/src/cara/cara.py:15-95``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import CaraError, check, ptr, stream
+
+
+def _rp(rank: int) -> int:
+    return 32 if rank <= 32 else 64
+
+
+class _VitFn(torch.autograd.Function):
+    """logits = ViT+CaRA(images); gradients only into the head and the 12 CP tensors."""
+
+    @staticmethod
+    def forward(ctx, eng, images, droppath, head_w, head_b, *cp):
+        logits = eng._run_forward(images, droppath, head_w, head_b, cp)
+        ctx.eng, ctx.droppath, ctx.shape_key = eng, droppath, eng._last_key
+        ctx.save_for_backward(head_w, *cp)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        head_w, *cp = ctx.saved_tensors
+        eng = ctx.eng
+        if eng._last_key != ctx.shape_key or eng._fwd_serial != eng._bwd_ready:
+            raise CaraError("backward must follow its own forward: the activation workspace holds one step")
+        g = eng._run_backward(dlogits, ctx.droppath, head_w, cp)
+        return (None, None, None, g["head_w"], g["head_b"], *[g[n] for n in L.CP_FIELDS])
+
+
+class CaraEngine:
+    def __init__(self, model, rank: int, scale: float):
+        self._model = weakref.ref(model)
+        self.rank, self.Rp, self.scale = rank, _rp(rank), scale
+        self.weight_dropout = "off"  # dropout on the materialised dW (cara.py:35,57,81,92) is not factorable; see DESIGN.md
+        self._ingested = None
+        self._ingest_sig = None
+        self._ws = {}
+        self._last_key = None
+        self._fwd_serial = 0
+        self._bwd_ready = -1
+        self._flat_grad = None
+        self._grad_views = None
+
+    # ------------------------------------------------------------------ frozen weights -> HBM layout
+    def _backbone_params(self, model):
+        return [p for n, p in model.named_parameters() if not n.startswith("CP_") and not n.startswith("head.")]
+
+    def _signature(self, model):
+        return tuple((p.data_ptr(), p._version) for p in self._backbone_params(model))
+
+    def _ingest(self, model, dev):
+        """One-time (and after any in-place change / load_state_dict): frozen fp32 parameters ->
+        bf16 [depth, out, in] stacks plus transposed copies for the dX GEMMs, fp32 vectors stacked."""
+        lib = L.lib()
+        blocks = list(model.blocks)
+        depth, D = len(blocks), model.embed_dim
+
+        def f32(ts):
+            return torch.stack([t.detach().to(dev, torch.float32) for t in ts]).contiguous()
+
+        def bf16_pair(ws, out_f, in_f):
+            src = f32(ws)  # [depth, out, in]
+            w = torch.empty(depth, out_f, in_f, dtype=torch.bfloat16, device=dev)
+            wt = torch.empty(depth, in_f, out_f, dtype=torch.bfloat16, device=dev)
+            check(lib.cara_f32_to_bf16(ptr(src), ptr(w), C.c_size_t(src.numel()), stream()), "cara_f32_to_bf16")
+            for l in range(depth):
+                check(lib.cara_transpose_bf16(ptr(w[l]), ptr(wt[l]), out_f, in_f, stream()), "cara_transpose_bf16")
+            return w, wt
+
+        t = {}
+        pw = model.patch_embed.proj.weight.detach().to(dev, torch.float32).reshape(D, -1).contiguous()
+        t["patch_w"] = torch.empty_like(pw, dtype=torch.bfloat16)
+        check(lib.cara_f32_to_bf16(ptr(pw), ptr(t["patch_w"]), C.c_size_t(pw.numel()), stream()), "cara_f32_to_bf16")
+        t["patch_b"] = model.patch_embed.proj.bias.detach().to(dev, torch.float32).contiguous()
+        t["cls"] = model.cls_token.detach().to(dev, torch.float32).reshape(-1).contiguous()
+        t["pos"] = model.pos_embed.detach().to(dev, torch.float32).reshape(-1, D).contiguous()
+        t["ln1_g"], t["ln1_b"] = f32([b.norm1.weight for b in blocks]), f32([b.norm1.bias for b in blocks])
+        t["ln2_g"], t["ln2_b"] = f32([b.norm2.weight for b in blocks]), f32([b.norm2.bias for b in blocks])
+        t["qkv_w"], t["qkv_wt"] = bf16_pair([b.attn.qkv.weight for b in blocks], 3 * D, D)
+        t["proj_w"], t["proj_wt"] = bf16_pair([b.attn.proj.weight for b in blocks], D, D)
+        t["fc1_w"], t["fc1_wt"] = bf16_pair([b.mlp.fc1.weight for b in blocks], 4 * D, D)
+        t["fc2_w"], t["fc2_wt"] = bf16_pair([b.mlp.fc2.weight for b in blocks], D, 4 * D)
+        t["qkv_b"] = f32([b.attn.qkv.bias for b in blocks])
+        t["proj_b"] = f32([b.attn.proj.bias for b in blocks])
+        t["fc1_b"] = f32([b.mlp.fc1.bias for b in blocks])
+        t["fc2_b"] = f32([b.mlp.fc2.bias for b in blocks])
+        t["norm_g"] = model.norm.weight.detach().to(dev, torch.float32).contiguous()
+        t["norm_b"] = model.norm.bias.detach().to(dev, torch.float32).contiguous()
+        w = L.VitWeights(**{n: ptr(t[n]) for n, _ in L.VitWeights._fields_})
+        self._ingested = (t, w)
+        self._ingest_sig = self._signature(model)
+
+    # ------------------------------------------------------------------ per-shape state
+    def _state(self, model, B, img, dev):
+        if self._ingested is None or self._ingest_sig != self._signature(model) or self._ingested[0]["cls"].device != dev:
+            self._ingest(model, dev)
+            self._ws.clear()
+        ncls = model.head.out_features
+        key = (B, img, ncls, str(dev))
+        st = self._ws.get(key)
+        if st is None:
+            pe = model.patch_embed
+            geom = L.Geom(len(model.blocks), model.embed_dim, model.blocks[0].attn.num_heads, self.rank, self.Rp, self.scale)
+            shape = L.VitShape(B, img, pe.patch_size[0], model.in_chans, (img // pe.patch_size[0]) ** 2 + 1, ncls,
+                               float(model.norm.eps))
+            nbytes = L.lib().cara_vit_workspace_bytes(C.byref(geom), C.byref(shape))
+            if nbytes == 0:
+                raise CaraError(f"unsupported geometry for the HIP path: {geom.depth=} {geom.dim=} {geom.heads=} "
+                                f"{shape.tokens=} (needs head dim 64, tokens <= 224, dim % 256 == 0)")
+            self._ws.clear()  # one live workspace: activations of one step
+            ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            st = {"geom": geom, "shape": shape, "ws": ws, "logits": torch.empty(B, ncls, device=dev)}
+            self._ws[key] = st
+        self._last_key = key
+        return st
+
+    def _cp_ptrs(self, cp):
+        return L.CpPtrs(*[ptr(t) for t in cp])
+
+    # ------------------------------------------------------------------ forward / backward
+    def _run_forward(self, images, droppath, head_w, head_b, cp):
+        model = self._model()
+        if images.ndim != 4 or images.shape[2] != images.shape[3]:
+            raise CaraError("images must be [B, C, H, H]")
+        images = images.contiguous().float()
+        st = self._state(model, images.shape[0], images.shape[2], images.device)
+        cps = self._cp_ptrs([t.detach().contiguous() for t in cp])
+        logits = torch.empty_like(st["logits"])
+        check(L.lib().cara_vit_forward(C.byref(st["geom"]), C.byref(st["shape"]), C.byref(self._ingested[1]), C.byref(cps),
+                                       ptr(head_w.detach().contiguous()), ptr(head_b.detach().contiguous()), ptr(images),
+                                       ptr(droppath), ptr(st["ws"]), ptr(logits), stream()), "cara_vit_forward")
+        self._fwd_serial += 1
+        self._bwd_ready = self._fwd_serial
+        return logits
+
+    def _grad_buffers(self, model, dev):
+        names = [(n, getattr(model, "CP_" + n)) for n in L.CP_FIELDS] + [("head_w", model.head.weight), ("head_b", model.head.bias)]
+        sizes = [p.numel() for _, p in names]
+        if self._flat_grad is None or self._flat_grad.numel() != sum(sizes) or self._flat_grad.device != dev:
+            from .dist import flat_views
+            self._flat_grad, self._grad_views = flat_views([(n, p.shape) for n, p in names], dev)
+        return self._grad_views
+
+    def _run_backward(self, dlogits, droppath, head_w, cp):
+        model = self._model()
+        st = self._ws[self._last_key]
+        g = self._grad_buffers(model, dlogits.device)
+        cps = self._cp_ptrs([t.detach().contiguous() for t in cp])
+        gps = L.CpPtrs(*[ptr(g[n]) for n in L.CP_FIELDS])
+        check(L.lib().cara_vit_backward(C.byref(st["geom"]), C.byref(st["shape"]), C.byref(self._ingested[1]), C.byref(cps),
+                                        ptr(head_w.detach().contiguous()), ptr(dlogits.contiguous().float()), ptr(droppath),
+                                        ptr(st["ws"]), C.byref(gps), ptr(g["head_w"]), ptr(g["head_b"]), stream()),
+              "cara_vit_backward")
+        self._bwd_ready = -1
+        return g
+
+    def draw_droppath(self, model, B, dev) -> Optional[torch.Tensor]:
+        """Per-sample multipliers mask/keep_prob of timm DropPath for both branches of every block,
+        [depth, 2, B]; None in eval mode or when every rate is 0."""
+        if not model.training:
+            return None
+        rates = [float(getattr(b.drop_path, "drop_prob", 0.0) or 0.0) for b in model.blocks]
+        if not any(r > 0 for r in rates):
+            return None
+        keep = 1.0 - torch.tensor(rates, device=dev).reshape(-1, 1, 1)
+        return ((keep + torch.rand(len(rates), 2, B, device=dev)).floor_() / keep).contiguous()
+
+    def forward(self, images, droppath: Optional[torch.Tensor] = None):
+        model = self._model()
+        if not images.is_cuda:
+            raise CaraError("cara_amd runs on the GPU only: move the model and the images to a ROCm device "
+                            "(there is no CPU fallback)")
+        if not hasattr(model.head, "weight"):
+            raise CaraError("the classifier head must be a Linear (num_classes > 0)")
+        if droppath is None:
+            droppath = self.draw_droppath(model, images.shape[0], images.device)
+        cp = [getattr(model, "CP_" + n) for n in L.CP_FIELDS]
+        if model.head.weight.device != images.device or cp[0].device != images.device:
+            raise CaraError("model parameters and images must be on the same device")
+        return _VitFn.apply(self, images, droppath, model.head.weight, model.head.bias, *cp)
+
+    # ------------------------------------------------------------------ fused train step
+    def trainable_parameters(self):
+        """The selection rule of vit_cp.py:175-183: names containing "CP" or "head"."""
+        model = self._model()
+        return [getattr(model, "CP_" + n) for n in L.CP_FIELDS] + [model.head.weight, model.head.bias]
+
+    def train_step(self, images, labels, optimizer=None, group=None, droppath: Optional[torch.Tensor] = None):
+        """One fine-tuning step of vit_cp.py:45-50 without autograd bookkeeping:
+        forward -> mean cross-entropy -> backward straight into ONE flat fp32 gradient buffer
+        (12 CP tensors + head) -> a single all-reduce of that buffer when ``group``/the default
+        process group has more than one rank -> ``optimizer.step()``.  Returns the loss (device
+        scalar, local to this rank).  ``p.grad`` of every trainable parameter is a view of the flat
+        buffer, so any torch optimizer consumes it unchanged."""
+        model = self._model()
+        if not images.is_cuda:
+            raise CaraError("cara_amd runs on the GPU only (no CPU fallback)")
+        dev = images.device
+        if droppath is None:
+            droppath = self.draw_droppath(model, images.shape[0], dev)
+        cp = [getattr(model, "CP_" + n) for n in L.CP_FIELDS]
+        hw, hb = model.head.weight, model.head.bias
+        with torch.no_grad():
+            logits = self._run_forward(images, droppath, hw, hb, cp)
+            B, ncls = logits.shape
+            if self.__dict__.get("_loss_buf") is None or self._loss_buf.numel() != 1 + B or self._loss_buf.device != dev:
+                self._loss_buf = torch.empty(1 + B, device=dev)
+                self._dlogits = torch.empty(B, ncls, device=dev)
+            if self._dlogits.shape != logits.shape:
+                self._dlogits = torch.empty(B, ncls, device=dev)
+            check(L.lib().cara_cross_entropy(ptr(logits), ptr(labels.contiguous()), ptr(self._loss_buf), ptr(self._dlogits),
+                                             B, ncls, stream()), "cara_cross_entropy")
+            g = self._run_backward(self._dlogits, droppath, hw, cp)
+            for n, p in zip(list(L.CP_FIELDS) + ["head_w", "head_b"], cp + [hw, hb]):
+                if p.grad is None or p.grad.data_ptr() != g[n].data_ptr():
+                    p.grad = g[n]
+            # the only data-path collective of a step: one RCCL all-reduce over xGMI of the flat buffer
+            from .dist import allreduce_mean_
+            allreduce_mean_(self._flat_grad, group)
+            if optimizer is not None:
+                optimizer.step()
+        return self._loss_buf[0]
+
+    # module-level entries (cara.cp_attn / cara.cp_mlp)
+    def attn_forward(self, child, x):
+        raise CaraError("module-level Attention.forward is served by the fused whole-model path in this round: "
+                        "call the VisionTransformer itself")
+
+    def mlp_forward(self, child, x):
+        raise CaraError("module-level Mlp.forward is served by the fused whole-model path in this round: "
+                        "call the VisionTransformer itself")

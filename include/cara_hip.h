@@ -180,6 +180,13 @@ int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, const cara_vi
 int cara_head_backward(const float* dlogits, const void* xn_bf16, const float* head_w, float* dhead_w,
                        float* dhead_b, void* dxn_bf16, int B, int classes, int D, void* stream);
 
+/* ---- diagnostics ---------------------------------------------------------------------------- */
+/* Bracket the fc1 forward GEMM of every layer (the dominant kernel) with HIP events recorded on
+ * the compute stream inside cara_vit_forward; read the average duration of the last forward's
+ * launches after synchronising.  Process-global diagnostic state; off by default.              */
+int cara_profile_fc1(int enable);
+int cara_profile_fc1_read(float* avg_ms, int* launches);   /* host pointers */
+
 #ifdef __cplusplus
 }
 #endif

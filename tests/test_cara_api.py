@@ -1,0 +1,127 @@
+"""CPU tests of the host-side mirror of the reference interface (no compute on CPU):
+the reference's own structural tests (/root/reference/tests/test_cara.py:43-90) plus the
+bookkeeping the golden vectors pin, and the C-ABI library's exports."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch as th
+
+from cara_amd import CaraError, cara, create_model
+from cara_amd import _lib
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "cara_reference_vectors.npz"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _get_vit(**kw):
+    return create_model("vit_base_patch16_224_in21k", drop_path_rate=0.1, **kw)
+
+
+def _cfg(**kw):
+    th.manual_seed(0)
+    return {"model": _get_vit(**kw), "rank": 32, "scale": 1.0, "l_mu": 1.0, "l_std": 0.0}
+
+
+def test_vit_without_cara():
+    vit = _get_vit(depth=2)
+    for n in ("CP_A1", "CP_A2", "CP_A3", "CP_A4", "CP_P1", "CP_P2", "CP_P3", "CP_R1", "CP_R2"):
+        assert not hasattr(vit, n)
+
+
+def test_vit_with_cara():
+    vit = cara(_cfg(depth=2))
+    for n in ("CP_A1", "CP_A2", "CP_A3", "CP_A4", "CP_P1", "CP_P2", "CP_P3", "CP_R1", "CP_R2"):
+        assert hasattr(vit, n)
+
+
+def test_cara_zero_init():
+    vit = cara(_cfg(depth=2))
+    assert th.allclose(vit.CP_A2, th.zeros_like(vit.CP_A2))
+    assert th.allclose(vit.CP_P2, th.zeros_like(vit.CP_P2))
+
+
+def test_cara_lambda_init():
+    vit = cara(_cfg(depth=2))
+    assert th.allclose(vit.CP_R1, th.ones_like(vit.CP_R1))
+    assert th.allclose(vit.CP_R2, th.ones_like(vit.CP_R2))
+
+
+def test_returns_same_module_and_missing_key():
+    cfg = _cfg(depth=1)
+    assert cara(cfg) is cfg["model"]
+    with pytest.raises(KeyError):
+        cara({"model": _get_vit(depth=1), "rank": 8, "scale": 1.0, "l_mu": 1.0})
+
+
+def test_parameter_names_shapes_and_walk():
+    vit = _get_vit()
+    th.manual_seed(0)
+    m = cara({"model": vit, "rank": 8, "scale": 0.3, "l_mu": 1.5, "l_std": 0.1})
+    names = [n for n, _ in m.named_parameters() if n.startswith("CP_")]
+    assert names == ["CP_A1", "CP_A2", "CP_A3", "CP_A4", "CP_P1", "CP_P2", "CP_P3", "CP_R1", "CP_R2",
+                     "CP_bias1", "CP_bias2", "CP_bias3"]
+    shapes = {n: tuple(getattr(m, n).shape) for n in names}
+    assert shapes == {"CP_A1": (36, 8), "CP_A2": (768, 8), "CP_A3": (12, 8), "CP_A4": (64, 8), "CP_P1": (108, 8),
+                      "CP_P2": (768, 8), "CP_P3": (768, 8), "CP_R1": (8,), "CP_R2": (8,), "CP_bias1": (768,),
+                      "CP_bias2": (3072,), "CP_bias3": (768,)}
+    walk = [[b.attn.idx, b.attn.attn_idx, b.mlp.idx] for b in m.blocks]
+    assert walk == G["idx_walk"].tolist()          # recorded from the reference's set_cara
+    assert [m.idx, m.attn_idx] == G["final_idx"].tolist() == [108, 36]
+    for b in m.blocks:
+        assert b.attn.s == 0.3 and b.mlp.s == 0.3 and b.attn.dim == 8 and isinstance(b.attn.dp, th.nn.Dropout)
+        assert b.attn.dp.p == 0.1 and b.mlp.dp.p == 0.1
+    # trainable-selection rule of vit_cp.py:175-183 finds exactly CP_* and head.*
+    sel = [n for n, _ in m.named_parameters() if "CP" in n or "head" in n]
+    assert sel == names + ["head.weight", "head.bias"]
+    assert sum(getattr(m, n).numel() for n in names) == 2526 * 8 + 4608
+
+
+@pytest.mark.parametrize("rank", [8, 16, 32, 64])
+def test_init_matches_reference_draws(rank):
+    """Same initialisers in the same order => the reference's tensors under the same seed."""
+    vit = _get_vit()
+    th.manual_seed(0)
+    m = cara({"model": vit, "rank": rank, "scale": 1.0, "l_mu": 1.5, "l_std": 0.1})
+    for n in ("CP_A1", "CP_A3", "CP_A4", "CP_P1", "CP_R1", "CP_R2"):
+        assert th.equal(getattr(m, n).detach(), th.from_numpy(G[f"init_r{rank}_{n}"])), n
+    assert th.equal(m.CP_P3.detach()[:8], th.from_numpy(G[f"init_r{rank}_CP_P3_rows0_8"]))
+
+
+def test_state_dict_roundtrip_and_reset_classifier():
+    m = cara(_cfg(depth=2))
+    m.reset_classifier(100)
+    sd = m.state_dict()
+    for k in ("CP_A1", "CP_bias3", "cls_token", "pos_embed", "patch_embed.proj.weight", "blocks.1.attn.qkv.weight",
+              "blocks.0.mlp.fc2.bias", "norm.weight", "head.weight"):
+        assert k in sd
+    assert sd["head.weight"].shape == (100, 768)
+    m2 = cara(_cfg(depth=2))
+    m2.reset_classifier(100)
+    m2.load_state_dict(sd)
+    assert th.equal(m2.CP_A1, m.CP_A1)
+
+
+def test_no_cpu_fallback():
+    m = cara(_cfg(depth=1))
+    with pytest.raises(CaraError):
+        m(th.randn(2, 3, 224, 224))
+    with pytest.raises(CaraError):
+        _get_vit(depth=1)(th.randn(1, 3, 224, 224))
+
+
+def test_two_models_do_not_alias():
+    """cara.py:185-186 rebinds a module global; this build binds factors per model."""
+    a, b = cara(_cfg(depth=1)), cara(_cfg(depth=1))
+    assert a.blocks[0].attn._cara_owner() is a and b.blocks[0].attn._cara_owner() is b
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "cara_hip.h")).read()
+    declared = set(re.findall(r"\b(cara_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.lib()
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.cara_abi_version() == 1 and lib.cara_build_arch() == b"gfx950"

@@ -1,0 +1,192 @@
+"""GPU parity of the whole adapted ViT (cara_vit_forward / cara_vit_backward through the Python
+mirror of the reference API) against (a) vectors recorded from the reference's own cara.py and
+(b) the CPU oracle on the same seeded inputs.
+
+Tolerances.  The device path rounds GEMM operands and stored activations to bf16 (fp32
+accumulate, fp32 residual stream, fp32 softmax/LayerNorm statistics); the reference is fp32.
+BASELINE.json asks for 1e-3 relative on bf16 logits.  With 8-bit-mantissa operands that is below
+the rounding floor: the oracle evaluated with the SAME bf16 rounding points (``bf16_sim``) is
+itself 6.6e-3 (depth 2, golden case) away from the fp32 reference, and two implementations that
+are not bitwise identical decorrelate within a few rounding stages, so they sit ~one floor apart
+too.  What is asserted is therefore: (1) device-vs-fp32-reference error <= 1.5 x the error the
+rounding model predicts (the kernels add no error of their own), (2) an absolute cap of 1.5e-2
+(SURVEY.md section 7 H3 measured 9.5e-3 for plain autocast), (3) exact class indices wherever
+the fp32 top-2 margin exceeds the noise.  Measured values are printed (-s) and recorded in
+DESIGN.md.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "cara_reference_vectors.npz"))
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def build(w, cp, rank, scale, depth, img, num_classes=100, drop_path_rate=0.1):
+    from cara_amd import cara, create_model
+    m = create_model("vit_base_patch16_224_in21k", drop_path_rate=drop_path_rate, depth=depth, img_size=img,
+                     num_classes=num_classes)
+    m = cara({"model": m, "rank": rank, "scale": scale, "l_mu": 1.5, "l_std": 0.1})
+    sd = dict(w)
+    sd.update(cp)
+    # the reference hard-codes 36 / 108 rows (cara.py:112,118 = 3 / 9 per block at depth 12); this
+    # build sizes them 3*depth / 9*depth, and a shallower test model only ever reads its own rows
+    sd["CP_A1"], sd["CP_P1"] = cp["CP_A1"][:3 * depth], cp["CP_P1"][:9 * depth]
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    return m.to(DEV)
+
+
+def test_reference_structural_forward_shape():
+    """/root/reference/tests/test_cara.py:93-98: [2,3,224,224] -> (2, 21843), train-mode default."""
+    from cara_amd import cara, create_model
+    torch.manual_seed(0)
+    vit = cara({"model": create_model("vit_base_patch16_224_in21k", drop_path_rate=0.1), "rank": 32, "scale": 1.0,
+                "l_mu": 1.0, "l_std": 0.0}).to(DEV)
+    out = vit(torch.randn(2, 3, 224, 224, device=DEV))
+    assert tuple(out.shape) == (2, 21843) and torch.isfinite(out).all()
+
+
+def test_depth2_against_reference_vectors():
+    """Golden case 6 of make_golden.py: depth 2, 197 tokens, rank 16, s = 0.1 -- logits and all 12 CP
+    gradients of sum(logsumexp(logits)) as produced by the reference's cara.py."""
+    from oracle import cara_oracle as O
+    from tests.golden.inputs import oracle_case
+    R, depth, imgsz, sb, sc, sx, sg = G["d2_cfg"].tolist()
+    w, cp = oracle_case(sg, sb, sc, R, depth, imgsz)
+    m = build(w, cp, R, 0.1, depth, imgsz).eval()
+    img = torch.randn(2, 3, imgsz, imgsz, generator=torch.Generator().manual_seed(sx))
+    logits = m(img.to(DEV))
+    ref = torch.from_numpy(G["d2_logits"])
+    with torch.no_grad():
+        sim = O.vit_cara_forward(img, w, cp, s=0.1, depth=depth, factored=True, bf16_sim=True)
+    r_ref, r_sim = rel(logits, ref), rel(logits, sim)
+    print(f"depth2 logits rel-L2: vs fp32 reference {r_ref:.2e}, vs bf16-rounded oracle {r_sim:.2e}")
+    r_model = rel(sim, ref)   # what bf16 rounding at the same points costs, per the oracle
+    assert r_ref < 1.5e-2 and r_ref < 1.5 * max(r_model, 4e-3), (r_ref, r_model)
+    assert r_sim < 1.5 * max(r_model, 4e-3), (r_sim, r_model)
+    assert torch.equal(logits.argmax(1).cpu(), ref.argmax(1))
+    torch.logsumexp(logits, dim=1).sum().backward()
+    worst = 0.0
+    for n in O.CP_NAMES:
+        g, gr = getattr(m, n).grad, torch.from_numpy(G["d2_grad_" + n])
+        if n in ("CP_A1", "CP_P1"):
+            assert torch.count_nonzero(gr[g.shape[0]:]) == 0   # rows of blocks that do not exist
+            gr = gr[:g.shape[0]]
+        r = rel(g, gr)
+        worst = max(worst, r)
+        assert r < 3e-2, (n, r)     # bf16 activations/gradients vs fp32 autograd of the dense form
+    print(f"depth2 CP-gradient worst rel-L2 vs reference: {worst:.2e}")
+
+
+def test_depth12_headline_shapes_against_oracle():
+    """ViT-B/16 depth 12, rank 16, 197 tokens, synthetic weights of SURVEY 8(d), batch 4."""
+    from oracle import cara_oracle as O
+    torch.manual_seed(0)
+    w = O.synthetic_backbone()
+    cp = O.synthetic_cp(rank=16)
+    x, y = O.synthetic_batch(batch=4)
+    m = build(w, cp, 16, 0.1, 12, 224).eval()
+    logits = m(x.to(DEV))
+    with torch.no_grad():
+        ref = O.vit_cara_forward(x, w, cp, s=0.1)
+        sim = O.vit_cara_forward(x, w, cp, s=0.1, factored=True, bf16_sim=True)
+    r_ref, r_sim = rel(logits, ref), rel(logits, sim)
+    print(f"depth12 logits rel-L2: vs fp32 oracle {r_ref:.2e}, vs bf16-rounded oracle {r_sim:.2e}")
+    r_model = rel(sim, ref)
+    assert r_ref < 1.5e-2 and r_ref < 1.5 * max(r_model, 4e-3), (r_ref, r_model)
+    assert r_sim < 1.5 * max(r_model, 4e-3), (r_sim, r_model)
+    top2 = ref.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 4 * (logits.cpu() - ref).abs().max()
+    assert torch.equal(logits.argmax(1).cpu()[safe], ref.argmax(1)[safe])
+    # gradients of the training loss against fp32 autograd of the as-written algorithm
+    loss = torch.nn.functional.cross_entropy(logits, y.to(DEV))
+    loss.backward()
+    head = {"weight": w["head.weight"], "bias": w["head.bias"]}
+    _, _, gref = O.train_step_as_written(x, y, w, cp, head, s=0.1)
+    for n in O.CP_NAMES:
+        r = rel(getattr(m, n).grad, gref[n][:getattr(m, n).shape[0]])
+        assert r < 5e-2, (n, r)
+    assert rel(m.head.weight.grad, gref["head.weight"]) < 2e-2
+    assert rel(m.head.bias.grad, gref["head.bias"]) < 2e-2
+
+
+def test_zero_init_known_answer_bitwise():
+    """CP_A2 = CP_P2 = 0 (reference tests/test_cara.py:79-83) => the adapter contributes exactly
+    nothing: logits are bitwise independent of every other CP tensor."""
+    from oracle import cara_oracle as O
+    w = O.synthetic_backbone(depth=2)
+    x, _ = O.synthetic_batch(batch=2)
+    outs = []
+    for seed, rank in ((14, 16), (99, 8)):
+        cp = O.synthetic_cp(rank=rank, seed=seed)
+        cp["CP_A2"].zero_(); cp["CP_P2"].zero_()
+        for k in ("CP_bias1", "CP_bias2", "CP_bias3"):
+            cp[k].zero_()
+        outs.append(build(w, cp, rank, 1.0, 2, 224).eval()(x.to(DEV)).detach())
+    assert torch.equal(outs[0], outs[1])
+    with torch.no_grad():
+        base = O.vit_cara_forward(x, w, O.init_cp_params(4, 1.0, 0.0), s=1.0, depth=2)
+    assert rel(outs[0], base) < 1e-2 and torch.equal(outs[0].argmax(1).cpu(), base.argmax(1))
+
+
+def test_drop_path_masks_and_train_mode():
+    from oracle import cara_oracle as O
+    w = O.synthetic_backbone(depth=3)
+    cp = O.synthetic_cp(rank=16)
+    x, _ = O.synthetic_batch(batch=4)
+    m = build(w, cp, 16, 0.1, 3, 224).train()
+    keep = torch.tensor([[[1, 1, 1, 1], [1, 1, 1, 1]], [[1 / .95, 0, 1 / .95, 1 / .95], [0, 1 / .95, 1 / .95, 0]],
+                         [[0, 0, 1 / .9, 1 / .9], [1 / .9, 1 / .9, 0, 1 / .9]]], dtype=torch.float32)
+    logits = m._cara_engine.forward(x.to(DEV), droppath=keep.to(DEV))
+    with torch.no_grad():
+        sim = O.vit_cara_forward(x, w, cp, s=0.1, depth=3, drop_path_keep=keep, factored=True, bf16_sim=True)
+    with torch.no_grad():
+        ref = O.vit_cara_forward(x, w, cp, s=0.1, depth=3, drop_path_keep=keep)
+    assert rel(logits, ref) < 1.5 * max(rel(sim, ref), 4e-3) and rel(logits, ref) < 1.5e-2
+    # a wrong mask moves the logits by far more than the rounding floor
+    with torch.no_grad():
+        wrong = O.vit_cara_forward(x, w, cp, s=0.1, depth=3)
+    assert rel(wrong, ref) > 5 * rel(logits, ref)
+    # engine-drawn masks: shape, values in {0, 1/keep}, block 0 never dropped
+    dp = m._cara_engine.draw_droppath(m, 64, torch.device(DEV))
+    assert dp.shape == (3, 2, 64) and torch.equal(dp[0], torch.ones(2, 64, device=DEV))
+    assert set(torch.unique(dp[2]).tolist()) <= {0.0, 1 / 0.9}
+    torch.logsumexp(logits, 1).sum().backward()
+    assert all(torch.isfinite(getattr(m, n).grad).all() for n in O.CP_NAMES)
+
+
+def test_gradients_finite_difference_direction():
+    """Directional derivative of the loss along a random CP direction vs the analytic gradient
+    (device path only; catches sign/scale errors independently of the oracle)."""
+    from oracle import cara_oracle as O
+    w = O.synthetic_backbone(depth=2)
+    cp = O.synthetic_cp(rank=16)
+    x, y = O.synthetic_batch(batch=4)
+    m = build(w, cp, 16, 1.0, 2, 224).eval()
+    xd, yd = x.to(DEV), y.to(DEV)
+    loss = torch.nn.functional.cross_entropy(m(xd), yd)
+    loss.backward()
+    g = torch.Generator().manual_seed(5)
+    num, ana = 0.0, 0.0
+    dirs = {n: torch.randn(getattr(m, n).shape, generator=g).to(DEV) for n in ("CP_A2", "CP_P2", "CP_P1", "CP_R2")}
+    ana = sum((getattr(m, n).grad * d).sum().item() for n, d in dirs.items())
+    eps = 2e-2
+    vals = []
+    for sgn in (1, -1):
+        with torch.no_grad():
+            for n, d in dirs.items():
+                getattr(m, n).add_(sgn * eps * d)
+            vals.append(torch.nn.functional.cross_entropy(m(xd), yd).item())
+            for n, d in dirs.items():
+                getattr(m, n).sub_(sgn * eps * d)
+    num = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(num - ana) <= 0.1 * abs(ana) + 1e-3, (num, ana)
