@@ -12,11 +12,12 @@
 // + one cross-half shuffle) and the probability accumulators are already the A operand of P.V
 // (no LDS round trip).  V is staged transposed so that its B fragments are two 8-byte LDS reads.
 //
-// Backward: one workgroup of 7 waves per (batch, head); wave w owns keys 32w..32w+31 and keeps
-// dK^T, dV^T of them in accumulators while sweeping the query tiles; S and dP are computed with the
-// key on the lane, so P and dS feed dV^T += dO^T P and dK^T += Q^T dS straight from the
-// accumulators; only dS crosses LDS (wave-private scratch) for dQ += dS K, which is summed across
-// the waves by LDS float adds.
+// Backward: two kernels, both recomputing P from Q, K and the forward's LSE.  (1) dK/dV: a
+// workgroup of 7 waves per (batch, head); wave w owns keys 32w..32w+31 and keeps dK^T, dV^T in
+// accumulators while sweeping the query tiles; S and dP are computed with the key on the lane, so
+// P and dS feed dV^T += dO^T P and dK^T += Q^T dS straight from the accumulators.  (2) dQ: the
+// forward's structure (wave = 32 queries, query on the lane): dS^T feeds dQ += dS K from the
+// accumulators.  No atomics, no cross-wave sums: results are bitwise reproducible.
 #include "common.h"
 
 namespace {
@@ -163,28 +164,38 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// backward
+// backward, kernel 1: dK, dV.  One workgroup of 7 waves per (batch, head); wave w owns keys
+// 32w..32w+31 and keeps dK^T, dV^T in accumulators while sweeping the query tiles.  Q and dO are
+// staged in LDS twice: row-major (A operands of S = Q K^T and dP = dO V^T) and transposed (A
+// operands of dV^T += dO^T P and dK^T += Q^T dS, whose B operands are the P / dS accumulators).
 // ------------------------------------------------------------------------------------------
 constexpr int BWD_WAVES = 7;
-constexpr int DS_STRIDE = 40;  // bf16 per row of the wave-private dS scratch (80 B: 16-B aligned)
-constexpr int BWD_OFF_QT = 0;
-constexpr int BWD_OFF_DOT = BWD_OFF_QT + HD * KP * 2;
-constexpr int BWD_OFF_DQ = BWD_OFF_DOT + HD * KP * 2;
-constexpr int BWD_OFF_DS = BWD_OFF_DQ + NMAX * HD * 4;
-constexpr int BWD_OFF_ROW = BWD_OFF_DS + BWD_WAVES * 32 * DS_STRIDE * 2;
-constexpr int BWD_LDS = BWD_OFF_ROW + 2 * NMAX * 4;
+constexpr int DKV_OFF_Q = 0;
+constexpr int DKV_OFF_DO = DKV_OFF_Q + NMAX * 128;
+constexpr int DKV_OFF_QT = DKV_OFF_DO + NMAX * 128;
+constexpr int DKV_OFF_DOT = DKV_OFF_QT + HD * KP * 2;
+constexpr int DKV_OFF_ROW = DKV_OFF_DOT + HD * KP * 2;
+constexpr int DKV_LDS = DKV_OFF_ROW + 2 * NMAX * 4;
 
-__global__ __launch_bounds__(448, 2) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
-                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                          bf16* __restrict__ dqkv, int N, int H, float scale) {
+__device__ __forceinline__ void stage_rows_swz(const bf16* __restrict__ src, int ld, int N, char* img, int tid, int nthreads) {
+  for (int idx = tid; idx < NMAX * 8; idx += nthreads) {
+    const int n = idx >> 3, c = idx & 7;
+    const int nn = n < N ? n : N - 1;
+    *reinterpret_cast<uint4*>(img + swz128(n, c)) = *reinterpret_cast<const uint4*>(src + (size_t)nn * ld + c * 8);
+  }
+}
+
+__global__ __launch_bounds__(448, 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                              const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                              bf16* __restrict__ dqkv, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* Qt = reinterpret_cast<bf16*>(smem + BWD_OFF_QT);
-  bf16* dOt = reinterpret_cast<bf16*>(smem + BWD_OFF_DOT);
-  float* dQ = reinterpret_cast<float*>(smem + BWD_OFF_DQ);
-  float* lse_s = reinterpret_cast<float*>(smem + BWD_OFF_ROW);
+  char* Qs = smem + DKV_OFF_Q;
+  char* dOs = smem + DKV_OFF_DO;
+  bf16* Qt = reinterpret_cast<bf16*>(smem + DKV_OFF_QT);
+  bf16* dOt = reinterpret_cast<bf16*>(smem + DKV_OFF_DOT);
+  float* lse_s = reinterpret_cast<float*>(smem + DKV_OFF_ROW);
   float* del_s = lse_s + NMAX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  bf16* dSw = reinterpret_cast<bf16*>(smem + BWD_OFF_DS) + wave * 32 * DS_STRIDE;
   const int bh = blockIdx.x, b = bh / H, head = bh - b * H;
   const int ld = 3 * H * HD, ldo = H * HD;
   const bf16* qb = qkv + (size_t)b * N * ld + head * HD;
@@ -193,9 +204,10 @@ __global__ __launch_bounds__(448, 2) void attn_bwd_kernel(const bf16* __restrict
   const bf16* ob = out + (size_t)b * N * ldo + head * HD;
   const bf16* dob = dout + (size_t)b * N * ldo + head * HD;
 
+  stage_rows_swz(qb, ld, N, Qs, tid, 448);
+  stage_rows_swz(dob, ldo, N, dOs, tid, 448);
   stage_transposed(qb, ld, N, Qt, tid, 448);
   stage_transposed(dob, ldo, N, dOt, tid, 448);
-  for (int i = tid; i < NMAX * HD; i += 448) dQ[i] = 0.f;
   if (tid < NMAX) {
     const int n = tid < N ? tid : N - 1;
     float dl = 0.f;
@@ -207,121 +219,175 @@ __global__ __launch_bounds__(448, 2) void attn_bwd_kernel(const bf16* __restrict
       for (int j = 0; j < 8; ++j) dl += (float)a[j] * (float)g[j];
     }
     del_s[tid] = dl;
-    lse_s[tid] = lse[(size_t)bh * N + n];
+    lse_s[tid] = lse[(size_t)bh * N + n] * 1.4426950408889634f;
   }
   __syncthreads();
 
   const int key0 = wave * 32;
+  if (key0 >= N) return;
   const int kl = lane & 31, h = lane >> 5;
   const float c2 = scale * 1.4426950408889634f;
-  const float l2e = 1.4426950408889634f;
-  if (key0 < N) {
-    const int key = key0 + kl;
-    const int keyc = key < N ? key : N - 1;
-    const bool kvalid = key < N;
-    // B operands with the key on the lane: K[key][16ks + 8h + j], V likewise
-    bf16x8 kf[4], vf[4];
+  const int key = key0 + kl;
+  const int keyc = key < N ? key : N - 1;
+  const bool kvalid = key < N;
+  // B operands with the key on the lane: K[key][16ks + 8h + j], V likewise
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8*>(kb + (size_t)keyc * ld + ks * 16 + h * 8);
+    vf[ks] = *reinterpret_cast<const bf16x8*>(vb + (size_t)keyc * ld + ks * 16 + h * 8);
+  }
+  f32x16 dkt[2], dvt[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkt[dt][r] = 0.f; dvt[dt][r] = 0.f; }
+
+  const int nqt = (N + 31) >> 5;
+  for (int qt = 0; qt < nqt; ++qt) {
+    const int q0 = qt * 32;
+    f32x16 sacc, pacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      kf[ks] = *reinterpret_cast<const bf16x8*>(kb + (size_t)keyc * ld + ks * 16 + h * 8);
-      vf[ks] = *reinterpret_cast<const bf16x8*>(vb + (size_t)keyc * ld + ks * 16 + h * 8);
+      const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + swz128(q0 + kl, ks * 2 + h));
+      const bf16x8 da = *reinterpret_cast<const bf16x8*>(dOs + swz128(q0 + kl, ks * 2 + h));
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], pacc, 0, 0, 0);
     }
-    // B operand of dQ += dS K: lane = d (dt*32 + kl), element j = K[key0 + 16 st + 8h + j][d]
-    bf16x8 ktf[2][2];
+    // layout: column (lane & 31) = key, row = query q0 + crow(r, h).  Rows q >= N carry clamped
+    // duplicates of row N-1: force their P to zero.
+    f32x16 p, ds;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          int kk = key0 + 16 * st + 8 * h + j;
-          kk = kk < N ? kk : N - 1;
-          ktf[dt][st][j] = kb[(size_t)kk * ld + dt * 32 + kl];
-        }
-    f32x16 dkt[2], dvt[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { dkt[dt][r] = 0.f; dvt[dt][r] = 0.f; }
-
-    const int nqt = (N + 31) >> 5;
-    for (int qt = 0; qt < nqt; ++qt) {
-      const int q0 = qt * 32;
-      const int qrow = (q0 + kl) < N ? (q0 + kl) : N - 1;  // A-operand row of this lane
-      f32x16 sacc, pacc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qb + (size_t)qrow * ld + ks * 16 + h * 8);
-        const bf16x8 da = *reinterpret_cast<const bf16x8*>(dob + (size_t)qrow * ldo + ks * 16 + h * 8);
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], pacc, 0, 0, 0);
-      }
-      // layout: column (lane & 31) = key, row = query q0 + crow(r, h)
-      f32x16 p, ds;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int q = q0 + crow(r, h);
-        const bool ok = kvalid && (q < N);
-        const float pv = ok ? exp2f(sacc[r] * c2 - lse_s[q] * l2e) : 0.f;
-        p[r] = pv;
-        ds[r] = pv * (pacc[r] - del_s[q]);
-      }
-      // dV^T += dO^T P ; dK^T += Q^T dS   (sum over the 32 queries = the accumulators' row index)
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        const bf16x8 pb = pack8(p, st), dsb = pack8(ds, st);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 doa = tr_frag(dOt, dt * 32 + kl, q0 + st * 16, h);
-          const bf16x8 qta = tr_frag(Qt, dt * 32 + kl, q0 + st * 16, h);
-          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa, pb, dvt[dt], 0, 0, 0);
-          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsb, dkt[dt], 0, 0, 0);
-        }
-      }
-      // dQ[q, d] += sum_key dS[q, key] K[key, d]: dS through the wave-private scratch
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dSw[crow(r, h) * DS_STRIDE + kl] = (bf16)ds[r];
-      f32x16 dq[2];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(dSw + kl * DS_STRIDE + st * 16 + h * 8);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ktf[dt][st], dq[dt], 0, 0, 0);
-      }
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(&dQ[(q0 + crow(r, h)) * HD + dt * 32 + kl], dq[dt][r]);
+    for (int r = 0; r < 16; ++r) {
+      const int q = q0 + crow(r, h);
+      const float e = exp2f(sacc[r] * c2 - lse_s[q]);
+      const float pv = (kvalid && q < N) ? e : 0.f;
+      p[r] = pv;
+      ds[r] = pv * (pacc[r] - del_s[q]);
     }
-    // dK[key][d] = scale * dK^T[d][key]; registers 4g..4g+3 hold d = dt*32 + 8g + 4h + (0..3)
-    if (kvalid) {
-      bf16* dk = dqkv + (size_t)(b * N + key) * ld + H * HD + head * HD;
-      bf16* dv = dk + H * HD;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+    for (int st = 0; st < 2; ++st) {
+      const bf16x8 pb = pack8(p, st), dsb = pack8(ds, st);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d = dt * 32 + 8 * g + 4 * h;
-          bf16x4 a = {(bf16)(dkt[dt][4 * g] * scale), (bf16)(dkt[dt][4 * g + 1] * scale),
-                      (bf16)(dkt[dt][4 * g + 2] * scale), (bf16)(dkt[dt][4 * g + 3] * scale)};
-          bf16x4 c = {(bf16)dvt[dt][4 * g], (bf16)dvt[dt][4 * g + 1], (bf16)dvt[dt][4 * g + 2], (bf16)dvt[dt][4 * g + 3]};
-          *reinterpret_cast<bf16x4*>(dk + d) = a;
-          *reinterpret_cast<bf16x4*>(dv + d) = c;
-        }
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16x8 doa = tr_frag(dOt, dt * 32 + kl, q0 + st * 16, h);
+        const bf16x8 qta = tr_frag(Qt, dt * 32 + kl, q0 + st * 16, h);
+        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa, pb, dvt[dt], 0, 0, 0);
+        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsb, dkt[dt], 0, 0, 0);
+      }
     }
   }
+  // dK[key][d] = scale * dK^T[d][key]; registers 4g..4g+3 hold d = dt*32 + 8g + 4h + (0..3)
+  if (kvalid) {
+    bf16* dk = dqkv + (size_t)(b * N + key) * ld + H * HD + head * HD;
+    bf16* dv = dk + H * HD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + 8 * g + 4 * h;
+        bf16x4 a = {(bf16)(dkt[dt][4 * g] * scale), (bf16)(dkt[dt][4 * g + 1] * scale),
+                    (bf16)(dkt[dt][4 * g + 2] * scale), (bf16)(dkt[dt][4 * g + 3] * scale)};
+        bf16x4 c = {(bf16)dvt[dt][4 * g], (bf16)dvt[dt][4 * g + 1], (bf16)dvt[dt][4 * g + 2], (bf16)dvt[dt][4 * g + 3]};
+        *reinterpret_cast<bf16x4*>(dk + d) = a;
+        *reinterpret_cast<bf16x4*>(dv + d) = c;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, kernel 2: dQ.  Same shape as the forward: a wave owns 32 queries; per key tile it
+// recomputes S^T = K Q^T and dP^T = V dO^T (key on the accumulator row, query on the lane, so the
+// row constants LSE and delta are lane-local scalars), forms dS^T in registers and feeds it as
+// the A operand of dQ += dS K (B fragments from the transposed K image): no LDS round trip, no
+// cross-wave sum, no atomics.
+// ------------------------------------------------------------------------------------------
+constexpr int DQ_LDS = 2 * NMAX * 128 + HD * KP * 2;  // K rows, V rows (swizzled) + K^T
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                             const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                             bf16* __restrict__ dqkv, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + NMAX * 128;
+  bf16* Kt = reinterpret_cast<bf16*>(smem + 2 * NMAX * 128);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x, b = bh / H, head = bh - b * H;
+  const int ld = 3 * H * HD, ldo = H * HD;
+  const bf16* qb = qkv + (size_t)b * N * ld + head * HD;
+  const bf16* kb = qb + H * HD;
+  const bf16* vb = qb + 2 * H * HD;
+  const bf16* ob = out + (size_t)b * N * ldo + head * HD;
+  const bf16* dob = dout + (size_t)b * N * ldo + head * HD;
+  stage_rows_swz(kb, ld, N, Ks, tid, 256);
+  stage_rows_swz(vb, ld, N, Vs, tid, 256);
+  stage_transposed(kb, ld, N, Kt, tid, 256);
   __syncthreads();
-  for (int idx = tid; idx < N * 16; idx += 448) {
-    const int q = idx >> 4, c = idx & 15;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(dQ + q * HD + c * 4);
-    bf16x4 o = {(bf16)(v[0] * scale), (bf16)(v[1] * scale), (bf16)(v[2] * scale), (bf16)(v[3] * scale)};
-    *reinterpret_cast<bf16x4*>(dqkv + (size_t)(b * N + q) * ld + head * HD + c * 4) = o;
+
+  const int q0 = (blockIdx.y * 4 + wave) * 32;
+  if (q0 >= N) return;
+  const int ql = lane & 31, h = lane >> 5;
+  const int qrow = (q0 + ql) < N ? (q0 + ql) : N - 1;
+  bf16x8 qf[4], dof[4];
+  float dl = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    qf[ks] = *reinterpret_cast<const bf16x8*>(qb + (size_t)qrow * ld + ks * 16 + h * 8);
+    dof[ks] = *reinterpret_cast<const bf16x8*>(dob + (size_t)qrow * ldo + ks * 16 + h * 8);
+    const bf16x8 of = *reinterpret_cast<const bf16x8*>(ob + (size_t)qrow * ldo + ks * 16 + h * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dl += (float)of[j] * (float)dof[ks][j];
+  }
+  dl += __shfl_xor(dl, 32, 64);   // delta[q] = sum_d dO[q,d] O[q,d]
+  const float lq = lse[(size_t)bh * N + qrow] * 1.4426950408889634f;
+  const float c2 = scale * 1.4426950408889634f;
+
+  f32x16 dq[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+  const int nkt = (N + 31) >> 5;
+  for (int kt = 0; kt < nkt; ++kt) {
+    f32x16 sT, dpT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sT[r] = 0.f; dpT[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 ka = *reinterpret_cast<const bf16x8*>(Ks + swz128(kt * 32 + ql, ks * 2 + h));
+      const bf16x8 va = *reinterpret_cast<const bf16x8*>(Vs + swz128(kt * 32 + ql, ks * 2 + h));
+      sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], sT, 0, 0, 0);
+      dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dpT, 0, 0, 0);
+    }
+    // layout: column (lane & 31) = query, row = key kt*32 + crow(r, h)
+    f32x16 ds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + crow(r, h);
+      const float e = exp2f(sT[r] * c2 - lq);
+      ds[r] = key < N ? e * (dpT[r] - dl) : 0.f;
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const bf16x8 a = pack8(ds, st);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16x8 kf = tr_frag(Kt, dt * 32 + ql, kt * 32 + st * 16, h);
+        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf, dq[dt], 0, 0, 0);
+      }
+    }
+  }
+  // dQ layout: column (lane & 31) = d, row = query q0 + crow(r, h)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int q = q0 + crow(r, h);
+    if (q < N) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        dqkv[(size_t)(b * N + q) * ld + head * HD + dt * 32 + ql] = (bf16)(dq[dt][r] * scale);
+    }
   }
 }
 
@@ -331,7 +397,7 @@ extern "C" int cara_attention_fwd(const void* qkv, void* out, float* lse, int B,
   if (!qkv || !out || !lse || B <= 0 || H <= 0 || N <= 0 || N > NMAX) return CARA_E_ARG;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
     attr_set = true;
   }
   const dim3 grid(B * H, (N + 127) / 128);
@@ -346,11 +412,16 @@ extern "C" int cara_attention_bwd(const void* qkv, const void* out, const void* 
   if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || H <= 0 || N <= 0 || N > NMAX) return CARA_E_ARG;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(448), BWD_LDS, static_cast<hipStream_t>(stream),
-                     (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H), dim3(448), DKV_LDS, st, (const bf16*)qkv, (const bf16*)out,
+                     (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale);
+  CARA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * H, (N + 127) / 128), dim3(256), DQ_LDS, st, (const bf16*)qkv,
+                     (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }

@@ -26,11 +26,25 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below the bf16 output resolution):
+// one v_rcp + one v_exp + 6 FMAs instead of the branchy libm erff.  e = exp(-x^2) is returned too:
+// with x = u / sqrt(2) it is also the Gaussian of gelu'(u), so forward and backward share it.
+__device__ __forceinline__ float erf_as(float x, float& e) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  e = __expf(-ax * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.0f - poly * e;
+  return x < 0.f ? -r : r;
+}
+__device__ __forceinline__ float gelu_erf(float u) {
+  float e;
+  return 0.5f * u * (1.0f + erf_as(u * 0.70710678118654752f, e));
+}
 __device__ __forceinline__ float gelu_erf_grad(float u) {
-  const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __expf(-0.5f * u * u);
-  return cdf + u * pdf;
+  float e;
+  const float cdf = 0.5f * (1.0f + erf_as(u * 0.70710678118654752f, e));
+  return cdf + u * 0.39894228040143268f * e;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -185,67 +185,88 @@ __global__ __launch_bounds__(256) void grad_colred_kernel(PackDims g, cara_cp cp
   }
 }
 
-// (c) dA3[hh, r] and dA4[d, r]
-__global__ __launch_bounds__(256) void grad_a34_kernel(PackDims g, cara_cp cp, cara_layer_grads lg, cara_cp out) {
+// (c) dA3[hh, r] and dA4[d, r]: one block per (layer, k) writes its partial (already multiplied by
+// A1[3l+k, r]) into scratch; the final kernel sums the 3*depth partials in a fixed order.
+//   scratch layout: pa3 [3L][H][R], pa4 [3L][hd][R], zv [L][R]
+__global__ __launch_bounds__(256) void grad_a34_partial_kernel(PackDims g, cara_cp cp, cara_layer_grads lg,
+                                                               float* __restrict__ scratch) {
   const int R = g.rank, Rp = g.Rp, dim = g.dim, H = g.heads, hd = g.hd, L = g.depth;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e < H * R) {
+  const int lk = blockIdx.x, l = lk / 3, k = lk - 3 * l;
+  const float* W = lg.dVs_qkv + ((size_t)l * 3 * dim + (size_t)k * dim) * Rp;   // [H*hd, Rp]
+  float* pa3 = scratch + (size_t)lk * H * R;
+  float* pa4 = scratch + (size_t)3 * L * H * R + (size_t)lk * hd * R;
+  for (int e = threadIdx.x; e < H * R; e += 256) {
     const int hh = e / R, r = e - hh * R;
-    float acc = 0.f;
-    for (int lk = 0; lk < 3 * L; ++lk) {
-      const int l = lk / 3, k = lk - 3 * l;
-      float in = 0.f;
-      for (int d = 0; d < hd; ++d) in += lg.dVs_qkv[((size_t)l * 3 * dim + k * dim + hh * hd + d) * Rp + r] * cp.A4[d * R + r];
-      acc += cp.A1[lk * R + r] * in;
-    }
-    out.A3[e] = g.s * cp.R1[r] * acc;
-  } else if (e < H * R + hd * R) {
-    const int e2 = e - H * R;
-    const int d = e2 / R, r = e2 - d * R;
-    float acc = 0.f;
-    for (int lk = 0; lk < 3 * L; ++lk) {
-      const int l = lk / 3, k = lk - 3 * l;
-      float in = 0.f;
-      for (int hh = 0; hh < H; ++hh) in += lg.dVs_qkv[((size_t)l * 3 * dim + k * dim + hh * hd + d) * Rp + r] * cp.A3[hh * R + r];
-      acc += cp.A1[lk * R + r] * in;
-    }
-    out.A4[e2] = g.s * cp.R1[r] * acc;
+    float in = 0.f;
+    for (int d = 0; d < hd; ++d) in += W[(size_t)(hh * hd + d) * Rp + r] * cp.A4[d * R + r];
+    pa3[e] = cp.A1[lk * R + r] * in;
+  }
+  for (int e = threadIdx.x; e < hd * R; e += 256) {
+    const int d = e / R, r = e - d * R;
+    float in = 0.f;
+    for (int hh = 0; hh < H; ++hh) in += W[(size_t)(hh * hd + d) * Rp + r] * cp.A3[hh * R + r];
+    pa4[e] = cp.A1[lk * R + r] * in;
   }
 }
 
-// (d) lambda gradients, then scale the Z rows by the lambda (one block).  dR1 = sum A1 (.) Z;
-// dR2 = sum over the R2-carrying P1 rows (9l .. 9l+4) of P1 (.) Z  +  s * sum dVs_fc2 (.) P3.
-__global__ __launch_bounds__(256) void grad_lambda_kernel(PackDims g, cara_cp cp, cara_layer_grads lg, cara_cp out) {
+// zv[l, r] = sum_c dVs_fc2[l, c, r] * P3[c, r]   (the R2-gradient carried by fc2's output factor)
+__global__ __launch_bounds__(256) void grad_zv_kernel(PackDims g, cara_cp cp, cara_layer_grads lg, float* __restrict__ scratch) {
   __shared__ float red[256];
-  const int R = g.rank, Rp = g.Rp, dim = g.dim, L = g.depth;
+  const int R = g.rank, Rp = g.Rp, dim = g.dim, H = g.heads, hd = g.hd, L = g.depth;
+  float* zv = scratch + (size_t)3 * L * (H + hd) * R;
+  const int l = blockIdx.x;
   const int r = threadIdx.x % 32, part = threadIdx.x / 32;
   for (int rb = 0; rb < R; rb += 32) {
     const int rr = rb + r;
     float v = 0.f;
     if (rr < R)
-      for (int i = part; i < L * dim; i += 8) v += lg.dVs_fc2[(size_t)i * Rp + rr] * cp.P3[(i % dim) * R + rr];
+      for (int c = part; c < dim; c += 8) v += lg.dVs_fc2[((size_t)l * dim + c) * Rp + rr] * cp.P3[c * R + rr];
     red[threadIdx.x] = v;
     __syncthreads();
     if (part == 0 && rr < R) {
-      float zv = 0.f;
-      for (int p = 0; p < 8; ++p) zv += red[p * 32 + r];
-      float d1 = 0.f, d2 = g.s * zv;
-      for (int row = 0; row < 3 * L; ++row) {
-        const float z = out.A1[row * R + rr];
-        d1 += cp.A1[row * R + rr] * z;
-        out.A1[row * R + rr] = cp.R1[rr] * z;
-      }
-      for (int row = 0; row < 9 * L; ++row) {
-        if (row % 9 < 5) {
-          const float z = out.P1[row * R + rr];
-          d2 += cp.P1[row * R + rr] * z;
-          out.P1[row * R + rr] = cp.R2[rr] * z;
-        }
-      }
-      out.R1[rr] = d1;
-      out.R2[rr] = d2;
+      float s = 0.f;
+      for (int p = 0; p < 8; ++p) s += red[p * 32 + r];
+      zv[l * R + rr] = s;
     }
     __syncthreads();
+  }
+}
+
+// (d) finish: dA3/dA4 from the partials, lambda gradients, then scale the Z rows by the lambda.
+//   dR1 = sum A1 (.) Z ; dR2 = sum over the R2-carrying P1 rows (9l .. 9l+4) of P1 (.) Z + s * sum_l zv
+__global__ __launch_bounds__(256) void grad_finish_kernel(PackDims g, cara_cp cp, const float* __restrict__ scratch, cara_cp out) {
+  const int R = g.rank, H = g.heads, hd = g.hd, L = g.depth;
+  const float* pa3 = scratch;
+  const float* pa4 = scratch + (size_t)3 * L * H * R;
+  const float* zv = scratch + (size_t)3 * L * (H + hd) * R;
+  for (int e = threadIdx.x; e < (H + hd) * R; e += 256) {
+    const bool is3 = e < H * R;
+    const int e2 = is3 ? e : e - H * R;
+    const int r = e2 % R;
+    const int per = is3 ? H * R : hd * R;
+    const float* p = is3 ? pa3 : pa4;
+    float acc = 0.f;
+    for (int lk = 0; lk < 3 * L; ++lk) acc += p[(size_t)lk * per + e2];
+    (is3 ? out.A3 : out.A4)[e2] = g.s * cp.R1[r] * acc;
+  }
+  for (int rr = threadIdx.x; rr < R; rr += 256) {
+    float d1 = 0.f, d2 = 0.f;
+    for (int l = 0; l < L; ++l) d2 += zv[l * R + rr];
+    d2 *= g.s;
+    for (int row = 0; row < 3 * L; ++row) {
+      const float z = out.A1[row * R + rr];
+      d1 += cp.A1[row * R + rr] * z;
+      out.A1[row * R + rr] = cp.R1[rr] * z;
+    }
+    for (int row = 0; row < 9 * L; ++row) {
+      if (row % 9 < 5) {
+        const float z = out.P1[row * R + rr];
+        d2 += cp.P1[row * R + rr] * z;
+        out.P1[row * R + rr] = cp.R2[rr] * z;
+      }
+    }
+    out.R1[rr] = d1;
+    out.R2[rr] = d2;
   }
 }
 
@@ -293,9 +314,15 @@ extern "C" int cara_factor_prep(const cara_geom* g, const cara_cp* cp, const flo
   return CARA_OK;
 }
 
+extern "C" size_t cara_factor_grad_scratch_bytes(const cara_geom* g) {
+  if (!geom_ok(g)) return 0;
+  const size_t L = g->depth, R = g->rank, H = g->heads, hd = g->dim / g->heads;
+  return (3 * L * (H + hd) * R + L * R) * sizeof(float);
+}
+
 extern "C" int cara_factor_grad_reduce(const cara_geom* g, const cara_cp* cp, const cara_layer_grads* lg,
-                                       const cara_cp* grads, void* stream) {
-  if (!geom_ok(g) || !cp_ok(cp) || !cp_ok(grads) || !lg) return CARA_E_ARG;
+                                       const cara_cp* grads, void* scratch, void* stream) {
+  if (!geom_ok(g) || !cp_ok(cp) || !cp_ok(grads) || !lg || !scratch) return CARA_E_ARG;
   if (!lg->dU_qkv || !lg->dVs_qkv || !lg->dU_proj || !lg->dVs_proj || !lg->dU_fc1 || !lg->dVs_fc1 || !lg->dU_fc2 ||
       !lg->dVs_fc2 || !lg->dc_proj || !lg->dc_fc1 || !lg->dc_fc2)
     return CARA_E_ARG;
@@ -306,10 +333,12 @@ extern "C" int cara_factor_grad_reduce(const cara_geom* g, const cara_cp* cp, co
   CARA_CHECK_LAUNCH();
   hipLaunchKernelGGL(grad_colred_kernel, dim3(g->depth * 12), dim3(256), 0, st, d, *cp, *lg, *grads);
   CARA_CHECK_LAUNCH();
-  const int n3 = (g->heads + g->dim / g->heads) * g->rank;
-  hipLaunchKernelGGL(grad_a34_kernel, dim3((n3 + 255) / 256), dim3(256), 0, st, d, *cp, *lg, *grads);
+  float* sc = static_cast<float*>(scratch);
+  hipLaunchKernelGGL(grad_a34_partial_kernel, dim3(3 * g->depth), dim3(256), 0, st, d, *cp, *lg, sc);
   CARA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(grad_lambda_kernel, dim3(1), dim3(256), 0, st, d, *cp, *lg, *grads);
+  hipLaunchKernelGGL(grad_zv_kernel, dim3(g->depth), dim3(256), 0, st, d, *cp, *lg, sc);
+  CARA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(grad_finish_kernel, dim3(1), dim3(256), 0, st, d, *cp, sc, *grads);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }

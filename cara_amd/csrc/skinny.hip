@@ -12,7 +12,7 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// T = X . Ut^T.  Block = 32 rows x all Rp columns; the 4 waves split K (k-step w, w+4, ...:
+// T = X . Ut^T.  Block = 16 rows x all Rp columns; the 4 waves split K (k-step w, w+4, ...:
 // adjacent waves read adjacent 64-B pieces of a row) and reduce through LDS.
 // ------------------------------------------------------------------------------------------
 template <int NT>  // Rp / 16
@@ -20,49 +20,41 @@ __global__ __launch_bounds__(256) void skinny_xu_kernel(const bf16* __restrict__
                                                         const bf16* __restrict__ Ut,
                                                         bf16* __restrict__ T, bf16* __restrict__ Tt,
                                                         int ldt, int M, int K) {
-  __shared__ f32x4 red[4][2 * NT][64];
+  __shared__ f32x4 red[4][NT][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int m0 = blockIdx.x * 32;
+  const int m0 = blockIdx.x * 16;
   constexpr int Rp = NT * 16;
-  f32x4 acc[2][NT];
+  f32x4 acc[NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int r0 = m0 + fr, r1 = m0 + 16 + fr;
+  for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int r0 = m0 + fr;
   r0 = r0 < M ? r0 : M - 1;
-  r1 = r1 < M ? r1 : M - 1;
-  const bf16* xa0 = X + (size_t)r0 * ldx + fq * 8;
-  const bf16* xa1 = X + (size_t)r1 * ldx + fq * 8;
+  const bf16* xa = X + (size_t)r0 * ldx + fq * 8;
   const bf16* ub = Ut + (size_t)fr * K + fq * 8;
   const int nks = K >> 5;
-#pragma unroll 4
+  // wave w takes k-steps w, w+4, ...: the four waves read adjacent 64-B pieces of each row
+#pragma unroll 6
   for (int ks = wave; ks < nks; ks += 4) {
-    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(xa0 + ks * 32);
-    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(xa1 + ks * 32);
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(xa + ks * 32);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const bf16x8 b = *reinterpret_cast<const bf16x8*>(ub + (size_t)j * 16 * K + ks * 32);
-      acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][j], 0, 0, 0);
-      acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) red[wave][i * NT + j][lane] = acc[i][j];
+  for (int j = 0; j < NT; ++j) red[wave][j][lane] = acc[j];
   __syncthreads();
-  for (int t = wave; t < 2 * NT; t += 4) {
-    f32x4 s = red[0][t][lane];
+  for (int nt = wave; nt < NT; nt += 4) {
+    f32x4 s = red[0][nt][lane];
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
-      const f32x4 v = red[w][t][lane];
+      const f32x4 v = red[w][nt][lane];
       s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
-    const int mt = t / NT, nt = t - mt * NT;
     const int n = nt * 16 + fr;
-    const int mb = m0 + mt * 16 + fq * 4;  // rows mb..mb+3, column n
+    const int mb = m0 + fq * 4;  // rows mb..mb+3, column n
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (mb + r < M) T[(size_t)(mb + r) * Rp + n] = (bf16)s[r];
@@ -242,11 +234,14 @@ __global__ __launch_bounds__(256) void tskinny_kernel(const bf16* __restrict__ X
   }
 }
 
-// D[i][r] = sum_chunk slab[chunk*colblocks + i/64][i%64][r]   (fixed order)
-__global__ void tskinny_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ cs_slabs,
+// D[b][i][r] = sum_chunk slab[b][chunk*colblocks + i/64][i%64][r]   (fixed order); grid.y = batch
+__global__ void tskinny_reduce_kernel(const char* __restrict__ slabs_base, size_t slab_stride,
                                       float* __restrict__ D, float* __restrict__ colsum, int K1, int Rp,
                                       int nchunks) {
   const int colblocks = K1 / TS_COLS;
+  const int nblk = colblocks * nchunks;
+  const float* slabs = reinterpret_cast<const float*>(slabs_base + (size_t)blockIdx.y * slab_stride);
+  const float* cs_slabs = slabs + (size_t)nblk * TS_COLS * Rp;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int total = K1 * Rp;
   if (idx < total) {
@@ -254,13 +249,13 @@ __global__ void tskinny_reduce_kernel(const float* __restrict__ slabs, const flo
     const int cb = i / TS_COLS, il = i - cb * TS_COLS;
     float s = 0.f;
     for (int c = 0; c < nchunks; ++c) s += slabs[((size_t)(c * colblocks + cb) * TS_COLS + il) * Rp + r];
-    D[idx] = s;
+    D[(size_t)blockIdx.y * total + idx] = s;
   }
   if (colsum && idx < K1) {
     const int cb = idx / TS_COLS, il = idx - cb * TS_COLS;
     float s = 0.f;
     for (int c = 0; c < nchunks; ++c) s += cs_slabs[(size_t)(c * colblocks + cb) * TS_COLS + il];
-    colsum[idx] = s;
+    colsum[(size_t)blockIdx.y * K1 + idx] = s;
   }
 }
 
@@ -271,7 +266,7 @@ extern "C" int cara_skinny_xu(const void* X, int ldx, const void* Ut, void* T, v
   if (!X || !Ut || !T || M <= 0 || K <= 0 || (K & 31) || (ldx & 7) || ldx < K) return CARA_E_ARG;
   if (Tt && (ldt < M || (ldt & 7))) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid((M + 31) / 32), block(256);
+  const dim3 grid((M + 15) / 16), block(256);
   if (Rp == 32)
     hipLaunchKernelGGL(skinny_xu_kernel<2>, grid, block, 0, st, (const bf16*)X, ldx, (const bf16*)Ut, (bf16*)T, (bf16*)Tt, ldt, M, K);
   else if (Rp == 64)
@@ -288,9 +283,9 @@ extern "C" size_t cara_tskinny_scratch_bytes(int M, int K1, int Rp) {
   return nblk * TS_COLS * Rp * sizeof(float) + nblk * TS_COLS * sizeof(float);
 }
 
-extern "C" int cara_tskinny_xtg(const void* X, int ldx, const void* Gt, int ldg, float* D, float* colsum,
-                                void* slabs, int M, int K1, int Rp, void* stream) {
-  if (!X || !Gt || !D || !slabs || M <= 0 || K1 <= 0 || (K1 % TS_COLS) || (ldx & 7) || ldx < K1) return CARA_E_ARG;
+extern "C" int cara_tskinny_partial(const void* X, int ldx, const void* Gt, int ldg, void* slabs, int want_colsum,
+                                    int M, int K1, int Rp, void* stream) {
+  if (!X || !Gt || !slabs || M <= 0 || K1 <= 0 || (K1 % TS_COLS) || (ldx & 7) || ldx < K1) return CARA_E_ARG;
   // Gt rows must be readable (and zero) up to the next multiple of 32 rows of M
   if ((ldg & 7) || ldg < ((M + 31) / 32) * 32) return CARA_E_ARG;
   if (!(Rp == 32 || Rp == 64)) return CARA_E_ARG;
@@ -303,16 +298,37 @@ extern "C" int cara_tskinny_xtg(const void* X, int ldx, const void* Gt, int ldg,
   const bf16* g = (const bf16*)Gt;
   if (Rp == 32) {
     const size_t lds = 4 * TsRing<2>::WAVE_BYTES;
-    if (colsum) hipLaunchKernelGGL((tskinny_kernel<2, true>), dim3(nblk), dim3(256), lds, st, x, ldx, g, ldg, sl, cs, M, K1, nchunks);
+    if (want_colsum) hipLaunchKernelGGL((tskinny_kernel<2, true>), dim3(nblk), dim3(256), lds, st, x, ldx, g, ldg, sl, cs, M, K1, nchunks);
     else hipLaunchKernelGGL((tskinny_kernel<2, false>), dim3(nblk), dim3(256), lds, st, x, ldx, g, ldg, sl, cs, M, K1, nchunks);
   } else {
+    static bool attr_set = false;
     const size_t lds = 4 * TsRing<4>::WAVE_BYTES;
-    if (colsum) hipLaunchKernelGGL((tskinny_kernel<4, true>), dim3(nblk), dim3(256), lds, st, x, ldx, g, ldg, sl, cs, M, K1, nchunks);
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tskinny_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tskinny_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    if (want_colsum) hipLaunchKernelGGL((tskinny_kernel<4, true>), dim3(nblk), dim3(256), lds, st, x, ldx, g, ldg, sl, cs, M, K1, nchunks);
     else hipLaunchKernelGGL((tskinny_kernel<4, false>), dim3(nblk), dim3(256), lds, st, x, ldx, g, ldg, sl, cs, M, K1, nchunks);
   }
   CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
+extern "C" int cara_tskinny_reduce(const void* slabs, size_t slab_stride, float* D, float* colsum, int batch, int M,
+                                   int K1, int Rp, void* stream) {
+  if (!slabs || !D || batch <= 0 || M <= 0 || K1 <= 0 || (K1 % TS_COLS) || !(Rp == 32 || Rp == 64)) return CARA_E_ARG;
   const int total = K1 * Rp;
-  hipLaunchKernelGGL(tskinny_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, sl, cs, D, colsum, K1, Rp, nchunks);
+  hipLaunchKernelGGL(tskinny_reduce_kernel, dim3((total + 255) / 256, batch), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const char*>(slabs), slab_stride, D, colsum, K1, Rp, ts_chunks(M, K1));
   CARA_CHECK_LAUNCH();
   return CARA_OK;
+}
+
+extern "C" int cara_tskinny_xtg(const void* X, int ldx, const void* Gt, int ldg, float* D, float* colsum,
+                                void* slabs, int M, int K1, int Rp, void* stream) {
+  if (!D) return CARA_E_ARG;
+  const int st = cara_tskinny_partial(X, ldx, Gt, ldg, slabs, colsum != nullptr, M, K1, Rp, stream);
+  if (st != CARA_OK) return st;
+  return cara_tskinny_reduce(slabs, 0, D, colsum, 1, M, K1, Rp, stream);
 }

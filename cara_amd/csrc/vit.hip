@@ -28,8 +28,9 @@ struct Ws {
   size_t pack, patches, emb, head_wb, clsn, meanF, rstdF, x_last;
   LayerWs layer[64];
   // backward
-  size_t dx, dyb, dH, dXn, dAO, dQKV, G, Gt, slabs, dclsn;
+  size_t dx, dyb, dH, dXn, dAO, dQKV, G, Gt, slabs, dclsn, gscratch;
   size_t dU[4], dVs[4], dc[4];
+  size_t slabU[4], slabV[4], strideU[4], strideV[4];   // per linear: depth regions of tskinny slabs
   size_t total;
   int M, ldt;
 };
@@ -82,16 +83,18 @@ bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
   w->dQKV = c.take(M * 3 * D * 2);
   w->G = c.take(M * Rp * 2);
   w->Gt = c.take(Rp * ldt * 2);
-  size_t sl = 0;
-  const int k1s[3] = {(int)D, (int)(3 * D), (int)(4 * D)};
-  for (int i = 0; i < 3; ++i) sl = max_sz(sl, cara_tskinny_scratch_bytes((int)M, k1s[i], (int)Rp));
-  w->slabs = c.take(sl);
+  w->slabs = 0;
   w->dclsn = c.take((size_t)s->B * D * 2);
+  w->gscratch = c.take(cara_factor_grad_scratch_bytes(g));
   const size_t ins[4] = {D, D, D, 4 * D}, outs[4] = {3 * D, D, 4 * D, D};
   for (int i = 0; i < 4; ++i) {
     w->dU[i] = c.take((size_t)g->depth * ins[i] * Rp * 4);
     w->dVs[i] = c.take((size_t)g->depth * outs[i] * Rp * 4);
     w->dc[i] = c.take((size_t)g->depth * outs[i] * 4);
+    w->strideU[i] = (cara_tskinny_scratch_bytes((int)M, (int)ins[i], (int)Rp) + 255) & ~(size_t)255;
+    w->strideV[i] = (cara_tskinny_scratch_bytes((int)M, (int)outs[i], (int)Rp) + 255) & ~(size_t)255;
+    w->slabU[i] = c.take(w->strideU[i] * g->depth);
+    w->slabV[i] = c.take(w->strideV[i] * g->depth);
   }
   w->total = c.off;
   return true;
@@ -132,11 +135,10 @@ int lin_bwd(const Lin& L, const bf16* dY, const bf16* X, int M, int Rp, int ldt,
     a.M = M; a.N = L.in; a.K = L.out; a.bias = nullptr; a.ldc = L.in;
     TRY(cara_gemm_bf16(&a, st));
   }
-  float* dU = reinterpret_cast<float*>(ws + W.dU[L.slot]) + (size_t)layer * L.in * Rp;
-  float* dVs = reinterpret_cast<float*>(ws + W.dVs[L.slot]) + (size_t)layer * L.out * Rp;
-  float* dc = want_dc ? reinterpret_cast<float*>(ws + W.dc[L.slot]) + (size_t)layer * L.out : nullptr;
-  TRY(cara_tskinny_xtg(X, L.in, Gt, ldt, dU, nullptr, ws + W.slabs, M, L.in, Rp, st));
-  TRY(cara_tskinny_xtg(dY, L.out, ws + lw.Tt[L.slot], ldt, dVs, dc, ws + W.slabs, M, L.out, Rp, st));
+  // partial slabs now; their fixed-order sums run once per linear after the layer loop
+  TRY(cara_tskinny_partial(X, L.in, Gt, ldt, ws + W.slabU[L.slot] + (size_t)layer * W.strideU[L.slot], 0, M, L.in, Rp, st));
+  TRY(cara_tskinny_partial(dY, L.out, ws + lw.Tt[L.slot], ldt, ws + W.slabV[L.slot] + (size_t)layer * W.strideV[L.slot],
+                           want_dc ? 1 : 0, M, L.out, Rp, st));
   return CARA_OK;
 }
 
@@ -359,6 +361,15 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
                              reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), dx, dx, dyb,
                              dp_prev, N, M, D, stream));
   }
+  {
+    const int ins[4] = {D, D, D, 4 * D}, outs[4] = {3 * D, D, 4 * D, D};
+    for (int i = 0; i < 4; ++i) {
+      TRY(cara_tskinny_reduce(ws + W.slabU[i], W.strideU[i], reinterpret_cast<float*>(ws + W.dU[i]), nullptr, g->depth, M,
+                              ins[i], Rp, stream));
+      TRY(cara_tskinny_reduce(ws + W.slabV[i], W.strideV[i], reinterpret_cast<float*>(ws + W.dVs[i]),
+                              i == 0 ? nullptr : reinterpret_cast<float*>(ws + W.dc[i]), g->depth, M, outs[i], Rp, stream));
+    }
+  }
   cara_layer_grads lg;
   lg.dU_qkv = reinterpret_cast<float*>(ws + W.dU[0]); lg.dVs_qkv = reinterpret_cast<float*>(ws + W.dVs[0]);
   lg.dU_proj = reinterpret_cast<float*>(ws + W.dU[1]); lg.dVs_proj = reinterpret_cast<float*>(ws + W.dVs[1]);
@@ -366,5 +377,5 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
   lg.dU_fc2 = reinterpret_cast<float*>(ws + W.dU[3]); lg.dVs_fc2 = reinterpret_cast<float*>(ws + W.dVs[3]);
   lg.dc_proj = reinterpret_cast<float*>(ws + W.dc[1]); lg.dc_fc1 = reinterpret_cast<float*>(ws + W.dc[2]);
   lg.dc_fc2 = reinterpret_cast<float*>(ws + W.dc[3]);
-  return cara_factor_grad_reduce(g, cp, &lg, grads, stream);
+  return cara_factor_grad_reduce(g, cp, &lg, grads, ws + W.gscratch, stream);
 }

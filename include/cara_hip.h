@@ -68,6 +68,14 @@ int cara_skinny_xu(const void* X, int ldx, const void* Ut, void* T, void* Tt, in
 size_t cara_tskinny_scratch_bytes(int M, int K1, int Rp);
 int cara_tskinny_xtg(const void* X, int ldx, const void* Gt, int ldg, float* D, float* colsum,
                      void* slabs, int M, int K1, int Rp, void* stream);
+/* The same in two steps, so that the tiny fixed-order slab sums of many products (the 12 layers
+ * of one linear) run as ONE launch: _partial writes the per-block slabs of one product into its
+ * own scratch region; _reduce sums `batch` regions spaced slab_stride bytes apart into
+ * D[batch,K1,Rp] (and colsum[batch,K1] when non-NULL; every region must then hold column sums). */
+int cara_tskinny_partial(const void* X, int ldx, const void* Gt, int ldg, void* slabs, int want_colsum,
+                         int M, int K1, int Rp, void* stream);
+int cara_tskinny_reduce(const void* slabs, size_t slab_stride, float* D, float* colsum, int batch,
+                        int M, int K1, int Rp, void* stream);
 
 /* ---- LayerNorm (eps inside the sqrt, biased variance; timm Block norm1/norm2/norm) ------- */
 /* y bf16 [M,C] = (x - mean) * rstd * gamma + beta; saves mean, rstd fp32 [M].  x fp32 rows with
@@ -136,13 +144,15 @@ int cara_factor_prep(const cara_geom* g, const cara_cp* cp, const float* base_bi
                      void* stream);
 /* Scatter per-layer skinny gradients onto the 12 shared tensors (A.4).  dU_x / dVs_x are fp32
  * [depth, in|out, Rp]; dc_x fp32 [depth, out] (column sums of dY of proj/fc1/fc2).  grads are
- * OVERWRITTEN.                                                                                */
+ * OVERWRITTEN.  scratch: cara_factor_grad_scratch_bytes(g) bytes (partials, summed in a fixed
+ * order: bitwise reproducible).                                                                */
 typedef struct {
   const float *dU_qkv, *dVs_qkv, *dU_proj, *dVs_proj, *dU_fc1, *dVs_fc1, *dU_fc2, *dVs_fc2;
   const float *dc_proj, *dc_fc1, *dc_fc2;
 } cara_layer_grads;
+size_t cara_factor_grad_scratch_bytes(const cara_geom* g);
 int cara_factor_grad_reduce(const cara_geom* g, const cara_cp* cp, const cara_layer_grads* lg,
-                            const cara_cp* grads, void* stream);
+                            const cara_cp* grads, void* scratch, void* stream);
 
 /* ---- whole adapted ViT: forward and backward as stream-ordered kernel sequences ------------ */
 /* What model(x) / loss.backward() of vit_cp.py:46-49 run, for the factored adapters.  Both calls

@@ -321,7 +321,8 @@ def test_factor_prep_and_grad_reduce(rank, Rp):
     lg = L().LayerGrads(*[p(t) for t in keep])
     gout = {n: torch.full_like(cpd["CP_" + n], float("nan")) for n in L().CP_FIELDS}
     gp = L().CpPtrs(*[p(gout[n]) for n in L().CP_FIELDS])
-    L().check(lib.cara_factor_grad_reduce(C.byref(geom), C.byref(cps), C.byref(lg), C.byref(gp), st()), "grad reduce")
+    scratch = torch.empty(lib.cara_factor_grad_scratch_bytes(C.byref(geom)), dtype=torch.uint8, device=DEV)
+    L().check(lib.cara_factor_grad_reduce(C.byref(geom), C.byref(cps), C.byref(lg), C.byref(gp), p(scratch), st()), "grad reduce")
     torch.cuda.synchronize()
     for n in L().CP_FIELDS:
         ref = cpv["CP_" + n].grad

@@ -159,7 +159,7 @@ def test_drop_path_masks_and_train_mode():
     # engine-drawn masks: shape, values in {0, 1/keep}, block 0 never dropped
     dp = m._cara_engine.draw_droppath(m, 64, torch.device(DEV))
     assert dp.shape == (3, 2, 64) and torch.equal(dp[0], torch.ones(2, 64, device=DEV))
-    assert set(torch.unique(dp[2]).tolist()) <= {0.0, 1 / 0.9}
+    assert all(min(abs(v), abs(v - 1 / 0.9)) < 1e-6 for v in torch.unique(dp[2]).tolist())
     torch.logsumexp(logits, 1).sum().backward()
     assert all(torch.isfinite(getattr(m, n).grad).all() for n in O.CP_NAMES)
 

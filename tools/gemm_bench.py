@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of cara_gemm_bf16 on the GEMM shapes of one adapted ViT-B block (bs 64):
+random bf16 operands (never zeros: MI355X clocks higher on zero data), HIP-event timing of
+back-to-back launches in one process.  Usage: python tools/gemm_bench.py [--iters 30] [--only NAME]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cara_amd import _lib as L  # noqa: E402
+
+M = 64 * 197
+SHAPES = [  # name, N, K, epi
+    ("qkv_fwd", 2304, 768, "bf16"), ("proj_fwd", 768, 768, "resid"), ("fc1_fwd", 3072, 768, "gelu"),
+    ("fc2_fwd", 768, 3072, "resid"), ("fc2_bwd", 3072, 768, "dgelu"), ("fc1_bwd", 768, 3072, "bf16"),
+    ("proj_bwd", 768, 768, "bf16"), ("qkv_bwd", 768, 2304, "bf16"),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--rp", type=int, default=32)
+    args = ap.parse_args()
+    dev = "cuda"
+    g = torch.Generator().manual_seed(0)
+    tot_t = tot_f = 0.0
+    for name, N, K, epi in SHAPES:
+        if args.only and args.only != name:
+            continue
+        A = torch.randn(M, K, generator=g).bfloat16().to(dev)
+        B = (torch.randn(N, K, generator=g) * 0.02).bfloat16().to(dev)
+        A2 = torch.randn(M, args.rp, generator=g).bfloat16().to(dev)
+        B2 = (torch.randn(N, args.rp, generator=g) * 0.02).bfloat16().to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        kw = dict(A2=A2, B2=B2, bias=bias)
+        if epi == "bf16":
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            kw.update(epi=L.EPI_BF16)
+        elif epi == "gelu":
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            kw.update(epi=L.EPI_GELU, C2=torch.empty_like(out))
+        elif epi == "dgelu":
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            kw.update(epi=L.EPI_DGELU, aux=torch.randn(M, N, generator=g).bfloat16().to(dev))
+            kw["bias"] = None
+        else:
+            out = torch.empty(M, N, dtype=torch.float32, device=dev)
+            kw.update(epi=L.EPI_RESID, aux=torch.randn(M, N, generator=g).to(dev),
+                      rowscale=torch.ones(64, device=dev), rows_per_sample=197)
+        for _ in range(3):
+            L.gemm(A, B, out, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.iters):
+            L.gemm(A, B, out, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        fl = 2.0 * M * N * (K + 16)
+        tot_t += us
+        tot_f += fl
+        print(f"{name:9s} N={N:5d} K={K:5d} {epi:6s} {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
+    if tot_t:
+        print(f"block total {tot_t:8.1f} us  {tot_f / tot_t / 1e6:7.1f} TF/s  (x12 layers = {12 * tot_t / 1e3:.2f} ms/step)")
+
+
+if __name__ == "__main__":
+    main()
