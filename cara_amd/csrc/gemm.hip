@@ -15,7 +15,10 @@
 // 16-byte chunk index XOR-swizzled by (row>>1)&7, applied on the global SOURCE address (the DMA
 // destination is lane-linear) and again on the ds_read_b128 address: conflict-free fragment reads.
 // 1-D grid remapped so that each XCD's L2 sees a contiguous run of tiles.
+#include <stdlib.h>
+
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -134,98 +137,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const cara_gemm_args p, co
 #pragma unroll
         for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[i][j][r];
   }
-  const int mbase = m0 + wr * 64, nbase = n0 + wc * 64;
-  if constexpr (EPI == CARA_EPI_F32 || EPI == CARA_EPI_RESID) {
-    // fp32 output: 4 rows x 256 B per pass, 16 B per lane
-    const int c4 = (lane & 15) * 4, n = nbase + c4;
-    const bool vec = (n + 4 <= p.N) && ((p.ldc & 3) == 0);
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) bv[k] = (n + k < p.N) ? p.bias[n + k] : 0.f;
-    }
-#pragma unroll 4
-    for (int pass = 0; pass < 16; ++pass) {
-      const int row = pass * 4 + (lane >> 4), m = mbase + row;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(stg + row * 64 + c4);
-      if (m >= p.M || n >= p.N) continue;
-      float v[4] = {a[0] + bv[0], a[1] + bv[1], a[2] + bv[2], a[3] + bv[3]};
-      const size_t o = (size_t)m * p.ldc + n;
-      if constexpr (EPI == CARA_EPI_RESID) {
-        const float rs = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.f;
-        const float* xin = static_cast<const float*>(p.aux) + o;
-        if (vec) {
-          const f32x4 x = *reinterpret_cast<const f32x4*>(xin);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = x[k] + rs * v[k];
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = (n + k < p.N) ? xin[k] + rs * v[k] : 0.f;
-        }
-      }
-      float* dst = static_cast<float*>(p.C) + o;
-      if (vec) {
-        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (n + k < p.N) dst[k] = v[k];
-      }
-    }
-  } else {
-    // bf16 output(s): 8 rows x 128 B per pass, 16 B per lane
-    const int c8 = (lane & 7) * 8, n = nbase + c8;
-    const bool vec = (n + 8 <= p.N) && ((p.ldc & 7) == 0);
-    float bv[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) bv[k] = (p.bias && n + k < p.N) ? p.bias[n + k] : 0.f;
-#pragma unroll 2
-    for (int pass = 0; pass < 8; ++pass) {
-      const int row = pass * 8 + (lane >> 3), m = mbase + row;
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + row * 64 + c8);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(stg + row * 64 + c8 + 4);
-      if (m >= p.M || n >= p.N) continue;
-      float v[8] = {a0[0] + bv[0], a0[1] + bv[1], a0[2] + bv[2], a0[3] + bv[3],
-                    a1[0] + bv[4], a1[1] + bv[5], a1[2] + bv[6], a1[3] + bv[7]};
-      const size_t o = (size_t)m * p.ldc + n;
-      bf16x8 out, out2;
-      if constexpr (EPI == CARA_EPI_BF16) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) out[k] = (bf16)v[k];
-      } else if constexpr (EPI == CARA_EPI_GELU) {
-        // the stored pre-activation is the bf16 value; GELU is taken of that same rounded value so
-        // that forward h and backward gelu'(u) see one consistent u
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          out2[k] = (bf16)v[k];
-          out[k] = (bf16)gelu_erf((float)out2[k]);
-        }
-      } else {  // CARA_EPI_DGELU
-        const bf16* up = static_cast<const bf16*>(p.aux) + o;
-        bf16x8 u;
-        if (vec) {
-          u = *reinterpret_cast<const bf16x8*>(up);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) u[k] = (n + k < p.N) ? up[k] : (bf16)0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) out[k] = (bf16)(v[k] * gelu_erf_grad((float)u[k]));
-      }
-      bf16* dst = static_cast<bf16*>(p.C) + o;
-      if (vec) {
-        *reinterpret_cast<bf16x8*>(dst) = out;
-        if constexpr (EPI == CARA_EPI_GELU) *reinterpret_cast<bf16x8*>(static_cast<bf16*>(p.C2) + o) = out2;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if (n + k < p.N) {
-            dst[k] = out[k];
-            if constexpr (EPI == CARA_EPI_GELU) (static_cast<bf16*>(p.C2) + o)[k] = out2[k];
-          }
-      }
-    }
-  }
+  epilogue_64x64<EPI>(p, stg, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
 template <int EPI>
@@ -239,6 +151,21 @@ int launch(const cara_gemm_args* a, hipStream_t st) {
 
 }  // namespace
 
+int cara_gemm256_dispatch(const cara_gemm_args* a, hipStream_t st);  // gemm256.hip
+
+// 256x256 tile for the large products, 128x128 for small ones (head, tests).  CARA_GEMM_TILE=128|256
+// in the environment pins one tile for A/B measurements.
+static bool use_tile256(const cara_gemm_args* a) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("CARA_GEMM_TILE");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced == 128) return false;
+  if (forced == 256) return true;
+  return a->M >= 1024 && a->N >= 512;
+}
+
 extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->B || !a->C) return CARA_E_ARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % BK) != 0) return CARA_E_ARG;
@@ -246,6 +173,10 @@ extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
   if (!(a->Rp == 0 || a->Rp == 32 || a->Rp == 64)) return CARA_E_ARG;
   if (a->Rp && (!a->A2 || !a->B2)) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a->epi == CARA_EPI_GELU && !a->C2) return CARA_E_ARG;
+  if (a->epi == CARA_EPI_RESID && (!a->aux || (a->rowscale && a->rows_per_sample <= 0))) return CARA_E_ARG;
+  if (a->epi == CARA_EPI_DGELU && !a->aux) return CARA_E_ARG;
+  if (use_tile256(a)) return cara_gemm256_dispatch(a, st);
   switch (a->epi) {
     case CARA_EPI_BF16: return launch<CARA_EPI_BF16>(a, st);
     case CARA_EPI_F32: return launch<CARA_EPI_F32>(a, st);

@@ -1,0 +1,102 @@
+// Epilogue of the MFMA GEMMs (gfx950): one wave turns a 64x64 fp32 sub-tile that it has just
+// written to its private LDS image `stg` ([64][64] floats) into the final global stores, with every
+// global access (output, residual / pre-activation input, bias) 16 bytes wide on 128..256-byte
+// contiguous row segments.
+#pragma once
+#include "common.h"
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_64x64(const cara_gemm_args& p, const float* stg, const int mbase,
+                                               const int nbase, const int lane) {
+  if constexpr (EPI == CARA_EPI_F32 || EPI == CARA_EPI_RESID) {
+    // fp32 output: 4 rows x 256 B per pass, 16 B per lane
+    const int c4 = (lane & 15) * 4, n = nbase + c4;
+    const bool vec = (n + 4 <= p.N) && ((p.ldc & 3) == 0);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bv[k] = (n + k < p.N) ? p.bias[n + k] : 0.f;
+    }
+#pragma unroll 4
+    for (int pass = 0; pass < 16; ++pass) {
+      const int row = pass * 4 + (lane >> 4), m = mbase + row;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(stg + row * 64 + c4);
+      if (m >= p.M || n >= p.N) continue;
+      float v[4] = {a[0] + bv[0], a[1] + bv[1], a[2] + bv[2], a[3] + bv[3]};
+      const size_t o = (size_t)m * p.ldc + n;
+      if constexpr (EPI == CARA_EPI_RESID) {
+        const float rs = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.f;
+        const float* xin = static_cast<const float*>(p.aux) + o;
+        if (vec) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(xin);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = x[k] + rs * v[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = (n + k < p.N) ? xin[k] + rs * v[k] : 0.f;
+        }
+      }
+      float* dst = static_cast<float*>(p.C) + o;
+      if (vec) {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (n + k < p.N) dst[k] = v[k];
+      }
+    }
+  } else {
+    // bf16 output(s): 8 rows x 128 B per pass, 16 B per lane
+    const int c8 = (lane & 7) * 8, n = nbase + c8;
+    const bool vec = (n + 8 <= p.N) && ((p.ldc & 7) == 0);
+    float bv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bv[k] = (p.bias && n + k < p.N) ? p.bias[n + k] : 0.f;
+#pragma unroll 2
+    for (int pass = 0; pass < 8; ++pass) {
+      const int row = pass * 8 + (lane >> 3), m = mbase + row;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + row * 64 + c8);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(stg + row * 64 + c8 + 4);
+      if (m >= p.M || n >= p.N) continue;
+      float v[8] = {a0[0] + bv[0], a0[1] + bv[1], a0[2] + bv[2], a0[3] + bv[3],
+                    a1[0] + bv[4], a1[1] + bv[5], a1[2] + bv[6], a1[3] + bv[7]};
+      const size_t o = (size_t)m * p.ldc + n;
+      bf16x8 out, out2;
+      if constexpr (EPI == CARA_EPI_BF16) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = (bf16)v[k];
+      } else if constexpr (EPI == CARA_EPI_GELU) {
+        // the stored pre-activation is the bf16 value; GELU is taken of that same rounded value so
+        // that forward h and backward gelu'(u) see one consistent u
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          out2[k] = (bf16)v[k];
+          out[k] = (bf16)gelu_erf((float)out2[k]);
+        }
+      } else {  // CARA_EPI_DGELU
+        const bf16* up = static_cast<const bf16*>(p.aux) + o;
+        bf16x8 u;
+        if (vec) {
+          u = *reinterpret_cast<const bf16x8*>(up);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) u[k] = (n + k < p.N) ? up[k] : (bf16)0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = (bf16)(v[k] * gelu_erf_grad((float)u[k]));
+      }
+      bf16* dst = static_cast<bf16*>(p.C) + o;
+      if (vec) {
+        *reinterpret_cast<bf16x8*>(dst) = out;
+        if constexpr (EPI == CARA_EPI_GELU) *reinterpret_cast<bf16x8*>(static_cast<bf16*>(p.C2) + o) = out2;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (n + k < p.N) {
+            dst[k] = out[k];
+            if constexpr (EPI == CARA_EPI_GELU) (static_cast<bf16*>(p.C2) + o)[k] = out2[k];
+          }
+      }
+    }
+  }
+}
