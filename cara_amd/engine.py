@@ -55,6 +55,8 @@ class CaraEngine:
         self._bwd_ready = -1
         self._flat_grad = None
         self._grad_views = None
+        from .modules import FactorPack
+        self._factors = FactorPack(self)
 
     # ------------------------------------------------------------------ frozen weights -> HBM layout
     def _backbone_params(self, model):
@@ -236,11 +238,27 @@ class CaraEngine:
                 optimizer.step()
         return self._loss_buf[0]
 
-    # module-level entries (cara.cp_attn / cara.cp_mlp)
+    # module-level entries (cara.cp_attn / cara.cp_mlp): the reference's patched forwards
+    def _weights(self, model, dev):
+        if self._ingested is None or self._ingest_sig != self._signature(model) or self._ingested[0]["cls"].device != dev:
+            self._ingest(model, dev)
+            self._ws.clear()
+        return self._ingested
+
+    def _module_args(self, x):
+        model = self._model()
+        if not x.is_cuda:
+            raise CaraError("cara_amd runs on the GPU only (no CPU fallback)")
+        if x.ndim != 3 or x.shape[2] != model.embed_dim or x.shape[1] > 224:
+            raise CaraError("module-level forward expects x of shape [B, N <= 224, embed_dim]")
+        return model, [getattr(model, "CP_" + n) for n in L.CP_FIELDS]
+
     def attn_forward(self, child, x):
-        raise CaraError("module-level Attention.forward is served by the fused whole-model path in this round: "
-                        "call the VisionTransformer itself")
+        from .modules import AttnFn
+        model, cp = self._module_args(x)
+        return AttnFn.apply(self, child, x, *cp)
 
     def mlp_forward(self, child, x):
-        raise CaraError("module-level Mlp.forward is served by the fused whole-model path in this round: "
-                        "call the VisionTransformer itself")
+        from .modules import MlpFn
+        model, cp = self._module_args(x)
+        return MlpFn.apply(self, child, x, *cp)

@@ -190,3 +190,66 @@ def test_gradients_finite_difference_direction():
                 getattr(m, n).sub_(sgn * eps * d)
     num = (vals[0] - vals[1]) / (2 * eps)
     assert abs(num - ana) <= 0.1 * abs(ana) + 1e-3, (num, ana)
+
+
+def test_module_level_forwards_against_reference_vectors():
+    """The reference's patched Attention.forward / Mlp.forward (cara.py:15-60, :63-95) called on
+    their own: golden case 2 of make_golden.py (block 5 of a depth-12 model, rank 8, x [2,7,768]) --
+    outputs recorded from the reference's own modules; gradients against fp64 autograd of the
+    oracle's as-written restatement."""
+    from oracle import cara_oracle as O
+    from tests.golden.inputs import oracle_case
+    R, Lb, sb, sc, sx, sg = G["mod_cfg"].tolist()
+    S = float(G["mod_scale"][0])
+    w, cp = oracle_case(sg, sb, sc, R, 12, 32)
+    m = build(w, cp, R, S, 12, 32).eval()
+    x = torch.randn(2, 7, 768, generator=torch.Generator().manual_seed(sx))
+    blk = m.blocks[Lb]
+    a_idx, a_aidx, m_idx = O.block_indices(12)[Lb]
+    assert (blk.attn.idx, blk.attn.attn_idx, blk.mlp.idx) == (a_idx, a_aidx, m_idx)
+    p = f"blocks.{Lb}."
+    d = lambda t: t.double()  # noqa: E731
+    for kind, mod, key in (("attn", blk.attn, "mod_attn_out"), ("mlp", blk.mlp, "mod_mlp_out")):
+        xd = x.to(DEV).requires_grad_(True)
+        for n in O.CP_NAMES:
+            getattr(m, n).grad = None
+        y = mod(xd)
+        ref = torch.from_numpy(G[key])
+        r = rel(y, ref)
+        print(f"module {kind}: rel-L2 vs reference output {r:.2e}")
+        assert r < 1e-2, (kind, r)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7))
+        y.backward(gy.to(DEV))
+        cpv = {k: d(v).clone().requires_grad_(True) for k, v in cp.items()}
+        xr = d(x).clone().requires_grad_(True)
+        if kind == "attn":
+            yr = O.attn_as_written(xr, cpv, d(w[p + "attn.qkv.weight"]), d(w[p + "attn.qkv.bias"]), d(w[p + "attn.proj.weight"]),
+                                   d(w[p + "attn.proj.bias"]), attn_idx=a_aidx, idx=a_idx, s=S, num_heads=12, scale=64 ** -0.5)
+            touched = ("CP_A1", "CP_A2", "CP_A3", "CP_A4", "CP_R1", "CP_P1", "CP_P2", "CP_P3", "CP_R2", "CP_bias1")
+        else:
+            yr = O.mlp_as_written(xr, cpv, d(w[p + "mlp.fc1.weight"]), d(w[p + "mlp.fc1.bias"]), d(w[p + "mlp.fc2.weight"]),
+                                  d(w[p + "mlp.fc2.bias"]), idx=m_idx, s=S)
+            touched = ("CP_P1", "CP_P2", "CP_P3", "CP_R2", "CP_bias2", "CP_bias3")
+        yr.backward(d(gy))
+        assert rel(xd.grad, xr.grad) < 2e-2, (kind, rel(xd.grad, xr.grad))
+        for n in touched:
+            assert rel(getattr(m, n).grad, cpv[n].grad) < 3e-2, (kind, n, rel(getattr(m, n).grad, cpv[n].grad))
+
+
+def test_blockwise_path_equals_fused_path():
+    """Calling the blocks one by one (torch LayerNorm / residual around the module-level forwards)
+    gives the fused whole-model logits up to bf16 rounding."""
+    from oracle import cara_oracle as O
+    w = O.synthetic_backbone(depth=2)
+    cp = O.synthetic_cp(rank=16)
+    x, _ = O.synthetic_batch(batch=2)
+    m = build(w, cp, 16, 0.1, 2, 224).eval()
+    with torch.no_grad():
+        fused = m(x.to(DEV))
+        pe = m.patch_embed.proj
+        t = torch.nn.functional.conv2d(x.to(DEV), pe.weight, pe.bias, stride=16).flatten(2).transpose(1, 2)
+        t = torch.cat((m.cls_token.expand(2, -1, -1), t), 1) + m.pos_embed
+        for blk in m.blocks:
+            t = blk(t)
+        blockwise = m.head(m.norm(t)[:, 0])
+    assert rel(blockwise, fused) < 1.2e-2 and torch.equal(blockwise.argmax(1), fused.argmax(1))
