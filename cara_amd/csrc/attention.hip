@@ -18,6 +18,8 @@
 // P and dS feed dV^T += dO^T P and dK^T += Q^T dS straight from the accumulators.  (2) dQ: the
 // forward's structure (wave = 32 queries, query on the lane): dS^T feeds dQ += dS K from the
 // accumulators.  No atomics, no cross-wave sums: results are bitwise reproducible.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -63,8 +65,9 @@ __device__ __forceinline__ void stage_transposed(const bf16* __restrict__ src, i
 // ------------------------------------------------------------------------------------------
 constexpr int FWD_LDS = NMAX * 128 + HD * KP * 2;  // K (swizzled rows) + V^T
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                          float* __restrict__ lse, int N, int H, float scale) {
+template <int NW>  // waves per workgroup: 7 covers N <= 224 with ONE staging of K/V per head
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                              float* __restrict__ lse, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   bf16* Vt = reinterpret_cast<bf16*>(smem + NMAX * 128);
@@ -75,15 +78,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
   const bf16* kb = qb + H * HD;
   const bf16* vb = qb + 2 * H * HD;
 
-  for (int idx = tid; idx < NMAX * 8; idx += 256) {
+  for (int idx = tid; idx < NMAX * 8; idx += NW * 64) {
     const int n = idx >> 3, c = idx & 7;
     const int nn = n < N ? n : N - 1;
     *reinterpret_cast<uint4*>(Ks + swz128(n, c)) = *reinterpret_cast<const uint4*>(kb + (size_t)nn * ld + c * 8);
   }
-  stage_transposed(vb, ld, N, Vt, tid, 256);
+  stage_transposed(vb, ld, N, Vt, tid, NW * 64);
   __syncthreads();
 
-  const int q0 = (blockIdx.y * 4 + wave) * 32;
+  const int q0 = (blockIdx.y * NW + wave) * 32;
   if (q0 >= N) return;
   const int ql = lane & 31, h = lane >> 5;
   const int qrow = (q0 + ql) < N ? (q0 + ql) : N - 1;
@@ -306,9 +309,10 @@ __global__ __launch_bounds__(448, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 // ------------------------------------------------------------------------------------------
 constexpr int DQ_LDS = 2 * NMAX * 128 + HD * KP * 2;  // K rows, V rows (swizzled) + K^T
 
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
-                                                             const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                             bf16* __restrict__ dqkv, int N, int H, float scale) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                                 const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                                 bf16* __restrict__ dqkv, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + NMAX * 128;
@@ -321,12 +325,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const bf16* __restr
   const bf16* vb = qb + 2 * H * HD;
   const bf16* ob = out + (size_t)b * N * ldo + head * HD;
   const bf16* dob = dout + (size_t)b * N * ldo + head * HD;
-  stage_rows_swz(kb, ld, N, Ks, tid, 256);
-  stage_rows_swz(vb, ld, N, Vs, tid, 256);
-  stage_transposed(kb, ld, N, Kt, tid, 256);
+  stage_rows_swz(kb, ld, N, Ks, tid, NW * 64);
+  stage_rows_swz(vb, ld, N, Vs, tid, NW * 64);
+  stage_transposed(kb, ld, N, Kt, tid, NW * 64);
   __syncthreads();
 
-  const int q0 = (blockIdx.y * 4 + wave) * 32;
+  const int q0 = (blockIdx.y * NW + wave) * 32;
   if (q0 >= N) return;
   const int ql = lane & 31, h = lane >> 5;
   const int qrow = (q0 + ql) < N ? (q0 + ql) : N - 1;
@@ -393,16 +397,30 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const bf16* __restr
 
 }  // namespace
 
+// CARA_ATTN_WAVES=4 selects the 4-wave workgroups (two per head at N = 197) for A/B measurements
+static int attn_waves(int N) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("CARA_ATTN_WAVES");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced == 4 || forced == 7) return forced;
+  return N > 128 ? 7 : 4;
+}
+
 extern "C" int cara_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, void* stream) {
   if (!qkv || !out || !lse || B <= 0 || H <= 0 || N <= 0 || N > NMAX) return CARA_E_ARG;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
     attr_set = true;
   }
-  const dim3 grid(B * H, (N + 127) / 128);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), FWD_LDS, static_cast<hipStream_t>(stream), (const bf16*)qkv,
-                     (bf16*)out, lse, N, H, scale);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (attn_waves(N) == 7)
+    hipLaunchKernelGGL(attn_fwd_kernel<7>, dim3(B * H, (N + 223) / 224), dim3(448), FWD_LDS, st, (const bf16*)qkv, (bf16*)out, lse, N, H, scale);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(B * H, (N + 127) / 128), dim3(256), FWD_LDS, st, (const bf16*)qkv, (bf16*)out, lse, N, H, scale);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }
@@ -413,15 +431,20 @@ extern "C" int cara_attention_bwd(const void* qkv, const void* out, const void* 
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS);
     attr_set = true;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H), dim3(448), DKV_LDS, st, (const bf16*)qkv, (const bf16*)out,
                      (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale);
   CARA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(B * H, (N + 127) / 128), dim3(256), DQ_LDS, st, (const bf16*)qkv,
-                     (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale);
+  if (attn_waves(N) == 7)
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<7>, dim3(B * H, (N + 223) / 224), dim3(448), DQ_LDS, st, (const bf16*)qkv,
+                       (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale);
+  else
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, dim3(B * H, (N + 127) / 128), dim3(256), DQ_LDS, st, (const bf16*)qkv,
+                       (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }

@@ -266,6 +266,12 @@ extern "C" int cara_skinny_xu(const void* X, int ldx, const void* Ut, void* T, v
   if (!X || !Ut || !T || M <= 0 || K <= 0 || (K & 31) || (ldx & 7) || ldx < K) return CARA_E_ARG;
   if (Tt && (ldt < M || (ldt & 7))) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // consumers (cara_tskinny_*) read Tt in whole 32-row steps: keep columns [M, roundup32(M)) zero even
+  // when the buffer is shared between products of different M
+  const int m32 = (M + 31) / 32 * 32;
+  if (Tt && m32 > M && m32 <= ldt &&
+      hipMemset2DAsync(static_cast<bf16*>(Tt) + M, (size_t)ldt * 2, 0, (size_t)(m32 - M) * 2, Rp, st) != hipSuccess)
+    return CARA_E_LAUNCH;
   const dim3 grid((M + 15) / 16), block(256);
   if (Rp == 32)
     hipLaunchKernelGGL(skinny_xu_kernel<2>, grid, block, 0, st, (const bf16*)X, ldx, (const bf16*)Ut, (bf16*)T, (bf16*)Tt, ldt, M, K);

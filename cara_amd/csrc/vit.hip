@@ -5,6 +5,8 @@
 // materialised and no dense weight gradient exists; the frozen backbone only propagates dX.
 // Host side is plain C++ in the library so a train step costs two FFI calls and the whole
 // sequence can be captured in a hipGraph (nothing here allocates or synchronises).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -113,32 +115,36 @@ struct Lin {  // one adapted linear of one layer
   int in, out, slot;
 };
 
-// forward of one adapted linear: T = X U ; C = [X | T] [W | Vs]^T + bias -> epilogue
-int lin_fwd(const Lin& L, const bf16* X, int M, int Rp, int ldt, char* ws, const LayerWs& lw, cara_gemm_args a, void* st) {
+// forward of one adapted linear on Mr rows of X (row stride ldx): T = X U ;
+// C = [X | T] [W | Vs]^T + bias -> epilogue (a.ldc == 0: dense output)
+int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char* ws, const LayerWs& lw, cara_gemm_args a, void* st) {
   bf16* T = reinterpret_cast<bf16*>(ws + lw.T[L.slot]);
   bf16* Tt = reinterpret_cast<bf16*>(ws + lw.Tt[L.slot]);
-  TRY(cara_skinny_xu(X, L.in, L.Ut, T, Tt, ldt, M, L.in, Rp, st));
-  a.A = X; a.lda = L.in; a.B = L.W; a.ldb = L.in; a.A2 = T; a.B2 = L.Vs; a.Rp = Rp;
-  a.M = M; a.N = L.out; a.K = L.in; a.bias = L.bias; a.ldc = L.out;
+  TRY(cara_skinny_xu(X, ldx, L.Ut, T, Tt, ldt, Mr, L.in, Rp, st));
+  a.A = X; a.lda = ldx; a.B = L.W; a.ldb = L.in; a.A2 = T; a.B2 = L.Vs; a.Rp = Rp;
+  a.M = Mr; a.N = L.out; a.K = L.in; a.bias = L.bias;
+  if (a.ldc == 0) a.ldc = L.out;
   return cara_gemm_bf16(&a, st);
 }
 
-// backward of one adapted linear given dY (bf16 [M,out]) and its saved input X:
+// backward of one adapted linear given dY (bf16, Mr rows, row stride lddy) and its saved input X
+// (row stride ldx):
 //   G' = dY Vs ; dX = [dY | G'] [W^T | U]^T (optional) ; dU = X^T G' ; dVs = dY^T T ; dc = colsum dY
-int lin_bwd(const Lin& L, const bf16* dY, const bf16* X, int M, int Rp, int ldt, char* ws, const Ws& W, const LayerWs& lw,
-            int layer, bool want_dx, cara_gemm_args a, bool want_dc, void* st) {
+int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int Mr, int Rp, int ldt, char* ws, const Ws& W,
+            const LayerWs& lw, int layer, bool want_dx, cara_gemm_args a, bool want_dc, void* st) {
   bf16* G = reinterpret_cast<bf16*>(ws + W.G);
   bf16* Gt = reinterpret_cast<bf16*>(ws + W.Gt);
-  TRY(cara_skinny_xu(dY, L.out, L.Vst, G, Gt, ldt, M, L.out, Rp, st));
+  TRY(cara_skinny_xu(dY, lddy, L.Vst, G, Gt, ldt, Mr, L.out, Rp, st));
   if (want_dx) {
-    a.A = dY; a.lda = L.out; a.B = L.Wt; a.ldb = L.out; a.A2 = G; a.B2 = L.U; a.Rp = Rp;
-    a.M = M; a.N = L.in; a.K = L.out; a.bias = nullptr; a.ldc = L.in;
+    a.A = dY; a.lda = lddy; a.B = L.Wt; a.ldb = L.out; a.A2 = G; a.B2 = L.U; a.Rp = Rp;
+    a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
+    if (a.ldc == 0) a.ldc = L.in;
     TRY(cara_gemm_bf16(&a, st));
   }
   // partial slabs now; their fixed-order sums run once per linear after the layer loop
-  TRY(cara_tskinny_partial(X, L.in, Gt, ldt, ws + W.slabU[L.slot] + (size_t)layer * W.strideU[L.slot], 0, M, L.in, Rp, st));
-  TRY(cara_tskinny_partial(dY, L.out, ws + lw.Tt[L.slot], ldt, ws + W.slabV[L.slot] + (size_t)layer * W.strideV[L.slot],
-                           want_dc ? 1 : 0, M, L.out, Rp, st));
+  TRY(cara_tskinny_partial(X, ldx, Gt, ldt, ws + W.slabU[L.slot] + (size_t)layer * W.strideU[L.slot], 0, Mr, L.in, Rp, st));
+  TRY(cara_tskinny_partial(dY, lddy, ws + lw.Tt[L.slot], ldt, ws + W.slabV[L.slot] + (size_t)layer * W.strideV[L.slot],
+                           want_dc ? 1 : 0, Mr, L.out, Rp, st));
   return CARA_OK;
 }
 
@@ -167,6 +173,16 @@ struct Prof {
   bool made = false;
 };
 Prof g_prof;
+
+// CARA_CLS_SHORTCUT=0 turns the exact last-block shortcut off (A/B measurements only)
+bool cls_shortcut_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CARA_CLS_SHORTCUT");
+    v = e ? atoi(e) : 1;
+  }
+  return v != 0;
+}
 
 // tiny classifier-head backward (B x classes x D, fp32 VALU)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl, const bf16* __restrict__ xn,
@@ -265,22 +281,30 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
     float* x_out = reinterpret_cast<float*>(ws + (l + 1 < g->depth ? W.layer[l + 1].x_in : W.x_last));
     const float* dp1 = droppath ? droppath + (size_t)(2 * l) * B : nullptr;
     const float* dp2 = droppath ? droppath + (size_t)(2 * l + 1) * B : nullptr;
+    // Only the cls token of the LAST block's output reaches the logits (timm takes x[:, 0] after
+    // the final norm), and proj / LayerNorm / fc1 / fc2 act per token: in the last block they run
+    // on the B cls rows only (row stride N*D).  Exact, not an approximation: every other row of
+    // that block's proj/MLP output is dead.  qkv and attention still see all tokens (keys/values).
+    const bool cls_only = (l == g->depth - 1) && cls_shortcut_enabled();
+    const int Mr = cls_only ? B : M;
+    const int ldr = cls_only ? N * D : D;          // row stride of the residual stream rows used
+    const int rps = cls_only ? 1 : N;              // rows per sample for the DropPath multipliers
     // x = x + drop_path(attn(norm1(x)))
     TRY(cara_layernorm_fwd(x_in, D, w->ln1_g + (size_t)l * D, w->ln1_b + (size_t)l * D, ws + lw.xn1,
                            reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), M, D, s->eps, stream));
     cara_gemm_args e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + lw.qkv;
-    TRY(lin_fwd(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), M, Rp, W.ldt, ws, lw, e, stream));
+    TRY(lin_fwd(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, W.ldt, ws, lw, e, stream));
     TRY(cara_attention_fwd(ws + lw.qkv, ws + lw.ao, reinterpret_cast<float*>(ws + lw.lse), B, N, g->heads, att_scale, stream));
     e = {};
-    e.epi = CARA_EPI_RESID; e.C = x_mid; e.aux = x_in; e.rowscale = dp1; e.rows_per_sample = N;
-    TRY(lin_fwd(lin[1], reinterpret_cast<bf16*>(ws + lw.ao), M, Rp, W.ldt, ws, lw, e, stream));
+    e.epi = CARA_EPI_RESID; e.C = x_mid; e.aux = x_in; e.rowscale = dp1; e.rows_per_sample = rps; e.ldc = ldr;
+    TRY(lin_fwd(lin[1], reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, lw, e, stream));
     // x = x + drop_path(mlp(norm2(x)))
-    TRY(cara_layernorm_fwd(x_mid, D, w->ln2_g + (size_t)l * D, w->ln2_b + (size_t)l * D, ws + lw.xn2,
-                           reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), M, D, s->eps, stream));
+    TRY(cara_layernorm_fwd(x_mid, ldr, w->ln2_g + (size_t)l * D, w->ln2_b + (size_t)l * D, ws + lw.xn2,
+                           reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), Mr, D, s->eps, stream));
     e = {};
     e.epi = CARA_EPI_GELU; e.C = ws + lw.h; e.C2 = ws + lw.u;
-    if (g_prof.on) {
+    if (g_prof.on && !cls_only) {
       // T first, so that the bracket holds exactly one kernel: the fc1 GEMM
       bf16* T = reinterpret_cast<bf16*>(ws + lw.T[2]);
       TRY(cara_skinny_xu(ws + lw.xn2, D, lin[2].Ut, T, ws + lw.Tt[2], W.ldt, M, D, Rp, stream));
@@ -292,11 +316,11 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
       hipEventRecord(g_prof.ev[l][1], static_cast<hipStream_t>(stream));
       g_prof.n = l + 1;
     } else {
-      TRY(lin_fwd(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), M, Rp, W.ldt, ws, lw, e, stream));
+      TRY(lin_fwd(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, W.ldt, ws, lw, e, stream));
     }
     e = {};
-    e.epi = CARA_EPI_RESID; e.C = x_out; e.aux = x_mid; e.rowscale = dp2; e.rows_per_sample = N;
-    TRY(lin_fwd(lin[3], reinterpret_cast<bf16*>(ws + lw.h), M, Rp, W.ldt, ws, lw, e, stream));
+    e.epi = CARA_EPI_RESID; e.C = x_out; e.aux = x_mid; e.rowscale = dp2; e.rows_per_sample = rps; e.ldc = ldr;
+    TRY(lin_fwd(lin[3], reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, W.ldt, ws, lw, e, stream));
   }
   // norm -> cls token -> head  (LayerNorm is per token, so only the cls rows are normalised)
   TRY(cara_layernorm_fwd(reinterpret_cast<float*>(ws + W.x_last), (long)N * D, w->norm_g, w->norm_b, ws + W.clsn,
@@ -334,28 +358,34 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     make_lins(g, w, ws + W.pack, pl, l, lin);
     const float* dp1 = droppath ? droppath + (size_t)(2 * l) * B : nullptr;
     const float* dp_prev = (droppath && l > 0) ? droppath + (size_t)(2 * (l - 1) + 1) * B : nullptr;
+    // last block: only the cls rows carry gradient into proj / MLP (see cara_vit_forward)
+    const bool cls_only = (l == g->depth - 1) && cls_shortcut_enabled();
+    const int Mr = cls_only ? B : M;
+    const int ldr = cls_only ? N * D : D;
+    const int rps = cls_only ? 1 : N;
     // ---- mlp branch: dY = drop_path scale * dx (already in dyb) ----
     cara_gemm_args e = {};
     e.epi = CARA_EPI_DGELU; e.C = ws + W.dH; e.aux = ws + lw.u;
-    TRY(lin_bwd(lin[3], dyb, reinterpret_cast<bf16*>(ws + lw.h), M, Rp, W.ldt, ws, W, lw, l, true, e, true, stream));
+    TRY(lin_bwd(lin[3], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, W.ldt, ws, W, lw, l, true, e, true, stream));
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
-    TRY(lin_bwd(lin[2], reinterpret_cast<bf16*>(ws + W.dH), reinterpret_cast<bf16*>(ws + lw.xn2), M, Rp, W.ldt, ws, W, lw, l,
-                true, e, true, stream));
-    TRY(cara_layernorm_bwd(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_mid), D, w->ln2_g + (size_t)l * D,
-                           reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyb, dp1, N,
-                           M, D, stream));
+    TRY(lin_bwd(lin[2], reinterpret_cast<bf16*>(ws + W.dH), 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, W.ldt, ws, W,
+                lw, l, true, e, true, stream));
+    TRY(cara_layernorm_bwd(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_mid), ldr, w->ln2_g + (size_t)l * D,
+                           reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyb, dp1, rps,
+                           Mr, D, stream));
     // ---- attention branch ----
     e = {};
-    e.epi = CARA_EPI_BF16; e.C = ws + W.dAO;
-    TRY(lin_bwd(lin[1], dyb, reinterpret_cast<bf16*>(ws + lw.ao), M, Rp, W.ldt, ws, W, lw, l, true, e, true, stream));
+    e.epi = CARA_EPI_BF16; e.C = ws + W.dAO; e.ldc = ldr;
+    if (cls_only && hipMemsetAsync(ws + W.dAO, 0, (size_t)M * D * 2, hs) != hipSuccess) return CARA_E_LAUNCH;
+    TRY(lin_bwd(lin[1], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, W, lw, l, true, e, true, stream));
     TRY(cara_attention_bwd(ws + lw.qkv, ws + lw.ao, ws + W.dAO, reinterpret_cast<float*>(ws + lw.lse), ws + W.dQKV, B, N,
                            g->heads, att_scale, stream));
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
     // block 0 has nothing trainable upstream of it: its dX GEMM and LayerNorm backward are skipped
-    TRY(lin_bwd(lin[0], reinterpret_cast<bf16*>(ws + W.dQKV), reinterpret_cast<bf16*>(ws + lw.xn1), M, Rp, W.ldt, ws, W, lw, l,
-                l > 0, e, false, stream));
+    TRY(lin_bwd(lin[0], reinterpret_cast<bf16*>(ws + W.dQKV), 3 * D, reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, W.ldt, ws, W,
+                lw, l, l > 0, e, false, stream));
     if (l > 0)
       TRY(cara_layernorm_bwd(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_in), D, w->ln1_g + (size_t)l * D,
                              reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), dx, dx, dyb,
@@ -363,11 +393,24 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
   }
   {
     const int ins[4] = {D, D, D, 4 * D}, outs[4] = {3 * D, D, 4 * D, D};
+    const int L = g->depth;
     for (int i = 0; i < 4; ++i) {
-      TRY(cara_tskinny_reduce(ws + W.slabU[i], W.strideU[i], reinterpret_cast<float*>(ws + W.dU[i]), nullptr, g->depth, M,
-                              ins[i], Rp, stream));
-      TRY(cara_tskinny_reduce(ws + W.slabV[i], W.strideV[i], reinterpret_cast<float*>(ws + W.dVs[i]),
-                              i == 0 ? nullptr : reinterpret_cast<float*>(ws + W.dc[i]), g->depth, M, outs[i], Rp, stream));
+      float* dU = reinterpret_cast<float*>(ws + W.dU[i]);
+      float* dVs = reinterpret_cast<float*>(ws + W.dVs[i]);
+      float* dc = i == 0 ? nullptr : reinterpret_cast<float*>(ws + W.dc[i]);
+      // qkv (i == 0) sees all tokens in every block; proj / fc1 / fc2 of the last block ran on B rows,
+      // so that block's slabs have their own chunking
+      const int full = (i == 0 || !cls_shortcut_enabled()) ? L : L - 1;
+      if (full > 0) {
+        TRY(cara_tskinny_reduce(ws + W.slabU[i], W.strideU[i], dU, nullptr, full, M, ins[i], Rp, stream));
+        TRY(cara_tskinny_reduce(ws + W.slabV[i], W.strideV[i], dVs, dc, full, M, outs[i], Rp, stream));
+      }
+      if (i != 0 && cls_shortcut_enabled()) {
+        const size_t l = L - 1;
+        TRY(cara_tskinny_reduce(ws + W.slabU[i] + l * W.strideU[i], 0, dU + l * ins[i] * Rp, nullptr, 1, B, ins[i], Rp, stream));
+        TRY(cara_tskinny_reduce(ws + W.slabV[i] + l * W.strideV[i], 0, dVs + l * outs[i] * Rp, dc + l * outs[i], 1, B, outs[i], Rp,
+                                stream));
+      }
     }
   }
   cara_layer_grads lg;
