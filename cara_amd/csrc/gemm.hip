@@ -153,17 +153,17 @@ int launch(const cara_gemm_args* a, hipStream_t st) {
 
 int cara_gemm256_dispatch(const cara_gemm_args* a, hipStream_t st);  // gemm256.hip
 
-// 256x256 tile for the large products, 128x128 for small ones (head, tests).  CARA_GEMM_TILE=128|256
-// in the environment pins one tile for A/B measurements.
+// The 128x128 tile is the default for every shape: on the shapes of this model it is the fastest
+// of the structures measured so far.  CARA_GEMM_TILE=256 in the environment
+// selects the 256x256 LDS-ring kernel of gemm256.hip for A/B measurements.
 static bool use_tile256(const cara_gemm_args* a) {
   static int forced = -1;
   if (forced < 0) {
     const char* e = getenv("CARA_GEMM_TILE");
     forced = e ? atoi(e) : 0;
   }
-  if (forced == 128) return false;
-  if (forced == 256) return true;
-  return a->M >= 1024 && a->N >= 512;
+  (void)a;
+  return forced == 256;
 }
 
 extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
