@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcara_hip.so")
+# CARA_LIB_PATH (diagnostic) points at another build of the same ABI for same-box A/B timing
+LIB_PATH = os.environ.get("CARA_LIB_PATH") or os.path.join(_HERE, "libcara_hip.so")
 
 # every symbol include/cara_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (

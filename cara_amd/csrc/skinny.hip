@@ -12,9 +12,90 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// T = X . Ut^T.  Block = 16 rows x all Rp columns; the 4 waves split K (k-step w, w+4, ...:
-// adjacent waves read adjacent 64-B pieces of a row) and reduce through LDS.
+// T = X . Ut^T.  A workgroup owns 64 rows (4 groups of 16); wave w owns the K-slice
+// [192 w, 192 w + 192) and keeps its Ut fragments (6 k-steps x NT) in registers for all four row
+// groups, so X is the only stream (v1 re-read Ut from L2 for every 16 rows: two thirds of its
+// load instructions).  The A fragments of the next row group are issued before the MFMAs of the
+// current one; per group the K-slices are summed through LDS and written as T (row-major bf16)
+// and T^T (the MFMA C layout holds 4 consecutive rows per lane: 8-byte stores).
+// Waves per workgroup = K / 192 (4 / 12 / 16 for K = 768 / 2304 / 3072); other K fall back to v1.
 // ------------------------------------------------------------------------------------------
+constexpr int XU_KSLICE = 192, XU_GROUPS = 4;
+
+template <int NT>
+__global__ __launch_bounds__(1024) void skinny_xu_sliced_kernel(const bf16* __restrict__ X, int ldx,
+                                                                const bf16* __restrict__ Ut,
+                                                                bf16* __restrict__ T, bf16* __restrict__ Tt,
+                                                                int ldt, int M, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* red = reinterpret_cast<f32x4*>(smem);   // [nwaves][NT][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  constexpr int Rp = NT * 16, KS = XU_KSLICE / 32;
+  const int k0 = wave * XU_KSLICE + fq * 8;
+  bf16x8 u[KS][NT];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) u[ks][j] = *reinterpret_cast<const bf16x8*>(Ut + (size_t)(j * 16 + fr) * K + k0 + ks * 32);
+  const int mblk = blockIdx.x * (16 * XU_GROUPS);
+  bf16x8 a[KS], an[KS];
+  {
+    int r = mblk + fr;
+    r = r < M ? r : M - 1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(X + (size_t)r * ldx + k0 + ks * 32);
+  }
+#pragma unroll
+  for (int g = 0; g < XU_GROUPS; ++g) {
+    const int m0 = mblk + g * 16;
+    if (g + 1 < XU_GROUPS) {
+      int r = m0 + 16 + fr;
+      r = r < M ? r : M - 1;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) an[ks] = *reinterpret_cast<const bf16x8*>(X + (size_t)r * ldx + k0 + ks * 32);
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], u[ks][j], acc[j], 0, 0, 0);
+    if (g > 0) __syncthreads();   // the previous group's sums have been read
+#pragma unroll
+    for (int j = 0; j < NT; ++j) red[(wave * NT + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    if (m0 < M) {
+      for (int nt = wave; nt < NT; nt += nwaves) {
+        f32x4 s = red[nt * 64 + lane];
+        for (int w = 1; w < nwaves; ++w) {
+          const f32x4 v = red[(w * NT + nt) * 64 + lane];
+          s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
+        const int n = nt * 16 + fr;
+        const int mb = m0 + fq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (mb + r < M) T[(size_t)(mb + r) * Rp + n] = (bf16)s[r];
+        if (Tt) {
+          if (mb + 3 < M) {
+            bf16x4 pk = {(bf16)s[0], (bf16)s[1], (bf16)s[2], (bf16)s[3]};
+            *reinterpret_cast<bf16x4*>(Tt + (size_t)n * ldt + mb) = pk;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (mb + r < M) Tt[(size_t)n * ldt + mb + r] = (bf16)s[r];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[ks] = an[ks];
+  }
+}
+
+// v1 (any K % 32 == 0): block = 16 rows, the 4 waves take k-steps w, w+4, ... and reduce through LDS.
 template <int NT>  // Rp / 16
 __global__ __launch_bounds__(256) void skinny_xu_kernel(const bf16* __restrict__ X, int ldx,
                                                         const bf16* __restrict__ Ut,
@@ -272,6 +353,18 @@ extern "C" int cara_skinny_xu(const void* X, int ldx, const void* Ut, void* T, v
   if (Tt && m32 > M && m32 <= ldt &&
       hipMemset2DAsync(static_cast<bf16*>(Tt) + M, (size_t)ldt * 2, 0, (size_t)(m32 - M) * 2, Rp, st) != hipSuccess)
     return CARA_E_LAUNCH;
+  const bf16* x = (const bf16*)X;
+  const bf16* u = (const bf16*)Ut;
+  // (Rp = 64 would need 96 VGPRs of Ut fragments per wave: over the 128-VGPR budget of a
+  // 1024-thread workgroup, so rank > 32 stays on v1)
+  if (Rp == 32 && K % XU_KSLICE == 0 && K / XU_KSLICE <= 16 && M >= 64) {
+    const int nw = K / XU_KSLICE;
+    const dim3 g2((M + 16 * XU_GROUPS - 1) / (16 * XU_GROUPS)), b2(nw * 64);
+    const size_t lds = (size_t)nw * 2 * 64 * sizeof(f32x4);
+    hipLaunchKernelGGL(skinny_xu_sliced_kernel<2>, g2, b2, lds, st, x, ldx, u, (bf16*)T, (bf16*)Tt, ldt, M, K);
+    CARA_CHECK_LAUNCH();
+    return CARA_OK;
+  }
   const dim3 grid((M + 15) / 16), block(256);
   if (Rp == 32)
     hipLaunchKernelGGL(skinny_xu_kernel<2>, grid, block, 0, st, (const bf16*)X, ldx, (const bf16*)Ut, (bf16*)T, (bf16*)Tt, ldt, M, K);
