@@ -213,19 +213,31 @@ __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N == 0, "unsupported vmcnt");
 }
 
+// one product D = X^T G; two of them (dU and dVs of one linear) share a launch
+struct TsProblem {
+  const bf16* X; const bf16* Gt;
+  float* slabs; float* cs_slabs;     // cs_slabs == nullptr: no column sums wanted for this problem
+  int ldx, K1, nchunks, nblk;
+};
+
 template <int NT, bool COLSUM>
-__global__ __launch_bounds__(256) void tskinny_kernel(const bf16* __restrict__ X, int ldx,
-                                                      const bf16* __restrict__ Gt, int ldg,
-                                                      float* __restrict__ slabs,
-                                                      float* __restrict__ cs_slabs, int M, int K1,
-                                                      int nchunks) {
+__global__ __launch_bounds__(256) void tskinny_kernel(const TsProblem p0, const TsProblem p1, int ldg, int M) {
   using R = TsRing<NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
+  const bool second = (int)blockIdx.x >= p0.nblk;
+  const TsProblem& P = second ? p1 : p0;
+  const int bid = second ? blockIdx.x - p0.nblk : blockIdx.x;
+  const bf16* __restrict__ X = P.X;
+  const bf16* __restrict__ Gt = P.Gt;
+  float* __restrict__ slabs = P.slabs;
+  float* __restrict__ cs_slabs = P.cs_slabs;
+  const int ldx = P.ldx, K1 = P.K1, nchunks = P.nchunks;
+  const bool want_cs = COLSUM && cs_slabs != nullptr;
   const int colblocks = K1 / TS_COLS;
-  const int cb = blockIdx.x % colblocks, chunk = blockIdx.x / colblocks;
+  const int cb = bid % colblocks, chunk = bid / colblocks;
   const int i0 = cb * TS_COLS;
   const int steps = (M + 31) / 32;
   const int s_begin = (int)((long)steps * chunk / nchunks), s_end = (int)((long)steps * (chunk + 1) / nchunks);
@@ -269,8 +281,10 @@ __global__ __launch_bounds__(256) void tskinny_kernel(const bf16* __restrict__ X
 #pragma unroll
       for (int j = 0; j < 8; ++j) b[j] = *reinterpret_cast<const bf16*>(sx + (fq * 8 + j) * 128 + off);
       if constexpr (COLSUM) {
+        if (want_cs) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) csum[it] += (mrow + j < M) ? (float)b[j] : 0.f;
+          for (int j = 0; j < 8; ++j) csum[it] += (mrow + j < M) ? (float)b[j] : 0.f;
+        }
       }
 #pragma unroll
       for (int rt = 0; rt < NT; ++rt)
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(256) void tskinny_kernel(const bf16* __restrict__ X
     for (int it = 0; it < 4; ++it) cred[(wave * 4 + it) * 64 + lane] = csum[it];
   }
   __syncthreads();
-  float* slab = slabs + (size_t)blockIdx.x * TS_COLS * (NT * 16);
+  float* slab = slabs + (size_t)bid * TS_COLS * (NT * 16);
   for (int t = wave; t < NT * 4; t += 4) {
     f32x4 s = red[t * 64 + lane];
 #pragma unroll
@@ -303,14 +317,14 @@ __global__ __launch_bounds__(256) void tskinny_kernel(const bf16* __restrict__ X
     *reinterpret_cast<f32x4*>(slab + (size_t)(it * 16 + fr) * (NT * 16) + rt * 16 + fq * 4) = s;
   }
   if constexpr (COLSUM) {
-    if (tid < TS_COLS) {
+    if (want_cs && tid < TS_COLS) {
       const int it = tid >> 4, f = tid & 15;
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w)
 #pragma unroll
         for (int q = 0; q < 4; ++q) s += cred[(w * 4 + it) * 64 + q * 16 + f];
-      cs_slabs[(size_t)blockIdx.x * TS_COLS + tid] = s;
+      cs_slabs[(size_t)bid * TS_COLS + tid] = s;
     }
   }
 }
@@ -382,36 +396,62 @@ extern "C" size_t cara_tskinny_scratch_bytes(int M, int K1, int Rp) {
   return nblk * TS_COLS * Rp * sizeof(float) + nblk * TS_COLS * sizeof(float);
 }
 
-extern "C" int cara_tskinny_partial(const void* X, int ldx, const void* Gt, int ldg, void* slabs, int want_colsum,
-                                    int M, int K1, int Rp, void* stream) {
-  if (!X || !Gt || !slabs || M <= 0 || K1 <= 0 || (K1 % TS_COLS) || (ldx & 7) || ldx < K1) return CARA_E_ARG;
+namespace {
+bool ts_args_ok(const void* X, int ldx, const void* Gt, int ldg, void* slabs, int M, int K1, int Rp) {
+  if (!X || !Gt || !slabs || M <= 0 || K1 <= 0 || (K1 % TS_COLS) || (ldx & 7) || ldx < K1) return false;
   // Gt rows must be readable (and zero) up to the next multiple of 32 rows of M
-  if ((ldg & 7) || ldg < ((M + 31) / 32) * 32) return CARA_E_ARG;
-  if (!(Rp == 32 || Rp == 64)) return CARA_E_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int nchunks = ts_chunks(M, K1);
-  const int nblk = (K1 / TS_COLS) * nchunks;
-  float* sl = static_cast<float*>(slabs);
-  float* cs = sl + (size_t)nblk * TS_COLS * Rp;
-  const bf16* x = (const bf16*)X;
-  const bf16* g = (const bf16*)Gt;
+  if ((ldg & 7) || ldg < ((M + 31) / 32) * 32) return false;
+  return Rp == 32 || Rp == 64;
+}
+TsProblem ts_problem(const void* X, int ldx, const void* Gt, void* slabs, int want_colsum, int M, int K1, int Rp) {
+  TsProblem p;
+  p.X = (const bf16*)X; p.Gt = (const bf16*)Gt; p.ldx = ldx; p.K1 = K1;
+  p.nchunks = ts_chunks(M, K1);
+  p.nblk = (K1 / TS_COLS) * p.nchunks;
+  p.slabs = static_cast<float*>(slabs);
+  p.cs_slabs = want_colsum ? p.slabs + (size_t)p.nblk * TS_COLS * Rp : nullptr;
+  return p;
+}
+int ts_launch(const TsProblem& a, const TsProblem& b, int ldg, int M, int Rp, bool any_cs, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tskinny_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TsRing<4>::WAVE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tskinny_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TsRing<4>::WAVE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tskinny_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TsRing<2>::WAVE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tskinny_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TsRing<2>::WAVE_BYTES);
+    attr_set = true;
+  }
+  const dim3 grid(a.nblk + b.nblk), block(256);
   if (Rp == 32) {
     const size_t lds = 4 * TsRing<2>::WAVE_BYTES;
-    if (want_colsum) hipLaunchKernelGGL((tskinny_kernel<2, true>), dim3(nblk), dim3(256), lds, st, x, ldx, g, ldg, sl, cs, M, K1, nchunks);
-    else hipLaunchKernelGGL((tskinny_kernel<2, false>), dim3(nblk), dim3(256), lds, st, x, ldx, g, ldg, sl, cs, M, K1, nchunks);
+    if (any_cs) hipLaunchKernelGGL((tskinny_kernel<2, true>), grid, block, lds, st, a, b, ldg, M);
+    else hipLaunchKernelGGL((tskinny_kernel<2, false>), grid, block, lds, st, a, b, ldg, M);
   } else {
-    static bool attr_set = false;
     const size_t lds = 4 * TsRing<4>::WAVE_BYTES;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tskinny_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tskinny_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
-    }
-    if (want_colsum) hipLaunchKernelGGL((tskinny_kernel<4, true>), dim3(nblk), dim3(256), lds, st, x, ldx, g, ldg, sl, cs, M, K1, nchunks);
-    else hipLaunchKernelGGL((tskinny_kernel<4, false>), dim3(nblk), dim3(256), lds, st, x, ldx, g, ldg, sl, cs, M, K1, nchunks);
+    if (any_cs) hipLaunchKernelGGL((tskinny_kernel<4, true>), grid, block, lds, st, a, b, ldg, M);
+    else hipLaunchKernelGGL((tskinny_kernel<4, false>), grid, block, lds, st, a, b, ldg, M);
   }
   CARA_CHECK_LAUNCH();
   return CARA_OK;
+}
+}  // namespace
+
+extern "C" int cara_tskinny_partial(const void* X, int ldx, const void* Gt, int ldg, void* slabs, int want_colsum,
+                                    int M, int K1, int Rp, void* stream) {
+  if (!ts_args_ok(X, ldx, Gt, ldg, slabs, M, K1, Rp)) return CARA_E_ARG;
+  const TsProblem a = ts_problem(X, ldx, Gt, slabs, want_colsum, M, K1, Rp);
+  TsProblem none = a;
+  none.nblk = 0;
+  return ts_launch(a, none, ldg, M, Rp, want_colsum != 0, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cara_tskinny_partial2(const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
+                                     const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b,
+                                     int ldg, int M, int Rp, void* stream) {
+  if (!ts_args_ok(Xa, ldxa, Gta, ldg, slabs_a, M, K1a, Rp) || !ts_args_ok(Xb, ldxb, Gtb, ldg, slabs_b, M, K1b, Rp)) return CARA_E_ARG;
+  const TsProblem a = ts_problem(Xa, ldxa, Gta, slabs_a, 0, M, K1a, Rp);
+  const TsProblem b = ts_problem(Xb, ldxb, Gtb, slabs_b, want_colsum_b, M, K1b, Rp);
+  return ts_launch(a, b, ldg, M, Rp, want_colsum_b != 0, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int cara_tskinny_reduce(const void* slabs, size_t slab_stride, float* D, float* colsum, int batch, int M,

@@ -142,10 +142,9 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
     TRY(cara_gemm_bf16(&a, st));
   }
   // partial slabs now; their fixed-order sums run once per linear after the layer loop
-  TRY(cara_tskinny_partial(X, ldx, Gt, ldt, ws + W.slabU[L.slot] + (size_t)layer * W.strideU[L.slot], 0, Mr, L.in, Rp, st));
-  TRY(cara_tskinny_partial(dY, lddy, ws + lw.Tt[L.slot], ldt, ws + W.slabV[L.slot] + (size_t)layer * W.strideV[L.slot],
-                           want_dc ? 1 : 0, Mr, L.out, Rp, st));
-  return CARA_OK;
+  return cara_tskinny_partial2(X, ldx, Gt, ws + W.slabU[L.slot] + (size_t)layer * W.strideU[L.slot], L.in,
+                               dY, lddy, ws + lw.Tt[L.slot], ws + W.slabV[L.slot] + (size_t)layer * W.strideV[L.slot], L.out,
+                               want_dc ? 1 : 0, ldt, Mr, Rp, st);
 }
 
 void make_lins(const cara_geom* g, const cara_vit_weights* w, const char* pack, const cara_pack_layout& pl, int l, Lin* out) {

@@ -74,6 +74,11 @@ int cara_tskinny_xtg(const void* X, int ldx, const void* Gt, int ldg, float* D, 
  * D[batch,K1,Rp] (and colsum[batch,K1] when non-NULL; every region must then hold column sums). */
 int cara_tskinny_partial(const void* X, int ldx, const void* Gt, int ldg, void* slabs, int want_colsum,
                          int M, int K1, int Rp, void* stream);
+/* Two products in ONE launch (the dU = X^T G' and dVs = dY^T T of one linear; both Gt share ldg
+ * and M; only the second may ask for column sums).                                             */
+int cara_tskinny_partial2(const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
+                          const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b,
+                          int ldg, int M, int Rp, void* stream);
 int cara_tskinny_reduce(const void* slabs, size_t slab_stride, float* D, float* colsum, int batch,
                         int M, int K1, int Rp, void* stream);
 
