@@ -1,13 +1,13 @@
-// Epilogue of the MFMA GEMMs (gfx950): one wave turns a 64x64 fp32 sub-tile that it has just
-// written to its private LDS image `stg` ([64][64] floats) into the final global stores, with every
+// Epilogue of the MFMA GEMMs (gfx950): one wave turns a ROWS x 64 fp32 sub-tile that it has just
+// written to its private LDS image `stg` ([ROWS][64] floats) into the final global stores, with every
 // global access (output, residual / pre-activation input, bias) 16 bytes wide on 128..256-byte
 // contiguous row segments.
 #pragma once
 #include "common.h"
 
-template <int EPI>
-__device__ __forceinline__ void epilogue_64x64(const cara_gemm_args& p, const float* stg, const int mbase,
-                                               const int nbase, const int lane) {
+template <int EPI, int ROWS>
+__device__ __forceinline__ void epilogue_rows(const cara_gemm_args& p, const float* stg, const int mbase,
+                                              const int nbase, const int lane) {
   if constexpr (EPI == CARA_EPI_F32 || EPI == CARA_EPI_RESID) {
     // fp32 output: 4 rows x 256 B per pass, 16 B per lane
     const int c4 = (lane & 15) * 4, n = nbase + c4;
@@ -18,7 +18,7 @@ __device__ __forceinline__ void epilogue_64x64(const cara_gemm_args& p, const fl
       for (int k = 0; k < 4; ++k) bv[k] = (n + k < p.N) ? p.bias[n + k] : 0.f;
     }
 #pragma unroll 4
-    for (int pass = 0; pass < 16; ++pass) {
+    for (int pass = 0; pass < ROWS / 4; ++pass) {
       const int row = pass * 4 + (lane >> 4), m = mbase + row;
       const f32x4 a = *reinterpret_cast<const f32x4*>(stg + row * 64 + c4);
       if (m >= p.M || n >= p.N) continue;
@@ -53,7 +53,7 @@ __device__ __forceinline__ void epilogue_64x64(const cara_gemm_args& p, const fl
 #pragma unroll
     for (int k = 0; k < 8; ++k) bv[k] = (p.bias && n + k < p.N) ? p.bias[n + k] : 0.f;
 #pragma unroll 2
-    for (int pass = 0; pass < 8; ++pass) {
+    for (int pass = 0; pass < ROWS / 8; ++pass) {
       const int row = pass * 8 + (lane >> 3), m = mbase + row;
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + row * 64 + c8);
       const f32x4 a1 = *reinterpret_cast<const f32x4*>(stg + row * 64 + c8 + 4);
@@ -99,4 +99,10 @@ __device__ __forceinline__ void epilogue_64x64(const cara_gemm_args& p, const fl
       }
     }
   }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_64x64(const cara_gemm_args& p, const float* stg, const int mbase,
+                                               const int nbase, const int lane) {
+  epilogue_rows<EPI, 64>(p, stg, mbase, nbase, lane);
 }
