@@ -30,7 +30,7 @@ struct Ws {
   size_t pack, patches, emb, head_wb, clsn, meanF, rstdF, x_last;
   LayerWs layer[64];
   // backward
-  size_t dx, dyb, dH, dXn, dAO, dQKV, G, Gt, slabs, dclsn, gscratch;
+  size_t dx, dyb, dH, dXn, dAO, dQKV, G[4], Gt[4], slabs, dclsn, gscratch;
   size_t dU[4], dVs[4], dc[4];
   size_t slabU[4], slabV[4], strideU[4], strideV[4];   // per linear: depth regions of tskinny slabs
   size_t total;
@@ -83,8 +83,10 @@ bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
   w->dXn = c.take(M * D * 2);
   w->dAO = c.take(M * D * 2);
   w->dQKV = c.take(M * 3 * D * 2);
-  w->G = c.take(M * Rp * 2);
-  w->Gt = c.take(Rp * ldt * 2);
+  for (int i = 0; i < 4; ++i) {   // one G' = dY Vs pair per linear: the side stream reads it while the next is written
+    w->G[i] = c.take(M * Rp * 2);
+    w->Gt[i] = c.take(Rp * ldt * 2);
+  }
   w->slabs = 0;
   w->dclsn = c.take((size_t)s->B * D * 2);
   w->gscratch = c.take(cara_factor_grad_scratch_bytes(g));
@@ -107,6 +109,39 @@ bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
     const int _st = (expr);       \
     if (_st != CARA_OK) return _st; \
   } while (0)
+
+// Backward overlap: the two transposed skinny products of a linear (dU = X^T G', dVs = dY^T T) are
+// HBM-bound and independent of that linear's MFMA-bound dX GEMM, so they run on a side stream
+// (fork after G' is ready, join before any of their inputs is overwritten).  Process-global side
+// stream + events, created on first use; CARA_OVERLAP=0 keeps everything on the caller's stream.
+struct Side {
+  bool made = false, on = true;
+  hipStream_t s = nullptr;
+  hipEvent_t fork[4], join[4];
+};
+Side g_side;
+
+bool side_ready() {
+  if (!g_side.made) {
+    const char* e = getenv("CARA_OVERLAP");
+    g_side.on = !(e && atoi(e) == 0);
+    if (g_side.on) {
+      if (hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking) != hipSuccess) g_side.on = false;
+      for (int i = 0; i < 4 && g_side.on; ++i)
+        if (hipEventCreateWithFlags(&g_side.fork[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g_side.join[i], hipEventDisableTiming) != hipSuccess)
+          g_side.on = false;
+    }
+    g_side.made = true;
+  }
+  return g_side.on;
+}
+
+// main stream: do not pass this point before the side work of linear `slot` has finished
+int side_join(int slot, void* stream) {
+  if (!side_ready()) return CARA_OK;
+  return hipStreamWaitEvent(static_cast<hipStream_t>(stream), g_side.join[slot], 0) == hipSuccess ? CARA_OK : CARA_E_LAUNCH;
+}
 
 struct Lin {  // one adapted linear of one layer
   const bf16 *W, *Wt;
@@ -132,19 +167,27 @@ int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char*
 //   G' = dY Vs ; dX = [dY | G'] [W^T | U]^T (optional) ; dU = X^T G' ; dVs = dY^T T ; dc = colsum dY
 int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int Mr, int Rp, int ldt, char* ws, const Ws& W,
             const LayerWs& lw, int layer, bool want_dx, cara_gemm_args a, bool want_dc, void* st) {
-  bf16* G = reinterpret_cast<bf16*>(ws + W.G);
-  bf16* Gt = reinterpret_cast<bf16*>(ws + W.Gt);
+  bf16* G = reinterpret_cast<bf16*>(ws + W.G[L.slot]);
+  bf16* Gt = reinterpret_cast<bf16*>(ws + W.Gt[L.slot]);
   TRY(cara_skinny_xu(dY, lddy, L.Vst, G, Gt, ldt, Mr, L.out, Rp, st));
+  void* ts_stream = st;
+  if (side_ready()) {   // fork: the side stream may start once G' exists
+    if (hipEventRecord(g_side.fork[L.slot], static_cast<hipStream_t>(st)) != hipSuccess) return CARA_E_LAUNCH;
+    if (hipStreamWaitEvent(g_side.s, g_side.fork[L.slot], 0) != hipSuccess) return CARA_E_LAUNCH;
+    ts_stream = g_side.s;
+  }
+  // partial slabs now; their fixed-order sums run once per linear after the layer loop
+  TRY(cara_tskinny_partial2(X, ldx, Gt, ws + W.slabU[L.slot] + (size_t)layer * W.strideU[L.slot], L.in,
+                            dY, lddy, ws + lw.Tt[L.slot], ws + W.slabV[L.slot] + (size_t)layer * W.strideV[L.slot], L.out,
+                            want_dc ? 1 : 0, ldt, Mr, Rp, ts_stream));
+  if (side_ready() && hipEventRecord(g_side.join[L.slot], g_side.s) != hipSuccess) return CARA_E_LAUNCH;
   if (want_dx) {
     a.A = dY; a.lda = lddy; a.B = L.Wt; a.ldb = L.out; a.A2 = G; a.B2 = L.U; a.Rp = Rp;
     a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
     if (a.ldc == 0) a.ldc = L.in;
     TRY(cara_gemm_bf16(&a, st));
   }
-  // partial slabs now; their fixed-order sums run once per linear after the layer loop
-  return cara_tskinny_partial2(X, ldx, Gt, ws + W.slabU[L.slot] + (size_t)layer * W.strideU[L.slot], L.in,
-                               dY, lddy, ws + lw.Tt[L.slot], ws + W.slabV[L.slot] + (size_t)layer * W.strideV[L.slot], L.out,
-                               want_dc ? 1 : 0, ldt, Mr, Rp, st);
+  return CARA_OK;
 }
 
 void make_lins(const cara_geom* g, const cara_vit_weights* w, const char* pack, const cara_pack_layout& pl, int l, Lin* out) {
@@ -365,11 +408,13 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     // ---- mlp branch: dY = drop_path scale * dx (already in dyb) ----
     cara_gemm_args e = {};
     e.epi = CARA_EPI_DGELU; e.C = ws + W.dH; e.aux = ws + lw.u;
+    TRY(side_join(2, stream));   // the previous block's fc1 products still read dH / G'[2]
     TRY(lin_bwd(lin[3], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, W.ldt, ws, W, lw, l, true, e, true, stream));
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
     TRY(lin_bwd(lin[2], reinterpret_cast<bf16*>(ws + W.dH), 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, W.ldt, ws, W,
                 lw, l, true, e, true, stream));
+    TRY(side_join(3, stream));   // fc2's products read dyb, which this LayerNorm backward overwrites
     TRY(cara_layernorm_bwd(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_mid), ldr, w->ln2_g + (size_t)l * D,
                            reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyb, dp1, rps,
                            Mr, D, stream));
@@ -378,6 +423,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     e.epi = CARA_EPI_BF16; e.C = ws + W.dAO; e.ldc = ldr;
     if (cls_only && hipMemsetAsync(ws + W.dAO, 0, (size_t)M * D * 2, hs) != hipSuccess) return CARA_E_LAUNCH;
     TRY(lin_bwd(lin[1], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, W, lw, l, true, e, true, stream));
+    TRY(side_join(0, stream));   // the previous block's qkv products still read dQKV / G'[0]
     TRY(cara_attention_bwd(ws + lw.qkv, ws + lw.ao, ws + W.dAO, reinterpret_cast<float*>(ws + lw.lse), ws + W.dQKV, B, N,
                            g->heads, att_scale, stream));
     e = {};
@@ -385,11 +431,13 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     // block 0 has nothing trainable upstream of it: its dX GEMM and LayerNorm backward are skipped
     TRY(lin_bwd(lin[0], reinterpret_cast<bf16*>(ws + W.dQKV), 3 * D, reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, W.ldt, ws, W,
                 lw, l, l > 0, e, false, stream));
+    TRY(side_join(1, stream));   // proj's products read dyb, which the next LayerNorm backward overwrites
     if (l > 0)
       TRY(cara_layernorm_bwd(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_in), D, w->ln1_g + (size_t)l * D,
                              reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), dx, dx, dyb,
                              dp_prev, N, M, D, stream));
   }
+  for (int i = 0; i < 4; ++i) TRY(side_join(i, stream));   // all slabs written
   {
     const int ins[4] = {D, D, D, 4 * D}, outs[4] = {3 * D, D, 4 * D, D};
     const int L = g->depth;
