@@ -10,7 +10,8 @@
 // two-pass softmax, no online rescaling.  Scores are computed TRANSPOSED (S^T = K Q^T) with
 // v_mfma_f32_32x32x16_bf16 so that a query's row lives in ONE lane (max / sum = in-lane reduction
 // + one cross-half shuffle) and the probability accumulators are already the A operand of P.V
-// (no LDS round trip).  V is staged transposed so that its B fragments are two 8-byte LDS reads.
+// (no LDS round trip).  K and V sit in LDS as plain row-major (swizzled) images; the P.V B fragments
+// (keys on the k axis) come out of the V image with the transposing LDS read ds_read_b64_tr_b16.
 //
 // Backward: two kernels, both recomputing P from Q, K and the forward's LSE.  (1) dK/dV: a
 // workgroup of 7 waves per (batch, head); wave w owns keys 32w..32w+31 and keeps dK^T, dV^T in
@@ -26,7 +27,6 @@ namespace {
 
 constexpr int HD = 64;        // head dim
 constexpr int NMAX = 224;     // 7 tiles of 32
-constexpr int KP = 260;       // padded key stride of the transposed images (bank-conflict free b64 reads)
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 // row of the 32x32 C/D layout held in register r of lane half h
@@ -39,38 +39,47 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
   return o;
 }
 
-// 8 bf16 of row `d` of a transposed image at positions base+4h..+3 and base+8+4h..+3
-__device__ __forceinline__ bf16x8 tr_frag(const bf16* img, int d, int base, int h) {
-  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(img + d * KP + base + 4 * h);
-  const bf16x4 hi = *reinterpret_cast<const bf16x4*>(img + d * KP + base + 8 + 4 * h);
-  bf16x8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+// B/A fragment whose k axis runs over image ROWS: element j of lane (c = lane & 31, h = lane >> 5) is
+// img[base + 8*(j>>2) + 4h + (j&3)][cbase + c] -- the k order in which the 32x32x16 accumulator of a
+// previous product is consumed as an operand (register 8s+j of lane half h = row 16s + 8(j>>2) + 4h
+// + (j&3)).  Taken from a ROW-MAJOR swizzled [rows][64] image (rows of 128 B, chunk XOR of
+// swz128) with the CDNA4 transposing LDS read.  ds_read_b64_tr_b16 works per group of 16 lanes:
+// lane 4q+p of a group supplies the address of (row q, columns 4p..4p+3) of a 4 x 16 block and lane
+// i receives column i of the four rows.  Group g = lane >> 4 covers columns cbase + 16*(g&1) ..+15,
+// rows base + 4*(g>>1) .. +3 (first read) and +8 (second read).  All 64 lanes must be active.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x8 tr_frag_rm(const char* img, int cbase, int base, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int row = base + 4 * (g >> 1) + (i >> 2);
+  const int chunk = ((cbase + 16 * (g & 1)) >> 3) + ((i & 3) >> 1);
+  const int sub = (i & 1) * 8;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(img + swz128(row, chunk) + sub));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(img + swz128(row + 8, chunk) + sub));
+  // (bit-cast the whole vectors: __builtin_bit_cast of a single vector ELEMENT reads element 0)
+  const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+  bf16x8 o = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
   return o;
 }
 
-// stage rows [0, NMAX) (clamped to N-1) of a [N, 64] bf16 matrix with row stride ld, transposed:
-// img[d][n]
-__device__ __forceinline__ void stage_transposed(const bf16* __restrict__ src, int ld, int N, bf16* img,
-                                                 int tid, int nthreads) {
+__device__ __forceinline__ void stage_rows_swz(const bf16* __restrict__ src, int ld, int N, char* img, int tid, int nthreads) {
   for (int idx = tid; idx < NMAX * 8; idx += nthreads) {
     const int n = idx >> 3, c = idx & 7;
     const int nn = n < N ? n : N - 1;
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (size_t)nn * ld + c * 8);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) img[(c * 8 + j) * KP + n] = v[j];
+    *reinterpret_cast<uint4*>(img + swz128(n, c)) = *reinterpret_cast<const uint4*>(src + (size_t)nn * ld + c * 8);
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-constexpr int FWD_LDS = NMAX * 128 + HD * KP * 2;  // K (swizzled rows) + V^T
+constexpr int FWD_LDS = 2 * NMAX * 128;  // K and V, both as swizzled row-major images
 
 template <int NW>  // waves per workgroup: 7 covers N <= 224 with ONE staging of K/V per head
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                               float* __restrict__ lse, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
-  bf16* Vt = reinterpret_cast<bf16*>(smem + NMAX * 128);
+  char* Vs = smem + NMAX * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.x, b = bh / H, head = bh - b * H;
   const int ld = 3 * H * HD;
@@ -78,12 +87,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16* __rest
   const bf16* kb = qb + H * HD;
   const bf16* vb = qb + 2 * H * HD;
 
-  for (int idx = tid; idx < NMAX * 8; idx += NW * 64) {
-    const int n = idx >> 3, c = idx & 7;
-    const int nn = n < N ? n : N - 1;
-    *reinterpret_cast<uint4*>(Ks + swz128(n, c)) = *reinterpret_cast<const uint4*>(kb + (size_t)nn * ld + c * 8);
-  }
-  stage_transposed(vb, ld, N, Vt, tid, NW * 64);
+  stage_rows_swz(kb, ld, N, Ks, tid, NW * 64);
+  stage_rows_swz(vb, ld, N, Vs, tid, NW * 64);
   __syncthreads();
 
   const int q0 = (blockIdx.y * NW + wave) * 32;
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16* __rest
         const bf16x8 pa = pack8(s[kt], st);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 vf = tr_frag(Vt, dt * 32 + ql, kt * 32 + st * 16, h);
+          const bf16x8 vf = tr_frag_rm(Vs, dt * 32, kt * 32 + st * 16, lane);
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vf, o[dt], 0, 0, 0);
         }
       }
@@ -169,24 +174,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16* __rest
 // ------------------------------------------------------------------------------------------
 // backward, kernel 1: dK, dV.  One workgroup of 7 waves per (batch, head); wave w owns keys
 // 32w..32w+31 and keeps dK^T, dV^T in accumulators while sweeping the query tiles.  Q and dO are
-// staged in LDS twice: row-major (A operands of S = Q K^T and dP = dO V^T) and transposed (A
-// operands of dV^T += dO^T P and dK^T += Q^T dS, whose B operands are the P / dS accumulators).
+// staged in LDS once, row-major: plain ds_read_b128 rows feed S = Q K^T and dP = dO V^T, and the
+// transposing read ds_read_b64_tr_b16 of the same images feeds dV^T += dO^T P and dK^T += Q^T dS
+// (whose B operands are the P / dS accumulators).
 // ------------------------------------------------------------------------------------------
 constexpr int BWD_WAVES = 7;
 constexpr int DKV_OFF_Q = 0;
 constexpr int DKV_OFF_DO = DKV_OFF_Q + NMAX * 128;
-constexpr int DKV_OFF_QT = DKV_OFF_DO + NMAX * 128;
-constexpr int DKV_OFF_DOT = DKV_OFF_QT + HD * KP * 2;
-constexpr int DKV_OFF_ROW = DKV_OFF_DOT + HD * KP * 2;
+constexpr int DKV_OFF_ROW = DKV_OFF_DO + NMAX * 128;
 constexpr int DKV_LDS = DKV_OFF_ROW + 2 * NMAX * 4;
-
-__device__ __forceinline__ void stage_rows_swz(const bf16* __restrict__ src, int ld, int N, char* img, int tid, int nthreads) {
-  for (int idx = tid; idx < NMAX * 8; idx += nthreads) {
-    const int n = idx >> 3, c = idx & 7;
-    const int nn = n < N ? n : N - 1;
-    *reinterpret_cast<uint4*>(img + swz128(n, c)) = *reinterpret_cast<const uint4*>(src + (size_t)nn * ld + c * 8);
-  }
-}
 
 __global__ __launch_bounds__(448, 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                               const bf16* __restrict__ dout, const float* __restrict__ lse,
@@ -194,8 +190,6 @@ __global__ __launch_bounds__(448, 2) void attn_bwd_dkv_kernel(const bf16* __rest
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem + DKV_OFF_Q;
   char* dOs = smem + DKV_OFF_DO;
-  bf16* Qt = reinterpret_cast<bf16*>(smem + DKV_OFF_QT);
-  bf16* dOt = reinterpret_cast<bf16*>(smem + DKV_OFF_DOT);
   float* lse_s = reinterpret_cast<float*>(smem + DKV_OFF_ROW);
   float* del_s = lse_s + NMAX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -209,8 +203,6 @@ __global__ __launch_bounds__(448, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 
   stage_rows_swz(qb, ld, N, Qs, tid, 448);
   stage_rows_swz(dob, ldo, N, dOs, tid, 448);
-  stage_transposed(qb, ld, N, Qt, tid, 448);
-  stage_transposed(dob, ldo, N, dOt, tid, 448);
   if (tid < NMAX) {
     const int n = tid < N ? tid : N - 1;
     float dl = 0.f;
@@ -275,8 +267,8 @@ __global__ __launch_bounds__(448, 2) void attn_bwd_dkv_kernel(const bf16* __rest
       const bf16x8 pb = pack8(p, st), dsb = pack8(ds, st);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const bf16x8 doa = tr_frag(dOt, dt * 32 + kl, q0 + st * 16, h);
-        const bf16x8 qta = tr_frag(Qt, dt * 32 + kl, q0 + st * 16, h);
+        const bf16x8 doa = tr_frag_rm(dOs, dt * 32, q0 + st * 16, lane);
+        const bf16x8 qta = tr_frag_rm(Qs, dt * 32, q0 + st * 16, lane);
         dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa, pb, dvt[dt], 0, 0, 0);
         dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsb, dkt[dt], 0, 0, 0);
       }
@@ -307,16 +299,15 @@ __global__ __launch_bounds__(448, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 // the A operand of dQ += dS K (B fragments from the transposed K image): no LDS round trip, no
 // cross-wave sum, no atomics.
 // ------------------------------------------------------------------------------------------
-constexpr int DQ_LDS = 2 * NMAX * 128 + HD * KP * 2;  // K rows, V rows (swizzled) + K^T
+constexpr int DQ_LDS = 2 * NMAX * 128;  // K rows, V rows (swizzled row-major images)
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                                  const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                                  bf16* __restrict__ dqkv, int N, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = smem + NMAX * 128;
-  bf16* Kt = reinterpret_cast<bf16*>(smem + 2 * NMAX * 128);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.x, b = bh / H, head = bh - b * H;
   const int ld = 3 * H * HD, ldo = H * HD;
@@ -327,7 +318,6 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dq_kernel(const bf16* __r
   const bf16* dob = dout + (size_t)b * N * ldo + head * HD;
   stage_rows_swz(kb, ld, N, Ks, tid, NW * 64);
   stage_rows_swz(vb, ld, N, Vs, tid, NW * 64);
-  stage_transposed(kb, ld, N, Kt, tid, NW * 64);
   __syncthreads();
 
   const int q0 = (blockIdx.y * NW + wave) * 32;
@@ -378,7 +368,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dq_kernel(const bf16* __r
       const bf16x8 a = pack8(ds, st);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const bf16x8 kf = tr_frag(Kt, dt * 32 + ql, kt * 32 + st * 16, h);
+        const bf16x8 kf = tr_frag_rm(Ks, dt * 32, kt * 32 + st * 16, lane);
         dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf, dq[dt], 0, 0, 0);
       }
     }
@@ -395,7 +385,23 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dq_kernel(const bf16* __r
   }
 }
 
+// diagnostic: stage a [N,64] matrix like the kernels do and return every lane's transposed fragment
+__global__ void tr_frag_probe_kernel(const bf16* __restrict__ src, bf16* __restrict__ out, int N, int cbase, int base) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  stage_rows_swz(src, 64, N, smem, threadIdx.x, 64);
+  __syncthreads();
+  const bf16x8 f = tr_frag_rm(smem, cbase, base, threadIdx.x & 63);
+  for (int j = 0; j < 8; ++j) out[threadIdx.x * 8 + j] = f[j];
+}
+
 }  // namespace
+
+extern "C" int cara_debug_tr_frag(const void* src, void* out, int N, int cbase, int base, void* stream) {
+  hipLaunchKernelGGL(tr_frag_probe_kernel, dim3(1), dim3(64), NMAX * 128, static_cast<hipStream_t>(stream), (const bf16*)src,
+                     (bf16*)out, N, cbase, base);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
 
 // CARA_ATTN_WAVES=4 selects the 4-wave workgroups (two per head at N = 197) for A/B measurements
 static int attn_waves(int N) {

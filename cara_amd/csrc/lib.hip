@@ -3,3 +3,24 @@
 
 extern "C" int cara_abi_version(void) { return 1; }
 extern "C" const char* cara_build_arch(void) { return "gfx950"; }
+
+// Diagnostic: one ds_read_b64_tr_b16 per lane over an LDS image sm[i] = i (16-bit), with the byte
+// address of every lane given by the caller.  Used by tests to pin the lane semantics of the
+// transposing LDS read that the attention kernels rely on.
+namespace {
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__global__ void tr_probe_kernel(const int* __restrict__ byte_addr, short* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) short sm[8192];
+  for (int i = threadIdx.x; i < 8192; i += 64) sm[i] = (short)i;
+  __syncthreads();
+  const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4_t*)(reinterpret_cast<char*>(sm) + byte_addr[threadIdx.x]));
+  for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = v[j];
+}
+}  // namespace
+
+extern "C" int cara_debug_tr_probe(const int* byte_addr, short* out, void* stream) {
+  if (!byte_addr || !out) return CARA_E_ARG;
+  hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), byte_addr, out);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}

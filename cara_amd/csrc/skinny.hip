@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void skinny_xu_kernel(const bf16* __restrict__
 // ------------------------------------------------------------------------------------------
 // D[i, r] = sum_m X[m, i] * G[m, r]   with Gt[r, m] given.
 // MFMA orientation: rows = r (A operand = Gt, m-contiguous), cols = i (B operand = X, taken
-// from an LDS image of the [32 m][64 i] tile by 2-byte reads: k = m is the slow index of X).
+// from an LDS image of the [32 m][64 i] tile by ds_read_b64_tr_b16: k = m is the slow index of X).
 // Grid = (K1/64 column blocks) x (m-chunks); inside a block the 4 waves take alternate 32-row
 // steps, each with a PRIVATE 3-deep LDS ring filled by LDS-DMA (no block barrier in the loop,
 // only counted vmcnt), and combine through LDS at the end.  Each block writes one fp32 slab
@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void skinny_xu_kernel(const bf16* __restrict__
 // float atomics).
 // ------------------------------------------------------------------------------------------
 constexpr int TS_COLS = 64;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 __host__ __device__ inline int ts_chunks(int M, int K1) {
   const int colblocks = K1 / TS_COLS;
@@ -274,12 +275,16 @@ __global__ __launch_bounds__(256) void tskinny_kernel(const TsProblem p0, const 
     const int mrow = (first + 4 * t) * 32 + fq * 8;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      // B fragment: X[m = 8 fq + j][i = it*16 + fr], j = 0..7
-      const int col = it * 16 + fr;
-      const int off = ((((col >> 3) ^ fq) << 4) | ((col & 7) << 1));
-      bf16x8 b;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) b[j] = *reinterpret_cast<const bf16*>(sx + (fq * 8 + j) * 128 + off);
+      // B fragment: X[m = 8 fq + j][i = it*16 + fr], j = 0..7 -- k runs over the image ROWS, so it is
+      // taken with the transposing LDS read: the 16-lane group fq reads the 4x16 blocks of rows
+      // 8fq..8fq+3 and 8fq+4..8fq+7, columns it*16..it*16+15; lane 4q+p supplies (row q, cols 4p..4p+3),
+      // lane fr receives column fr (pinned by tests/test_kernels_gpu.py::test_transposing_lds_read_semantics)
+      const int trow = fq * 8 + (fr >> 2);
+      const int toff = ((((it * 2 + ((fr & 3) >> 1)) ^ fq) << 4) | ((fr & 1) << 3));
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(sx + trow * 128 + toff));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(sx + (trow + 4) * 128 + toff));
+      const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+      const bf16x8 b = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
       if constexpr (COLSUM) {
         if (want_cs) {
 #pragma unroll

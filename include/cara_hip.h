@@ -201,6 +201,12 @@ int cara_head_backward(const float* dlogits, const void* xn_bf16, const float* h
  * launches after synchronising.  Process-global diagnostic state; off by default.              */
 int cara_profile_fc1(int enable);
 int cara_profile_fc1_read(float* avg_ms, int* launches);   /* host pointers */
+/* One ds_read_b64_tr_b16 per lane (64 lanes) over an LDS image of 16-bit values sm[i] = i, lane l
+ * reading at byte address byte_addr[l] (device int[64], multiples of 8, < 16384); out = device
+ * short[256] (4 per lane).  Pins the lane semantics the attention kernels rely on.             */
+int cara_debug_tr_probe(const int* byte_addr, short* out, void* stream);
+/* The attention kernels' transposed fragment of a staged [N,64] bf16 matrix: out bf16 [64 lanes][8]. */
+int cara_debug_tr_frag(const void* src, void* out, int N, int cbase, int base, void* stream);
 
 #ifdef __cplusplus
 }

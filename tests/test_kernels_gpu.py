@@ -328,3 +328,30 @@ def test_factor_prep_and_grad_reduce(rank, Rp):
         ref = cpv["CP_" + n].grad
         scale_ = max(ref.abs().max().item(), 1e-6)
         close(gout[n], ref, 1e-4, 1e-4 * scale_, "grad " + n)
+
+
+def test_transposing_lds_read_semantics():
+    """ds_read_b64_tr_b16 as the attention kernels use it: (a) raw lane semantics over sm[i] = i
+    (lane 4q+p of a 16-lane group supplies row q / columns 4p..4p+3 of a 4x16 block, lane i receives
+    column i of the four rows), (b) the kernels' own staging + fragment helper on a real matrix."""
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+    ad = []
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        ad.append(2 * (g * 1024 + (i >> 2) * 64 + 4 * (i & 3)))
+    a = torch.tensor(ad, dtype=torch.int32, device=DEV)
+    o = torch.empty(256, dtype=torch.int16, device=DEV)
+    L().check(lib.cara_debug_tr_probe(p(a), p(o), st()), "tr probe")
+    got = o.cpu().reshape(64, 4)
+    exp = torch.tensor([[(l >> 4) * 1024 + q * 64 + (l & 15) for q in range(4)] for l in range(64)], dtype=torch.int16)
+    assert torch.equal(got, exp)
+    N = 197
+    V = (torch.arange(N).reshape(N, 1) % 16 * 16 + torch.arange(64).reshape(1, 64) % 16).float() + (torch.arange(64).reshape(1, 64) // 16) * 0.25
+    Vb = V.bfloat16().to(DEV).contiguous()
+    for cbase, base in ((0, 0), (32, 16), (0, 176), (32, 208)):
+        out = torch.empty(64, 8, dtype=torch.bfloat16, device=DEV)
+        L().check(lib.cara_debug_tr_frag(p(Vb), p(out), N, cbase, base, st()), "tr frag")
+        rows = torch.tensor([[min(base + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3), N - 1) for j in range(8)] for l in range(64)])
+        cols = torch.tensor([[cbase + (l & 31)] * 8 for l in range(64)])
+        assert torch.equal(out.cpu(), Vb.cpu()[rows, cols]), (cbase, base)
