@@ -169,7 +169,7 @@ def main():
                        "gpu_event_ms_per_step": round(ev_ms / args.steps, 3), "loss": float(loss)},
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "kernel": "gemm_kernel<CARA_EPI_GELU> (fc1 forward, M=12608 N=3072 K=768+16)",
+                         "kernel": "gemm32_kernel<CARA_EPI_GELU> (fc1 forward, M=12608 N=3072 K=768+16; the rocprofv3 name is gemm32_kernel<2>)",
                          "avg_launch_ms": round(avg_ms.value, 4), "launches_timed": nl.value},
         }
         if world == 1 and not args.no_cpu_baseline:
