@@ -148,17 +148,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const cara_gemm_args p, co
 // 32-row halves so that the fp32 image also fits the 32 KiB.
 // ---------------------------------------------------------------------------------------------
 constexpr int BK32 = 32;
-constexpr int TILE32_BYTES = BM * BK32 * 2;     // 8 KiB per operand tile
-constexpr int LDS32_BYTES = 4 * TILE32_BYTES;   // 32 KiB
+constexpr int B32_BYTES = BN * BK32 * 2;        // 8 KiB: the B tile (128 rows x 64 B)
 
 __device__ __forceinline__ int swz32(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 3) & 1) * 3)) << 4); }
 
-// 8 one-KiB pieces (16 rows x 64 B) per operand; wave w issues pieces 2w, 2w+1
+// ROWS x 64 B operand tile = ROWS/16 one-KiB pieces (16 rows each), spread over the 4 waves
+template <int ROWS>
 __device__ __forceinline__ void stage_tile32(const bf16* __restrict__ P, int ld, int r0, int rmax, int k0, char* lds_tile,
                                              int wave, int lane) {
+  constexpr int PPW = ROWS / 64;   // pieces per wave: 2 (128 rows) or 1 (64 rows)
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int q = wave * 2 + t;
+  for (int t = 0; t < PPW; ++t) {
+    const int q = wave * PPW + t;
     const int r = q * 16 + (lane >> 2);
     const int cg = (lane & 3) ^ (((r >> 3) & 1) * 3);
     int gr = r0 + r;
@@ -167,23 +168,24 @@ __device__ __forceinline__ void stage_tile32(const bf16* __restrict__ P, int ld,
   }
 }
 
-__device__ __forceinline__ void mma_tile32(const char* sA, const char* sB, f32x4 (&acc)[4][4], int wr, int wc, int lane) {
+template <int MI>
+__device__ __forceinline__ void mma_tile32(const char* sA, const char* sB, f32x4 (&acc)[MI][4], int wr, int wc, int lane) {
   const int fr = lane & 15, fq = lane >> 4;
-  bf16x8 a[4], b[4];
+  bf16x8 a[MI], b[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    a[i] = *reinterpret_cast<const bf16x8*>(sA + swz32(wr * 64 + i * 16 + fr, fq));
-    b[i] = *reinterpret_cast<const bf16x8*>(sB + swz32(wc * 64 + i * 16 + fr, fq));
-  }
+  for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sA + swz32(wr * (MI * 16) + i * 16 + fr, fq));
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sB + swz32(wc * 64 + j * 16 + fr, fq));
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
 }
 
 // extension operands [rows, Rp] into 64-byte-row images, one image per 32 columns of Rp
+template <int ROWS>
 __device__ __forceinline__ void stage_ext32(const bf16* __restrict__ P, int Rp, int r0, int rmax, int kk, char* lds_tile, int tid) {
-  for (int idx = tid; idx < 128 * 4; idx += 256) {
+  for (int idx = tid; idx < ROWS * 4; idx += 256) {
     const int r = idx >> 2, c = idx & 3;
     int gr = r0 + r;
     gr = gr < rmax ? gr : rmax;
@@ -191,65 +193,89 @@ __device__ __forceinline__ void stage_ext32(const bf16* __restrict__ P, int Rp, 
   }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 4) void gemm32_kernel(const cara_gemm_args p, const int tiles_n, const int nwg) {
+// MI = 16-row MFMA tiles per wave along M: 4 -> 128x128 tile (32 KiB LDS, 4 workgroups/CU),
+// 2 -> 64x128 tile (24 KiB LDS, 6 workgroups/CU, twice the tiles: used for the N = 768 products)
+template <int EPI, int MI>
+__global__ __launch_bounds__(256, MI == 4 ? 4 : 6) void gemm32_kernel(const cara_gemm_args p, const int tiles_n, const int nwg) {
+  constexpr int TBM = MI * 32;
+  constexpr int A_BYTES = TBM * BK32 * 2;
+  constexpr int SLOT = A_BYTES + B32_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int tile = xcd_remap(blockIdx.x, nwg);
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * TBM, n0 = tn * BN;
   const bf16* __restrict__ A = static_cast<const bf16*>(p.A);
   const bf16* __restrict__ B = static_cast<const bf16*>(p.B);
-  f32x4 acc[4][4];
+  f32x4 acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nk = p.K / BK32;
-  stage_tile32(A, p.lda, m0, p.M - 1, 0, smem, wave, lane);
-  stage_tile32(B, p.ldb, n0, p.N - 1, 0, smem + TILE32_BYTES, wave, lane);
+  stage_tile32<TBM>(A, p.lda, m0, p.M - 1, 0, smem, wave, lane);
+  stage_tile32<BN>(B, p.ldb, n0, p.N - 1, 0, smem + A_BYTES, wave, lane);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    char* sA = smem + cur * (2 * TILE32_BYTES);
+    char* sA = smem + cur * SLOT;
     if (kt + 1 < nk) {
-      char* nA = smem + (cur ^ 1) * (2 * TILE32_BYTES);
-      stage_tile32(A, p.lda, m0, p.M - 1, (kt + 1) * BK32, nA, wave, lane);
-      stage_tile32(B, p.ldb, n0, p.N - 1, (kt + 1) * BK32, nA + TILE32_BYTES, wave, lane);
+      char* nA = smem + (cur ^ 1) * SLOT;
+      stage_tile32<TBM>(A, p.lda, m0, p.M - 1, (kt + 1) * BK32, nA, wave, lane);
+      stage_tile32<BN>(B, p.ldb, n0, p.N - 1, (kt + 1) * BK32, nA + A_BYTES, wave, lane);
     }
-    mma_tile32(sA, sA + TILE32_BYTES, acc, wr, wc, lane);
+    mma_tile32<MI>(sA, sA + A_BYTES, acc, wr, wc, lane);
     cur ^= 1;
   }
   for (int kk = 0; kk < (p.Rp >> 5); ++kk) {
     __syncthreads();
-    stage_ext32(static_cast<const bf16*>(p.A2), p.Rp, m0, p.M - 1, kk, smem, tid);
-    stage_ext32(static_cast<const bf16*>(p.B2), p.Rp, n0, p.N - 1, kk, smem + TILE32_BYTES, tid);
+    stage_ext32<TBM>(static_cast<const bf16*>(p.A2), p.Rp, m0, p.M - 1, kk, smem, tid);
+    stage_ext32<BN>(static_cast<const bf16*>(p.B2), p.Rp, n0, p.N - 1, kk, smem + A_BYTES, tid);
     __syncthreads();
-    mma_tile32(smem, smem + TILE32_BYTES, acc, wr, wc, lane);
+    mma_tile32<MI>(smem, smem + A_BYTES, acc, wr, wc, lane);
   }
-  // epilogue in two 32-row halves: wave-private [32][64] fp32 image (8 KiB per wave)
+  // epilogue in two halves of HALF rows: wave-private [HALF][64] fp32 image
+  constexpr int HALF = MI * 8;
   __syncthreads();
-  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+  float* stg = reinterpret_cast<float*>(smem) + wave * (HALF * 64);
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI / 2; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[half * 2 + i][j][r];
-    epilogue_rows<EPI, 32>(p, stg, m0 + wr * 64 + half * 32, n0 + wc * 64, lane);
+        for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[half * (MI / 2) + i][j][r];
+    epilogue_rows<EPI, HALF>(p, stg, m0 + wr * (MI * 16) + half * HALF, n0 + wc * 64, lane);
   }
+}
+
+// CARA_GEMM_BM=64 selects the 64-row tile (A/B only).  Measured same-box in the real step: 64-row
+// tiles everywhere 14.07 ms, 64 rows only for the N <= 768 products 13.3 ms, 128 rows 12.2 ms -- the
+// better balance over 256 CUs does not pay for the lower FLOP per staged byte, so 128 is the default.
+static int bm_choice(const cara_gemm_args* a) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("CARA_GEMM_BM");
+    forced = e ? atoi(e) : 0;
+  }
+  (void)a;
+  return forced == 64 ? 64 : 128;
 }
 
 template <int EPI>
 int launch32(const cara_gemm_args* a, hipStream_t st) {
-  const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
-  const int nwg = tiles_m * tiles_n;
-  hipLaunchKernelGGL(gemm32_kernel<EPI>, dim3(nwg), dim3(256), LDS32_BYTES, st, *a, tiles_n, nwg);
+  const int tiles_n = (a->N + BN - 1) / BN;
+  if (bm_choice(a) == 64) {
+    const int nwg = ((a->M + 63) / 64) * tiles_n;
+    hipLaunchKernelGGL((gemm32_kernel<EPI, 2>), dim3(nwg), dim3(256), 2 * (64 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg);
+  } else {
+    const int nwg = ((a->M + 127) / 128) * tiles_n;
+    hipLaunchKernelGGL((gemm32_kernel<EPI, 4>), dim3(nwg), dim3(256), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg);
+  }
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }
