@@ -100,8 +100,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # CARA_BENCH_REHEARSAL=1: rehearse the multi-rank plumbing on a ONE-GPU box (all ranks on
+        # cuda:0, gloo instead of RCCL).  Never used for reported numbers.
+        rehearsal = os.environ.get("CARA_BENCH_REHEARSAL") == "1"
+        if rehearsal:
+            local = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if args.gpus != world:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)

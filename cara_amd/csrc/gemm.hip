@@ -153,10 +153,10 @@ constexpr int B32_BYTES = BN * BK32 * 2;        // 8 KiB: the B tile (128 rows x
 __device__ __forceinline__ int swz32(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 3) & 1) * 3)) << 4); }
 
 // ROWS x 64 B operand tile = ROWS/16 one-KiB pieces (16 rows each), spread over the 4 waves
-template <int ROWS>
+template <int ROWS, int NW = 4>
 __device__ __forceinline__ void stage_tile32(const bf16* __restrict__ P, int ld, int r0, int rmax, int k0, char* lds_tile,
                                              int wave, int lane) {
-  constexpr int PPW = ROWS / 64;   // pieces per wave: 2 (128 rows) or 1 (64 rows)
+  constexpr int PPW = ROWS / (16 * NW);   // pieces per wave
 #pragma unroll
   for (int t = 0; t < PPW; ++t) {
     const int q = wave * PPW + t;
@@ -183,9 +183,9 @@ __device__ __forceinline__ void mma_tile32(const char* sA, const char* sB, f32x4
 }
 
 // extension operands [rows, Rp] into 64-byte-row images, one image per 32 columns of Rp
-template <int ROWS>
+template <int ROWS, int NW = 4>
 __device__ __forceinline__ void stage_ext32(const bf16* __restrict__ P, int Rp, int r0, int rmax, int kk, char* lds_tile, int tid) {
-  for (int idx = tid; idx < ROWS * 4; idx += 256) {
+  for (int idx = tid; idx < ROWS * 4; idx += NW * 64) {
     const int r = idx >> 2, c = idx & 3;
     int gr = r0 + r;
     gr = gr < rmax ? gr : rmax;
@@ -195,9 +195,12 @@ __device__ __forceinline__ void stage_ext32(const bf16* __restrict__ P, int Rp, 
 
 // MI = 16-row MFMA tiles per wave along M: 4 -> 128x128 tile (32 KiB LDS, 4 workgroups/CU),
 // 2 -> 64x128 tile (24 KiB LDS, 6 workgroups/CU, twice the tiles: used for the N = 768 products)
-template <int EPI, int MI>
-__global__ __launch_bounds__(256, MI == 4 ? 4 : 6) void gemm32_kernel(const cara_gemm_args p, const int tiles_n, const int nwg) {
-  constexpr int TBM = MI * 32;
+// NW = waves per workgroup (NW/2 along M x 2 along N): 4, or 8 with MI = 2 for a 128-row tile made of
+// 32x64 wave tiles (more resident waves per CU)
+template <int EPI, int MI, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 3 : (MI == 4 ? 4 : 6)) void gemm32_kernel(const cara_gemm_args p, const int tiles_n,
+                                                                                          const int nwg) {
+  constexpr int TBM = MI * 16 * (NW / 2);
   constexpr int A_BYTES = TBM * BK32 * 2;
   constexpr int SLOT = A_BYTES + B32_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -214,8 +217,8 @@ __global__ __launch_bounds__(256, MI == 4 ? 4 : 6) void gemm32_kernel(const cara
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nk = p.K / BK32;
-  stage_tile32<TBM>(A, p.lda, m0, p.M - 1, 0, smem, wave, lane);
-  stage_tile32<BN>(B, p.ldb, n0, p.N - 1, 0, smem + A_BYTES, wave, lane);
+  stage_tile32<TBM, NW>(A, p.lda, m0, p.M - 1, 0, smem, wave, lane);
+  stage_tile32<BN, NW>(B, p.ldb, n0, p.N - 1, 0, smem + A_BYTES, wave, lane);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -223,16 +226,16 @@ __global__ __launch_bounds__(256, MI == 4 ? 4 : 6) void gemm32_kernel(const cara
     char* sA = smem + cur * SLOT;
     if (kt + 1 < nk) {
       char* nA = smem + (cur ^ 1) * SLOT;
-      stage_tile32<TBM>(A, p.lda, m0, p.M - 1, (kt + 1) * BK32, nA, wave, lane);
-      stage_tile32<BN>(B, p.ldb, n0, p.N - 1, (kt + 1) * BK32, nA + A_BYTES, wave, lane);
+      stage_tile32<TBM, NW>(A, p.lda, m0, p.M - 1, (kt + 1) * BK32, nA, wave, lane);
+      stage_tile32<BN, NW>(B, p.ldb, n0, p.N - 1, (kt + 1) * BK32, nA + A_BYTES, wave, lane);
     }
     mma_tile32<MI>(sA, sA + A_BYTES, acc, wr, wc, lane);
     cur ^= 1;
   }
   for (int kk = 0; kk < (p.Rp >> 5); ++kk) {
     __syncthreads();
-    stage_ext32<TBM>(static_cast<const bf16*>(p.A2), p.Rp, m0, p.M - 1, kk, smem, tid);
-    stage_ext32<BN>(static_cast<const bf16*>(p.B2), p.Rp, n0, p.N - 1, kk, smem + A_BYTES, tid);
+    stage_ext32<TBM, NW>(static_cast<const bf16*>(p.A2), p.Rp, m0, p.M - 1, kk, smem, tid);
+    stage_ext32<BN, NW>(static_cast<const bf16*>(p.B2), p.Rp, n0, p.N - 1, kk, smem + A_BYTES, tid);
     __syncthreads();
     mma_tile32<MI>(smem, smem + A_BYTES, acc, wr, wc, lane);
   }
@@ -263,13 +266,16 @@ static int bm_choice(const cara_gemm_args* a) {
     forced = e ? atoi(e) : 0;
   }
   (void)a;
-  return forced == 64 ? 64 : 128;
+  return forced == 64 ? 64 : (forced == 8 ? 8 : 128);   // 8 = 128-row tile with 8 waves
 }
 
 template <int EPI>
 int launch32(const cara_gemm_args* a, hipStream_t st) {
   const int tiles_n = (a->N + BN - 1) / BN;
-  if (bm_choice(a) == 64) {
+  if (bm_choice(a) == 8) {
+    const int nwg = ((a->M + 127) / 128) * tiles_n;
+    hipLaunchKernelGGL((gemm32_kernel<EPI, 2, 8>), dim3(nwg), dim3(512), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg);
+  } else if (bm_choice(a) == 64) {
     const int nwg = ((a->M + 63) / 64) * tiles_n;
     hipLaunchKernelGGL((gemm32_kernel<EPI, 2>), dim3(nwg), dim3(256), 2 * (64 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg);
   } else {
