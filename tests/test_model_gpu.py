@@ -253,3 +253,23 @@ def test_blockwise_path_equals_fused_path():
             t = blk(t)
         blockwise = m.head(m.norm(t)[:, 0])
     assert rel(blockwise, fused) < 1.2e-2 and torch.equal(blockwise.argmax(1), fused.argmax(1))
+
+
+def test_recipe_fit_learns_and_keeps_reference_quirks():
+    """cara_amd.recipe.fit = the loop of vit_cp.py:19-70 on a tiny synthetic task (depth 2)."""
+    from cara_amd import cara, create_model
+    from cara_amd.recipe import fit
+    torch.manual_seed(0)
+    m = cara({"model": create_model("vit_base_patch16_224_in21k", depth=2, num_classes=4, drop_path_rate=0.1), "rank": 8,
+              "scale": 1.0, "l_mu": 1.0, "l_std": 0.0}).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    y = torch.arange(16) % 4
+    x = (torch.randn(16, 3, 224, 224, generator=g) * 0.3 + y.float().reshape(-1, 1, 1, 1)).to(DEV)   # class = mean level
+    y = y.to(DEV)
+    evals = []
+    best, opt = fit(m, lambda epoch: [(x, y)], lambda: [(x, y)], epochs=21, lr=1e-2, on_eval=lambda e, a: evals.append((e, a)))
+    assert [e for e, _ in evals] == [10, 20]                 # vit_cp.py:57
+    assert not m.training                                     # vit_cp.py:75: eval() sticks
+    assert best >= 0.75, evals                                # it learns the toy task
+    assert all(p.grad is not None for n, p in m.named_parameters() if "CP" in n or "head" in n)
+    assert all(p.grad is None for n, p in m.named_parameters() if not ("CP" in n or "head" in n))
