@@ -273,3 +273,31 @@ def test_recipe_fit_learns_and_keeps_reference_quirks():
     assert best >= 0.75, evals                                # it learns the toy task
     assert all(p.grad is not None for n, p in m.named_parameters() if "CP" in n or "head" in n)
     assert all(p.grad is None for n, p in m.named_parameters() if not ("CP" in n or "head" in n))
+
+
+@pytest.mark.parametrize("rank,batch", [(8, 16), (64, 4), (32, 3)])
+def test_baseline_configs_rank_variants(rank, batch):
+    """BASELINE.json configs[0] (rank 8, bs 16) and configs[3] (rank 64: Rp = 64 paths of the
+    K-extension, skinny v1 and tskinny NT = 4) plus the reference's CLI default rank 32: depth-12
+    ViT-B/16 logits and CP gradients against the oracle."""
+    from oracle import cara_oracle as O
+    w = O.synthetic_backbone()
+    cp = O.synthetic_cp(rank=rank)
+    x, y = O.synthetic_batch(batch=batch)
+    m = build(w, cp, rank, 0.1, 12, 224).eval()
+    logits = m(x.to(DEV))
+    with torch.no_grad():
+        ref = O.vit_cara_forward(x, w, cp, s=0.1)
+        sim = O.vit_cara_forward(x, w, cp, s=0.1, factored=True, bf16_sim=True)
+    r_ref, r_model = rel(logits, ref), rel(sim, ref)
+    print(f"rank {rank} bs {batch}: logits rel-L2 vs fp32 oracle {r_ref:.2e} (rounding model {r_model:.2e})")
+    assert r_ref < 1.5e-2 and r_ref < 1.5 * max(r_model, 4e-3)
+    top2 = ref.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 4 * (logits.cpu() - ref).abs().max()
+    assert torch.equal(logits.argmax(1).cpu()[safe], ref.argmax(1)[safe])
+    torch.nn.functional.cross_entropy(logits, y.to(DEV)).backward()
+    head = {"weight": w["head.weight"], "bias": w["head.bias"]}
+    _, _, gref = O.train_step_as_written(x, y, w, cp, head, s=0.1)
+    worst = max(rel(getattr(m, n).grad, gref[n]) for n in O.CP_NAMES)
+    print(f"rank {rank}: worst CP-gradient rel-L2 {worst:.2e}")
+    assert worst < 6e-2
