@@ -199,15 +199,32 @@ __device__ __forceinline__ void stage_ext32(const bf16* __restrict__ P, int Rp, 
 // 32x64 wave tiles (more resident waves per CU)
 template <int EPI, int MI, int NW = 4>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 3 : (MI == 4 ? 4 : 6)) void gemm32_kernel(const cara_gemm_args p, const int tiles_n,
-                                                                                          const int nwg) {
+                                                                                          const int nwg, const int gm) {
   constexpr int TBM = MI * 16 * (NW / 2);
   constexpr int A_BYTES = TBM * BK32 * 2;
   constexpr int SLOT = A_BYTES + B32_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
+  // Tile order: each XCD gets a contiguous run of logical tile indices (xcd_remap); inside the run
+  // the tiles are walked in groups of `gm` tile rows, row index fastest (a "supertile"), so that the
+  // ~128 tiles an XCD keeps in flight touch about sqrt(128)+sqrt(128) operand panels instead of
+  // 5 + tiles_n -- rocprofv3 FETCH_SIZE showed 9x re-fetch on the N = 3072 products with the plain
+  // row-major order (their W panels alone exceed the XCD's 4 MiB L2).
   const int tile = xcd_remap(blockIdx.x, nwg);
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  int tm, tn;
+  if (gm <= 1) {
+    tm = tile / tiles_n;
+    tn = tile - tm * tiles_n;
+  } else {
+    const int tiles_m = nwg / tiles_n;
+    const int per_group = gm * tiles_n;
+    const int gid = tile / per_group, rem = tile - gid * per_group;
+    const int first = gid * gm;
+    const int gsz = (tiles_m - first) < gm ? (tiles_m - first) : gm;
+    tn = rem / gsz;
+    tm = first + (rem - tn * gsz);
+  }
   const int m0 = tm * TBM, n0 = tn * BN;
   const bf16* __restrict__ A = static_cast<const bf16*>(p.A);
   const bf16* __restrict__ B = static_cast<const bf16*>(p.B);
@@ -269,18 +286,33 @@ static int bm_choice(const cara_gemm_args* a) {
   return forced == 64 ? 64 : (forced == 8 ? 8 : 128);   // 8 = 128-row tile with 8 waves
 }
 
+// rows per supertile; CARA_GEMM_GROUPM overrides (1 = plain row-major order)
+static int group_m(int tiles_n) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("CARA_GEMM_GROUPM");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced > 0) return forced;
+  // measured with rocprofv3 FETCH_SIZE (x2 gfx950 correction), per launch, plain order -> groups of 8:
+  // fc1 fwd (24 column tiles) 224 -> 133 MB, fc2 bwd 297 -> 207 MB, but the 6-column products
+  // 82 -> 113 MB and qkv (18 columns) flat: group only when there are many column tiles
+  return tiles_n >= 20 ? 8 : 1;
+}
+
 template <int EPI>
 int launch32(const cara_gemm_args* a, hipStream_t st) {
   const int tiles_n = (a->N + BN - 1) / BN;
+  const int gm = group_m(tiles_n);
   if (bm_choice(a) == 8) {
     const int nwg = ((a->M + 127) / 128) * tiles_n;
-    hipLaunchKernelGGL((gemm32_kernel<EPI, 2, 8>), dim3(nwg), dim3(512), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg);
+    hipLaunchKernelGGL((gemm32_kernel<EPI, 2, 8>), dim3(nwg), dim3(512), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm);
   } else if (bm_choice(a) == 64) {
     const int nwg = ((a->M + 63) / 64) * tiles_n;
-    hipLaunchKernelGGL((gemm32_kernel<EPI, 2>), dim3(nwg), dim3(256), 2 * (64 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg);
+    hipLaunchKernelGGL((gemm32_kernel<EPI, 2>), dim3(nwg), dim3(256), 2 * (64 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm);
   } else {
     const int nwg = ((a->M + 127) / 128) * tiles_n;
-    hipLaunchKernelGGL((gemm32_kernel<EPI, 4>), dim3(nwg), dim3(256), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg);
+    hipLaunchKernelGGL((gemm32_kernel<EPI, 4>), dim3(nwg), dim3(256), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm);
   }
   CARA_CHECK_LAUNCH();
   return CARA_OK;

@@ -1,0 +1,6 @@
+# HBM traffic of the dominant kernel (fc1 forward GEMM) and of the adapter-contraction kernels:
+# FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (TCC slots), kernel-trace only.
+export TMPDIR=/tmp
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_fetch.log 2>&1 || echo fetch pass failed
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_write.log 2>&1 || echo write pass failed
+ls gpurun_out/pmc_fetch/*/ gpurun_out/pmc_write/*/ | head
