@@ -66,12 +66,12 @@ __device__ __forceinline__ void epilogue_rows(const cara_gemm_args& p, const flo
 #pragma unroll
         for (int k = 0; k < 8; ++k) out[k] = (bf16)v[k];
       } else if constexpr (EPI == CARA_EPI_GELU) {
-        // the stored pre-activation is the bf16 value; GELU is taken of that same rounded value so
-        // that forward h and backward gelu'(u) see one consistent u
+        // h = gelu of the UNROUNDED fp32 pre-activation (rounding u first costs 3.4e-3 of logit error at
+        // depth 12, oracle study in DESIGN.md); the bf16 copy of u is kept for gelu'(u) in backward only
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           out2[k] = (bf16)v[k];
-          out[k] = (bf16)gelu_erf((float)out2[k]);
+          out[k] = (bf16)gelu_erf(v[k]);
         }
       } else {  // CARA_EPI_DGELU
         const bf16* up = static_cast<const bf16*>(p.aux) + o;

@@ -456,8 +456,8 @@ def _attn_factored(xn, w, p, fac, num_heads, scale, r):
 
 
 def _mlp_factored(xn, w, p, fac, r):
-    up = r(adapter_linear(xn, w[p + "mlp.fc1.weight"], w[p + "mlp.fc1.bias"], fac["fc1"], r))
-    h = r(F.gelu(up))
+    up = adapter_linear(xn, w[p + "mlp.fc1.weight"], w[p + "mlp.fc1.bias"], fac["fc1"], r)
+    h = r(F.gelu(up))   # the device path takes GELU of the fp32 accumulator; its bf16 copy of `up` is for backward only
     return adapter_linear(h, w[p + "mlp.fc2.weight"], w[p + "mlp.fc2.bias"], fac["fc2"], r)
 
 
