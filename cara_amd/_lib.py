@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("CARA_LIB_PATH") or os.path.join(_HERE, "libcara_hip.s
 
 # every symbol include/cara_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "cara_abi_version", "cara_build_arch", "cara_gemm_bf16", "cara_skinny_xu",
+    "cara_abi_version", "cara_build_arch", "cara_gemm_bf16", "cara_gemm_scratch_bytes", "cara_debug_gemm_persistent_launches", "cara_skinny_xu",
     "cara_tskinny_scratch_bytes", "cara_tskinny_xtg", "cara_tskinny_partial", "cara_tskinny_partial2", "cara_tskinny_reduce", "cara_layernorm_fwd", "cara_layernorm_bwd",
     "cara_attention_fwd", "cara_attention_bwd", "cara_im2col_patches", "cara_assemble_tokens",
     "cara_cross_entropy", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_pack_offsets",
@@ -33,7 +33,8 @@ class GemmArgs(C.Structure):
                 ("A2", C.c_void_p), ("B2", C.c_void_p), ("Rp", C.c_int),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("bias", C.c_void_p), ("epi", C.c_int),
                 ("C", C.c_void_p), ("ldc", C.c_int), ("C2", C.c_void_p), ("aux", C.c_void_p),
-                ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int)]
+                ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int),
+                ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t)]
 
 
 class Geom(C.Structure):
@@ -97,6 +98,8 @@ def lib() -> C.CDLL:
         _lib.cara_factor_grad_scratch_bytes.restype = C.c_size_t
         if hasattr(_lib, "cara_vit_workspace_bytes"):
             _lib.cara_vit_workspace_bytes.restype = C.c_size_t
+            _lib.cara_gemm_scratch_bytes.restype = C.c_size_t
+            _lib.cara_debug_gemm_persistent_launches.restype = C.c_long
     return _lib
 
 
@@ -123,8 +126,10 @@ def stream() -> C.c_void_p:
 # ---- thin per-op wrappers (used by tests and by the module-level drop-in) ---------------------
 
 def gemm(A, B, out, *, epi, bias=None, A2=None, B2=None, C2=None, aux=None, rowscale=None,
-         rows_per_sample=0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None):
+         rows_per_sample=0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, scratch=None):
     a = GemmArgs()
+    if scratch is not None:   # zero-initialised uint8 tensor of gemm_scratch_bytes(): enables the stream-K kernel
+        a.scratch, a.scratch_bytes = ptr(scratch), scratch.numel() * scratch.element_size()
     a.M = M if M is not None else A.shape[0]
     a.K = K if K is not None else A.shape[1]
     a.N = N if N is not None else B.shape[0]
@@ -138,6 +143,14 @@ def gemm(A, B, out, *, epi, bias=None, A2=None, B2=None, C2=None, aux=None, rows
     a.rows_per_sample = rows_per_sample
     check(lib().cara_gemm_bf16(C.byref(a), stream()), "cara_gemm_bf16")
     return out
+
+
+def gemm_scratch_bytes() -> int:
+    return int(lib().cara_gemm_scratch_bytes())
+
+
+def gemm_persistent_launches() -> int:
+    return int(lib().cara_debug_gemm_persistent_launches())
 
 
 def skinny_xu(X, Ut, T, Tt=None):

@@ -330,6 +330,22 @@ int launch(const cara_gemm_args* a, hipStream_t st) {
 }  // namespace
 
 int cara_gemm256_dispatch(const cara_gemm_args* a, hipStream_t st);  // gemm256.hip
+int cara_gemm_sk_dispatch(const cara_gemm_args* a, hipStream_t st);   // gemm_sk.hip
+
+// The persistent 256x256 kernel of gemm_sk.hip is OPT-IN (CARA_GEMM_SK=1 and caller scratch): its main loop
+// runs at twice the MFMA rate of the 128x128 kernels (half the LDS-DMA bytes per flop), but one workgroup per
+// CU means every CU writes its output tile at the same time while no MFMA runs, and on the shapes of this
+// model (K = 768..3072, 40-155 MB of output per product) that burst costs what the loop gains: same-box
+// block total 706 us vs 663 us for the default kernels.
+static bool use_stream_k(const cara_gemm_args* a) {
+  const char* e = getenv("CARA_GEMM_SK");   // read per call: tests switch it
+  const int v = e ? atoi(e) : 0;
+  if (v == 0 || !a->scratch || a->M < 1024 || a->N < 256) return false;
+  // its staging addresses are 32-bit byte offsets built with a 24-bit multiply
+  const unsigned long long abytes = (unsigned long long)a->M * a->lda * 2, bbytes = (unsigned long long)a->N * a->ldb * 2;
+  return a->M < (1 << 24) && a->N < (1 << 24) && a->lda < (1 << 22) && a->ldb < (1 << 22) && abytes < (1ull << 32) &&
+         bbytes < (1ull << 32);
+}
 
 // The 128x128 tile is the default for every shape: on the shapes of this model it is the fastest
 // of the structures measured so far.  CARA_GEMM_TILE=256 in the environment
@@ -367,6 +383,7 @@ extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
   if (a->epi == CARA_EPI_RESID && (!a->aux || (a->rowscale && a->rows_per_sample <= 0))) return CARA_E_ARG;
   if (a->epi == CARA_EPI_DGELU && !a->aux) return CARA_E_ARG;
   if (use_tile256(a)) return cara_gemm256_dispatch(a, st);
+  if (use_stream_k(a)) return cara_gemm_sk_dispatch(a, st);
   if (use_bk32()) {
     switch (a->epi) {
       case CARA_EPI_BF16: return launch32<CARA_EPI_BF16>(a, st);

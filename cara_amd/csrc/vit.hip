@@ -30,7 +30,7 @@ struct Ws {
   size_t pack, patches, emb, head_wb, clsn, meanF, rstdF, x_last;
   LayerWs layer[64];
   // backward
-  size_t dx, dyb, dH, dXn, dAO, dQKV, G[4], Gt[4], slabs, dclsn, gscratch;
+  size_t dx, dyb, dH, dXn, dAO, dQKV, G[4], Gt[4], slabs, dclsn, gscratch, gemm_scratch;
   size_t dU[4], dVs[4], dc[4];
   size_t slabU[4], slabV[4], strideU[4], strideV[4];   // per linear: depth regions of tskinny slabs
   size_t total;
@@ -90,6 +90,7 @@ bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
   w->slabs = 0;
   w->dclsn = c.take((size_t)s->B * D * 2);
   w->gscratch = c.take(cara_factor_grad_scratch_bytes(g));
+  w->gemm_scratch = c.take(cara_gemm_scratch_bytes());   // stream-K partial tiles + flags (workspace is zeroed at allocation)
   const size_t ins[4] = {D, D, D, 4 * D}, outs[4] = {3 * D, D, 4 * D, D};
   for (int i = 0; i < 4; ++i) {
     w->dU[i] = c.take((size_t)g->depth * ins[i] * Rp * 4);
@@ -150,6 +151,14 @@ struct Lin {  // one adapted linear of one layer
   int in, out, slot;
 };
 
+// stream-K scratch of the workspace in use (set on entry of cara_vit_forward / _backward: one
+// workspace per stream, as for the side stream above)
+char* g_sk_scratch = nullptr;
+void with_scratch(cara_gemm_args& a) {
+  a.scratch = g_sk_scratch;
+  a.scratch_bytes = g_sk_scratch ? cara_gemm_scratch_bytes() : 0;
+}
+
 // forward of one adapted linear on Mr rows of X (row stride ldx): T = X U ;
 // C = [X | T] [W | Vs]^T + bias -> epilogue (a.ldc == 0: dense output)
 int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char* ws, const LayerWs& lw, cara_gemm_args a, void* st) {
@@ -159,6 +168,7 @@ int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char*
   a.A = X; a.lda = ldx; a.B = L.W; a.ldb = L.in; a.A2 = T; a.B2 = L.Vs; a.Rp = Rp;
   a.M = Mr; a.N = L.out; a.K = L.in; a.bias = L.bias;
   if (a.ldc == 0) a.ldc = L.out;
+  with_scratch(a);
   return cara_gemm_bf16(&a, st);
 }
 
@@ -185,6 +195,7 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
     a.A = dY; a.lda = lddy; a.B = L.Wt; a.ldb = L.out; a.A2 = G; a.B2 = L.U; a.Rp = Rp;
     a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
     if (a.ldc == 0) a.ldc = L.in;
+    with_scratch(a);
     TRY(cara_gemm_bf16(&a, st));
   }
   return CARA_OK;
@@ -311,6 +322,8 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
   cara_gemm_args a = {};
   a.A = ws + W.patches; a.lda = kp; a.B = w->patch_w; a.ldb = kp; a.M = B * P; a.N = D; a.K = kp;
   a.bias = w->patch_b; a.epi = CARA_EPI_F32; a.C = ws + W.emb; a.ldc = D;
+  g_sk_scratch = ws + W.gemm_scratch;
+  with_scratch(a);
   TRY(cara_gemm_bf16(&a, stream));
   TRY(cara_assemble_tokens(reinterpret_cast<float*>(ws + W.emb), w->cls, w->pos,
                            reinterpret_cast<float*>(ws + W.layer[0].x_in), B, P, D, stream));
@@ -353,6 +366,7 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
       cara_gemm_args a2 = e;
       a2.A = ws + lw.xn2; a2.lda = D; a2.B = lin[2].W; a2.ldb = D; a2.A2 = T; a2.B2 = lin[2].Vs; a2.Rp = Rp;
       a2.M = M; a2.N = 4 * D; a2.K = D; a2.bias = lin[2].bias; a2.ldc = 4 * D;
+      with_scratch(a2);
       hipEventRecord(g_prof.ev[l][0], static_cast<hipStream_t>(stream));
       TRY(cara_gemm_bf16(&a2, stream));
       hipEventRecord(g_prof.ev[l][1], static_cast<hipStream_t>(stream));
@@ -379,6 +393,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
   Ws W;
   if (!layout(g, s, &W) || !w || !cp || !head_w || !dlogits || !workspace || !grads || !dhead_w || !dhead_b) return CARA_E_ARG;
   char* ws = static_cast<char*>(workspace);
+  g_sk_scratch = ws + W.gemm_scratch;
   hipStream_t hs = static_cast<hipStream_t>(stream);
   const int D = g->dim, M = W.M, Rp = g->Rp, B = s->B, N = s->tokens;
   const float att_scale = 1.0f / sqrtf((float)(D / g->heads));

@@ -54,8 +54,15 @@ typedef struct {
   const void* aux;              /* CARA_EPI_RESID: fp32 [M,ldc]; CARA_EPI_DGELU: bf16 [M,ldc] */
   const float* rowscale;        /* CARA_EPI_RESID: fp32 [M / rows_per_sample] or NULL (=1) */
   int rows_per_sample;
+  void* scratch;                /* optional: cara_gemm_scratch_bytes() of caller memory, zeroed once at   */
+  size_t scratch_bytes;         /* allocation, used by ONE stream at a time.  With it, products of at     */
+                                /* least 1024 rows and 256 columns run on the persistent stream-K kernel  */
+                                /* (partial tiles + flags live there); NULL = one tile per workgroup.     */
 } cara_gemm_args;
 int cara_gemm_bf16(const cara_gemm_args* a, void* stream);
+size_t cara_gemm_scratch_bytes(void);
+/* number of launches of the persistent 256x256 kernel so far in this process (tests assert the path taken) */
+long cara_debug_gemm_persistent_launches(void);
 
 /* ---- skinny adapter contractions (HBM-bound) --------------------------------------------- */
 /* T[M,Rp] = X[M,K] * Ut[Rp,K]^T, bf16 out, also written transposed Tt[Rp,ldt] when Tt != NULL

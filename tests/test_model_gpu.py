@@ -87,6 +87,35 @@ def test_depth2_against_reference_vectors():
     print(f"depth2 CP-gradient worst rel-L2 vs reference: {worst:.2e}")
 
 
+def test_whole_model_with_persistent_gemm(monkeypatch):
+    """The opt-in 256x256 persistent GEMM (CARA_GEMM_SK=1) inside the real forward/backward: batch 8 x 197
+    rows >= 1024, so qkv/proj/fc1/fc2 and their dX products all take it.  Same model, same input, both GEMM
+    paths: logits and CP gradients agree to bf16 rounding (the two sum the K steps in different orders)."""
+    from oracle import cara_oracle as O
+    torch.manual_seed(0)
+    w = O.synthetic_backbone()
+    cp = O.synthetic_cp(rank=16)
+    x, y = O.synthetic_batch(batch=8)
+    from cara_amd import _lib as L
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CARA_GEMM_SK", mode)
+        m = build(w, cp, 16, 0.1, 12, 224).eval()
+        before = L.gemm_persistent_launches()
+        logits = m(x.to(DEV))
+        torch.nn.functional.cross_entropy(logits, y.to(DEV)).backward()
+        # patch embedding + 12 x (4 forward + 4 dX) products, minus the cls-row-only ones of the last block
+        # (proj, fc1, fc2 forward; fc2, fc1, proj dX run on 8 rows) and the first block's unused qkv dX... >= 80
+        assert (L.gemm_persistent_launches() - before >= 80) == (mode == "1")
+        out[mode] = (logits.detach().float().cpu(), {n: getattr(m, n).grad.float().cpu() for n in O.CP_NAMES})
+    r = rel(out["1"][0], out["0"][0])
+    worst = max(rel(out["1"][1][n], out["0"][1][n]) for n in O.CP_NAMES)
+    print(f"persistent vs tile GEMM: logits rel-L2 {r:.2e}, worst CP-gradient rel-L2 {worst:.2e}")
+    # (with whole-tile rounds the persistent kernel adds the K steps in the tile kernel's order: often bitwise equal)
+    assert r < 8e-3 and worst < 2e-2, (r, worst)
+    assert torch.equal(out["1"][0].argmax(1), out["0"][0].argmax(1))
+
+
 def test_depth12_headline_shapes_against_oracle():
     """ViT-B/16 depth 12, rank 16, 197 tokens, synthetic weights of SURVEY 8(d), batch 4."""
     from oracle import cara_oracle as O

@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cara_amd import _lib as L  # noqa: E402
 
-M = 64 * 197
+M0 = 64 * 197
 SHAPES = [  # name, N, K, epi
     ("qkv_fwd", 2304, 768, "bf16"), ("proj_fwd", 768, 768, "resid"), ("fc1_fwd", 3072, 768, "gelu"),
     ("fc2_fwd", 768, 3072, "resid"), ("fc2_bwd", 3072, 768, "dgelu"), ("fc1_bwd", 768, 3072, "bf16"),
@@ -25,11 +25,24 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--only", default=None)
     ap.add_argument("--rp", type=int, default=32)
+    ap.add_argument("--shape", action="append", default=[],
+                    help="M,N,K[,epi] instead of the block shapes (repeatable), e.g. 4096,4096,768,bf16")
+    ap.add_argument("--sk", action="store_true", help="give the GEMM stream-K scratch (persistent kernel)")
+    ap.add_argument("--blas", action="store_true",
+                    help="also time torch.matmul (hipBLASLt, plain GEMM, no adapter columns, no epilogue) on the "
+                         "same operands: a known-good ceiling for these shapes, measurement only")
     args = ap.parse_args()
     dev = "cuda"
     g = torch.Generator().manual_seed(0)
     tot_t = tot_f = 0.0
-    for name, N, K, epi in SHAPES:
+    scratch = torch.zeros(L.gemm_scratch_bytes(), dtype=torch.uint8, device=dev) if args.sk else None
+    shapes = [(n, M0, N, K, e) for n, N, K, e in SHAPES]
+    if args.shape:
+        shapes = []
+        for sp in args.shape:
+            f = sp.split(",")
+            shapes.append((sp, int(f[0]), int(f[1]), int(f[2]), f[3] if len(f) > 3 else "bf16"))
+    for name, M, N, K, epi in shapes:
         if args.only and args.only != name:
             continue
         A = torch.randn(M, K, generator=g).bfloat16().to(dev)
@@ -38,6 +51,8 @@ def main():
         B2 = (torch.randn(N, args.rp, generator=g) * 0.02).bfloat16().to(dev)
         bias = torch.randn(N, generator=g).to(dev)
         kw = dict(A2=A2, B2=B2, bias=bias)
+        if args.sk:
+            kw["scratch"] = scratch
         if epi == "bf16":
             out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
             kw.update(epi=L.EPI_BF16)
@@ -51,7 +66,7 @@ def main():
         else:
             out = torch.empty(M, N, dtype=torch.float32, device=dev)
             kw.update(epi=L.EPI_RESID, aux=torch.randn(M, N, generator=g).to(dev),
-                      rowscale=torch.ones(64, device=dev), rows_per_sample=197)
+                      rowscale=torch.ones((M + 196) // 197, device=dev), rows_per_sample=197)
         for _ in range(3):
             L.gemm(A, B, out, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -65,7 +80,20 @@ def main():
         fl = 2.0 * M * N * (K + 16)
         tot_t += us
         tot_f += fl
-        print(f"{name:9s} N={N:5d} K={K:5d} {epi:6s} {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s", flush=True)
+        extra = ""
+        if args.blas:
+            Bt = B.t()
+            for _ in range(3):
+                torch.matmul(A, Bt)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.iters):
+                torch.matmul(A, Bt)
+            e1.record()
+            torch.cuda.synchronize()
+            ub = e0.elapsed_time(e1) * 1e3 / args.iters
+            extra = f"   | hipBLASLt plain {ub:8.1f} us {2.0 * M * N * K / ub / 1e6:7.1f} TF/s"
+        print(f"{name:9s} N={N:5d} K={K:5d} {epi:6s} {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s{extra}", flush=True)
     if tot_t:
         print(f"block total {tot_t:8.1f} us  {tot_f / tot_t / 1e6:7.1f} TF/s  (x12 layers = {12 * tot_t / 1e3:.2f} ms/step)")
 
