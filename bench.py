@@ -156,6 +156,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = t.item()
 
+    # forward-only rate (SURVEY 8d asks for it next to the train rate): eval mode, no autograd, same batch;
+    # outside the timed region above, rank 0's own clock
+    fwd_ms = None
+    if rank == 0:
+        model.eval()
+        with torch.no_grad():
+            for _ in range(3):
+                model(x)
+            torch.cuda.synchronize()
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record()
+            for _ in range(10):
+                model(x)
+            f1.record()
+            torch.cuda.synchronize()
+        fwd_ms = f0.elapsed_time(f1) / 10
+        model.train()
+
     if rank == 0:
         ms_step = wall * 1e3 / args.steps
         ips = world * args.batch * args.steps / wall
@@ -181,7 +199,10 @@ def main():
                        "step_algorithmic_gflop": round(GF_PER_IMG["step"] * args.batch, 1),
                        "step_tflops_per_gpu": round(GF_PER_IMG["step"] * args.batch / ms_step, 1),
                        "step_frac_of_mfma_peak": round(GF_PER_IMG["step"] * args.batch / ms_step / PEAK_BF16_TFLOPS, 4),
-                       "gpu_event_ms_per_step": round(ev_ms / args.steps, 3), "loss": float(loss)},
+                       "gpu_event_ms_per_step": round(ev_ms / args.steps, 3), "loss": float(loss),
+                       "forward_only_ms": round(fwd_ms, 3),
+                       "forward_only_images_per_sec_per_gpu": round(args.batch / fwd_ms * 1e3, 1),
+                       "forward_frac_of_mfma_peak": round(GF_PER_IMG["fwd"] * args.batch / fwd_ms / PEAK_BF16_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "kernel": "gemm32_kernel<CARA_EPI_GELU> (fc1 forward, M=12608 N=3072 K=768+16; the rocprofv3 name is gemm32_kernel<2>)",

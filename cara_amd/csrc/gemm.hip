@@ -329,7 +329,8 @@ int launch(const cara_gemm_args* a, hipStream_t st) {
 
 }  // namespace
 
-int cara_gemm256_dispatch(const cara_gemm_args* a, hipStream_t st);  // gemm256.hip
+int cara_gemm256_dispatch(const cara_gemm_args* a, hipStream_t st);      // gemm256.hip, 256 x 256 ring
+int cara_gemm128x256_dispatch(const cara_gemm_args* a, hipStream_t st);   // gemm256.hip, 128 x 256 ring, 2 workgroups per CU
 int cara_gemm_sk_dispatch(const cara_gemm_args* a, hipStream_t st);   // gemm_sk.hip
 
 // The persistent 256x256 kernel of gemm_sk.hip is OPT-IN (CARA_GEMM_SK=1 and caller scratch): its main loop
@@ -350,14 +351,10 @@ static bool use_stream_k(const cara_gemm_args* a) {
 // The 128x128 tile is the default for every shape: on the shapes of this model it is the fastest
 // of the structures measured so far.  CARA_GEMM_TILE=256 in the environment
 // selects the 256x256 LDS-ring kernel of gemm256.hip for A/B measurements.
-static bool use_tile256(const cara_gemm_args* a) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("CARA_GEMM_TILE");
-    forced = e ? atoi(e) : 0;
-  }
+static int tile_choice(const cara_gemm_args* a) {
+  const char* e = getenv("CARA_GEMM_TILE");   // read per call: tests and A/B runs switch it
   (void)a;
-  return forced == 256;
+  return e ? atoi(e) : 0;
 }
 
 // Default: the 32-deep, 4-workgroups-per-CU variant -- in the real train step it is 7 % faster
@@ -382,7 +379,9 @@ extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
   if (a->epi == CARA_EPI_GELU && !a->C2) return CARA_E_ARG;
   if (a->epi == CARA_EPI_RESID && (!a->aux || (a->rowscale && a->rows_per_sample <= 0))) return CARA_E_ARG;
   if (a->epi == CARA_EPI_DGELU && !a->aux) return CARA_E_ARG;
-  if (use_tile256(a)) return cara_gemm256_dispatch(a, st);
+  const int tile = tile_choice(a);
+  if (tile == 256) return cara_gemm256_dispatch(a, st);
+  if (tile == 1282) return cara_gemm128x256_dispatch(a, st);   // 128 x 256
   if (use_stream_k(a)) return cara_gemm_sk_dispatch(a, st);
   if (use_bk32()) {
     switch (a->epi) {

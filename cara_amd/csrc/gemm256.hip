@@ -16,6 +16,11 @@
 // other waves': the barrier); every wave has finished reading slot kt%4 (it read it before this
 // barrier), so tile kt+4 is issued into it; then the fragment reads of tile kt+1 overlap the 32
 // MFMAs of tile kt (two register sets, loop unrolled by two so that they are statically named).
+//
+// WM = 1 instantiates the same loop for a 128 x 256 tile: 4 waves (1 x 4, the same 128 x 64 wave tile), a
+// three-slot ring of 24 KiB = 72 KiB, so TWO independent workgroups share a CU (one's epilogue and prologue
+// run under the other's K loop, which the 256 x 256 form cannot do) at 3/4 of the 128 x 128 kernels' LDS-DMA
+// bytes per flop and ONE barrier per 32 MFMAs (they pay one per 16).
 #include <stdlib.h>
 
 #include "common.h"
@@ -23,40 +28,55 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 32, NSLOT = 4;
-constexpr int OP_BYTES = BM * BK * 2;      // 16 KiB per operand per K-tile
-constexpr int SLOT_BYTES = 2 * OP_BYTES;   // A + B
-constexpr int LDS_BYTES = NSLOT * SLOT_BYTES;   // 128 KiB
-constexpr int PIECES = 4;                  // LDS-DMA instructions per wave per K-tile
+constexpr int BN = 256, BK = 32;
+constexpr int OP_BYTES = 256 * BK * 2;     // 16 KiB: the B operand (and A when WM = 2) per K-tile
+template <int WM>
+struct Geo {
+  static constexpr int BM = WM * 128, NW = WM * 4, NSLOT = WM == 2 ? 4 : 3;
+  static constexpr int A_BYTES = BM * BK * 2, SLOT_BYTES = A_BYTES + OP_BYTES, LDS_BYTES = NSLOT * SLOT_BYTES;
+  static constexpr int PIECES = (BM / 16 + 16) / NW;   // LDS-DMA instructions per wave per K-tile: 4 (WM 2), 6 (WM 1)
+  static constexpr int INFLIGHT = (NSLOT - 2) * PIECES;   // pieces that may stay in flight behind the tile being waited for
+};
 
 // [256 rows][4 chunks of 16 B]; chunk' = chunk ^ (row & 8 ? 3 : 0): the 16 lanes that a ds_read_b128
 // services together (4 row classes mod 4 x 4 chunks) then hit 64 distinct banks
 __device__ __forceinline__ int swz32(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 3) & 1) * 3)) << 4); }
 __device__ __forceinline__ int swz64(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-// one K-tile of both operands: 2 x 16 pieces of 1 KiB (16 rows x 64 B); wave w issues A pieces
-// 2w, 2w+1 and B pieces 2w, 2w+1
+// one K-tile of both operands as 1-KiB pieces (16 rows x 64 B): A has BM/16 of them, B 16; every wave issues
+// its share of each (WM 2: A 2 + B 2; WM 1: A 2 + B 4)
+template <int WM>
 __device__ __forceinline__ void stage_ktile(const bf16* __restrict__ A, int lda, int m0, int mmax,
                                             const bf16* __restrict__ B, int ldb, int n0, int nmax, int k0,
                                             char* slot, int wave, int lane) {
+  using G = Geo<WM>;
+  constexpr int APW = (G::BM / 16) / G::NW, BPW = 16 / G::NW;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int q = wave * 2 + t;
+  for (int t = 0; t < APW; ++t) {
+    const int q = wave * APW + t;
     const int r = q * 16 + (lane >> 2);
     const int cg = (lane & 3) ^ (((r >> 3) & 1) * 3);
-    int ga = m0 + r, gb = n0 + r;
+    int ga = m0 + r;
     ga = ga < mmax ? ga : mmax;
-    gb = gb < nmax ? gb : nmax;
     glds16(A + (size_t)ga * lda + k0 + cg * 8, slot + q * 1024);
-    glds16(B + (size_t)gb * ldb + k0 + cg * 8, slot + OP_BYTES + q * 1024);
+  }
+#pragma unroll
+  for (int t = 0; t < BPW; ++t) {
+    const int q = wave * BPW + t;
+    const int r = q * 16 + (lane >> 2);
+    const int cg = (lane & 3) ^ (((r >> 3) & 1) * 3);
+    int gb = n0 + r;
+    gb = gb < nmax ? gb : nmax;
+    glds16(B + (size_t)gb * ldb + k0 + cg * 8, slot + G::A_BYTES + q * 1024);
   }
 }
 
 // the K-extension operands ([rows, Rp], Rp = 32 or 64) go through registers into a [256][64]
 // image with the 128-byte-row swizzle
-__device__ __forceinline__ void stage_ext(const bf16* __restrict__ P, int Rp, int r0, int rmax, char* img, int tid) {
+__device__ __forceinline__ void stage_ext(const bf16* __restrict__ P, int Rp, int r0, int rmax, char* img, int tid, int rows,
+                                          int nthreads) {
   const int cpr = Rp >> 3;
-  for (int idx = tid; idx < 256 * cpr; idx += 512) {
+  for (int idx = tid; idx < rows * cpr; idx += nthreads) {
     const int r = idx / cpr, c = idx - r * cpr;
     int gr = r0 + r;
     gr = gr < rmax ? gr : rmax;
@@ -68,6 +88,8 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else static_assert(N == 0, "unsupported vmcnt");
 }
@@ -108,33 +130,48 @@ __device__ __forceinline__ void mma_kstep(f32x4 (&acc)[8][4], const char* sA, co
 // one pipelined iteration: fragments of tile kt are in `cur`; make tile kt+1 visible, refill the
 // slot tile kt was read from with tile kt+4, read tile kt+1's fragments into `nxt` WHILE the 32
 // MFMAs of tile kt execute (the two are independent, the compiler interleaves them).
+template <int WM>
 __device__ __forceinline__ void pipe_step(f32x4 (&acc)[8][4], const Frags& cur, Frags& nxt, int kt, int nk,
                                           const bf16* __restrict__ A, int lda, int m0, int mmax,
                                           const bf16* __restrict__ B, int ldb, int n0, int nmax,
                                           char* smem, int wm, int wn, int wave, int lane, const int ablate) {
-  const int after = nk - 2 - kt;   // tiles issued after kt+1 that may stay in flight: min(2, after)
-  if (after >= 2) wait_vm<2 * PIECES>();
-  else if (after == 1) wait_vm<PIECES>();
+  using G = Geo<WM>;
+  // tiles issued after kt+1 that may stay in flight: min(NSLOT - 2, nk - 2 - kt)
+  const int after = nk - 2 - kt;
+  if (after >= G::NSLOT - 2) wait_vm<G::INFLIGHT>();
+  else if (after == 1) wait_vm<G::PIECES>();   // (only reachable with NSLOT = 4)
   else wait_vm<0>();
   if (!(ablate & 8)) __syncthreads();
-  if (kt + 4 < nk && !(ablate & 1))
-    stage_ktile(A, lda, m0, mmax, B, ldb, n0, nmax, (kt + 4) * BK, smem + (kt & 3) * SLOT_BYTES, wave, lane);
+  if (kt + G::NSLOT < nk && !(ablate & 1))
+    stage_ktile<WM>(A, lda, m0, mmax, B, ldb, n0, nmax, (kt + G::NSLOT) * BK, smem + (kt % G::NSLOT) * G::SLOT_BYTES, wave, lane);
   if (kt + 1 < nk && !(ablate & 2)) {
-    const char* sA = smem + ((kt + 1) & 3) * SLOT_BYTES;
-    load_frags<false>(nxt, sA, sA + OP_BYTES, wm, wn, lane, 0);
+    const char* sA = smem + ((kt + 1) % G::NSLOT) * G::SLOT_BYTES;
+    load_frags<false>(nxt, sA, sA + G::A_BYTES, wm, wn, lane, 0);
   }
   mma_frags(acc, cur);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(const cara_gemm_args p, const int tiles_n, const int nwg,
-                                                         const int ablate) {
+// walk the tiles in column groups of gw tiles, row index slow inside a group: the tiles an XCD has in flight
+// then form a compact block sharing few operand panels (gw = tiles_n: plain row-major)
+__device__ __forceinline__ void tile_coords(int idx, int tiles_m, int tiles_n, int gw, int& tm, int& tn) {
+  const int per_group = tiles_m * gw;
+  const int gi = idx / per_group, rem = idx - gi * per_group;
+  const int c0 = gi * gw;
+  const int w = (tiles_n - c0) < gw ? (tiles_n - c0) : gw;
+  tm = rem / w;
+  tn = c0 + (rem - tm * w);
+}
+
+template <int EPI, int WM>
+__global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(const cara_gemm_args p, const int tiles_m, const int tiles_n,
+                                                                const int gw, const int ablate) {
+  using G = Geo<WM>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
-  const int tile = xcd_remap(blockIdx.x, nwg);
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, gw, tm, tn);
+  const int m0 = tm * G::BM, n0 = tn * BN;
   const bf16* __restrict__ A = static_cast<const bf16*>(p.A);
   const bf16* __restrict__ B = static_cast<const bf16*>(p.B);
   const int mmax = p.M - 1, nmax = p.N - 1;
@@ -147,19 +184,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const cara_gemm_args p,
 
   const int nk = p.K / BK;   // even, >= 2 (K % 64 == 0)
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
-    if (t < nk) stage_ktile(A, p.lda, m0, mmax, B, p.ldb, n0, nmax, t * BK, smem + t * SLOT_BYTES, wave, lane);
-  // tile 0 landed: up to 3 younger tiles may stay in flight
-  if (nk >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else wait_vm<PIECES>();   // nk == 2: one younger tile
+  for (int t = 0; t < G::NSLOT; ++t)
+    if (t < nk) stage_ktile<WM>(A, p.lda, m0, mmax, B, p.ldb, n0, nmax, t * BK, smem + t * G::SLOT_BYTES, wave, lane);
+  // tile 0 landed: the NSLOT - 1 younger tiles may stay in flight (12 pieces in both geometries)
+  if (nk >= G::NSLOT) wait_vm<(G::NSLOT - 1) * G::PIECES>();
+  else wait_vm<G::PIECES>();   // nk == 2: one younger tile
   __syncthreads();
   Frags fa, fb;
-  load_frags<false>(fa, smem, smem + OP_BYTES, wm, wn, lane, 0);
-  if (ablate & 2) load_frags<false>(fb, smem, smem + OP_BYTES, wm, wn, lane, 0);
+  load_frags<false>(fa, smem, smem + G::A_BYTES, wm, wn, lane, 0);
+  if (ablate & 2) load_frags<false>(fb, smem, smem + G::A_BYTES, wm, wn, lane, 0);
   if (ablate & 16) return;  // timing-only: launch + prologue
   for (int kt = 0; kt < nk; kt += 2) {
-    pipe_step(acc, fa, fb, kt, nk, A, p.lda, m0, mmax, B, p.ldb, n0, nmax, smem, wm, wn, wave, lane, ablate);
-    pipe_step(acc, fb, fa, kt + 1, nk, A, p.lda, m0, mmax, B, p.ldb, n0, nmax, smem, wm, wn, wave, lane, ablate);
+    pipe_step<WM>(acc, fa, fb, kt, nk, A, p.lda, m0, mmax, B, p.ldb, n0, nmax, smem, wm, wn, wave, lane, ablate);
+    pipe_step<WM>(acc, fb, fa, kt + 1, nk, A, p.lda, m0, mmax, B, p.ldb, n0, nmax, smem, wm, wn, wave, lane, ablate);
   }
   if (ablate & 4) {   // timing-only: no K-extension, no epilogue (one store keeps the accumulators live)
     float s = 0.f;
@@ -171,11 +208,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const cara_gemm_args p,
     return;
   }
   if (p.Rp > 0) {
+    char* extB = smem + G::BM * 128;   // A image [BM][64] first, then B image [256][64]
     __syncthreads();
-    stage_ext(static_cast<const bf16*>(p.A2), p.Rp, m0, mmax, smem, tid);
-    stage_ext(static_cast<const bf16*>(p.B2), p.Rp, n0, nmax, smem + 2 * OP_BYTES, tid);
+    stage_ext(static_cast<const bf16*>(p.A2), p.Rp, m0, mmax, smem, tid, G::BM, G::NW * 64);
+    stage_ext(static_cast<const bf16*>(p.B2), p.Rp, n0, nmax, extB, tid, 256, G::NW * 64);
     __syncthreads();
-    for (int kk = 0; kk < (p.Rp >> 5); ++kk) mma_kstep<true>(acc, smem, smem + 2 * OP_BYTES, wm, wn, lane, kk);
+    for (int kk = 0; kk < (p.Rp >> 5); ++kk) mma_kstep<true>(acc, smem, extB, wm, wn, lane, kk);
   }
 
   // ---- epilogue: two 64-row halves through a wave-private 64x64 fp32 LDS image ----
@@ -194,37 +232,47 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const cara_gemm_args p,
   }
 }
 
-template <int EPI>
+template <int EPI, int WM>
 int launch256(const cara_gemm_args* a, hipStream_t st) {
+  using G = Geo<WM>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI, WM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              G::LDS_BYTES);
     attr_set = true;
   }
-  const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
+  const int tiles_m = (a->M + G::BM - 1) / G::BM, tiles_n = (a->N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
   // CARA_GEMM_ABLATE (diagnostic, results become wrong): 1 = no in-loop DMA, 2 = no in-loop fragment
   // reads, 4 = stop before the K-extension/epilogue
-  static int ablate = -1;
+  static int ablate = -1, gw_forced = -1;
   if (ablate < 0) {
     const char* e = getenv("CARA_GEMM_ABLATE");
     ablate = e ? atoi(e) : 0;
+    const char* g = getenv("CARA_GEMM_GW");
+    gw_forced = g ? atoi(g) : 0;
   }
-  hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(nwg), dim3(512), LDS_BYTES, st, *a, tiles_n, nwg, ablate);
+  const int ngroups = (tiles_n + 7) / 8;
+  const int gw = gw_forced > 0 ? gw_forced : (tiles_n + ngroups - 1) / ngroups;
+  hipLaunchKernelGGL((gemm256_kernel<EPI, WM>), dim3(nwg), dim3(G::NW * 64), G::LDS_BYTES, st, *a, tiles_m, tiles_n, gw, ablate);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }
 
-}  // namespace
-
-// internal entry used by cara_gemm_bf16 (arguments already validated there)
-int cara_gemm256_dispatch(const cara_gemm_args* a, hipStream_t st) {
+template <int WM>
+int dispatch_wm(const cara_gemm_args* a, hipStream_t st) {
   switch (a->epi) {
-    case CARA_EPI_BF16: return launch256<CARA_EPI_BF16>(a, st);
-    case CARA_EPI_F32: return launch256<CARA_EPI_F32>(a, st);
-    case CARA_EPI_GELU: return launch256<CARA_EPI_GELU>(a, st);
-    case CARA_EPI_RESID: return launch256<CARA_EPI_RESID>(a, st);
-    case CARA_EPI_DGELU: return launch256<CARA_EPI_DGELU>(a, st);
+    case CARA_EPI_BF16: return launch256<CARA_EPI_BF16, WM>(a, st);
+    case CARA_EPI_F32: return launch256<CARA_EPI_F32, WM>(a, st);
+    case CARA_EPI_GELU: return launch256<CARA_EPI_GELU, WM>(a, st);
+    case CARA_EPI_RESID: return launch256<CARA_EPI_RESID, WM>(a, st);
+    case CARA_EPI_DGELU: return launch256<CARA_EPI_DGELU, WM>(a, st);
     default: return CARA_E_ARG;
   }
 }
+
+}  // namespace
+
+// internal entries used by cara_gemm_bf16 (arguments already validated there)
+int cara_gemm256_dispatch(const cara_gemm_args* a, hipStream_t st) { return dispatch_wm<2>(a, st); }
+int cara_gemm128x256_dispatch(const cara_gemm_args* a, hipStream_t st) { return dispatch_wm<1>(a, st); }

@@ -96,6 +96,29 @@ def test_gemm_epilogues():
     close(dg, (A.double() @ B.double().t()) * ud.grad, 2 ** -8, 2e-3, "epi dgelu")
 
 
+# ---- LDS-ring kernels (CARA_GEMM_TILE = 256: 256x256, one workgroup per CU; 1282: 128x256, two per CU) --------
+@pytest.mark.parametrize("tile", ["256", "1282"])
+@pytest.mark.parametrize("M,N,K,Rp", [(12608, 768, 768, 32), (1500, 3072, 768, 64), (333, 300, 128, 32), (777, 640, 64, 0),
+                                      (130, 2304, 3072, 32)])
+def test_gemm_ring_tiles(M, N, K, Rp, tile, monkeypatch):
+    monkeypatch.setenv("CARA_GEMM_TILE", tile)
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    bias = rnd(N, seed=3, dtype=torch.float32)
+    A2 = rnd(M, Rp, seed=4) if Rp else None
+    B2 = rnd(N, Rp, seed=5) if Rp else None
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    L().gemm(A, B, out, epi=L().EPI_F32, bias=bias, A2=A2, B2=B2)
+    ref = A.double() @ B.double().t() + bias.double()
+    if Rp:
+        ref = ref + A2.double() @ B2.double().t()
+    close(out, ref, 1e-4, 1e-3 * math.sqrt(K / 64) + 2e-3, f"ring tile {tile}: {M}x{N}x{K}+{Rp}")
+    h = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L().gemm(A, B, h, epi=L().EPI_GELU, bias=bias, A2=A2, B2=B2, C2=u)
+    close(u, ref, 2 ** -8, 2e-3 * math.sqrt(K / 64) + 2e-3, "ring gelu u")
+    close(h, torch.nn.functional.gelu(ref), 2 ** -8, 2e-3 * math.sqrt(K / 64) + 2e-3, "ring gelu h")
+
+
 # ---- persistent 256x256 kernel (opt-in: CARA_GEMM_SK=1 + caller scratch; M >= 1024, N >= 256) ----------
 def _sk_scratch():
     return torch.zeros(L().gemm_scratch_bytes(), dtype=torch.uint8, device=DEV)
