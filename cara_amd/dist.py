@@ -30,6 +30,10 @@ def world_size(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def get_rank(group=None) -> int:
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
 def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
     """In-place mean over ranks of the flat gradient buffer: a single collective per step."""
     ws = world_size(group)
