@@ -30,12 +30,15 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
 # algorithmic GFLOP per image, SURVEY.md 8(d) / BASELINE.md section 3 (ViT-B/16, R=16)
 GF_PER_IMG = {"fwd": 36.06, "bwd": 38.18, "step": 74.24}
+# --model vit_large_patch16_384 (BASELINE.json configs[4], bs 32, rank 16): informational runs only, the
+# reported metric stays the ViT-B configuration
+GF_PER_IMG_L384 = {"fwd": 389.39, "bwd": 428.47, "step": 817.87}
 
 
-def build_model(rank, scale, num_classes, device, seed):
+def build_model(rank, scale, num_classes, device, seed, name="vit_base_patch16_224_in21k"):
     from cara_amd import cara, create_model
     torch.manual_seed(seed)
-    vit = create_model("vit_base_patch16_224_in21k", drop_path_rate=0.1, num_classes=num_classes)
+    vit = create_model(name, drop_path_rate=0.1, num_classes=num_classes)
     vit = cara({"model": vit, "rank": rank, "scale": scale, "l_mu": 1.5, "l_std": 0.1})   # cifar row of vtab_config.py:2-8
     g = torch.Generator().manual_seed(3)
     with torch.no_grad():  # non-zero adapters (zero-init would make the K-extension trivially zero)
@@ -92,6 +95,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="vit_base_patch16_224_in21k",
+                    help="vit_large_patch16_384 runs BASELINE.json configs[4] (use --batch 32); informational only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,14 +123,16 @@ def main():
     from cara_amd import _lib
     lib = _lib.lib()
     scale, ncls = 0.1, 100
-    model, trainable = build_model(args.rank, scale, ncls, dev, seed=14)  # identical replicas on every rank
+    large = args.model == "vit_large_patch16_384"
+    gf, img, tokens, dim = (GF_PER_IMG_L384, 384, 577, 1024) if large else (GF_PER_IMG, 224, 197, 768)
+    model, trainable = build_model(args.rank, scale, ncls, dev, seed=14, name=args.model)  # identical replicas on every rank
     eng = model._cara_engine
     try:
         opt = torch.optim.AdamW(trainable, lr=1e-3, weight_decay=1e-4, fused=True)
     except Exception:
         opt = torch.optim.AdamW(trainable, lr=1e-3, weight_decay=1e-4)
     gx = torch.Generator().manual_seed(1000 + rank)   # each rank its own shard of the global batch
-    x = torch.randn(args.batch, 3, 224, 224, generator=gx).to(dev)
+    x = torch.randn(args.batch, 3, img, img, generator=gx).to(dev)
     y = torch.randint(0, ncls, (args.batch,), generator=gx).to(dev)
 
     def step():
@@ -177,7 +184,7 @@ def main():
     if rank == 0:
         ms_step = wall * 1e3 / args.steps
         ips = world * args.batch * args.steps / wall
-        M, D = args.batch * 197, 768
+        M, D = args.batch * tokens, dim
         fl_launch = 2.0 * M * (4 * D) * (D + args.rank)          # algorithmic: K = dim + rank (not the padded Rp)
         ach = fl_launch / (avg_ms.value * 1e-3) / 1e12
         # HBM-side bytes per launch of that kernel from a committed rocprofv3 PMC run (separate
@@ -185,30 +192,34 @@ def main():
         # guide); only valid for the headline shape
         traffic = None
         tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic_fc1.json")
-        if os.path.exists(tj) and args.batch == 64 and args.rank == 16:
+        if os.path.exists(tj) and args.batch == 64 and args.rank == 16 and not large:
             with open(tj) as fh:
                 traffic = json.load(fh).get("hbm_bytes_per_launch_corrected")
         out = {
-            "metric": "fine-tune images/sec ViT-B/16+CaRA r=16 @224, bs=64/GPU, 1/2/4/8 MI355X",
+            "metric": ("fine-tune images/sec ViT-L/16+CaRA r=16 @384, bs=32/GPU (BASELINE.json configs[4], informational)" if large
+                       else "fine-tune images/sec ViT-B/16+CaRA r=16 @224, bs=64/GPU, 1/2/4/8 MI355X"),
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"ViT-B/16 + CaRA rank={args.rank}, synthetic 224x224, bs={args.batch}/GPU, bf16 "
-                                   "(BASELINE.json configs[1]); fwd + CE + bwd + AdamW, drop-path 0.1, factored adapters",
+            "config": {"workload": (f"ViT-L/16 + CaRA rank={args.rank}, synthetic 384x384, bs={args.batch}/GPU, bf16 "
+                                    "(BASELINE.json configs[4], informational); fwd + CE + bwd + AdamW, drop-path 0.1, factored adapters"
+                                    if large else
+                                    f"ViT-B/16 + CaRA rank={args.rank}, synthetic 224x224, bs={args.batch}/GPU, bf16 "
+                                    "(BASELINE.json configs[1]); fwd + CE + bwd + AdamW, drop-path 0.1, factored adapters"),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
-                       "step_algorithmic_gflop": round(GF_PER_IMG["step"] * args.batch, 1),
-                       "step_tflops_per_gpu": round(GF_PER_IMG["step"] * args.batch / ms_step, 1),
-                       "step_frac_of_mfma_peak": round(GF_PER_IMG["step"] * args.batch / ms_step / PEAK_BF16_TFLOPS, 4),
+                       "step_algorithmic_gflop": round(gf["step"] * args.batch, 1),
+                       "step_tflops_per_gpu": round(gf["step"] * args.batch / ms_step, 1),
+                       "step_frac_of_mfma_peak": round(gf["step"] * args.batch / ms_step / PEAK_BF16_TFLOPS, 4),
                        "gpu_event_ms_per_step": round(ev_ms / args.steps, 3), "loss": float(loss),
                        "forward_only_ms": round(fwd_ms, 3),
                        "forward_only_images_per_sec_per_gpu": round(args.batch / fwd_ms * 1e3, 1),
-                       "forward_frac_of_mfma_peak": round(GF_PER_IMG["fwd"] * args.batch / fwd_ms / PEAK_BF16_TFLOPS, 4)},
+                       "forward_frac_of_mfma_peak": round(gf["fwd"] * args.batch / fwd_ms / PEAK_BF16_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "gemm32_kernel<CARA_EPI_GELU> (fc1 forward, M=12608 N=3072 K=768+16; the rocprofv3 name is gemm32_kernel<2>)",
+                         "kernel": f"gemm32_kernel<CARA_EPI_GELU> (fc1 forward, M={M} N={4 * D} K={D}+{args.rank}; the rocprofv3 name is gemm32_kernel<2>)",
                          "avg_launch_ms": round(avg_ms.value, 4), "launches_timed": nl.value},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not large:
             out["cpu_baseline"] = cpu_baseline(args.rank, scale)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1,4 +1,7 @@
-// Fused attention forward / backward for the ViT token counts (N <= 224, head dim 64) on gfx950.
+// Fused attention forward / backward for the ViT token counts (head dim 64) on gfx950: N <= 224 (ViT-B/16
+// @224: 197 tokens) on the register-resident path described below, N <= 608 (ViT-L/16 @384: 577 tokens) on
+// the same kernels with the whole K/V (or Q/dO) of a head still in LDS (152 KiB, one workgroup per CU) and a
+// forward that sweeps the key tiles twice (max + sum, then P.V) instead of holding the score rows.
 // Reference semantics: /root/reference/src/cara/cara.py:43-48
 //     attn = softmax((q @ k^T) * scale); x = (attn @ v).transpose(1, 2).reshape(B, N, C)
 // with q, k, v the three [B,H,N,64] views of the qkv activation laid out exactly as cara.py:39
@@ -26,7 +29,8 @@
 namespace {
 
 constexpr int HD = 64;        // head dim
-constexpr int NMAX = 224;     // 7 tiles of 32
+constexpr int NMAX = 224;     // 7 tiles of 32: the score rows of a wave fit in registers
+constexpr int NMAX_LONG = 608;  // 19 tiles: two [608][64] bf16 images + the row constants are 160 512 B of the 160 KiB
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 // row of the 32x32 C/D layout held in register r of lane half h
@@ -61,8 +65,10 @@ __device__ __forceinline__ bf16x8 tr_frag_rm(const char* img, int cbase, int bas
   return o;
 }
 
-__device__ __forceinline__ void stage_rows_swz(const bf16* __restrict__ src, int ld, int N, char* img, int tid, int nthreads) {
-  for (int idx = tid; idx < NMAX * 8; idx += nthreads) {
+// npad = N rounded up to a multiple of 32: the images hold npad rows (rows >= N duplicate row N-1)
+__device__ __forceinline__ void stage_rows_swz(const bf16* __restrict__ src, int ld, int N, char* img, int tid, int nthreads,
+                                               int npad) {
+  for (int idx = tid; idx < npad * 8; idx += nthreads) {
     const int n = idx >> 3, c = idx & 7;
     const int nn = n < N ? n : N - 1;
     *reinterpret_cast<uint4*>(img + swz128(n, c)) = *reinterpret_cast<const uint4*>(src + (size_t)nn * ld + c * 8);
@@ -72,14 +78,14 @@ __device__ __forceinline__ void stage_rows_swz(const bf16* __restrict__ src, int
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-constexpr int FWD_LDS = 2 * NMAX * 128;  // K and V, both as swizzled row-major images
+// LDS: K and V, both as swizzled row-major images of npad rows
 
 template <int NW>  // waves per workgroup: 7 covers N <= 224 with ONE staging of K/V per head
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                              float* __restrict__ lse, int N, int H, float scale) {
+                                                              float* __restrict__ lse, int N, int H, float scale, int npad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
-  char* Vs = smem + NMAX * 128;
+  char* Vs = smem + npad * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.x, b = bh / H, head = bh - b * H;
   const int ld = 3 * H * HD;
@@ -87,8 +93,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16* __rest
   const bf16* kb = qb + H * HD;
   const bf16* vb = qb + 2 * H * HD;
 
-  stage_rows_swz(kb, ld, N, Ks, tid, NW * 64);
-  stage_rows_swz(vb, ld, N, Vs, tid, NW * 64);
+  stage_rows_swz(kb, ld, N, Ks, tid, NW * 64, npad);
+  stage_rows_swz(vb, ld, N, Vs, tid, NW * 64, npad);
   __syncthreads();
 
   const int q0 = (blockIdx.y * NW + wave) * 32;
@@ -171,6 +177,96 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16* __rest
   if (h == 0 && q0 + ql < N) lse[(size_t)bh * N + q0 + ql] = mx * scale + __logf(sum);
 }
 
+// Forward for 224 < N <= 608: same staging and fragment scheme, but the score rows no longer fit in
+// registers, so the key tiles are swept twice -- pass 1 recomputes S^T tile by tile for the row maxima and
+// the sums of exp, pass 2 recomputes it again and feeds P straight into P.V.  Still the exact softmax of
+// the short kernel (no running rescale); QK^T is 1/3 of the work, so the second sweep costs about a third.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_long_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                                   float* __restrict__ lse, int N, int H, float scale, int npad) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + npad * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x, b = bh / H, head = bh - b * H;
+  const int ld = 3 * H * HD;
+  const bf16* qb = qkv + (size_t)b * N * ld + head * HD;
+  const bf16* kb = qb + H * HD;
+  const bf16* vb = qb + 2 * H * HD;
+  stage_rows_swz(kb, ld, N, Ks, tid, NW * 64, npad);
+  stage_rows_swz(vb, ld, N, Vs, tid, NW * 64, npad);
+  __syncthreads();
+
+  const int q0 = (blockIdx.y * NW + wave) * 32;
+  if (q0 >= N) return;
+  const int ql = lane & 31, h = lane >> 5;
+  const int qrow = (q0 + ql) < N ? (q0 + ql) : N - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qb + (size_t)qrow * ld + ks * 16 + h * 8);
+  const int nkt = npad >> 5;
+  const float c2 = scale * 1.4426950408889634f;
+
+  auto score_tile = [&](int kt) {
+    f32x16 t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + swz128(kt * 32 + ql, ks * 2 + h));
+      t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], t, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = (kt * 32 + crow(r, h)) < N ? t[r] : -3.0e38f;   // S^T: row = key, column = query
+    return t;
+  };
+  // pass 1: row maximum, then (with the maximum known) the sum of exponentials, in the key order of pass 2
+  float mx = -3.0e38f;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const f32x16 t = score_tile(kt);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, t[r]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  // pass 2: P = exp(S - max) (masked keys give exp(-huge) = 0), sum and P.V together
+  for (int kt = 0; kt < nkt; ++kt) {
+    f32x16 t = score_tile(kt);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      t[r] = exp2f((t[r] - mx) * c2);
+      sum += t[r];
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const bf16x8 pa = pack8(t, st);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16x8 vf = tr_frag_rm(Vs, dt * 32, kt * 32 + st * 16, lane);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vf, o[dt], 0, 0, 0);
+      }
+    }
+  }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  bf16* ob = out + (size_t)b * N * (H * HD) + head * HD;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int qq = crow(r, h);
+    const float iv = __shfl(inv, qq, 64);
+    if (q0 + qq < N) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) ob[(size_t)(q0 + qq) * (H * HD) + dt * 32 + ql] = (bf16)(o[dt][r] * iv);
+    }
+  }
+  if (h == 0 && q0 + ql < N) lse[(size_t)bh * N + q0 + ql] = mx * scale + __logf(sum);
+}
+
 // ------------------------------------------------------------------------------------------
 // backward, kernel 1: dK, dV.  One workgroup of 7 waves per (batch, head); wave w owns keys
 // 32w..32w+31 and keeps dK^T, dV^T in accumulators while sweeping the query tiles.  Q and dO are
@@ -178,20 +274,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16* __rest
 // transposing read ds_read_b64_tr_b16 of the same images feeds dV^T += dO^T P and dK^T += Q^T dS
 // (whose B operands are the P / dS accumulators).
 // ------------------------------------------------------------------------------------------
-constexpr int BWD_WAVES = 7;
-constexpr int DKV_OFF_Q = 0;
-constexpr int DKV_OFF_DO = DKV_OFF_Q + NMAX * 128;
-constexpr int DKV_OFF_ROW = DKV_OFF_DO + NMAX * 128;
-constexpr int DKV_LDS = DKV_OFF_ROW + 2 * NMAX * 4;
+constexpr int BWD_WAVES = 7;   // keys per workgroup = 7 * 32; blockIdx.y walks the key groups when N > 224
+__host__ __device__ constexpr int dkv_lds_bytes(int npad) { return 2 * npad * 128 + 2 * npad * 4; }
 
 __global__ __launch_bounds__(448, 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                               const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                              bf16* __restrict__ dqkv, int N, int H, float scale) {
+                                                              bf16* __restrict__ dqkv, int N, int H, float scale, int npad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Qs = smem + DKV_OFF_Q;
-  char* dOs = smem + DKV_OFF_DO;
-  float* lse_s = reinterpret_cast<float*>(smem + DKV_OFF_ROW);
-  float* del_s = lse_s + NMAX;
+  char* Qs = smem;
+  char* dOs = smem + npad * 128;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * npad * 128);
+  float* del_s = lse_s + npad;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.x, b = bh / H, head = bh - b * H;
   const int ld = 3 * H * HD, ldo = H * HD;
@@ -201,10 +294,10 @@ __global__ __launch_bounds__(448, 2) void attn_bwd_dkv_kernel(const bf16* __rest
   const bf16* ob = out + (size_t)b * N * ldo + head * HD;
   const bf16* dob = dout + (size_t)b * N * ldo + head * HD;
 
-  stage_rows_swz(qb, ld, N, Qs, tid, 448);
-  stage_rows_swz(dob, ldo, N, dOs, tid, 448);
-  if (tid < NMAX) {
-    const int n = tid < N ? tid : N - 1;
+  stage_rows_swz(qb, ld, N, Qs, tid, 448, npad);
+  stage_rows_swz(dob, ldo, N, dOs, tid, 448, npad);
+  for (int row = tid; row < npad; row += 448) {
+    const int n = row < N ? row : N - 1;
     float dl = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -213,12 +306,12 @@ __global__ __launch_bounds__(448, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 #pragma unroll
       for (int j = 0; j < 8; ++j) dl += (float)a[j] * (float)g[j];
     }
-    del_s[tid] = dl;
-    lse_s[tid] = lse[(size_t)bh * N + n] * 1.4426950408889634f;
+    del_s[row] = dl;
+    lse_s[row] = lse[(size_t)bh * N + n] * 1.4426950408889634f;
   }
   __syncthreads();
 
-  const int key0 = wave * 32;
+  const int key0 = (blockIdx.y * BWD_WAVES + wave) * 32;
   if (key0 >= N) return;
   const int kl = lane & 31, h = lane >> 5;
   const float c2 = scale * 1.4426950408889634f;
@@ -238,7 +331,7 @@ __global__ __launch_bounds__(448, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dkt[dt][r] = 0.f; dvt[dt][r] = 0.f; }
 
-  const int nqt = (N + 31) >> 5;
+  const int nqt = npad >> 5;
   for (int qt = 0; qt < nqt; ++qt) {
     const int q0 = qt * 32;
     f32x16 sacc, pacc;
@@ -299,15 +392,14 @@ __global__ __launch_bounds__(448, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 // the A operand of dQ += dS K (B fragments from the transposed K image): no LDS round trip, no
 // cross-wave sum, no atomics.
 // ------------------------------------------------------------------------------------------
-constexpr int DQ_LDS = 2 * NMAX * 128;  // K rows, V rows (swizzled row-major images)
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                                  const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                                 bf16* __restrict__ dqkv, int N, int H, float scale) {
+                                                                 bf16* __restrict__ dqkv, int N, int H, float scale, int npad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
-  char* Vs = smem + NMAX * 128;
+  char* Vs = smem + npad * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.x, b = bh / H, head = bh - b * H;
   const int ld = 3 * H * HD, ldo = H * HD;
@@ -316,8 +408,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16* __r
   const bf16* vb = qb + 2 * H * HD;
   const bf16* ob = out + (size_t)b * N * ldo + head * HD;
   const bf16* dob = dout + (size_t)b * N * ldo + head * HD;
-  stage_rows_swz(kb, ld, N, Ks, tid, NW * 64);
-  stage_rows_swz(vb, ld, N, Vs, tid, NW * 64);
+  stage_rows_swz(kb, ld, N, Ks, tid, NW * 64, npad);
+  stage_rows_swz(vb, ld, N, Vs, tid, NW * 64, npad);
   __syncthreads();
 
   const int q0 = (blockIdx.y * NW + wave) * 32;
@@ -343,7 +435,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16* __r
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-  const int nkt = (N + 31) >> 5;
+  const int nkt = npad >> 5;
   for (int kt = 0; kt < nkt; ++kt) {
     f32x16 sT, dpT;
 #pragma unroll
@@ -388,7 +480,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16* __r
 // diagnostic: stage a [N,64] matrix like the kernels do and return every lane's transposed fragment
 __global__ void tr_frag_probe_kernel(const bf16* __restrict__ src, bf16* __restrict__ out, int N, int cbase, int base) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  stage_rows_swz(src, 64, N, smem, threadIdx.x, 64);
+  stage_rows_swz(src, 64, N, smem, threadIdx.x, 64, NMAX);
   __syncthreads();
   const bf16x8 f = tr_frag_rm(smem, cbase, base, threadIdx.x & 63);
   for (int j = 0; j < 8; ++j) out[threadIdx.x * 8 + j] = f[j];
@@ -414,43 +506,53 @@ static int attn_waves(int N) {
   return N > 128 ? 7 : 4;
 }
 
+constexpr int MAX_LDS = 160 * 1024;
+static void attn_set_lds_limits() {
+  static bool done = false;
+  if (done) return;
+  const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<4>), at, MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<7>), at, MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_long_kernel<7>), at, MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), at, MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<4>), at, MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<7>), at, MAX_LDS);
+  done = true;
+}
+
 extern "C" int cara_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, void* stream) {
-  if (!qkv || !out || !lse || B <= 0 || H <= 0 || N <= 0 || N > NMAX) return CARA_E_ARG;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
-    attr_set = true;
-  }
+  if (!qkv || !out || !lse || B <= 0 || H <= 0 || N <= 0 || N > NMAX_LONG) return CARA_E_ARG;
+  attn_set_lds_limits();
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (attn_waves(N) == 7)
-    hipLaunchKernelGGL(attn_fwd_kernel<7>, dim3(B * H, (N + 223) / 224), dim3(448), FWD_LDS, st, (const bf16*)qkv, (bf16*)out, lse, N, H, scale);
+  const int npad = (N + 31) / 32 * 32, lds = 2 * npad * 128;
+  if (N > NMAX)
+    hipLaunchKernelGGL(attn_fwd_long_kernel<7>, dim3(B * H, (N + 223) / 224), dim3(448), lds, st, (const bf16*)qkv, (bf16*)out, lse, N,
+                       H, scale, npad);
+  else if (attn_waves(N) == 7)
+    hipLaunchKernelGGL(attn_fwd_kernel<7>, dim3(B * H, (N + 223) / 224), dim3(448), lds, st, (const bf16*)qkv, (bf16*)out, lse, N, H,
+                       scale, npad);
   else
-    hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(B * H, (N + 127) / 128), dim3(256), FWD_LDS, st, (const bf16*)qkv, (bf16*)out, lse, N, H, scale);
+    hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(B * H, (N + 127) / 128), dim3(256), lds, st, (const bf16*)qkv, (bf16*)out, lse, N, H,
+                       scale, npad);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }
 
 extern "C" int cara_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                                   int B, int N, int H, float scale, void* stream) {
-  if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || H <= 0 || N <= 0 || N > NMAX) return CARA_E_ARG;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS);
-    attr_set = true;
-  }
+  if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || H <= 0 || N <= 0 || N > NMAX_LONG) return CARA_E_ARG;
+  attn_set_lds_limits();
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H), dim3(448), DKV_LDS, st, (const bf16*)qkv, (const bf16*)out,
-                     (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale);
+  const int npad = (N + 31) / 32 * 32, lds = 2 * npad * 128;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H, (N + 223) / 224), dim3(448), dkv_lds_bytes(npad), st, (const bf16*)qkv,
+                     (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale, npad);
   CARA_CHECK_LAUNCH();
-  if (attn_waves(N) == 7)
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<7>, dim3(B * H, (N + 223) / 224), dim3(448), DQ_LDS, st, (const bf16*)qkv,
-                       (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale);
+  if (N > NMAX || attn_waves(N) == 7)
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<7>, dim3(B * H, (N + 223) / 224), dim3(448), lds, st, (const bf16*)qkv,
+                       (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale, npad);
   else
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, dim3(B * H, (N + 127) / 128), dim3(256), DQ_LDS, st, (const bf16*)qkv,
-                       (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, dim3(B * H, (N + 127) / 128), dim3(256), lds, st, (const bf16*)qkv,
+                       (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale, npad);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }

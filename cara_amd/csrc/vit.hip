@@ -41,7 +41,7 @@ size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 
 bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
   if (!g || !s || g->depth <= 0 || g->depth > 64 || g->dim % g->heads || g->dim / g->heads != 64) return false;
-  if (!(g->Rp == 32 || g->Rp == 64) || g->rank > g->Rp || s->B <= 0 || s->tokens <= 1 || s->tokens > 224) return false;
+  if (!(g->Rp == 32 || g->Rp == 64) || g->rank > g->Rp || s->B <= 0 || s->tokens <= 1 || s->tokens > 608) return false;
   if (s->img % s->patch || (s->img / s->patch) * (s->img / s->patch) + 1 != s->tokens) return false;
   if ((s->chans * s->patch * s->patch) % 64 || g->dim % 256) return false;
   const size_t D = g->dim, M = (size_t)s->B * s->tokens, Rp = g->Rp;

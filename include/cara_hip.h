@@ -104,7 +104,8 @@ int cara_layernorm_bwd(const void* dy, const float* x, long ldx, const float* ga
 
 /* ---- attention (cara.py:43-48; softmax(q k^T * scale) v per head) ------------------------- */
 /* qkv bf16 [B*N, 3*H*64] with column k*H*64 + h*64 + d (k = q,k,v): exactly the layout
- * cara.py:39 reshapes.  out bf16 [B*N, H*64]; lse fp32 [B,H,N].  N <= 224, head dim 64.        */
+ * cara.py:39 reshapes.  out bf16 [B*N, H*64]; lse fp32 [B,H,N].  N <= 608, head dim 64 (N <= 224:   *
+ * score rows in registers; above: two sweeps over the key tiles, whole K/V of a head in LDS).  */
 int cara_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale,
                        void* stream);
 int cara_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,

@@ -30,10 +30,9 @@ def rel(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-def build(w, cp, rank, scale, depth, img, num_classes=100, drop_path_rate=0.1):
+def build(w, cp, rank, scale, depth, img, num_classes=100, drop_path_rate=0.1, name="vit_base_patch16_224_in21k"):
     from cara_amd import cara, create_model
-    m = create_model("vit_base_patch16_224_in21k", drop_path_rate=drop_path_rate, depth=depth, img_size=img,
-                     num_classes=num_classes)
+    m = create_model(name, drop_path_rate=drop_path_rate, depth=depth, img_size=img, num_classes=num_classes)
     m = cara({"model": m, "rank": rank, "scale": scale, "l_mu": 1.5, "l_std": 0.1})
     sd = dict(w)
     sd.update(cp)
@@ -114,6 +113,42 @@ def test_whole_model_with_persistent_gemm(monkeypatch):
     # (with whole-tile rounds the persistent kernel adds the K steps in the tile kernel's order: often bitwise equal)
     assert r < 8e-3 and worst < 2e-2, (r, worst)
     assert torch.equal(out["1"][0].argmax(1), out["0"][0].argmax(1))
+
+
+def test_vit_large_384_against_oracle():
+    """BASELINE.json configs[4] dimensioning: ViT-L/16 @384 -- dim 1024, 16 heads, 24 blocks, 577 tokens (the
+    two-sweep attention path), CP_A1 [72,R], CP_A3 [16,R], CP_P1 [216,R], CP_A2/P2/P3 [1024,R], biases
+    1024/4096/1024.  Batch 2, rank 16: logits and every CP gradient against the fp32 oracle
+    (as-written dense-dW algorithm) and the rounding model."""
+    from oracle import cara_oracle as O
+    torch.manual_seed(0)
+    dims = dict(depth=24, dim=1024, heads=16)
+    w = O.synthetic_backbone(img=384, **dims)
+    cp = O.synthetic_cp(rank=16, **dims)
+    x, y = O.synthetic_batch(batch=2, img=384)
+    m = build(w, cp, 16, 0.1, 24, 384, name="vit_large_patch16_384").eval()
+    assert m.CP_A1.shape == (72, 16) and m.CP_A3.shape == (16, 16) and m.CP_P1.shape == (216, 16)
+    assert m.CP_P2.shape == (1024, 16) and m.CP_bias2.shape == (4096,) and m.idx == 216 and m.attn_idx == 72
+    logits = m(x.to(DEV))
+    with torch.no_grad():
+        ref = O.vit_cara_forward(x, w, cp, s=0.1, depth=24, num_heads=16)
+        sim = O.vit_cara_forward(x, w, cp, s=0.1, depth=24, num_heads=16, factored=True, bf16_sim=True)
+    r_ref, r_sim, r_model = rel(logits, ref), rel(logits, sim), rel(sim, ref)
+    print(f"ViT-L/16@384 logits rel-L2: vs fp32 oracle {r_ref:.2e}, vs bf16-rounded oracle {r_sim:.2e} (rounding model {r_model:.2e})")
+    assert r_ref < 2e-2 and r_ref < 1.5 * max(r_model, 4e-3), (r_ref, r_model)
+    top2 = ref.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 4 * (logits.cpu() - ref).abs().max()
+    assert torch.equal(logits.argmax(1).cpu()[safe], ref.argmax(1)[safe])
+    torch.nn.functional.cross_entropy(logits, y.to(DEV)).backward()
+    head = {"weight": w["head.weight"], "bias": w["head.bias"]}
+    _, _, gref = O.train_step_as_written(x, y, w, cp, head, s=0.1, depth=24, num_heads=16)
+    worst = 0.0
+    for n in O.CP_NAMES:
+        r = rel(getattr(m, n).grad, gref[n])
+        worst = max(worst, r)
+        assert r < 6e-2, (n, r)
+    print(f"ViT-L/16@384 worst CP-gradient rel-L2 vs fp32 autograd of the as-written form: {worst:.2e}")
+    assert rel(m.head.weight.grad, gref["head.weight"]) < 3e-2
 
 
 def test_depth12_headline_shapes_against_oracle():
