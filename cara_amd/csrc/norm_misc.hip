@@ -7,16 +7,78 @@
 
 namespace {
 
-template <int V4>  // C / 256 : float4 per lane
+// Skinny adapter contraction fused into the kernel that PRODUCES its input (T = X U in
+// the forward, G' = dY Vs in the backward; K = C columns, Rp = 32 output columns of which the first `rank`
+// are non-zero).  A block of 4 waves normalises 16 rows (4 each), leaves their bf16 images in LDS
+// ([16][C + 8]: the 16-byte pad spreads the rows of an MFMA A fragment over the banks), then contracts them
+// with Ut [32][C] on the matrix cores: wave w takes the K steps w, w+4, ... (its B fragments come straight
+// from global / L2: 1.5 KB per row, the cost of the staging the separate cara_skinny_xu pass pays too), the
+// four partial 16 x 32 tiles are summed through LDS in fixed order.  Two earlier forms were measured and
+// dropped: per-lane v_dot2 sums with the factor slice read per row (more L1 traffic than the pass it
+// replaces) or held in LDS (as slow as LayerNorm + cara_skinny_xu: ~250 VALU instructions per row).
+constexpr int XU_ROWS = 4;          // rows per wave, 16 per block
+template <int V4>
+struct XuLds {
+  static constexpr int LDY = V4 * 256 + 8;   // bf16 elements per staged row
+  bf16 y[16 * LDY];
+  float part[4][2][64 * 4];
+};
+template <int V4>
+__device__ __forceinline__ void block_contract(XuLds<V4>& L, const bf16* __restrict__ Ut, bf16* __restrict__ T,
+                                               bf16* __restrict__ Tt, const int ldt, const int row_base, const int M) {
+  constexpr int C = V4 * 256, KS = C / 32, LDY = XuLds<V4>::LDY;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  __syncthreads();   // the 16 staged rows are complete
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int s = wave; s < KS; s += 4) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(L.y + fr * LDY + s * 32 + fq * 8);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const bf16x8 u = *reinterpret_cast<const bf16x8*>(Ut + (size_t)(nt * 16 + fr) * C + s * 32 + fq * 8);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, u, acc[nt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<f32x4*>(&L.part[wave][nt][lane * 4]) = acc[nt];
+  __syncthreads();
+  if (wave < 2) {   // wave nt sums column tile nt: lane (fr, fq) holds rows fq*4 .. +3 of column nt*16 + fr
+    const int nt = wave;
+    f32x4 t = *reinterpret_cast<const f32x4*>(&L.part[0][nt][lane * 4]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(&L.part[w][nt][lane * 4]);
+    const int col = nt * 16 + fr, m0 = row_base + fq * 4;
+    const bf16x4 o = {(bf16)t[0], (bf16)t[1], (bf16)t[2], (bf16)t[3]};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (m0 + r < M) T[(size_t)(m0 + r) * 32 + col] = o[r];
+    if (Tt) {
+      if (m0 + 4 <= M) {
+        *reinterpret_cast<bf16x4*>(Tt + (size_t)col * ldt + m0) = o;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (m0 + r < M) Tt[(size_t)col * ldt + m0 + r] = o[r];
+      }
+    }
+  }
+}
+
+template <int V4, bool XU>  // V4 = C / 256 : float4 per lane; XU: fused contraction, XU_ROWS rows per wave
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta,
                                                      bf16* __restrict__ y, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int M, float eps) {
+                                                     float* __restrict__ rstd, int M, float eps,
+                                                     const bf16* __restrict__ Ut, int rank, int Rp, bf16* __restrict__ T,
+                                                     bf16* __restrict__ Tt, int ldt) {
   constexpr int C = V4 * 256;
+  constexpr int RPW = XU ? XU_ROWS : 1;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  __shared__ __attribute__((aligned(16))) XuLds<XU ? V4 : 0> L;
+  for (int row = row0; row < row0 + RPW && row < M; ++row) {
   const float* xr = x + (size_t)row * ldx;
   float4 v[V4];
   float s = 0.f;
@@ -34,6 +96,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
   const float rs = rsqrtf(wave_sum(q) * (1.0f / C) + eps);
   bf16* yr = y + (size_t)row * C;
+  bf16x4 yb[V4];
 #pragma unroll
   for (int i = 0; i < V4; ++i) {
     const int c0 = i * 256 + lane * 4;
@@ -42,15 +105,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     bf16x4 o = {(bf16)((v[i].x - mu) * rs * g.x + b.x), (bf16)((v[i].y - mu) * rs * g.y + b.y),
                 (bf16)((v[i].z - mu) * rs * g.z + b.z), (bf16)((v[i].w - mu) * rs * g.w + b.w)};
     *reinterpret_cast<bf16x4*>(yr + c0) = o;
+    yb[i] = o;
   }
   if (lane == 0) {
     mean[row] = mu;
     rstd[row] = rs;
   }
+  if constexpr (XU) {
+#pragma unroll
+    for (int i = 0; i < V4; ++i)
+      *reinterpret_cast<bf16x4*>(L.y + (row - blockIdx.x * 16) * XuLds<V4>::LDY + i * 256 + lane * 4) = yb[i];
+  }
+  }
+  if constexpr (XU) block_contract<V4>(L, Ut, T, Tt, ldt, blockIdx.x * 16, M);   // T = LN(x) U of the next linear
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mu) * rstd
-template <int V4>
+template <int V4, bool XU>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
                                                      long ldx, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean,
@@ -58,11 +129,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
                                                      const float* __restrict__ dx_in,
                                                      float* __restrict__ dx_out, bf16* __restrict__ dyb,
                                                      const float* __restrict__ rowscale,
-                                                     int rows_per_sample, int M) {
+                                                     int rows_per_sample, int M,
+                                                     const bf16* __restrict__ Vst, int rank, int Rp, bf16* __restrict__ G,
+                                                     bf16* __restrict__ Gt, int ldt) {
   constexpr int C = V4 * 256;
+  constexpr int RPW = XU ? XU_ROWS : 1;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  __shared__ __attribute__((aligned(16))) XuLds<XU ? V4 : 0> L;
+  for (int row = row0; row < row0 + RPW && row < M; ++row) {
   const float mu = mean[row], rs = rstd[row];
   const float* xr = x + (size_t)row * ldx;
   const bf16* dr = dy + (size_t)row * C;
@@ -84,6 +159,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
   const float* di = dx_in ? dx_in + (size_t)row * ldx : nullptr;
   float* dor = dx_out + (size_t)row * ldx;
   bf16* db = dyb ? dyb + (size_t)row * ldx : nullptr;
+  bf16x4 yb[V4];
 #pragma unroll
   for (int i = 0; i < V4; ++i) {
     const int c0 = i * 256 + lane * 4;
@@ -94,11 +170,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
       o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
     }
     *reinterpret_cast<float4*>(dor + c0) = o;
-    if (db) {
-      bf16x4 b = {(bf16)(o.x * sc), (bf16)(o.y * sc), (bf16)(o.z * sc), (bf16)(o.w * sc)};
-      *reinterpret_cast<bf16x4*>(db + c0) = b;
-    }
+    bf16x4 b = {(bf16)(o.x * sc), (bf16)(o.y * sc), (bf16)(o.z * sc), (bf16)(o.w * sc)};
+    if (db) *reinterpret_cast<bf16x4*>(db + c0) = b;
+    yb[i] = b;
   }
+  if constexpr (XU) {
+#pragma unroll
+    for (int i = 0; i < V4; ++i)
+      *reinterpret_cast<bf16x4*>(L.y + (row - blockIdx.x * 16) * XuLds<V4>::LDY + i * 256 + lane * 4) = yb[i];
+  }
+  }
+  if constexpr (XU) block_contract<V4>(L, Vst, G, Gt, ldt, blockIdx.x * 16, M);   // G' = dY Vs of the linear below
 }
 
 // images fp32 [B,C,Hi,Wi] -> patch rows bf16 [B*gh*gw, C*p*p], column = (c*p + py)*p + px
@@ -190,35 +272,99 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__
 
 }  // namespace
 
-extern "C" int cara_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, void* y,
-                                  float* mean, float* rstd, int M, int C, float eps, void* stream) {
-  if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0 || ldx < C || (ldx & 3)) return CARA_E_ARG;
+namespace {
+struct XuArgs {   // optional fused skinny product (all NULL / 0 = plain LayerNorm)
+  const bf16* Ut;
+  int rank, Rp;
+  bf16 *T, *Tt;
+  int ldt;
+};
+bool xu_ok(const XuArgs& a, int M, int C) {
+  if (!a.Ut) return true;
+  // two 16-column MFMA tiles = Rp 32 (rows of Ut beyond the rank are zero, so the pad columns come out zero)
+  return a.T && a.Rp == 32 && a.rank > 0 && a.rank <= 32 && (!a.Tt || (a.ldt >= M && !(a.ldt & 7))) &&
+         (C == 768 || C == 256 || C == 1024);
+}
+// consumers (cara_tskinny_*) read Tt in whole 32-row steps: keep columns [M, roundup32(M)) zero (as cara_skinny_xu does)
+int xu_pad(const XuArgs& a, int M, hipStream_t st) {
+  const int m32 = (M + 31) / 32 * 32;
+  if (a.Ut && a.Tt && m32 > M && m32 <= a.ldt &&
+      hipMemset2DAsync(a.Tt + M, (size_t)a.ldt * 2, 0, (size_t)(m32 - M) * 2, a.Rp, st) != hipSuccess)
+    return CARA_E_LAUNCH;
+  return CARA_OK;
+}
+
+int ln_fwd_launch(const float* x, long ldx, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M,
+                  int C, float eps, const XuArgs& a, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0 || ldx < C || (ldx & 3) || !xu_ok(a, M, C)) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid((M + 3) / 4), block(256);
-  if (C == 768) hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, st, x, ldx, gamma, beta, (bf16*)y, mean, rstd, M, eps);
-  else if (C == 1024) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, st, x, ldx, gamma, beta, (bf16*)y, mean, rstd, M, eps);
-  else if (C == 256) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, st, x, ldx, gamma, beta, (bf16*)y, mean, rstd, M, eps);
+  if (xu_pad(a, M, st) != CARA_OK) return CARA_E_LAUNCH;
+  const int rows_per_block = a.Ut ? 4 * XU_ROWS : 4;
+  const dim3 grid((M + rows_per_block - 1) / rows_per_block), block(256);
+#define LNF(V, X) hipLaunchKernelGGL((ln_fwd_kernel<V, X>), grid, block, 0, st, x, ldx, gamma, beta, (bf16*)y, mean, rstd, M, eps, \
+                                     a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt)
+  if (a.Ut) {
+    if (C == 768) LNF(3, true);
+    else if (C == 1024) LNF(4, true);
+    else LNF(1, true);
+  } else if (C == 768) LNF(3, false);
+  else if (C == 1024) LNF(4, false);
+  else if (C == 256) LNF(1, false);
   else return CARA_E_ARG;
+#undef LNF
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }
 
-extern "C" int cara_layernorm_bwd(const void* dy, const float* x, long ldx, const float* gamma, const float* mean,
-                                  const float* rstd, const float* dx_in, float* dx_out, void* dyb,
-                                  const float* rowscale, int rows_per_sample, int M, int C, void* stream) {
-  if (!dy || !x || !gamma || !mean || !rstd || !dx_out || M <= 0 || ldx < C || (ldx & 3)) return CARA_E_ARG;
+int ln_bwd_launch(const void* dy, const float* x, long ldx, const float* gamma, const float* mean, const float* rstd,
+                  const float* dx_in, float* dx_out, void* dyb, const float* rowscale, int rows_per_sample, int M, int C,
+                  const XuArgs& a, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx_out || M <= 0 || ldx < C || (ldx & 3) || !xu_ok(a, M, C)) return CARA_E_ARG;
   if (rowscale && rows_per_sample <= 0) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid((M + 3) / 4), block(256);
-#define LNB(V) hipLaunchKernelGGL(ln_bwd_kernel<V>, grid, block, 0, st, (const bf16*)dy, x, ldx, gamma, mean, rstd, \
-                                  dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M)
-  if (C == 768) LNB(3);
-  else if (C == 1024) LNB(4);
-  else if (C == 256) LNB(1);
+  if (xu_pad(a, M, st) != CARA_OK) return CARA_E_LAUNCH;
+  const int rows_per_block = a.Ut ? 4 * XU_ROWS : 4;
+  const dim3 grid((M + rows_per_block - 1) / rows_per_block), block(256);
+#define LNB(V, X) hipLaunchKernelGGL((ln_bwd_kernel<V, X>), grid, block, 0, st, (const bf16*)dy, x, ldx, gamma, mean, rstd, \
+                                     dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M, a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt)
+  if (a.Ut) {
+    if (C == 768) LNB(3, true);
+    else if (C == 1024) LNB(4, true);
+    else LNB(1, true);
+  } else if (C == 768) LNB(3, false);
+  else if (C == 1024) LNB(4, false);
+  else if (C == 256) LNB(1, false);
   else return CARA_E_ARG;
 #undef LNB
   CARA_CHECK_LAUNCH();
   return CARA_OK;
+}
+}  // namespace
+
+extern "C" int cara_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, void* y,
+                                  float* mean, float* rstd, int M, int C, float eps, void* stream) {
+  return ln_fwd_launch(x, ldx, gamma, beta, y, mean, rstd, M, C, eps, XuArgs{nullptr, 0, 0, nullptr, nullptr, 0}, stream);
+}
+extern "C" int cara_layernorm_fwd_xu(const float* x, long ldx, const float* gamma, const float* beta, void* y,
+                                     float* mean, float* rstd, int M, int C, float eps, const void* Ut, int rank, int Rp,
+                                     void* T, void* Tt, int ldt, void* stream) {
+  if (!Ut) return CARA_E_ARG;
+  return ln_fwd_launch(x, ldx, gamma, beta, y, mean, rstd, M, C, eps,
+                       XuArgs{static_cast<const bf16*>(Ut), rank, Rp, static_cast<bf16*>(T), static_cast<bf16*>(Tt), ldt}, stream);
+}
+extern "C" int cara_layernorm_bwd(const void* dy, const float* x, long ldx, const float* gamma, const float* mean,
+                                  const float* rstd, const float* dx_in, float* dx_out, void* dyb,
+                                  const float* rowscale, int rows_per_sample, int M, int C, void* stream) {
+  return ln_bwd_launch(dy, x, ldx, gamma, mean, rstd, dx_in, dx_out, dyb, rowscale, rows_per_sample, M, C,
+                       XuArgs{nullptr, 0, 0, nullptr, nullptr, 0}, stream);
+}
+extern "C" int cara_layernorm_bwd_xu(const void* dy, const float* x, long ldx, const float* gamma, const float* mean,
+                                     const float* rstd, const float* dx_in, float* dx_out, void* dyb,
+                                     const float* rowscale, int rows_per_sample, int M, int C, const void* Vst, int rank,
+                                     int Rp, void* G, void* Gt, int ldt, void* stream) {
+  if (!Vst) return CARA_E_ARG;
+  return ln_bwd_launch(dy, x, ldx, gamma, mean, rstd, dx_in, dx_out, dyb, rowscale, rows_per_sample, M, C,
+                       XuArgs{static_cast<const bf16*>(Vst), rank, Rp, static_cast<bf16*>(G), static_cast<bf16*>(Gt), ldt}, stream);
 }
 
 extern "C" int cara_im2col_patches(const float* img, void* patches, int B, int C, int Hi, int Wi, int p, void* stream) {

@@ -151,6 +151,17 @@ struct Lin {  // one adapted linear of one layer
   int in, out, slot;
 };
 
+// CARA_FUSE_XU=0 keeps the K = dim adapter contractions (T = LN(x) U of qkv / fc1, G' = dY Vs of proj / fc2) as
+// separate cara_skinny_xu passes instead of fusing them into the LayerNorm kernels (A/B measurements)
+bool fuse_xu(const cara_geom* g) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CARA_FUSE_XU");
+    v = e ? atoi(e) : 1;
+  }
+  return v != 0 && g->Rp == 32 && (g->dim == 768 || g->dim == 1024 || g->dim == 256);   // what cara_layernorm_*_xu take
+}
+
 // stream-K scratch of the workspace in use (set on entry of cara_vit_forward / _backward: one
 // workspace per stream, as for the side stream above)
 char* g_sk_scratch = nullptr;
@@ -161,10 +172,12 @@ void with_scratch(cara_gemm_args& a) {
 
 // forward of one adapted linear on Mr rows of X (row stride ldx): T = X U ;
 // C = [X | T] [W | Vs]^T + bias -> epilogue (a.ldc == 0: dense output)
-int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char* ws, const LayerWs& lw, cara_gemm_args a, void* st) {
+// (have_T: the LayerNorm that produced X already left T = X U and its transpose, cara_layernorm_fwd_xu)
+int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char* ws, const LayerWs& lw, cara_gemm_args a, void* st,
+            bool have_T = false) {
   bf16* T = reinterpret_cast<bf16*>(ws + lw.T[L.slot]);
   bf16* Tt = reinterpret_cast<bf16*>(ws + lw.Tt[L.slot]);
-  TRY(cara_skinny_xu(X, ldx, L.Ut, T, Tt, ldt, Mr, L.in, Rp, st));
+  if (!have_T) TRY(cara_skinny_xu(X, ldx, L.Ut, T, Tt, ldt, Mr, L.in, Rp, st));
   a.A = X; a.lda = ldx; a.B = L.W; a.ldb = L.in; a.A2 = T; a.B2 = L.Vs; a.Rp = Rp;
   a.M = Mr; a.N = L.out; a.K = L.in; a.bias = L.bias;
   if (a.ldc == 0) a.ldc = L.out;
@@ -176,10 +189,11 @@ int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char*
 // (row stride ldx):
 //   G' = dY Vs ; dX = [dY | G'] [W^T | U]^T (optional) ; dU = X^T G' ; dVs = dY^T T ; dc = colsum dY
 int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int Mr, int Rp, int ldt, char* ws, const Ws& W,
-            const LayerWs& lw, int layer, bool want_dx, cara_gemm_args a, bool want_dc, void* st) {
+            const LayerWs& lw, int layer, bool want_dx, cara_gemm_args a, bool want_dc, void* st, bool have_G = false) {
   bf16* G = reinterpret_cast<bf16*>(ws + W.G[L.slot]);
   bf16* Gt = reinterpret_cast<bf16*>(ws + W.Gt[L.slot]);
-  TRY(cara_skinny_xu(dY, lddy, L.Vst, G, Gt, ldt, Mr, L.out, Rp, st));
+  // (have_G: the LayerNorm backward that produced dY already left G' and its transpose, cara_layernorm_bwd_xu)
+  if (!have_G) TRY(cara_skinny_xu(dY, lddy, L.Vst, G, Gt, ldt, Mr, L.out, Rp, st));
   void* ts_stream = st;
   if (side_ready()) {   // fork: the side stream may start once G' exists
     if (hipEventRecord(g_side.fork[L.slot], static_cast<hipStream_t>(st)) != hipSuccess) return CARA_E_LAUNCH;
@@ -345,24 +359,35 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
     const int ldr = cls_only ? N * D : D;          // row stride of the residual stream rows used
     const int rps = cls_only ? 1 : N;              // rows per sample for the DropPath multipliers
     // x = x + drop_path(attn(norm1(x)))
-    TRY(cara_layernorm_fwd(x_in, D, w->ln1_g + (size_t)l * D, w->ln1_b + (size_t)l * D, ws + lw.xn1,
-                           reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), M, D, s->eps, stream));
+    const bool fx = fuse_xu(g);
+    if (fx)
+      TRY(cara_layernorm_fwd_xu(x_in, D, w->ln1_g + (size_t)l * D, w->ln1_b + (size_t)l * D, ws + lw.xn1,
+                                reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), M, D, s->eps,
+                                lin[0].Ut, g->rank, Rp, ws + lw.T[0], ws + lw.Tt[0], W.ldt, stream));
+    else
+      TRY(cara_layernorm_fwd(x_in, D, w->ln1_g + (size_t)l * D, w->ln1_b + (size_t)l * D, ws + lw.xn1,
+                             reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), M, D, s->eps, stream));
     cara_gemm_args e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + lw.qkv;
-    TRY(lin_fwd(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, W.ldt, ws, lw, e, stream));
+    TRY(lin_fwd(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, W.ldt, ws, lw, e, stream, fx));
     TRY(cara_attention_fwd(ws + lw.qkv, ws + lw.ao, reinterpret_cast<float*>(ws + lw.lse), B, N, g->heads, att_scale, stream));
     e = {};
     e.epi = CARA_EPI_RESID; e.C = x_mid; e.aux = x_in; e.rowscale = dp1; e.rows_per_sample = rps; e.ldc = ldr;
     TRY(lin_fwd(lin[1], reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, lw, e, stream));
     // x = x + drop_path(mlp(norm2(x)))
-    TRY(cara_layernorm_fwd(x_mid, ldr, w->ln2_g + (size_t)l * D, w->ln2_b + (size_t)l * D, ws + lw.xn2,
-                           reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), Mr, D, s->eps, stream));
+    if (fx)
+      TRY(cara_layernorm_fwd_xu(x_mid, ldr, w->ln2_g + (size_t)l * D, w->ln2_b + (size_t)l * D, ws + lw.xn2,
+                                reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), Mr, D, s->eps,
+                                lin[2].Ut, g->rank, Rp, ws + lw.T[2], ws + lw.Tt[2], W.ldt, stream));
+    else
+      TRY(cara_layernorm_fwd(x_mid, ldr, w->ln2_g + (size_t)l * D, w->ln2_b + (size_t)l * D, ws + lw.xn2,
+                             reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), Mr, D, s->eps, stream));
     e = {};
     e.epi = CARA_EPI_GELU; e.C = ws + lw.h; e.C2 = ws + lw.u;
     if (g_prof.on && !cls_only) {
       // T first, so that the bracket holds exactly one kernel: the fc1 GEMM
       bf16* T = reinterpret_cast<bf16*>(ws + lw.T[2]);
-      TRY(cara_skinny_xu(ws + lw.xn2, D, lin[2].Ut, T, ws + lw.Tt[2], W.ldt, M, D, Rp, stream));
+      if (!fx) TRY(cara_skinny_xu(ws + lw.xn2, D, lin[2].Ut, T, ws + lw.Tt[2], W.ldt, M, D, Rp, stream));
       cara_gemm_args a2 = e;
       a2.A = ws + lw.xn2; a2.lda = D; a2.B = lin[2].W; a2.ldb = D; a2.A2 = T; a2.B2 = lin[2].Vs; a2.Rp = Rp;
       a2.M = M; a2.N = 4 * D; a2.K = D; a2.bias = lin[2].bias; a2.ldc = 4 * D;
@@ -372,7 +397,7 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
       hipEventRecord(g_prof.ev[l][1], static_cast<hipStream_t>(stream));
       g_prof.n = l + 1;
     } else {
-      TRY(lin_fwd(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, W.ldt, ws, lw, e, stream));
+      TRY(lin_fwd(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, W.ldt, ws, lw, e, stream, fx));
     }
     e = {};
     e.epi = CARA_EPI_RESID; e.C = x_out; e.aux = x_mid; e.rowscale = dp2; e.rows_per_sample = rps; e.ldc = ldr;
@@ -409,6 +434,8 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
   TRY(cara_layernorm_bwd(ws + W.dclsn, reinterpret_cast<float*>(ws + W.x_last), (long)N * D, w->norm_g,
                          reinterpret_cast<float*>(ws + W.meanF), reinterpret_cast<float*>(ws + W.rstdF), nullptr, dx, dyb,
                          dp_last, 1, B, D, stream));
+  const bool fx = fuse_xu(g);
+  bool have_G_fc2 = false;   // G' of this block's fc2 was left by the LayerNorm backward of the block above
   for (int l = g->depth - 1; l >= 0; --l) {
     const LayerWs& lw = W.layer[l];
     Lin lin[4];
@@ -424,20 +451,28 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     cara_gemm_args e = {};
     e.epi = CARA_EPI_DGELU; e.C = ws + W.dH; e.aux = ws + lw.u;
     TRY(side_join(2, stream));   // the previous block's fc1 products still read dH / G'[2]
-    TRY(lin_bwd(lin[3], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, W.ldt, ws, W, lw, l, true, e, true, stream));
+    TRY(lin_bwd(lin[3], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, W.ldt, ws, W, lw, l, true, e, true, stream,
+                have_G_fc2));
+    have_G_fc2 = false;
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
     TRY(lin_bwd(lin[2], reinterpret_cast<bf16*>(ws + W.dH), 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, W.ldt, ws, W,
                 lw, l, true, e, true, stream));
     TRY(side_join(3, stream));   // fc2's products read dyb, which this LayerNorm backward overwrites
-    TRY(cara_layernorm_bwd(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_mid), ldr, w->ln2_g + (size_t)l * D,
-                           reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyb, dp1, rps,
-                           Mr, D, stream));
+    // dyb = dY of this block's proj: its G' = dY Vs comes out of the same kernel
+    if (fx)
+      TRY(cara_layernorm_bwd_xu(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_mid), ldr, w->ln2_g + (size_t)l * D,
+                                reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyb, dp1,
+                                rps, Mr, D, lin[1].Vst, g->rank, Rp, ws + W.G[1], ws + W.Gt[1], W.ldt, stream));
+    else
+      TRY(cara_layernorm_bwd(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_mid), ldr, w->ln2_g + (size_t)l * D,
+                             reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyb, dp1, rps,
+                             Mr, D, stream));
     // ---- attention branch ----
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dAO; e.ldc = ldr;
     if (cls_only && hipMemsetAsync(ws + W.dAO, 0, (size_t)M * D * 2, hs) != hipSuccess) return CARA_E_LAUNCH;
-    TRY(lin_bwd(lin[1], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, W, lw, l, true, e, true, stream));
+    TRY(lin_bwd(lin[1], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, W, lw, l, true, e, true, stream, fx));
     TRY(side_join(0, stream));   // the previous block's qkv products still read dQKV / G'[0]
     TRY(cara_attention_bwd(ws + lw.qkv, ws + lw.ao, ws + W.dAO, reinterpret_cast<float*>(ws + lw.lse), ws + W.dQKV, B, N,
                            g->heads, att_scale, stream));
@@ -447,10 +482,21 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     TRY(lin_bwd(lin[0], reinterpret_cast<bf16*>(ws + W.dQKV), 3 * D, reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, W.ldt, ws, W,
                 lw, l, l > 0, e, false, stream));
     TRY(side_join(1, stream));   // proj's products read dyb, which the next LayerNorm backward overwrites
-    if (l > 0)
-      TRY(cara_layernorm_bwd(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_in), D, w->ln1_g + (size_t)l * D,
-                             reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), dx, dx, dyb,
-                             dp_prev, N, M, D, stream));
+    if (l > 0) {
+      if (fx) {
+        // dyb = dY of fc2 of the block BELOW (all M rows there: only the last block runs on cls rows)
+        Lin below[4];
+        make_lins(g, w, ws + W.pack, pl, l - 1, below);
+        TRY(cara_layernorm_bwd_xu(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_in), D, w->ln1_g + (size_t)l * D,
+                                  reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), dx, dx, dyb,
+                                  dp_prev, N, M, D, below[3].Vst, g->rank, Rp, ws + W.G[3], ws + W.Gt[3], W.ldt, stream));
+        have_G_fc2 = true;
+      } else {
+        TRY(cara_layernorm_bwd(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_in), D, w->ln1_g + (size_t)l * D,
+                               reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), dx, dx, dyb,
+                               dp_prev, N, M, D, stream));
+      }
+    }
   }
   for (int i = 0; i < 4; ++i) TRY(side_join(i, stream));   // all slabs written
   {

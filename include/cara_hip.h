@@ -101,6 +101,20 @@ int cara_layernorm_bwd(const void* dy, const float* x, long ldx, const float* ga
                        const float* mean, const float* rstd, const float* dx_in, float* dx_out,
                        void* dyb, const float* rowscale, int rows_per_sample, int M, int C,
                        void* stream);
+/* The same with the skinny adapter product of the NEXT linear fused in (its input row is in registers
+ * here, so the separate cara_skinny_xu pass and its re-read of the activations disappear):
+ *   _fwd_xu: T[M,Rp] = y Ut^T (Ut bf16 [Rp,C], rows >= rank zero), Tt[Rp,ldt] its transpose (or NULL);
+ *   _bwd_xu: G[M,Rp] = dyb Vst^T with dyb the row-scaled bf16 gradient this kernel emits (dyb may be NULL
+ *            when only G is wanted), Gt its transpose.  Same rounding points as cara_skinny_xu.
+ * Rp == 32 only (rank <= 32), C in {256, 768, 1024}; else CARA_E_ARG (callers then keep the separate
+ * cara_skinny_xu pass).                                                                                  */
+int cara_layernorm_fwd_xu(const float* x, long ldx, const float* gamma, const float* beta, void* y,
+                          float* mean, float* rstd, int M, int C, float eps, const void* Ut, int rank,
+                          int Rp, void* T, void* Tt, int ldt, void* stream);
+int cara_layernorm_bwd_xu(const void* dy, const float* x, long ldx, const float* gamma,
+                          const float* mean, const float* rstd, const float* dx_in, float* dx_out,
+                          void* dyb, const float* rowscale, int rows_per_sample, int M, int C,
+                          const void* Vst, int rank, int Rp, void* G, void* Gt, int ldt, void* stream);
 
 /* ---- attention (cara.py:43-48; softmax(q k^T * scale) v per head) ------------------------- */
 /* qkv bf16 [B*N, 3*H*64] with column k*H*64 + h*64 + d (k = q,k,v): exactly the layout

@@ -269,6 +269,52 @@ def test_layernorm_fwd_bwd(M, C_):
     close(dyb, refdx * rs.double().repeat_interleave(rps)[:M, None], 2 ** -8, 1e-3, "ln bwd dyb")
 
 
+@pytest.mark.parametrize("M,C_,rank,Rp", [(12608, 768, 16, 32), (333, 768, 8, 32), (197, 1024, 16, 32), (70, 768, 32, 32), (5, 256, 3, 32)])
+def test_layernorm_fused_adapter_contraction(M, C_, rank, Rp):
+    """cara_layernorm_fwd_xu / _bwd_xu: LayerNorm + the skinny product of the next linear (T = y U, G' = dyb Vs)
+    from the row held in registers; must agree with the separate cara_skinny_xu pass on the same bf16 rows."""
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+    x = rnd(M, C_, seed=1, scale=2.0, dtype=torch.float32) + 0.5
+    g = 1 + 0.1 * rnd(C_, seed=2, dtype=torch.float32)
+    b = 0.1 * rnd(C_, seed=3, dtype=torch.float32)
+    Ut = rnd(Rp, C_, seed=6, scale=0.1)
+    Ut[rank:] = 0                                   # pack rows beyond the rank are zero
+    ldt = (M + 31) // 32 * 32
+    y = torch.empty(M, C_, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    T = torch.full((M, Rp), float("nan"), dtype=torch.bfloat16, device=DEV)
+    Tt = torch.full((Rp, ldt), float("nan"), dtype=torch.bfloat16, device=DEV)
+    L().check(lib.cara_layernorm_fwd_xu(p(x), C.c_long(C_), p(g), p(b), p(y), p(mean), p(rstd), M, C_, C.c_float(1e-6),
+                                        p(Ut), rank, Rp, p(T), p(Tt), ldt, st()), "ln fwd xu")
+    y2 = torch.empty_like(y)
+    L().check(lib.cara_layernorm_fwd(p(x), C.c_long(C_), p(g), p(b), p(y2), p(mean), p(rstd), M, C_, C.c_float(1e-6), st()), "ln fwd")
+    assert torch.equal(y, y2)
+    ref = y.double() @ Ut.double().t()
+    close(T, ref, 2 ** -8, 1e-3, "fused T")
+    assert torch.equal(Tt[:, :M], T.t()) and torch.count_nonzero(Tt[:, M:]) == 0
+    assert torch.count_nonzero(T[:, rank:]) == 0
+    T2 = torch.empty_like(T)
+    L().skinny_xu(y, Ut, T2)
+    close(T, T2.double(), 2 ** -7, 1e-3, "fused T vs cara_skinny_xu")   # two roundings of nearly equal fp32 sums: <= 1 bf16 ulp
+    # backward: G' from the row-scaled bf16 gradient the kernel emits
+    dy = rnd(M, C_, seed=4)
+    dx_in = rnd(M, C_, seed=5, dtype=torch.float32)
+    dx, dx2 = torch.empty(M, C_, device=DEV), torch.empty(M, C_, device=DEV)
+    dyb, dyb2 = torch.empty(M, C_, dtype=torch.bfloat16, device=DEV), torch.empty(M, C_, dtype=torch.bfloat16, device=DEV)
+    rps = 7
+    rs = (torch.arange((M + rps - 1) // rps, device=DEV) % 3).float() * 0.5 + 0.5
+    G = torch.full((M, Rp), float("nan"), dtype=torch.bfloat16, device=DEV)
+    Gt = torch.full((Rp, ldt), float("nan"), dtype=torch.bfloat16, device=DEV)
+    L().check(lib.cara_layernorm_bwd_xu(p(dy), p(x), C.c_long(C_), p(g), p(mean), p(rstd), p(dx_in), p(dx), p(dyb), p(rs),
+                                        rps, M, C_, p(Ut), rank, Rp, p(G), p(Gt), ldt, st()), "ln bwd xu")
+    L().check(lib.cara_layernorm_bwd(p(dy), p(x), C.c_long(C_), p(g), p(mean), p(rstd), p(dx_in), p(dx2), p(dyb2), p(rs),
+                                     rps, M, C_, st()), "ln bwd")
+    assert torch.equal(dx, dx2) and torch.equal(dyb, dyb2)
+    close(G, dyb.double() @ Ut.double().t(), 2 ** -8, 1e-3, "fused G'")
+    assert torch.equal(Gt[:, :M], G.t()) and torch.count_nonzero(Gt[:, M:]) == 0
+
+
 def test_layernorm_strided_cls_rows():
     """Final norm: only the cls row of each sample (row stride tokens*C)."""
     lib = L().lib()
