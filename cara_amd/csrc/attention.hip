@@ -525,7 +525,17 @@ extern "C" int cara_attention_fwd(const void* qkv, void* out, float* lse, int B,
   attn_set_lds_limits();
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int npad = (N + 31) / 32 * 32, lds = 2 * npad * 128;
-  if (N > NMAX)
+  // The two-sweep kernel is also the default for 128 < N <= 224: 123 VGPRs instead of 210 put two 7-wave
+  // workgroups on a CU, which more than pays for computing Q K^T twice (same-box 36.9 vs 41.4 us at N = 197).
+  // CARA_ATTN_LONG=0 keeps the register-resident score rows for A/B runs.  (Capping the backward kernels at
+  // 128 VGPRs for the same reason: dK/dV spills 38 registers, 145 vs 101 us for the pair; dQ alone 43.7 vs
+  // 44.6 us, i.e. nothing -- not done.)
+  static int use_long = -1;
+  if (use_long < 0) {
+    const char* e = getenv("CARA_ATTN_LONG");
+    use_long = e ? atoi(e) : 1;
+  }
+  if (N > NMAX || (use_long && N > 128))
     hipLaunchKernelGGL(attn_fwd_long_kernel<7>, dim3(B * H, (N + 223) / 224), dim3(448), lds, st, (const bf16*)qkv, (bf16*)out, lse, N,
                        H, scale, npad);
   else if (attn_waves(N) == 7)
