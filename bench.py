@@ -155,8 +155,8 @@ def main():
         dist.barrier()
     wall = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1)
-    avg_ms, nl = C.c_float(0), C.c_int(0)
-    _lib.check(lib.cara_profile_fc1_read(C.byref(avg_ms), C.byref(nl)), "cara_profile_fc1_read")
+    avg_ms, marker_ms, nl = C.c_float(0), C.c_float(0), C.c_int(0)
+    _lib.check(lib.cara_profile_fc1_read2(C.byref(avg_ms), C.byref(marker_ms), C.byref(nl)), "cara_profile_fc1_read2")
     lib.cara_profile_fc1(0)
     t = torch.tensor([wall], device=dev, dtype=torch.float64)
     if world > 1:
@@ -217,7 +217,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "kernel": f"gemm32_kernel<CARA_EPI_GELU> (fc1 forward, M={M} N={4 * D} K={D}+{args.rank}; the rocprofv3 name is gemm32_kernel<2>)",
-                         "avg_launch_ms": round(avg_ms.value, 4), "launches_timed": nl.value},
+                         "avg_launch_ms": round(avg_ms.value, 4), "launches_timed": nl.value,
+                         "event_marker_ms_subtracted": round(marker_ms.value, 4)},
         }
         if world == 1 and not args.no_cpu_baseline and not large:
             out["cpu_baseline"] = cpu_baseline(args.rank, scale)

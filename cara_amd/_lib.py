@@ -22,7 +22,7 @@ SYMBOLS = (
     "cara_attention_fwd", "cara_attention_bwd", "cara_im2col_patches", "cara_assemble_tokens",
     "cara_cross_entropy", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_pack_offsets",
     "cara_factor_prep", "cara_factor_grad_scratch_bytes", "cara_factor_grad_reduce", "cara_vit_workspace_bytes", "cara_vit_forward",
-    "cara_vit_backward", "cara_head_backward", "cara_profile_fc1", "cara_profile_fc1_read", "cara_debug_tr_probe", "cara_debug_tr_frag",
+    "cara_vit_backward", "cara_head_backward", "cara_profile_fc1", "cara_profile_fc1_read", "cara_profile_fc1_read2", "cara_debug_tr_probe", "cara_debug_tr_frag",
 )
 
 EPI_BF16, EPI_F32, EPI_GELU, EPI_RESID, EPI_DGELU = range(5)

@@ -236,7 +236,7 @@ void make_lins(const cara_geom* g, const cara_vit_weights* w, const char* pack, 
 struct Prof {
   bool on = false;
   int n = 0;
-  hipEvent_t ev[64][2];
+  hipEvent_t ev[64][3];
   bool made = false;
 };
 Prof g_prof;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 extern "C" int cara_profile_fc1(int enable) {
   if (enable && !g_prof.made) {
     for (int i = 0; i < 64; ++i)
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 3; ++j)
         if (hipEventCreate(&g_prof.ev[i][j]) != hipSuccess) return CARA_E_LAUNCH;
     g_prof.made = true;
   }
@@ -290,14 +290,23 @@ extern "C" int cara_profile_fc1(int enable) {
 }
 
 extern "C" int cara_profile_fc1_read(float* avg_ms, int* launches) {
-  if (!avg_ms || !launches || !g_prof.made || g_prof.n == 0) return CARA_E_ARG;
-  double tot = 0;
+  float overhead = 0.f;
+  return cara_profile_fc1_read2(avg_ms, &overhead, launches);
+}
+// avg_ms = mean (event 0 -> event 1) around the kernel MINUS marker_ms = mean (event 1 -> event 2) with nothing
+// between: two event records in a row are ~8 us apart on this stack, and that gap is inside every bracket
+extern "C" int cara_profile_fc1_read2(float* avg_ms, float* marker_ms, int* launches) {
+  if (!avg_ms || !marker_ms || !launches || !g_prof.made || g_prof.n == 0) return CARA_E_ARG;
+  double tot = 0, gap = 0;
   for (int i = 0; i < g_prof.n; ++i) {
-    float ms = 0.f;
+    float ms = 0.f, g = 0.f;
     if (hipEventElapsedTime(&ms, g_prof.ev[i][0], g_prof.ev[i][1]) != hipSuccess) return CARA_E_LAUNCH;
+    if (hipEventElapsedTime(&g, g_prof.ev[i][1], g_prof.ev[i][2]) != hipSuccess) return CARA_E_LAUNCH;
     tot += ms;
+    gap += g;
   }
-  *avg_ms = (float)(tot / g_prof.n);
+  *marker_ms = (float)(gap / g_prof.n);
+  *avg_ms = (float)((tot - gap) / g_prof.n);
   *launches = g_prof.n;
   return CARA_OK;
 }
@@ -395,6 +404,7 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
       hipEventRecord(g_prof.ev[l][0], static_cast<hipStream_t>(stream));
       TRY(cara_gemm_bf16(&a2, stream));
       hipEventRecord(g_prof.ev[l][1], static_cast<hipStream_t>(stream));
+      hipEventRecord(g_prof.ev[l][2], static_cast<hipStream_t>(stream));   // empty bracket: the markers' own cost
       g_prof.n = l + 1;
     } else {
       TRY(lin_fwd(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, W.ldt, ws, lw, e, stream, fx));

@@ -223,6 +223,9 @@ int cara_head_backward(const float* dlogits, const void* xn_bf16, const float* h
  * launches after synchronising.  Process-global diagnostic state; off by default.              */
 int cara_profile_fc1(int enable);
 int cara_profile_fc1_read(float* avg_ms, int* launches);   /* host pointers */
+/* The same with the markers' own cost made visible: every bracket is followed by an EMPTY bracket (two event
+ * records in a row); avg_ms is the mean kernel bracket minus marker_ms, the mean empty bracket.                */
+int cara_profile_fc1_read2(float* avg_ms, float* marker_ms, int* launches);
 /* One ds_read_b64_tr_b16 per lane (64 lanes) over an LDS image of 16-bit values sm[i] = i, lane l
  * reading at byte address byte_addr[l] (device int[64], multiples of 8, < 16384); out = device
  * short[256] (4 per lane).  Pins the lane semantics the attention kernels rely on.             */
