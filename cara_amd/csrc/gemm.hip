@@ -198,7 +198,7 @@ __device__ __forceinline__ void stage_ext32(const bf16* __restrict__ P, int Rp, 
 // NW = waves per workgroup (NW/2 along M x 2 along N): 4, or 8 with MI = 2 for a 128-row tile made of
 // 32x64 wave tiles (more resident waves per CU)
 template <int EPI, int MI, int NW = 4>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 3 : (MI == 4 ? 4 : 6)) void gemm32_kernel(const cara_gemm_args p, const int tiles_n,
+__global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? 4 : 6)) void gemm32_kernel(const cara_gemm_args p, const int tiles_n,
                                                                                           const int nwg, const int gm) {
   constexpr int TBM = MI * 16 * (NW / 2);
   constexpr int A_BYTES = TBM * BK32 * 2;
@@ -256,19 +256,21 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 3 : (MI == 4 ? 4 : 6)) void gemm
     __syncthreads();
     mma_tile32<MI>(smem, smem + A_BYTES, acc, wr, wc, lane);
   }
-  // epilogue in two halves of HALF rows: wave-private [HALF][64] fp32 image
-  constexpr int HALF = MI * 8;
+  // epilogue in NPASS passes of HALF rows: wave-private [HALF][64] fp32 image (8 waves x 4 row tiles: four
+  // 16-row passes, so that the images fit the 48 KiB the K loop uses)
+  constexpr int NPASS = (NW == 8 && MI == 4) ? 4 : 2;
+  constexpr int HALF = MI * 16 / NPASS;
   __syncthreads();
   float* stg = reinterpret_cast<float*>(smem) + wave * (HALF * 64);
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < NPASS; ++half) {
 #pragma unroll
-    for (int i = 0; i < MI / 2; ++i)
+    for (int i = 0; i < MI / NPASS; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[half * (MI / 2) + i][j][r];
+        for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[half * (MI / NPASS) + i][j][r];
     epilogue_rows<EPI, HALF>(p, stg, m0 + wr * (MI * 16) + half * HALF, n0 + wc * 64, lane);
   }
 }
@@ -277,13 +279,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 3 : (MI == 4 ? 4 : 6)) void gemm
 // tiles everywhere 14.07 ms, 64 rows only for the N <= 768 products 13.3 ms, 128 rows 12.2 ms -- the
 // better balance over 256 CUs does not pay for the lower FLOP per staged byte, so 128 is the default.
 static int bm_choice(const cara_gemm_args* a) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("CARA_GEMM_BM");
-    forced = e ? atoi(e) : 0;
-  }
-  (void)a;
-  return forced == 64 ? 64 : (forced == 8 ? 8 : 128);   // 8 = 128-row tile with 8 waves
+  const char* e = getenv("CARA_GEMM_BM");   // read per call: tests and A/B runs switch it
+  const int forced = e ? atoi(e) : 0;
+  // 8 = 128-row tile with 8 waves; 256 = 256 x 128 tile, 8 waves of 64 x 64 (two workgroups per CU: 3/4 of the
+  // LDS-DMA bytes per flop of the 128 x 128 tile), only for products with at least 18 column tiles
+  if (forced == 256) return a->N >= 2304 && a->M >= 1024 ? 256 : 128;
+  if (forced == 2560) return 256;   // every shape (tests)
+  return forced == 64 ? 64 : (forced == 8 ? 8 : 128);
 }
 
 // rows per supertile; CARA_GEMM_GROUPM overrides (1 = plain row-major order)
@@ -304,7 +306,10 @@ template <int EPI>
 int launch32(const cara_gemm_args* a, hipStream_t st) {
   const int tiles_n = (a->N + BN - 1) / BN;
   const int gm = group_m(tiles_n);
-  if (bm_choice(a) == 8) {
+  if (bm_choice(a) == 256) {
+    const int nwg = ((a->M + 255) / 256) * tiles_n;
+    hipLaunchKernelGGL((gemm32_kernel<EPI, 4, 8>), dim3(nwg), dim3(512), 2 * (256 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm);
+  } else if (bm_choice(a) == 8) {
     const int nwg = ((a->M + 127) / 128) * tiles_n;
     hipLaunchKernelGGL((gemm32_kernel<EPI, 2, 8>), dim3(nwg), dim3(512), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm);
   } else if (bm_choice(a) == 64) {

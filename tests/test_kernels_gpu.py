@@ -97,11 +97,14 @@ def test_gemm_epilogues():
 
 
 # ---- LDS-ring kernels (CARA_GEMM_TILE = 256: 256x256, one workgroup per CU; 1282: 128x256, two per CU) --------
-@pytest.mark.parametrize("tile", ["256", "1282"])
+@pytest.mark.parametrize("tile", ["256", "1282", "bm256"])
 @pytest.mark.parametrize("M,N,K,Rp", [(12608, 768, 768, 32), (1500, 3072, 768, 64), (333, 300, 128, 32), (777, 640, 64, 0),
                                       (130, 2304, 3072, 32)])
 def test_gemm_ring_tiles(M, N, K, Rp, tile, monkeypatch):
-    monkeypatch.setenv("CARA_GEMM_TILE", tile)
+    if tile == "bm256":   # the 256 x 128 form of the default double-buffered kernel (8 waves, two workgroups per CU)
+        monkeypatch.setenv("CARA_GEMM_BM", "2560")
+    else:
+        monkeypatch.setenv("CARA_GEMM_TILE", tile)
     A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
     bias = rnd(N, seed=3, dtype=torch.float32)
     A2 = rnd(M, Rp, seed=4) if Rp else None
