@@ -199,7 +199,7 @@ __device__ __forceinline__ void stage_ext32(const bf16* __restrict__ P, int Rp, 
 // 32x64 wave tiles (more resident waves per CU)
 template <int EPI, int MI, int NW = 4>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? 4 : 6)) void gemm32_kernel(const cara_gemm_args p, const int tiles_n,
-                                                                                          const int nwg, const int gm) {
+                                                                                          const int nwg, const int gm, const int ablate) {
   constexpr int TBM = MI * 16 * (NW / 2);
   constexpr int A_BYTES = TBM * BK32 * 2;
   constexpr int SLOT = A_BYTES + B32_BYTES;
@@ -233,7 +233,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? 4
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nk = p.K / BK32;
+  // CARA_GEMM_ABLATE (timing diagnostics, results become wrong): 32 = one K step only (epilogue + launch cost),
+  // 4 = no epilogue stores (K loop + launch cost), 64 = K loop always reads K tile 0 (L2-resident operands)
+  const int nk = (ablate & 32) ? 1 : p.K / BK32;
+  const int kmul = (ablate & 64) ? 0 : BK32;
   stage_tile32<TBM, NW>(A, p.lda, m0, p.M - 1, 0, smem, wave, lane);
   stage_tile32<BN, NW>(B, p.ldb, n0, p.N - 1, 0, smem + A_BYTES, wave, lane);
   int cur = 0;
@@ -243,8 +246,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? 4
     char* sA = smem + cur * SLOT;
     if (kt + 1 < nk) {
       char* nA = smem + (cur ^ 1) * SLOT;
-      stage_tile32<TBM, NW>(A, p.lda, m0, p.M - 1, (kt + 1) * BK32, nA, wave, lane);
-      stage_tile32<BN, NW>(B, p.ldb, n0, p.N - 1, (kt + 1) * BK32, nA + A_BYTES, wave, lane);
+      stage_tile32<TBM, NW>(A, p.lda, m0, p.M - 1, (kt + 1) * kmul, nA, wave, lane);
+      stage_tile32<BN, NW>(B, p.ldb, n0, p.N - 1, (kt + 1) * kmul, nA + A_BYTES, wave, lane);
     }
     mma_tile32<MI>(sA, sA + A_BYTES, acc, wr, wc, lane);
     cur ^= 1;
@@ -256,6 +259,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? 4
     __syncthreads();
     mma_tile32<MI>(smem, smem + A_BYTES, acc, wr, wc, lane);
   }
+  if ((ablate & 4) && acc[0][0][0] != 123.456f) return;
   // epilogue in NPASS passes of HALF rows: wave-private [HALF][64] fp32 image (8 waves x 4 row tiles: four
   // 16-row passes, so that the images fit the 48 KiB the K loop uses)
   constexpr int NPASS = (NW == 8 && MI == 4) ? 4 : 2;
@@ -306,18 +310,20 @@ template <int EPI>
 int launch32(const cara_gemm_args* a, hipStream_t st) {
   const int tiles_n = (a->N + BN - 1) / BN;
   const int gm = group_m(tiles_n);
+  const char* ea = getenv("CARA_GEMM_ABLATE");
+  const int ablate = ea ? atoi(ea) : 0;
   if (bm_choice(a) == 256) {
     const int nwg = ((a->M + 255) / 256) * tiles_n;
-    hipLaunchKernelGGL((gemm32_kernel<EPI, 4, 8>), dim3(nwg), dim3(512), 2 * (256 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm);
+    hipLaunchKernelGGL((gemm32_kernel<EPI, 4, 8>), dim3(nwg), dim3(512), 2 * (256 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm, ablate);
   } else if (bm_choice(a) == 8) {
     const int nwg = ((a->M + 127) / 128) * tiles_n;
-    hipLaunchKernelGGL((gemm32_kernel<EPI, 2, 8>), dim3(nwg), dim3(512), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm);
+    hipLaunchKernelGGL((gemm32_kernel<EPI, 2, 8>), dim3(nwg), dim3(512), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm, ablate);
   } else if (bm_choice(a) == 64) {
     const int nwg = ((a->M + 63) / 64) * tiles_n;
-    hipLaunchKernelGGL((gemm32_kernel<EPI, 2>), dim3(nwg), dim3(256), 2 * (64 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm);
+    hipLaunchKernelGGL((gemm32_kernel<EPI, 2>), dim3(nwg), dim3(256), 2 * (64 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm, ablate);
   } else {
     const int nwg = ((a->M + 127) / 128) * tiles_n;
-    hipLaunchKernelGGL((gemm32_kernel<EPI, 4>), dim3(nwg), dim3(256), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm);
+    hipLaunchKernelGGL((gemm32_kernel<EPI, 4>), dim3(nwg), dim3(256), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm, ablate);
   }
   CARA_CHECK_LAUNCH();
   return CARA_OK;
