@@ -9,19 +9,20 @@ namespace {
 
 // Skinny adapter contraction fused into the kernel that PRODUCES its input (T = X U in
 // the forward, G' = dY Vs in the backward; K = C columns, Rp = 32 output columns of which the first `rank`
-// are non-zero).  A block of 4 waves normalises 16 rows (4 each), leaves their bf16 images in LDS
+// are non-zero).  A block of 8 waves normalises 16 rows (2 each), leaves their bf16 images in LDS
 // ([16][C + 8]: the 16-byte pad spreads the rows of an MFMA A fragment over the banks), then contracts them
-// with Ut [32][C] on the matrix cores: wave w takes the K steps w, w+4, ... (its B fragments come straight
+// with Ut [32][C] on the matrix cores: wave w takes the K steps w, w+8, ... (its B fragments come straight
 // from global / L2: 1.5 KB per row, the cost of the staging the separate cara_skinny_xu pass pays too), the
-// four partial 16 x 32 tiles are summed through LDS in fixed order.  Two earlier forms were measured and
+// eight partial 16 x 32 tiles are summed through LDS in fixed order.  Two earlier forms were measured and
 // dropped: per-lane v_dot2 sums with the factor slice read per row (more L1 traffic than the pass it
 // replaces) or held in LDS (as slow as LayerNorm + cara_skinny_xu: ~250 VALU instructions per row).
-constexpr int XU_ROWS = 4;          // rows per wave, 16 per block
+constexpr int XU_WAVES = 8;         // waves per block of the fused kernels
+constexpr int XU_ROWS = 16 / XU_WAVES;   // rows per wave: 16 per block (one MFMA row tile)
 template <int V4>
 struct XuLds {
   static constexpr int LDY = V4 * 256 + 8;   // bf16 elements per staged row
   bf16 y[16 * LDY];
-  float part[4][2][64 * 4];
+  float part[XU_WAVES][2][64 * 4];
 };
 template <int V4>
 __device__ __forceinline__ void block_contract(XuLds<V4>& L, const bf16* __restrict__ Ut, bf16* __restrict__ T,
@@ -32,7 +33,7 @@ __device__ __forceinline__ void block_contract(XuLds<V4>& L, const bf16* __restr
   __syncthreads();   // the 16 staged rows are complete
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-  for (int s = wave; s < KS; s += 4) {
+  for (int s = wave; s < KS; s += XU_WAVES) {
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(L.y + fr * LDY + s * 32 + fq * 8);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -47,7 +48,7 @@ __device__ __forceinline__ void block_contract(XuLds<V4>& L, const bf16* __restr
     const int nt = wave;
     f32x4 t = *reinterpret_cast<const f32x4*>(&L.part[0][nt][lane * 4]);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(&L.part[w][nt][lane * 4]);
+    for (int w = 1; w < XU_WAVES; ++w) t += *reinterpret_cast<const f32x4*>(&L.part[w][nt][lane * 4]);
     const int col = nt * 16 + fr, m0 = row_base + fq * 4;
     const bf16x4 o = {(bf16)t[0], (bf16)t[1], (bf16)t[2], (bf16)t[3]};
 #pragma unroll
@@ -66,7 +67,7 @@ __device__ __forceinline__ void block_contract(XuLds<V4>& L, const bf16* __restr
 }
 
 template <int V4, bool XU>  // V4 = C / 256 : float4 per lane; XU: fused contraction, XU_ROWS rows per wave
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx,
+__global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_fwd_kernel(const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta,
                                                      bf16* __restrict__ y, float* __restrict__ mean,
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   constexpr int C = V4 * 256;
   constexpr int RPW = XU ? XU_ROWS : 1;
   const int lane = threadIdx.x & 63;
-  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  const int row0 = (blockIdx.x * (XU ? XU_WAVES : 4) + (threadIdx.x >> 6)) * RPW;
   __shared__ __attribute__((aligned(16))) XuLds<XU ? V4 : 0> L;
   for (int row = row0; row < row0 + RPW && row < M; ++row) {
   const float* xr = x + (size_t)row * ldx;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mu) * rstd
 template <int V4, bool XU>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
                                                      long ldx, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean,
                                                      const float* __restrict__ rstd,
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
   constexpr int C = V4 * 256;
   constexpr int RPW = XU ? XU_ROWS : 1;
   const int lane = threadIdx.x & 63;
-  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  const int row0 = (blockIdx.x * (XU ? XU_WAVES : 4) + (threadIdx.x >> 6)) * RPW;
   __shared__ __attribute__((aligned(16))) XuLds<XU ? V4 : 0> L;
   for (int row = row0; row < row0 + RPW && row < M; ++row) {
   const float mu = mean[row], rs = rstd[row];
@@ -299,8 +300,8 @@ int ln_fwd_launch(const float* x, long ldx, const float* gamma, const float* bet
   if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0 || ldx < C || (ldx & 3) || !xu_ok(a, M, C)) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (xu_pad(a, M, st) != CARA_OK) return CARA_E_LAUNCH;
-  const int rows_per_block = a.Ut ? 4 * XU_ROWS : 4;
-  const dim3 grid((M + rows_per_block - 1) / rows_per_block), block(256);
+  const int rows_per_block = a.Ut ? 16 : 4;
+  const dim3 grid((M + rows_per_block - 1) / rows_per_block), block(a.Ut ? XU_WAVES * 64 : 256);
 #define LNF(V, X) hipLaunchKernelGGL((ln_fwd_kernel<V, X>), grid, block, 0, st, x, ldx, gamma, beta, (bf16*)y, mean, rstd, M, eps, \
                                      a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt)
   if (a.Ut) {
@@ -323,8 +324,8 @@ int ln_bwd_launch(const void* dy, const float* x, long ldx, const float* gamma, 
   if (rowscale && rows_per_sample <= 0) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (xu_pad(a, M, st) != CARA_OK) return CARA_E_LAUNCH;
-  const int rows_per_block = a.Ut ? 4 * XU_ROWS : 4;
-  const dim3 grid((M + rows_per_block - 1) / rows_per_block), block(256);
+  const int rows_per_block = a.Ut ? 16 : 4;
+  const dim3 grid((M + rows_per_block - 1) / rows_per_block), block(a.Ut ? XU_WAVES * 64 : 256);
 #define LNB(V, X) hipLaunchKernelGGL((ln_bwd_kernel<V, X>), grid, block, 0, st, (const bf16*)dy, x, ldx, gamma, mean, rstd, \
                                      dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M, a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt)
   if (a.Ut) {
