@@ -21,7 +21,7 @@ SYMBOLS = (
     "cara_tskinny_scratch_bytes", "cara_tskinny_xtg", "cara_tskinny_partial", "cara_tskinny_partial2", "cara_tskinny_reduce", "cara_layernorm_fwd", "cara_layernorm_bwd", "cara_layernorm_fwd_xu", "cara_layernorm_bwd_xu",
     "cara_attention_fwd", "cara_attention_bwd", "cara_im2col_patches", "cara_assemble_tokens",
     "cara_cross_entropy", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_pack_offsets",
-    "cara_factor_prep", "cara_factor_grad_scratch_bytes", "cara_factor_grad_reduce", "cara_vit_workspace_bytes", "cara_vit_forward",
+    "cara_weight_dropout_hash", "cara_materialize_merge", "cara_dropout_grad_contract", "cara_colsum_bf16", "cara_factor_prep", "cara_factor_grad_scratch_bytes", "cara_factor_grad_reduce", "cara_vit_workspace_bytes", "cara_vit_forward",
     "cara_vit_backward", "cara_head_backward", "cara_profile_fc1", "cara_profile_fc1_read", "cara_profile_fc1_read2", "cara_debug_tr_probe", "cara_debug_tr_frag",
 )
 
@@ -99,6 +99,7 @@ def lib() -> C.CDLL:
         if hasattr(_lib, "cara_vit_workspace_bytes"):
             _lib.cara_vit_workspace_bytes.restype = C.c_size_t
             _lib.cara_gemm_scratch_bytes.restype = C.c_size_t
+            _lib.cara_weight_dropout_hash.restype = C.c_uint
             _lib.cara_debug_gemm_persistent_launches.restype = C.c_long
     return _lib
 

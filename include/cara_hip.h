@@ -181,6 +181,22 @@ size_t cara_factor_grad_scratch_bytes(const cara_geom* g);
 int cara_factor_grad_reduce(const cara_geom* g, const cara_cp* cp, const cara_layer_grads* lg,
                             const cara_cp* grads, void* scratch, void* stream);
 
+/* ---- exact weight-space dropout mode (the reference's train-mode arithmetic, cara.py:35,57,81,92) ---- */
+/* keep(o,i) of linear `linear_id` = (cara_weight_dropout_hash(o*in + i, seed, linear_id) >> 8) >= p * 2^24
+ * (host-callable mirror of the device hash, so that tests and the oracle can rebuild the masks).             */
+unsigned cara_weight_dropout_hash(unsigned idx, unsigned seed, unsigned linear_id);
+/* Weff bf16 [out,in] = W + keep/(1-p) * (Vs U^T): W bf16 [out,in], U bf16 [in,Rp], Vs bf16 [out,Rp] (= s g (.) V,
+ * the operand pack of cara_factor_prep).  p = 0 is the eval-time merge of the reference's dW into W.         */
+int cara_materialize_merge(const void* W, const void* U, const void* Vs, int Rp, int out, int in, float p,
+                           unsigned seed, unsigned linear_id, void* Weff, void* stream);
+/* From the dense weight gradient dW fp32 [out,in] (= dY^T X) to the skinny quantities cara_factor_grad_reduce
+ * takes: dVs[o,r] = sum_i keep/(1-p) dW[o,i] U[i,r], dU[i,r] = sum_o keep/(1-p) dW[o,i] Vs[o,r] (fp32
+ * [out,Rp] / [in,Rp], overwritten, fixed summation order).                                                  */
+int cara_dropout_grad_contract(const float* dW, const void* U, const void* Vs, int Rp, int out, int in, float p,
+                               unsigned seed, unsigned linear_id, float* dU, float* dVs, void* stream);
+/* out fp32 [N] = column sums of a bf16 [M, ld] matrix (dc = sum_m dY), fixed order.                         */
+int cara_colsum_bf16(const void* X, int ld, int M, int N, float* out, void* stream);
+
 /* ---- whole adapted ViT: forward and backward as stream-ordered kernel sequences ------------ */
 /* What model(x) / loss.backward() of vit_cp.py:46-49 run, for the factored adapters.  Both calls
  * only enqueue kernels on `stream` (no allocation, no sync): capturable in a hipGraph.         */
