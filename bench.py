@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--weight-dropout", default="off", choices=["off", "exact"],
+                    help="exact = the reference's train-mode Dropout(0.1) on the materialised adapters (merged weights + "
+                         "dense dW gradients); informational, the reported metric uses the factored default")
     ap.add_argument("--model", default="vit_base_patch16_224_in21k",
                     help="vit_large_patch16_384 runs BASELINE.json configs[4] (use --batch 32); informational only")
     args = ap.parse_args()
@@ -127,6 +130,7 @@ def main():
     gf, img, tokens, dim = (GF_PER_IMG_L384, 384, 577, 1024) if large else (GF_PER_IMG, 224, 197, 768)
     model, trainable = build_model(args.rank, scale, ncls, dev, seed=14, name=args.model)  # identical replicas on every rank
     eng = model._cara_engine
+    eng.weight_dropout = args.weight_dropout
     try:
         opt = torch.optim.AdamW(trainable, lr=1e-3, weight_decay=1e-4, fused=True)
     except Exception:
@@ -156,7 +160,10 @@ def main():
     wall = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1)
     avg_ms, marker_ms, nl = C.c_float(0), C.c_float(0), C.c_int(0)
-    _lib.check(lib.cara_profile_fc1_read2(C.byref(avg_ms), C.byref(marker_ms), C.byref(nl)), "cara_profile_fc1_read2")
+    if args.weight_dropout == "off":
+        _lib.check(lib.cara_profile_fc1_read2(C.byref(avg_ms), C.byref(marker_ms), C.byref(nl)), "cara_profile_fc1_read2")
+    else:   # the informational exact mode runs its linears through other entry points: no bracket
+        avg_ms.value = float("nan")
     lib.cara_profile_fc1(0)
     t = torch.tensor([wall], device=dev, dtype=torch.float64)
     if world > 1:
@@ -186,7 +193,7 @@ def main():
         ips = world * args.batch * args.steps / wall
         M, D = args.batch * tokens, dim
         fl_launch = 2.0 * M * (4 * D) * (D + args.rank)          # algorithmic: K = dim + rank (not the padded Rp)
-        ach = fl_launch / (avg_ms.value * 1e-3) / 1e12
+        ach = fl_launch / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value == avg_ms.value else 0.0
         # HBM-side bytes per launch of that kernel from a committed rocprofv3 PMC run (separate
         # FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 note of the microarch
         # guide); only valid for the headline shape
@@ -205,7 +212,9 @@ def main():
                                     "(BASELINE.json configs[4], informational); fwd + CE + bwd + AdamW, drop-path 0.1, factored adapters"
                                     if large else
                                     f"ViT-B/16 + CaRA rank={args.rank}, synthetic 224x224, bs={args.batch}/GPU, bf16 "
-                                    "(BASELINE.json configs[1]); fwd + CE + bwd + AdamW, drop-path 0.1, factored adapters"),
+                                    "(BASELINE.json configs[1]); fwd + CE + bwd + AdamW, drop-path 0.1, "
+                                    + ("factored adapters" if args.weight_dropout == "off" else
+                                       "EXACT weight-space dropout 0.1 (merged weights, dense dW; informational)")),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "step_algorithmic_gflop": round(gf["step"] * args.batch, 1),
                        "step_tflops_per_gpu": round(gf["step"] * args.batch / ms_step, 1),
@@ -217,7 +226,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "kernel": f"gemm32_kernel<CARA_EPI_GELU> (fc1 forward, M={M} N={4 * D} K={D}+{args.rank}; the rocprofv3 name is gemm32_kernel<2>)",
-                         "avg_launch_ms": round(avg_ms.value, 4), "launches_timed": nl.value,
+                         "avg_launch_ms": round(avg_ms.value, 4) if avg_ms.value == avg_ms.value else None, "launches_timed": nl.value,
                          "event_marker_ms_subtracted": round(marker_ms.value, 4)},
         }
         if world == 1 and not args.no_cpu_baseline and not large:

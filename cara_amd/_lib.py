@@ -20,8 +20,8 @@ SYMBOLS = (
     "cara_abi_version", "cara_build_arch", "cara_gemm_bf16", "cara_gemm_scratch_bytes", "cara_debug_gemm_persistent_launches", "cara_skinny_xu",
     "cara_tskinny_scratch_bytes", "cara_tskinny_xtg", "cara_tskinny_partial", "cara_tskinny_partial2", "cara_tskinny_reduce", "cara_layernorm_fwd", "cara_layernorm_bwd", "cara_layernorm_fwd_xu", "cara_layernorm_bwd_xu",
     "cara_attention_fwd", "cara_attention_bwd", "cara_im2col_patches", "cara_assemble_tokens",
-    "cara_cross_entropy", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_pack_offsets",
-    "cara_weight_dropout_hash", "cara_materialize_merge", "cara_dropout_grad_contract", "cara_colsum_bf16", "cara_factor_prep", "cara_factor_grad_scratch_bytes", "cara_factor_grad_reduce", "cara_vit_workspace_bytes", "cara_vit_forward",
+    "cara_cross_entropy", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_transpose_bf16_ld", "cara_pack_offsets",
+    "cara_weight_dropout_hash", "cara_materialize_merge", "cara_dropout_grad_scratch_bytes", "cara_dropout_grad_contract", "cara_colsum_scratch_bytes", "cara_colsum_bf16", "cara_factor_prep", "cara_factor_grad_scratch_bytes", "cara_factor_grad_reduce", "cara_vit_workspace_bytes", "cara_vit_forward",
     "cara_vit_backward", "cara_head_backward", "cara_profile_fc1", "cara_profile_fc1_read", "cara_profile_fc1_read2", "cara_debug_tr_probe", "cara_debug_tr_frag",
 )
 
@@ -34,7 +34,8 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("bias", C.c_void_p), ("epi", C.c_int),
                 ("C", C.c_void_p), ("ldc", C.c_int), ("C2", C.c_void_p), ("aux", C.c_void_p),
                 ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int),
-                ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t)]
+                ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
+                ("batch", C.c_int), ("strideA", C.c_longlong), ("strideB", C.c_longlong), ("strideC", C.c_longlong)]
 
 
 class Geom(C.Structure):
@@ -74,7 +75,8 @@ class VitWeights(C.Structure):
 
 class VitShape(C.Structure):
     _fields_ = [("B", C.c_int), ("img", C.c_int), ("patch", C.c_int), ("chans", C.c_int),
-                ("tokens", C.c_int), ("num_classes", C.c_int), ("eps", C.c_float)]
+                ("tokens", C.c_int), ("num_classes", C.c_int), ("eps", C.c_float),
+                ("wd_exact", C.c_int), ("wd_p", C.c_float), ("wd_seed", C.c_uint)]
 
 
 class CaraError(RuntimeError):
@@ -100,6 +102,8 @@ def lib() -> C.CDLL:
             _lib.cara_vit_workspace_bytes.restype = C.c_size_t
             _lib.cara_gemm_scratch_bytes.restype = C.c_size_t
             _lib.cara_weight_dropout_hash.restype = C.c_uint
+            _lib.cara_dropout_grad_scratch_bytes.restype = C.c_size_t
+            _lib.cara_colsum_scratch_bytes.restype = C.c_size_t
             _lib.cara_debug_gemm_persistent_launches.restype = C.c_long
     return _lib
 

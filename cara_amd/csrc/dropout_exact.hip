@@ -62,8 +62,16 @@ __global__ __launch_bounds__(256) void merge_kernel(const bf16* __restrict__ W, 
 }
 
 // dVs[o,:] = sum_i m dW[o,i] U[i,:]: one wave per output row, lanes stride the columns
+// dW arrives as `nslab` split-K partial slabs (fp32 [out,in] each, slab_stride floats apart) that are summed here
+__device__ __forceinline__ float slab_sum(const float* __restrict__ dW, size_t e, int nslab, size_t slab_stride) {
+  float g = dW[e];
+  for (int sidx = 1; sidx < nslab; ++sidx) g += dW[e + sidx * slab_stride];
+  return g;
+}
+
 template <int RP>
-__global__ __launch_bounds__(256) void contract_rows_kernel(const float* __restrict__ dW, const bf16* __restrict__ U, float* __restrict__ dVs,
+__global__ __launch_bounds__(256) void contract_rows_kernel(const float* __restrict__ dW, int nslab, size_t slab_stride,
+                                                            const bf16* __restrict__ U, float* __restrict__ dVs,
                                                             int out, int in, unsigned seed, unsigned lin, unsigned thresh, float inv_keep) {
   const int lane = threadIdx.x & 63, o = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (o >= out) return;
@@ -72,13 +80,14 @@ __global__ __launch_bounds__(256) void contract_rows_kernel(const float* __restr
   for (int r = 0; r < RP; ++r) acc[r] = 0.f;
   for (int i = lane; i < in; i += 64) {
     const size_t e = (size_t)o * in + i;
-    const float g = dW[e] * keep_scale((unsigned)e, seed, lin, thresh, inv_keep);
+    const float k = keep_scale((unsigned)e, seed, lin, thresh, inv_keep);
+    const float g = k != 0.f ? slab_sum(dW, e, nslab, slab_stride) * k : 0.f;
     if (g != 0.f) {
 #pragma unroll
       for (int r = 0; r < RP; r += 8) {
         const bf16x8 u = *reinterpret_cast<const bf16x8*>(U + (size_t)i * RP + r);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[r + k] += g * (float)u[k];
+        for (int kk = 0; kk < 8; ++kk) acc[r + kk] += g * (float)u[kk];
       }
     }
   }
@@ -89,26 +98,32 @@ __global__ __launch_bounds__(256) void contract_rows_kernel(const float* __restr
   }
 }
 
-// dU[i,:] = sum_o m dW[o,i] Vs[o,:]: a workgroup owns 64 columns; thread (column t%64, row group t/64) walks
-// rows with stride 4 (coalesced 256-byte row segments), the 4 row groups are summed through LDS in fixed order
+// dU[i,:] = sum_o m dW[o,i] Vs[o,:]: workgroup (x, y) owns 64 columns and the y-th of gridDim.y row chunks; thread
+// (column t%64, row group t/64) walks its rows with stride 4 (coalesced 256-byte row segments); the 4 row groups
+// are summed through LDS and the chunk's partial goes to scratch [chunk][in][RP]; reduce_chunks_kernel adds the
+// chunks in fixed order.
+constexpr int ROW_CHUNKS = 16;
 template <int RP>
-__global__ __launch_bounds__(256) void contract_cols_kernel(const float* __restrict__ dW, const bf16* __restrict__ Vs, float* __restrict__ dU,
+__global__ __launch_bounds__(256) void contract_cols_kernel(const float* __restrict__ dW, int nslab, size_t slab_stride,
+                                                            const bf16* __restrict__ Vs, float* __restrict__ scratch,
                                                             int out, int in, unsigned seed, unsigned lin, unsigned thresh, float inv_keep) {
   __shared__ float part[4][64][RP + 1];
   const int ic = threadIdx.x & 63, og = threadIdx.x >> 6, i = blockIdx.x * 64 + ic;
+  const int per = (out + gridDim.y - 1) / gridDim.y, o_begin = blockIdx.y * per, o_end = min(out, o_begin + per);
   float acc[RP];
 #pragma unroll
   for (int r = 0; r < RP; ++r) acc[r] = 0.f;
   if (i < in) {
-    for (int o = og; o < out; o += 4) {
+    for (int o = o_begin + og; o < o_end; o += 4) {
       const size_t e = (size_t)o * in + i;
-      const float g = dW[e] * keep_scale((unsigned)e, seed, lin, thresh, inv_keep);
+      const float k = keep_scale((unsigned)e, seed, lin, thresh, inv_keep);
+      const float g = k != 0.f ? slab_sum(dW, e, nslab, slab_stride) * k : 0.f;
       if (g != 0.f) {
 #pragma unroll
         for (int r = 0; r < RP; r += 8) {
           const bf16x8 v = *reinterpret_cast<const bf16x8*>(Vs + (size_t)o * RP + r);   // wave-uniform address: broadcast
 #pragma unroll
-          for (int k = 0; k < 8; ++k) acc[r + k] += g * (float)v[k];
+          for (int kk = 0; kk < 8; ++kk) acc[r + kk] += g * (float)v[kk];
         }
       }
     }
@@ -116,23 +131,36 @@ __global__ __launch_bounds__(256) void contract_cols_kernel(const float* __restr
 #pragma unroll
   for (int r = 0; r < RP; ++r) part[og][ic][r] = acc[r];
   __syncthreads();
+  float* dst = scratch + (size_t)blockIdx.y * in * RP;
   for (int idx = threadIdx.x; idx < 64 * RP; idx += 256) {
     const int r = idx % RP, c = idx / RP;
     if (blockIdx.x * 64 + c < in)
-      dU[(size_t)(blockIdx.x * 64 + c) * RP + r] = ((part[0][c][r] + part[1][c][r]) + part[2][c][r]) + part[3][c][r];
+      dst[(size_t)(blockIdx.x * 64 + c) * RP + r] = ((part[0][c][r] + part[1][c][r]) + part[2][c][r]) + part[3][c][r];
   }
 }
 
-// column sums of a bf16 [M, ld] matrix (dc = sum_m dY): a workgroup owns 64 columns, 4 row groups, fixed-order sum
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X, int ld, int M, int N, float* __restrict__ out) {
+// out[j] = sum over `chunks` partial arrays of n floats each (fixed order)
+__global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restrict__ scratch, int chunks, size_t n, float* __restrict__ out) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float s = scratch[j];
+  for (int c = 1; c < chunks; ++c) s += scratch[(size_t)c * n + j];
+  out[j] = s;
+}
+
+// column sums of a bf16 [M, ld] matrix (dc = sum_m dY): workgroup (x, y) owns 64 columns and the y-th row chunk,
+// 4 row groups summed in fixed order into scratch [chunk][N]; reduce_chunks_kernel finishes
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X, int ld, int M, int N, float* __restrict__ scratch) {
   __shared__ float part[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  const int per = (M + gridDim.y - 1) / gridDim.y, m_begin = blockIdx.y * per, m_end = min(M, m_begin + per);
   float s = 0.f;
   if (c < N)
-    for (int m = g; m < M; m += 4) s += (float)X[(size_t)m * ld + c];
+    for (int m = m_begin + g; m < m_end; m += 4) s += (float)X[(size_t)m * ld + c];
   part[g][threadIdx.x & 63] = s;
   __syncthreads();
-  if (g == 0 && c < N) out[c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+  if (g == 0 && c < N)
+    scratch[(size_t)blockIdx.y * N + c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
 }
 
 bool mask_params(float p, unsigned* thresh, float* inv_keep) {
@@ -164,27 +192,41 @@ extern "C" int cara_materialize_merge(const void* W, const void* U, const void* 
   return CARA_OK;
 }
 
-extern "C" int cara_dropout_grad_contract(const float* dW, const void* U, const void* Vs, int Rp, int out, int in, float p, unsigned seed,
-                                          unsigned linear_id, float* dU, float* dVs, void* stream) {
+extern "C" size_t cara_dropout_grad_scratch_bytes(int in, int Rp) { return (size_t)ROW_CHUNKS * in * Rp * sizeof(float); }
+
+extern "C" int cara_dropout_grad_contract(const float* dW, int nslab, size_t slab_stride, const void* U, const void* Vs, int Rp, int out,
+                                          int in, float p, unsigned seed, unsigned linear_id, float* dU, float* dVs, void* scratch,
+                                          void* stream) {
   unsigned thresh;
   float inv_keep;
-  if (!dW || !U || !Vs || !dU || !dVs || out <= 0 || in <= 0 || !(Rp == 32 || Rp == 64) || !mask_params(p, &thresh, &inv_keep)) return CARA_E_ARG;
+  if (!dW || !U || !Vs || !dU || !dVs || !scratch || nslab <= 0 || out <= 0 || in <= 0 || !(Rp == 32 || Rp == 64) ||
+      !mask_params(p, &thresh, &inv_keep))
+    return CARA_E_ARG;
   if ((unsigned long long)out * in >= (1ull << 32)) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  float* sc = static_cast<float*>(scratch);
+  const dim3 gc((in + 63) / 64, ROW_CHUNKS);
   if (Rp == 32) {
-    hipLaunchKernelGGL(contract_rows_kernel<32>, dim3((out + 3) / 4), dim3(256), 0, st, dW, (const bf16*)U, dVs, out, in, seed, linear_id, thresh, inv_keep);
-    hipLaunchKernelGGL(contract_cols_kernel<32>, dim3((in + 63) / 64), dim3(256), 0, st, dW, (const bf16*)Vs, dU, out, in, seed, linear_id, thresh, inv_keep);
+    hipLaunchKernelGGL(contract_rows_kernel<32>, dim3((out + 3) / 4), dim3(256), 0, st, dW, nslab, slab_stride, (const bf16*)U, dVs, out, in, seed, linear_id, thresh, inv_keep);
+    hipLaunchKernelGGL(contract_cols_kernel<32>, gc, dim3(256), 0, st, dW, nslab, slab_stride, (const bf16*)Vs, sc, out, in, seed, linear_id, thresh, inv_keep);
   } else {
-    hipLaunchKernelGGL(contract_rows_kernel<64>, dim3((out + 3) / 4), dim3(256), 0, st, dW, (const bf16*)U, dVs, out, in, seed, linear_id, thresh, inv_keep);
-    hipLaunchKernelGGL(contract_cols_kernel<64>, dim3((in + 63) / 64), dim3(256), 0, st, dW, (const bf16*)Vs, dU, out, in, seed, linear_id, thresh, inv_keep);
+    hipLaunchKernelGGL(contract_rows_kernel<64>, dim3((out + 3) / 4), dim3(256), 0, st, dW, nslab, slab_stride, (const bf16*)U, dVs, out, in, seed, linear_id, thresh, inv_keep);
+    hipLaunchKernelGGL(contract_cols_kernel<64>, gc, dim3(256), 0, st, dW, nslab, slab_stride, (const bf16*)Vs, sc, out, in, seed, linear_id, thresh, inv_keep);
   }
+  const size_t n = (size_t)in * Rp;
+  hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc, ROW_CHUNKS, n, dU);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }
 
-extern "C" int cara_colsum_bf16(const void* X, int ld, int M, int N, float* out, void* stream) {
-  if (!X || !out || M <= 0 || N <= 0 || ld < N) return CARA_E_ARG;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16*)X, ld, M, N, out);
+extern "C" size_t cara_colsum_scratch_bytes(int N) { return (size_t)32 * N * sizeof(float); }
+
+extern "C" int cara_colsum_bf16(const void* X, int ld, int M, int N, float* out, void* scratch, void* stream) {
+  if (!X || !out || !scratch || M <= 0 || N <= 0 || ld < N) return CARA_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int chunks = M >= 2048 ? 32 : (M >= 256 ? 8 : 1);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, (const bf16*)X, ld, M, N, static_cast<float*>(scratch));
+  hipLaunchKernelGGL(reduce_chunks_kernel, dim3((N + 255) / 256), dim3(256), 0, st, static_cast<const float*>(scratch), chunks, (size_t)N, out);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }

@@ -226,8 +226,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? 4
     tm = first + (rem - tn * gsz);
   }
   const int m0 = tm * TBM, n0 = tn * BN;
-  const bf16* __restrict__ A = static_cast<const bf16*>(p.A);
-  const bf16* __restrict__ B = static_cast<const bf16*>(p.B);
+  // batched launch (blockIdx.y = product index): advance the operand pointers and the output offset
+  const size_t zb = p.batch > 1 ? blockIdx.y : 0;
+  const bf16* __restrict__ A = static_cast<const bf16*>(p.A) + zb * p.strideA;
+  const bf16* __restrict__ B = static_cast<const bf16*>(p.B) + zb * p.strideB;
+  const size_t coff = zb * p.strideC;
   f32x4 acc[MI][4];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? 4
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[half * (MI / NPASS) + i][j][r];
-    epilogue_rows<EPI, HALF>(p, stg, m0 + wr * (MI * 16) + half * HALF, n0 + wc * 64, lane);
+    epilogue_rows<EPI, HALF>(p, stg, m0 + wr * (MI * 16) + half * HALF, n0 + wc * 64, lane, coff);
   }
 }
 
@@ -312,18 +315,19 @@ int launch32(const cara_gemm_args* a, hipStream_t st) {
   const int gm = group_m(tiles_n);
   const char* ea = getenv("CARA_GEMM_ABLATE");
   const int ablate = ea ? atoi(ea) : 0;
+  const int nb = a->batch > 1 ? a->batch : 1;
   if (bm_choice(a) == 256) {
     const int nwg = ((a->M + 255) / 256) * tiles_n;
-    hipLaunchKernelGGL((gemm32_kernel<EPI, 4, 8>), dim3(nwg), dim3(512), 2 * (256 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm, ablate);
+    hipLaunchKernelGGL((gemm32_kernel<EPI, 4, 8>), dim3(nwg, nb), dim3(512), 2 * (256 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm, ablate);
   } else if (bm_choice(a) == 8) {
     const int nwg = ((a->M + 127) / 128) * tiles_n;
-    hipLaunchKernelGGL((gemm32_kernel<EPI, 2, 8>), dim3(nwg), dim3(512), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm, ablate);
+    hipLaunchKernelGGL((gemm32_kernel<EPI, 2, 8>), dim3(nwg, nb), dim3(512), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm, ablate);
   } else if (bm_choice(a) == 64) {
     const int nwg = ((a->M + 63) / 64) * tiles_n;
-    hipLaunchKernelGGL((gemm32_kernel<EPI, 2>), dim3(nwg), dim3(256), 2 * (64 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm, ablate);
+    hipLaunchKernelGGL((gemm32_kernel<EPI, 2>), dim3(nwg, nb), dim3(256), 2 * (64 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm, ablate);
   } else {
     const int nwg = ((a->M + 127) / 128) * tiles_n;
-    hipLaunchKernelGGL((gemm32_kernel<EPI, 4>), dim3(nwg), dim3(256), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm, ablate);
+    hipLaunchKernelGGL((gemm32_kernel<EPI, 4>), dim3(nwg, nb), dim3(256), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm, ablate);
   }
   CARA_CHECK_LAUNCH();
   return CARA_OK;
@@ -390,6 +394,10 @@ extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
   if (a->epi == CARA_EPI_GELU && !a->C2) return CARA_E_ARG;
   if (a->epi == CARA_EPI_RESID && (!a->aux || (a->rowscale && a->rows_per_sample <= 0))) return CARA_E_ARG;
   if (a->epi == CARA_EPI_DGELU && !a->aux) return CARA_E_ARG;
+  if (a->batch > 1) {   // batched products: the default kernel family only, plain epilogues
+    if (a->A2 || a->aux || a->C2 || !(a->epi == CARA_EPI_F32 || a->epi == CARA_EPI_BF16) || a->batch > 65535) return CARA_E_ARG;
+    return a->epi == CARA_EPI_F32 ? launch32<CARA_EPI_F32>(a, st) : launch32<CARA_EPI_BF16>(a, st);
+  }
   const int tile = tile_choice(a);
   if (tile == 256) return cara_gemm256_dispatch(a, st);
   if (tile == 1282) return cara_gemm128x256_dispatch(a, st);   // 128 x 256

@@ -7,7 +7,7 @@
 
 template <int EPI, int ROWS>
 __device__ __forceinline__ void epilogue_rows(const cara_gemm_args& p, const float* stg, const int mbase,
-                                              const int nbase, const int lane) {
+                                              const int nbase, const int lane, const size_t coff = 0) {
   if constexpr (EPI == CARA_EPI_F32 || EPI == CARA_EPI_RESID) {
     // fp32 output: 4 rows x 256 B per pass, 16 B per lane
     const int c4 = (lane & 15) * 4, n = nbase + c4;
@@ -36,7 +36,7 @@ __device__ __forceinline__ void epilogue_rows(const cara_gemm_args& p, const flo
           for (int k = 0; k < 4; ++k) v[k] = (n + k < p.N) ? xin[k] + rs * v[k] : 0.f;
         }
       }
-      float* dst = static_cast<float*>(p.C) + o;
+      float* dst = static_cast<float*>(p.C) + o + coff;
       if (vec) {
         *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
       } else {
@@ -85,7 +85,7 @@ __device__ __forceinline__ void epilogue_rows(const cara_gemm_args& p, const flo
 #pragma unroll
         for (int k = 0; k < 8; ++k) out[k] = (bf16)(v[k] * gelu_erf_grad((float)u[k]));
       }
-      bf16* dst = static_cast<bf16*>(p.C) + o;
+      bf16* dst = static_cast<bf16*>(p.C) + o + coff;
       if (vec) {
         *reinterpret_cast<bf16x8*>(dst) = out;
         if constexpr (EPI == CARA_EPI_GELU) *reinterpret_cast<bf16x8*>(static_cast<bf16*>(p.C2) + o) = out2;

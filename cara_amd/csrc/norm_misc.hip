@@ -271,6 +271,46 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__
     if (c0 + k < cols && r0 + tx < rows) dst[(size_t)(c0 + k) * rows + r0 + tx] = tile[tx][k];
 }
 
+// dst[c * ldd + r] = src[r * lds + c] for a [rows, cols] matrix, 64 x 64 tiles, 16-byte global accesses both ways
+// (activation-sized transposes of the exact weight-dropout mode: dY^T and X^T feed the dense dW GEMM)
+__global__ __launch_bounds__(256) void transpose64_kernel(const bf16* __restrict__ src, long lds_, bf16* __restrict__ dst, long ldd,
+                                                          int rows, int cols) {
+  __shared__ bf16 tile[64][72];
+  const int t = threadIdx.x, c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (t >> 3) + 32 * j, c = (t & 7) * 8;
+    bf16x8 v = {};
+    if (r0 + r < rows) {
+      if (c0 + c + 8 <= cols) {
+        v = *reinterpret_cast<const bf16x8*>(src + (size_t)(r0 + r) * lds_ + c0 + c);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (c0 + c + k < cols) v[k] = src[(size_t)(r0 + r) * lds_ + c0 + c + k];
+      }
+    }
+    *reinterpret_cast<bf16x8*>(&tile[r][c]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = (t >> 3) + 32 * j, r = (t & 7) * 8;   // output row c0 + c, 8 consecutive source rows
+    if (c0 + c >= cols) continue;
+    bf16x8 v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = tile[r + k][c];
+    bf16* d = dst + (size_t)(c0 + c) * ldd + r0 + r;
+    if (r0 + r + 8 <= rows) {
+      *reinterpret_cast<bf16x8*>(d) = v;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (r0 + r + k < rows) d[k] = v[k];
+    }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -404,6 +444,14 @@ extern "C" int cara_f32_to_bf16(const float* src, void* dst, size_t n, void* str
   const size_t nthreads = (n + 3) / 4;
   hipLaunchKernelGGL(cvt_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      src, (bf16*)dst, n);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
+extern "C" int cara_transpose_bf16_ld(const void* src, long lds, void* dst, long ldd, int rows, int cols, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || lds < cols || ldd < rows || (lds & 7) || (ldd & 7)) return CARA_E_ARG;
+  hipLaunchKernelGGL(transpose64_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     (const bf16*)src, lds, (bf16*)dst, ldd, rows, cols);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }

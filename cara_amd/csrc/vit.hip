@@ -33,6 +33,10 @@ struct Ws {
   size_t dx, dyb, dH, dXn, dAO, dQKV, G[4], Gt[4], slabs, dclsn, gscratch, gemm_scratch;
   size_t dU[4], dVs[4], dc[4];
   size_t slabU[4], slabV[4], strideU[4], strideV[4];   // per linear: depth regions of tskinny slabs
+  // exact weight-dropout mode: merged weights of every layer (and their transposes), transposed activations, dense dW
+  size_t weff[4], wefft[4], dYt, Xt, dWd, xscratch;
+  int nslab;   // split-K slabs of the dense dW product
+  int ldk;   // row stride of the transposed activations: M rounded up to the GEMM's K granule
   size_t total;
   int M, ldt;
 };
@@ -100,6 +104,22 @@ bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
     w->strideV[i] = (cara_tskinny_scratch_bytes((int)M, (int)outs[i], (int)Rp) + 255) & ~(size_t)255;
     w->slabU[i] = c.take(w->strideU[i] * g->depth);
     w->slabV[i] = c.take(w->strideV[i] * g->depth);
+  }
+  w->ldk = (int)((M + 63) / 64 * 64);
+  w->nslab = 1;
+  if (s->wd_exact) {
+    // dW = dY^T X has only (out/128) x (in/128) = 36..144 output tiles: its K = M is cut into equal slabs (one
+    // batched launch fills the chip), which cara_dropout_grad_contract sums
+    w->nslab = M >= 8192 ? 4 : (M >= 3072 ? 2 : 1);
+    w->ldk = (int)((M + 64 * w->nslab - 1) / (64 * w->nslab) * (64 * w->nslab));
+    for (int i = 0; i < 4; ++i) {
+      w->weff[i] = c.take((size_t)g->depth * outs[i] * ins[i] * 2);
+      w->wefft[i] = c.take((size_t)g->depth * outs[i] * ins[i] * 2);
+    }
+    w->dYt = c.take((size_t)4 * D * w->ldk * 2);
+    w->Xt = c.take((size_t)4 * D * w->ldk * 2);
+    w->dWd = c.take((size_t)w->nslab * 4 * D * D * 4);
+    w->xscratch = c.take(max_sz(cara_dropout_grad_scratch_bytes((int)(4 * D), (int)Rp), cara_colsum_scratch_bytes((int)(4 * D))));
   }
   w->total = c.off;
   return true;
@@ -207,6 +227,62 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
   if (side_ready() && hipEventRecord(g_side.join[L.slot], g_side.s) != hipSuccess) return CARA_E_LAUNCH;
   if (want_dx) {
     a.A = dY; a.lda = lddy; a.B = L.Wt; a.ldb = L.out; a.A2 = G; a.B2 = L.U; a.Rp = Rp;
+    a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
+    if (a.ldc == 0) a.ldc = L.in;
+    with_scratch(a);
+    TRY(cara_gemm_bf16(&a, st));
+  }
+  return CARA_OK;
+}
+
+// ---- exact weight-dropout mode (cara_vit_shape::wd_exact): plain GEMMs on W_eff = W + keep/(1-p) dW ----------
+// forward of one linear: materialise W_eff (and its transpose, for dX) of this layer, then C = X W_eff^T + bias
+int lin_fwd_exact(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, char* ws, const Ws& W, int layer, const cara_vit_shape* s,
+                  cara_gemm_args a, void* st) {
+  const size_t wbytes = (size_t)L.out * L.in * 2;
+  bf16* weff = reinterpret_cast<bf16*>(ws + W.weff[L.slot] + layer * wbytes);
+  bf16* wefft = reinterpret_cast<bf16*>(ws + W.wefft[L.slot] + layer * wbytes);
+  TRY(cara_materialize_merge(L.W, L.U, L.Vs, Rp, L.out, L.in, s->wd_p, s->wd_seed, (unsigned)(4 * layer + L.slot), weff, st));
+  TRY(cara_transpose_bf16_ld(weff, L.in, wefft, L.out, L.out, L.in, st));
+  a.A = X; a.lda = ldx; a.B = weff; a.ldb = L.in; a.A2 = nullptr; a.B2 = nullptr; a.Rp = 0;
+  a.M = Mr; a.N = L.out; a.K = L.in; a.bias = L.bias;
+  if (a.ldc == 0) a.ldc = L.out;
+  with_scratch(a);
+  return cara_gemm_bf16(&a, st);
+}
+
+// backward of one linear: dc = colsum dY; dW = dY^T X (dense, fp32) -> dU, dVs through the regenerated mask;
+// dX = dY W_eff (optional).  X and dY are dense [Mr, in] / [Mr, out] (the cls-row shortcut is off in this mode).
+int lin_bwd_exact(const Lin& L, const bf16* dY, const bf16* X, int Mr, int Rp, char* ws, const Ws& W, int layer,
+                  const cara_vit_shape* s, bool want_dx, cara_gemm_args a, bool want_dc, void* st) {
+  hipStream_t hs = static_cast<hipStream_t>(st);
+  const size_t wbytes = (size_t)L.out * L.in * 2;
+  bf16* wefft = reinterpret_cast<bf16*>(ws + W.wefft[L.slot] + layer * wbytes);
+  bf16* dYt = reinterpret_cast<bf16*>(ws + W.dYt);
+  bf16* Xt = reinterpret_cast<bf16*>(ws + W.Xt);
+  float* dWd = reinterpret_cast<float*>(ws + W.dWd);
+  const int ldk = W.ldk;
+  if (want_dc)
+    TRY(cara_colsum_bf16(dY, L.out, Mr, L.out, reinterpret_cast<float*>(ws + W.dc[L.slot]) + (size_t)layer * L.out, ws + W.xscratch, st));
+  if (ldk > Mr) {   // K of the dW product is Mr rounded up to 64: the pad columns of both transposes must be zero
+    if (hipMemset2DAsync(dYt + Mr, (size_t)ldk * 2, 0, (size_t)(ldk - Mr) * 2, L.out, hs) != hipSuccess) return CARA_E_LAUNCH;
+    if (hipMemset2DAsync(Xt + Mr, (size_t)ldk * 2, 0, (size_t)(ldk - Mr) * 2, L.in, hs) != hipSuccess) return CARA_E_LAUNCH;
+  }
+  TRY(cara_transpose_bf16_ld(dY, L.out, dYt, ldk, Mr, L.out, st));
+  TRY(cara_transpose_bf16_ld(X, L.in, Xt, ldk, Mr, L.in, st));
+  // split-K in one batched launch: slab z covers K columns [z * ldk/nslab, ...) of both transposes
+  const size_t slab_stride = (size_t)L.out * L.in;
+  const int used = W.nslab;
+  cara_gemm_args d = {};
+  d.A = dYt; d.lda = ldk; d.B = Xt; d.ldb = ldk; d.M = L.out; d.N = L.in; d.K = ldk / used;
+  d.epi = CARA_EPI_F32; d.C = dWd; d.ldc = L.in;
+  d.batch = used; d.strideA = d.K; d.strideB = d.K; d.strideC = (long long)slab_stride;
+  TRY(cara_gemm_bf16(&d, st));
+  TRY(cara_dropout_grad_contract(dWd, used, slab_stride, L.U, L.Vs, Rp, L.out, L.in, s->wd_p, s->wd_seed, (unsigned)(4 * layer + L.slot),
+                                 reinterpret_cast<float*>(ws + W.dU[L.slot]) + (size_t)layer * L.in * Rp,
+                                 reinterpret_cast<float*>(ws + W.dVs[L.slot]) + (size_t)layer * L.out * Rp, ws + W.xscratch, st));
+  if (want_dx) {
+    a.A = dY; a.lda = L.out; a.B = wefft; a.ldb = L.out; a.A2 = nullptr; a.B2 = nullptr; a.Rp = 0;
     a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
     if (a.ldc == 0) a.ldc = L.in;
     with_scratch(a);
@@ -363,12 +439,13 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
     // the final norm), and proj / LayerNorm / fc1 / fc2 act per token: in the last block they run
     // on the B cls rows only (row stride N*D).  Exact, not an approximation: every other row of
     // that block's proj/MLP output is dead.  qkv and attention still see all tokens (keys/values).
-    const bool cls_only = (l == g->depth - 1) && cls_shortcut_enabled();
+    const bool cls_only = (l == g->depth - 1) && cls_shortcut_enabled() && !s->wd_exact;
     const int Mr = cls_only ? B : M;
     const int ldr = cls_only ? N * D : D;          // row stride of the residual stream rows used
     const int rps = cls_only ? 1 : N;              // rows per sample for the DropPath multipliers
     // x = x + drop_path(attn(norm1(x)))
-    const bool fx = fuse_xu(g);
+    const bool ex = s->wd_exact != 0;   // exact weight-dropout mode: plain GEMMs on the merged weights
+    const bool fx = fuse_xu(g) && !ex;
     if (fx)
       TRY(cara_layernorm_fwd_xu(x_in, D, w->ln1_g + (size_t)l * D, w->ln1_b + (size_t)l * D, ws + lw.xn1,
                                 reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), M, D, s->eps,
@@ -378,11 +455,13 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
                              reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), M, D, s->eps, stream));
     cara_gemm_args e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + lw.qkv;
-    TRY(lin_fwd(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, W.ldt, ws, lw, e, stream, fx));
+    if (ex) TRY(lin_fwd_exact(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, ws, W, l, s, e, stream));
+    else TRY(lin_fwd(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, W.ldt, ws, lw, e, stream, fx));
     TRY(cara_attention_fwd(ws + lw.qkv, ws + lw.ao, reinterpret_cast<float*>(ws + lw.lse), B, N, g->heads, att_scale, stream));
     e = {};
     e.epi = CARA_EPI_RESID; e.C = x_mid; e.aux = x_in; e.rowscale = dp1; e.rows_per_sample = rps; e.ldc = ldr;
-    TRY(lin_fwd(lin[1], reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, lw, e, stream));
+    if (ex) TRY(lin_fwd_exact(lin[1], reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, ws, W, l, s, e, stream));
+    else TRY(lin_fwd(lin[1], reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, lw, e, stream));
     // x = x + drop_path(mlp(norm2(x)))
     if (fx)
       TRY(cara_layernorm_fwd_xu(x_mid, ldr, w->ln2_g + (size_t)l * D, w->ln2_b + (size_t)l * D, ws + lw.xn2,
@@ -393,7 +472,9 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
                              reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), Mr, D, s->eps, stream));
     e = {};
     e.epi = CARA_EPI_GELU; e.C = ws + lw.h; e.C2 = ws + lw.u;
-    if (g_prof.on && !cls_only) {
+    if (ex) {
+      TRY(lin_fwd_exact(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, ws, W, l, s, e, stream));
+    } else if (g_prof.on && !cls_only) {
       // T first, so that the bracket holds exactly one kernel: the fc1 GEMM
       bf16* T = reinterpret_cast<bf16*>(ws + lw.T[2]);
       if (!fx) TRY(cara_skinny_xu(ws + lw.xn2, D, lin[2].Ut, T, ws + lw.Tt[2], W.ldt, M, D, Rp, stream));
@@ -411,7 +492,8 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
     }
     e = {};
     e.epi = CARA_EPI_RESID; e.C = x_out; e.aux = x_mid; e.rowscale = dp2; e.rows_per_sample = rps; e.ldc = ldr;
-    TRY(lin_fwd(lin[3], reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, W.ldt, ws, lw, e, stream));
+    if (ex) TRY(lin_fwd_exact(lin[3], reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, ws, W, l, s, e, stream));
+    else TRY(lin_fwd(lin[3], reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, W.ldt, ws, lw, e, stream));
   }
   // norm -> cls token -> head  (LayerNorm is per token, so only the cls rows are normalised)
   TRY(cara_layernorm_fwd(reinterpret_cast<float*>(ws + W.x_last), (long)N * D, w->norm_g, w->norm_b, ws + W.clsn,
@@ -444,7 +526,8 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
   TRY(cara_layernorm_bwd(ws + W.dclsn, reinterpret_cast<float*>(ws + W.x_last), (long)N * D, w->norm_g,
                          reinterpret_cast<float*>(ws + W.meanF), reinterpret_cast<float*>(ws + W.rstdF), nullptr, dx, dyb,
                          dp_last, 1, B, D, stream));
-  const bool fx = fuse_xu(g);
+  const bool ex = s->wd_exact != 0;
+  const bool fx = fuse_xu(g) && !ex;
   bool have_G_fc2 = false;   // G' of this block's fc2 was left by the LayerNorm backward of the block above
   for (int l = g->depth - 1; l >= 0; --l) {
     const LayerWs& lw = W.layer[l];
@@ -453,7 +536,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     const float* dp1 = droppath ? droppath + (size_t)(2 * l) * B : nullptr;
     const float* dp_prev = (droppath && l > 0) ? droppath + (size_t)(2 * (l - 1) + 1) * B : nullptr;
     // last block: only the cls rows carry gradient into proj / MLP (see cara_vit_forward)
-    const bool cls_only = (l == g->depth - 1) && cls_shortcut_enabled();
+    const bool cls_only = (l == g->depth - 1) && cls_shortcut_enabled() && !s->wd_exact;
     const int Mr = cls_only ? B : M;
     const int ldr = cls_only ? N * D : D;
     const int rps = cls_only ? 1 : N;
@@ -461,13 +544,16 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     cara_gemm_args e = {};
     e.epi = CARA_EPI_DGELU; e.C = ws + W.dH; e.aux = ws + lw.u;
     TRY(side_join(2, stream));   // the previous block's fc1 products still read dH / G'[2]
-    TRY(lin_bwd(lin[3], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, W.ldt, ws, W, lw, l, true, e, true, stream,
-                have_G_fc2));
+    if (ex) TRY(lin_bwd_exact(lin[3], dyb, reinterpret_cast<bf16*>(ws + lw.h), Mr, Rp, ws, W, l, s, true, e, true, stream));
+    else TRY(lin_bwd(lin[3], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, W.ldt, ws, W, lw, l, true, e, true, stream,
+                     have_G_fc2));
     have_G_fc2 = false;
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
-    TRY(lin_bwd(lin[2], reinterpret_cast<bf16*>(ws + W.dH), 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, W.ldt, ws, W,
-                lw, l, true, e, true, stream));
+    if (ex) TRY(lin_bwd_exact(lin[2], reinterpret_cast<bf16*>(ws + W.dH), reinterpret_cast<bf16*>(ws + lw.xn2), Mr, Rp, ws, W, l, s, true, e,
+                              true, stream));
+    else TRY(lin_bwd(lin[2], reinterpret_cast<bf16*>(ws + W.dH), 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, W.ldt, ws, W,
+                     lw, l, true, e, true, stream));
     TRY(side_join(3, stream));   // fc2's products read dyb, which this LayerNorm backward overwrites
     // dyb = dY of this block's proj: its G' = dY Vs comes out of the same kernel
     if (fx)
@@ -482,15 +568,18 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dAO; e.ldc = ldr;
     if (cls_only && hipMemsetAsync(ws + W.dAO, 0, (size_t)M * D * 2, hs) != hipSuccess) return CARA_E_LAUNCH;
-    TRY(lin_bwd(lin[1], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, W, lw, l, true, e, true, stream, fx));
+    if (ex) TRY(lin_bwd_exact(lin[1], dyb, reinterpret_cast<bf16*>(ws + lw.ao), Mr, Rp, ws, W, l, s, true, e, true, stream));
+    else TRY(lin_bwd(lin[1], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, W, lw, l, true, e, true, stream, fx));
     TRY(side_join(0, stream));   // the previous block's qkv products still read dQKV / G'[0]
     TRY(cara_attention_bwd(ws + lw.qkv, ws + lw.ao, ws + W.dAO, reinterpret_cast<float*>(ws + lw.lse), ws + W.dQKV, B, N,
                            g->heads, att_scale, stream));
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
     // block 0 has nothing trainable upstream of it: its dX GEMM and LayerNorm backward are skipped
-    TRY(lin_bwd(lin[0], reinterpret_cast<bf16*>(ws + W.dQKV), 3 * D, reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, W.ldt, ws, W,
-                lw, l, l > 0, e, false, stream));
+    if (ex) TRY(lin_bwd_exact(lin[0], reinterpret_cast<bf16*>(ws + W.dQKV), reinterpret_cast<bf16*>(ws + lw.xn1), M, Rp, ws, W, l, s, l > 0, e,
+                              false, stream));
+    else TRY(lin_bwd(lin[0], reinterpret_cast<bf16*>(ws + W.dQKV), 3 * D, reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, W.ldt, ws, W,
+                     lw, l, l > 0, e, false, stream));
     TRY(side_join(1, stream));   // proj's products read dyb, which the next LayerNorm backward overwrites
     if (l > 0) {
       if (fx) {
@@ -509,7 +598,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     }
   }
   for (int i = 0; i < 4; ++i) TRY(side_join(i, stream));   // all slabs written
-  {
+  if (!ex) {   // (the exact mode wrote dU / dVs / dc of every layer directly)
     const int ins[4] = {D, D, D, 4 * D}, outs[4] = {3 * D, D, 4 * D, D};
     const int L = g->depth;
     for (int i = 0; i < 4; ++i) {
@@ -518,7 +607,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
       float* dc = i == 0 ? nullptr : reinterpret_cast<float*>(ws + W.dc[i]);
       // qkv (i == 0) sees all tokens in every block; proj / fc1 / fc2 of the last block ran on B rows,
       // so that block's slabs have their own chunking
-      const int full = (i == 0 || !cls_shortcut_enabled()) ? L : L - 1;
+      const int full = (i == 0 || !cls_shortcut_enabled()) ? L : L - 1;   // (not reached in the exact mode)
       if (full > 0) {
         TRY(cara_tskinny_reduce(ws + W.slabU[i], W.strideU[i], dU, nullptr, full, M, ins[i], Rp, stream));
         TRY(cara_tskinny_reduce(ws + W.slabV[i], W.strideV[i], dVs, dc, full, M, outs[i], Rp, stream));

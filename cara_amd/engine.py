@@ -46,7 +46,13 @@ class CaraEngine:
     def __init__(self, model, rank: int, scale: float):
         self._model = weakref.ref(model)
         self.rank, self.Rp, self.scale = rank, _rp(rank), scale
-        self.weight_dropout = "off"  # dropout on the materialised dW (cara.py:35,57,81,92) is not factorable; see DESIGN.md
+        # Dropout(0.1) on the materialised dW (cara.py:35,57,81,92).  "off": factored adapters, no weight-space
+        # dropout (the fast default; a mask on dW's elements does not factor).  "exact": train-mode forwards run on
+        # W_eff = W + keep/(1-p) dW with a fresh mask per step and the adapter gradients come from the dense
+        # dW = dY^T X, as in the reference (cara_vit_shape::wd_exact; ~1.4x the step time).  Eval is identical in both.
+        self.weight_dropout = "off"
+        self.weight_dropout_p = 0.1
+        self.weight_dropout_seed = None   # tests pin the mask seed; None = a fresh draw from torch's RNG per forward
         self._ingested = None
         self._ingest_sig = None
         self._ws = {}
@@ -113,13 +119,18 @@ class CaraEngine:
             self._ingest(model, dev)
             self._ws.clear()
         ncls = model.head.out_features
-        key = (B, img, ncls, str(dev))
+        exact = self.weight_dropout == "exact"
+        if self.weight_dropout not in ("off", "exact"):
+            raise CaraError(f"weight_dropout must be 'off' or 'exact', not {self.weight_dropout!r}")
+        key = (B, img, ncls, str(dev), exact)
         st = self._ws.get(key)
         if st is None:
             pe = model.patch_embed
             geom = L.Geom(len(model.blocks), model.embed_dim, model.blocks[0].attn.num_heads, self.rank, self.Rp, self.scale)
+            # (sized with the exact-mode regions when that mode is selected; a call with wd_exact = 0 on the same
+            # workspace -- eval -- simply does not touch them)
             shape = L.VitShape(B, img, pe.patch_size[0], model.in_chans, (img // pe.patch_size[0]) ** 2 + 1, ncls,
-                               float(model.norm.eps))
+                               float(model.norm.eps), 1 if exact else 0, float(self.weight_dropout_p), 0)
             nbytes = L.lib().cara_vit_workspace_bytes(C.byref(geom), C.byref(shape))
             if nbytes == 0:
                 raise CaraError(f"unsupported geometry for the HIP path: {geom.depth=} {geom.dim=} {geom.heads=} "
@@ -141,6 +152,14 @@ class CaraEngine:
             raise CaraError("images must be [B, C, H, H]")
         images = images.contiguous().float()
         st = self._state(model, images.shape[0], images.shape[2], images.device)
+        # weight-space dropout is a train-mode thing (nn.Dropout is the identity in eval); the backward of this
+        # forward reads the same struct, i.e. the same seed, and regenerates the masks
+        use_exact = self.weight_dropout == "exact" and model.training and self.weight_dropout_p > 0
+        st["shape"].wd_exact = 1 if use_exact else 0
+        st["shape"].wd_p = float(self.weight_dropout_p)
+        if use_exact:
+            st["shape"].wd_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if self.weight_dropout_seed is None \
+                else int(self.weight_dropout_seed)
         cps = self._cp_ptrs([t.detach().contiguous() for t in cp])
         logits = torch.empty_like(st["logits"])
         check(L.lib().cara_vit_forward(C.byref(st["geom"]), C.byref(st["shape"]), C.byref(self._ingested[1]), C.byref(cps),

@@ -58,6 +58,8 @@ typedef struct {
   size_t scratch_bytes;         /* allocation, used by ONE stream at a time.  With it, products of at     */
                                 /* least 1024 rows and 256 columns run on the persistent stream-K kernel  */
                                 /* (partial tiles + flags live there); NULL = one tile per workgroup.     */
+  int batch;                    /* > 1: `batch` independent products in ONE launch; product z uses A, B,  */
+  long long strideA, strideB, strideC;   /* C advanced by z * stride (elements); no A2/B2/aux/C2 then     */
 } cara_gemm_args;
 int cara_gemm_bf16(const cara_gemm_args* a, void* stream);
 size_t cara_gemm_scratch_bytes(void);
@@ -139,6 +141,8 @@ int cara_cross_entropy(const float* logits, const int64_t* labels, float* loss, 
 /* bf16 <-> fp32 helpers (weight ingest)                                                        */
 int cara_f32_to_bf16(const float* src, void* dst, size_t n, void* stream);
 int cara_transpose_bf16(const void* src, void* dst, int rows, int cols, void* stream);
+/* the same for activation-sized matrices: row strides lds >= cols, ldd >= rows (multiples of 8), 16-byte accesses */
+int cara_transpose_bf16_ld(const void* src, long lds, void* dst, long ldd, int rows, int cols, void* stream);
 
 /* ---- CP factor preparation / gradient scatter --------------------- */
 /* Geometry of one adapted ViT.  The reference hard-codes dim 768 / heads 12 / depth 12
@@ -189,13 +193,18 @@ unsigned cara_weight_dropout_hash(unsigned idx, unsigned seed, unsigned linear_i
  * the operand pack of cara_factor_prep).  p = 0 is the eval-time merge of the reference's dW into W.         */
 int cara_materialize_merge(const void* W, const void* U, const void* Vs, int Rp, int out, int in, float p,
                            unsigned seed, unsigned linear_id, void* Weff, void* stream);
-/* From the dense weight gradient dW fp32 [out,in] (= dY^T X) to the skinny quantities cara_factor_grad_reduce
- * takes: dVs[o,r] = sum_i keep/(1-p) dW[o,i] U[i,r], dU[i,r] = sum_o keep/(1-p) dW[o,i] Vs[o,r] (fp32
- * [out,Rp] / [in,Rp], overwritten, fixed summation order).                                                  */
-int cara_dropout_grad_contract(const float* dW, const void* U, const void* Vs, int Rp, int out, int in, float p,
-                               unsigned seed, unsigned linear_id, float* dU, float* dVs, void* stream);
-/* out fp32 [N] = column sums of a bf16 [M, ld] matrix (dc = sum_m dY), fixed order.                         */
-int cara_colsum_bf16(const void* X, int ld, int M, int N, float* out, void* stream);
+/* From the dense weight gradient dW (= dY^T X, given as `nslab` split-K partial slabs of fp32 [out,in], slab_stride
+ * floats apart, summed on the fly) to the skinny quantities cara_factor_grad_reduce takes:
+ * dVs[o,r] = sum_i keep/(1-p) dW[o,i] U[i,r], dU[i,r] = sum_o keep/(1-p) dW[o,i] Vs[o,r] (fp32 [out,Rp] / [in,Rp],
+ * overwritten, fixed summation order).  scratch: cara_dropout_grad_scratch_bytes(in, Rp).                    */
+size_t cara_dropout_grad_scratch_bytes(int in, int Rp);
+int cara_dropout_grad_contract(const float* dW, int nslab, size_t slab_stride, const void* U, const void* Vs, int Rp,
+                               int out, int in, float p, unsigned seed, unsigned linear_id, float* dU, float* dVs,
+                               void* scratch, void* stream);
+/* out fp32 [N] = column sums of a bf16 [M, ld] matrix (dc = sum_m dY), fixed order; scratch:
+ * cara_colsum_scratch_bytes(N).                                                                               */
+size_t cara_colsum_scratch_bytes(int N);
+int cara_colsum_bf16(const void* X, int ld, int M, int N, float* out, void* scratch, void* stream);
 
 /* ---- whole adapted ViT: forward and backward as stream-ordered kernel sequences ------------ */
 /* What model(x) / loss.backward() of vit_cp.py:46-49 run, for the factored adapters.  Both calls
@@ -215,6 +224,14 @@ typedef struct {           /* frozen backbone (timm 0.4.12 VisionTransformer), d
 typedef struct {
   int B, img, patch, chans, tokens, num_classes;
   float eps;
+  /* weight-space dropout on the materialised adapters (cara.py:35,57,81,92).  0 = off: the factored path
+   * (eval semantics, and the fast training default: the mask does not factor).  1 = exact: every
+   * linear runs on W_eff = W + keep/(1-p) dW (cara_materialize_merge, linear id 4*layer + {qkv,proj,fc1,fc2},
+   * seed `wd_seed`, which the caller changes every step) and the adapter gradients come from the dense
+   * dW = dY^T X.  The workspace is larger in this mode (cara_vit_workspace_bytes sees the flag).           */
+  int wd_exact;
+  float wd_p;
+  unsigned wd_seed;
 } cara_vit_shape;
 size_t cara_vit_workspace_bytes(const cara_geom* g, const cara_vit_shape* s);
 /* images fp32 [B,chans,img,img]; droppath fp32 [depth,2,B] per-sample branch multipliers

@@ -283,15 +283,17 @@ def init_cp_params(rank: int, l_mu: float, l_std: float, dim=768, heads=12, dept
 def attn_as_written(x, cp, qkv_w, qkv_b, proj_w, proj_b, *, attn_idx: int, idx: int, s: float,
                     num_heads: int, scale: float, dp=None):
     """``cp_attn`` (``src/cara/cara.py:15-60``) over explicit tensors.  ``dp`` is the
-    weight-space dropout module (identity when None/eval)."""
+    weight-space dropout module (identity when None/eval); a dict {"qkv": f, "proj": f} gives each call site
+    (cara.py:35, :57) its own callable, so that a device path can be fed the same masks."""
     dp = dp or (lambda t: t)
+    dp_qkv, dp_proj = (dp["qkv"], dp["proj"]) if isinstance(dp, dict) else (dp, dp)
     B, N, C = x.shape
     hd = C // num_heads
     qkv = F.linear(x, qkv_w, qkv_b)
     t = cp_to_tensor((cp["CP_R1"], (cp["CP_A1"][attn_idx:attn_idx + 3], cp["CP_A2"], cp["CP_A3"], cp["CP_A4"])))
     K, E, H, D = t.shape
     t = t.reshape(K, E, H * D)
-    delta = torch.einsum("bnd,kde->kbne", x, dp(t))
+    delta = torch.einsum("bnd,kde->kbne", x, dp_qkv(t))
     delta = delta.reshape(3, B, N, num_heads, hd).permute(0, 1, 3, 2, 4)
     qkv = qkv.reshape(B, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
     qkv = qkv + delta * s
@@ -302,23 +304,24 @@ def attn_as_written(x, cp, qkv_w, qkv_b, proj_w, proj_b, *, attn_idx: int, idx: 
     out = F.linear(y, proj_w, proj_b)
     tp = cp_to_tensor((cp["CP_R2"], (cp["CP_P1"][idx:idx + 1], cp["CP_P2"], cp["CP_P3"])))
     tp = tp.reshape(tp.shape[0] * tp.shape[1], tp.shape[2])
-    out = out + (y @ dp(tp.t()) + cp["CP_bias1"]) * s
+    out = out + (y @ dp_proj(tp.t()) + cp["CP_bias1"]) * s
     return out
 
 
 def mlp_as_written(x, cp, fc1_w, fc1_b, fc2_w, fc2_b, *, idx: int, s: float, dp=None):
-    """``cp_mlp`` (``src/cara/cara.py:63-95``) over explicit tensors."""
+    """``cp_mlp`` (``src/cara/cara.py:63-95``) over explicit tensors (``dp``: callable or {"fc1": f, "fc2": f})."""
     dp = dp or (lambda t: t)
+    dp_fc1, dp_fc2 = (dp["fc1"], dp["fc2"]) if isinstance(dp, dict) else (dp, dp)
     up = F.linear(x, fc1_w, fc1_b)
     tu = cp_to_tensor((cp["CP_R2"], (cp["CP_P1"][idx:idx + 4], cp["CP_P2"], cp["CP_P3"])))
     a, b, c = tu.shape
     tu = tu.reshape(a * b, c)
-    up = up + (x @ dp(tu.t()) + cp["CP_bias2"]) * s
+    up = up + (x @ dp_fc1(tu.t()) + cp["CP_bias2"]) * s
     h = F.gelu(up)
     down = F.linear(h, fc2_w, fc2_b)
     td = cp_to_tensor((cp["CP_R2"], (cp["CP_P1"][idx + 4:idx + 8], cp["CP_P2"], cp["CP_P3"])))
     td = td.reshape(a * b, c)
-    down = down + (h @ dp(td) + cp["CP_bias3"]) * s
+    down = down + (h @ dp_fc2(td) + cp["CP_bias3"]) * s
     return down
 
 
@@ -344,7 +347,8 @@ def vit_weights(model: nn.Module) -> Dict[str, torch.Tensor]:
 def vit_cara_forward(images, w: Dict[str, torch.Tensor], cp: Dict[str, torch.Tensor], *, s: float,
                      depth: int = 12, num_heads: int = 12, patch: int = 16, eps: float = 1e-6,
                      drop_path_keep: Optional[torch.Tensor] = None, factored: bool = False,
-                     bf16_sim: bool = False, train: Optional[dict] = None):
+                     bf16_sim: bool = False, train: Optional[dict] = None,
+                     keep_masks=None, keep_p: float = 0.1):
     """Whole adapted forward (timm VisionTransformer.forward with cp_attn/cp_mlp patched in),
     functional form over the state-dict ``w`` and CP tensors ``cp``.
 
@@ -356,9 +360,21 @@ def vit_cara_forward(images, w: Dict[str, torch.Tensor], cp: Dict[str, torch.Ten
     ``train``: ``{"dp": 0.1, "dpr": [rate per block]}`` reproduces train mode as the reference
     runs it -- Dropout(0.1) on each materialised dW (``cara.py:35,57,81,92``) and timm DropPath
     on each branch -- drawing from the global torch RNG in the reference's order (as-written
-    form only).
+    form only).  ``keep_masks(layer, name)`` -> bool [out, in] keep mask of linear ``name`` in {"qkv","proj","fc1",
+    "fc2"} replaces the RNG draw of the weight-space dropout (probability ``keep_p``) so that the exact mode of the
+    device path, which builds its masks from a counter hash (cara_amd/dropout.py), can be checked element for element.
     """
     dpf = (lambda t: F.dropout(t, train["dp"], True)) if train else None
+
+    def masked(layer):
+        # orientation of each dropped tensor at its call site (see attn_as_written / mlp_as_written)
+        sc = 1.0 / (1.0 - keep_p)
+        mq = keep_masks(layer, "qkv").to(torch.float32)
+        mq = mq.reshape(3, mq.shape[0] // 3, mq.shape[1]).permute(0, 2, 1) * sc            # [k, e(in), o']
+        mp = keep_masks(layer, "proj").to(torch.float32).t() * sc                           # [c(in), j(out)]
+        m1 = keep_masks(layer, "fc1").to(torch.float32).t() * sc                            # [c(in), o]
+        m2 = keep_masks(layer, "fc2").to(torch.float32).t() * sc                            # [i(in), o]
+        return ({"qkv": lambda t: t * mq, "proj": lambda t: t * mp}, {"fc1": lambda t: t * m1, "fc2": lambda t: t * m2})
     r = (lambda t: t.to(torch.bfloat16).to(t.dtype)) if bf16_sim else (lambda t: t)
     B = images.shape[0]
     dim = w["cls_token"].shape[-1]
@@ -379,9 +395,10 @@ def vit_cara_forward(images, w: Dict[str, torch.Tensor], cp: Dict[str, torch.Ten
         if factored:
             y = _attn_factored(xn, w, p, fac[l], num_heads, scale, r)
         else:
+            dp_attn, dp_mlp = masked(l) if keep_masks is not None else (dpf, dpf)
             y = attn_as_written(xn, cp, w[p + "attn.qkv.weight"], w[p + "attn.qkv.bias"],
                                 w[p + "attn.proj.weight"], w[p + "attn.proj.bias"],
-                                attn_idx=a_aidx, idx=a_idx, s=s, num_heads=num_heads, scale=scale, dp=dpf)
+                                attn_idx=a_aidx, idx=a_idx, s=s, num_heads=num_heads, scale=scale, dp=dp_attn)
         if train:
             y = drop_path(y, train["dpr"][l], True)
         if drop_path_keep is not None:
@@ -392,7 +409,7 @@ def vit_cara_forward(images, w: Dict[str, torch.Tensor], cp: Dict[str, torch.Ten
             y = _mlp_factored(xn, w, p, fac[l], r)
         else:
             y = mlp_as_written(xn, cp, w[p + "mlp.fc1.weight"], w[p + "mlp.fc1.bias"],
-                               w[p + "mlp.fc2.weight"], w[p + "mlp.fc2.bias"], idx=m_idx, s=s, dp=dpf)
+                               w[p + "mlp.fc2.weight"], w[p + "mlp.fc2.bias"], idx=m_idx, s=s, dp=dp_mlp)
         if train:
             y = drop_path(y, train["dpr"][l], True)
         if drop_path_keep is not None:
@@ -518,14 +535,16 @@ def synthetic_batch(batch=64, img=224, num_classes=100, seed_x=0, seed_y=1):
     return x, y
 
 
-def train_step_as_written(images, labels, w, cp, head, *, s, depth=12, num_heads=12):
+def train_step_as_written(images, labels, w, cp, head, *, s, depth=12, num_heads=12, keep_masks=None, keep_p=0.1,
+                          drop_path_keep=None):
     """One fwd+bwd of the reference's as-written algorithm (dense dW + second GEMM, fp32,
     autograd producing dense ddW) -- the ``cpu_baseline`` workload.  Returns (loss, grads)."""
     cpv = {k: v.clone().requires_grad_(True) for k, v in cp.items()}
     hv = {k: v.clone().requires_grad_(True) for k, v in head.items()}
     ww = dict(w)
     ww["head.weight"], ww["head.bias"] = hv["weight"], hv["bias"]
-    logits = vit_cara_forward(images, ww, cpv, s=s, depth=depth, num_heads=num_heads)
+    logits = vit_cara_forward(images, ww, cpv, s=s, depth=depth, num_heads=num_heads, keep_masks=keep_masks, keep_p=keep_p,
+                              drop_path_keep=drop_path_keep)
     loss = F.cross_entropy(logits, labels)
     loss.backward()
     grads = {k: v.grad for k, v in cpv.items()}

@@ -53,19 +53,23 @@ def test_dropout_grad_contract_and_colsum(out, inn, Rp, p):
     U, Vs = _rnd(inn, Rp, seed=2, scale=0.2), _rnd(out, Rp, seed=3, scale=0.05)
     dU = torch.full((inn, Rp), float("nan"), device=DEV)
     dVs = torch.full((out, Rp), float("nan"), device=DEV)
-    L.check(lib.cara_dropout_grad_contract(L.ptr(dW), L.ptr(U), L.ptr(Vs), Rp, out, inn, C.c_float(p), 11, 5, L.ptr(dU), L.ptr(dVs),
-                                           L.stream()), "contract")
+    # the dense gradient arrives as split-K slabs that the kernels sum: hand it over in three pieces
+    slabs = torch.stack([0.5 * dW, 0.25 * dW, 0.25 * dW]).contiguous()
+    scratch = torch.empty(lib.cara_dropout_grad_scratch_bytes(inn, Rp), dtype=torch.uint8, device=DEV)
+    L.check(lib.cara_dropout_grad_contract(L.ptr(slabs), 3, C.c_size_t(out * inn), L.ptr(U), L.ptr(Vs), Rp, out, inn, C.c_float(p), 11, 5,
+                                           L.ptr(dU), L.ptr(dVs), L.ptr(scratch), L.stream()), "contract")
     keep = torch.from_numpy(keep_mask(out, inn, p, seed=11, linear_id=5)).to(DEV)
     g = dW.double() * keep.double() / (1.0 - p)
     for got, ref, what in ((dVs, g @ U.double(), "dVs"), (dU, g.t() @ Vs.double(), "dU")):
         err = (got.double() - ref).abs()
         assert (err <= 1e-4 * ref.abs() + 1e-3).all(), (what, float(err.max()))
     dU2, dVs2 = torch.empty_like(dU), torch.empty_like(dVs)
-    L.check(lib.cara_dropout_grad_contract(L.ptr(dW), L.ptr(U), L.ptr(Vs), Rp, out, inn, C.c_float(p), 11, 5, L.ptr(dU2), L.ptr(dVs2),
-                                           L.stream()), "contract")
+    L.check(lib.cara_dropout_grad_contract(L.ptr(slabs), 3, C.c_size_t(out * inn), L.ptr(U), L.ptr(Vs), Rp, out, inn, C.c_float(p), 11, 5,
+                                           L.ptr(dU2), L.ptr(dVs2), L.ptr(scratch), L.stream()), "contract")
     assert torch.equal(dU, dU2) and torch.equal(dVs, dVs2)          # fixed summation order
-    M = 333
-    X = _rnd(M, out + 8, seed=4)
-    cs = torch.empty(out, device=DEV)
-    L.check(lib.cara_colsum_bf16(L.ptr(X), out + 8, M, out, L.ptr(cs), L.stream()), "colsum")
-    assert torch.allclose(cs.double(), X[:, :out].double().sum(0), rtol=1e-5, atol=1e-3)
+    for M in (333, 5000, 100):
+        X = _rnd(M, out + 8, seed=4)
+        cs = torch.empty(out, device=DEV)
+        csc = torch.empty(lib.cara_colsum_scratch_bytes(out), dtype=torch.uint8, device=DEV)
+        L.check(lib.cara_colsum_bf16(L.ptr(X), out + 8, M, out, L.ptr(cs), L.ptr(csc), L.stream()), "colsum")
+        assert torch.allclose(cs.double(), X[:, :out].double().sum(0), rtol=1e-5, atol=2e-3)

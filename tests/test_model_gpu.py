@@ -86,6 +86,61 @@ def test_depth2_against_reference_vectors():
     print(f"depth2 CP-gradient worst rel-L2 vs reference: {worst:.2e}")
 
 
+def test_exact_weight_dropout_mode_against_oracle():
+    """engine.weight_dropout = "exact": the reference's TRAIN-mode arithmetic (Dropout(0.1) on every materialised
+    dW, cara.py:35,57,81,92) with the masks rebuilt on the CPU from the same counter hash and fed to the oracle's
+    as-written algorithm: logits, loss and all 12 CP gradients.  depth 3, batch 4 (788 rows: the zero-padded K of
+    the dense dW GEMM), s = 1 so that the dropped elements matter; DropPath off to isolate the weight dropout."""
+    from oracle import cara_oracle as O
+    from cara_amd.dropout import keep_mask
+    torch.manual_seed(0)
+    depth, R, s_, p, seed = 3, 16, 1.0, 0.1, 4242
+    w = O.synthetic_backbone(depth=depth)
+    cp = O.synthetic_cp(rank=R)
+    x, y = O.synthetic_batch(batch=4)
+    m = build(w, cp, R, s_, depth, 224, drop_path_rate=0.0).train()
+    eng = m._cara_engine
+    eng.weight_dropout, eng.weight_dropout_p, eng.weight_dropout_seed = "exact", p, seed
+    logits = m(x.to(DEV))
+    loss = torch.nn.functional.cross_entropy(logits, y.to(DEV))
+    loss.backward()
+    dims = {"qkv": (2304, 768, 0), "proj": (768, 768, 1), "fc1": (3072, 768, 2), "fc2": (768, 3072, 3)}
+
+    def masks(layer, name):
+        o, i, slot = dims[name]
+        return torch.from_numpy(keep_mask(o, i, p, seed, 4 * layer + slot))
+
+    cps = dict(cp)
+    cps["CP_A1"], cps["CP_P1"] = cp["CP_A1"][:3 * depth], cp["CP_P1"][:9 * depth]
+    head = {"weight": w["head.weight"], "bias": w["head.bias"]}
+    rloss, rlogits, gref = O.train_step_as_written(x, y, w, cps, head, s=s_, depth=depth, keep_masks=masks, keep_p=p)
+    r = rel(logits, rlogits)
+    # what the masks are worth: the same forward with no dropout, and with another seed
+    with torch.no_grad():
+        nodrop = O.vit_cara_forward(x, w, cps, s=s_, depth=depth)
+    eng.weight_dropout_seed = seed + 1
+    with torch.no_grad():
+        other = m(x.to(DEV))
+    print(f"exact weight dropout: logits rel-L2 vs oracle with the same masks {r:.2e}; masks move the logits by "
+          f"{rel(rlogits, nodrop):.2e}; another seed by {rel(other, rlogits):.2e}; loss {loss.item():.4f} vs {rloss.item():.4f}")
+    assert r < 1.5e-2 and rel(rlogits, nodrop) > 5 * r and rel(other, rlogits) > 5 * r
+    assert abs(loss.item() - rloss.item()) < 2e-2 * max(1.0, abs(rloss.item()))
+    worst = 0.0
+    for n in O.CP_NAMES:
+        rr = rel(getattr(m, n).grad, gref[n])
+        worst = max(worst, rr)
+        assert rr < 4e-2, (n, rr)
+    print(f"exact weight dropout: worst CP-gradient rel-L2 vs fp32 autograd with the same masks {worst:.2e}")
+    # eval is the factored path whatever the mode: bitwise the same logits as an engine with weight_dropout off
+    m.eval()
+    with torch.no_grad():
+        ev = m(x.to(DEV))
+    eng.weight_dropout = "off"
+    with torch.no_grad():
+        ev_off = m(x.to(DEV))
+    assert torch.equal(ev, ev_off)
+
+
 def test_whole_model_with_persistent_gemm(monkeypatch):
     """The opt-in 256x256 persistent GEMM (CARA_GEMM_SK=1) inside the real forward/backward: batch 8 x 197
     rows >= 1024, so qkv/proj/fc1/fc2 and their dX products all take it.  Same model, same input, both GEMM
