@@ -35,7 +35,8 @@ class GemmArgs(C.Structure):
                 ("C", C.c_void_p), ("ldc", C.c_int), ("C2", C.c_void_p), ("aux", C.c_void_p),
                 ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int),
                 ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
-                ("batch", C.c_int), ("strideA", C.c_longlong), ("strideB", C.c_longlong), ("strideC", C.c_longlong)]
+                ("batch", C.c_int), ("strideA", C.c_longlong), ("strideB", C.c_longlong), ("strideC", C.c_longlong),
+                ("Ut", C.c_void_p), ("T_out", C.c_void_p), ("Tt_out", C.c_void_p), ("ldt", C.c_int)]
 
 
 class Geom(C.Structure):
@@ -131,8 +132,12 @@ def stream() -> C.c_void_p:
 # ---- thin per-op wrappers (used by tests and by the module-level drop-in) ---------------------
 
 def gemm(A, B, out, *, epi, bias=None, A2=None, B2=None, C2=None, aux=None, rowscale=None,
-         rows_per_sample=0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, scratch=None):
+         rows_per_sample=0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, scratch=None, Ut=None, T_out=None,
+         Tt_out=None):
     a = GemmArgs()
+    if Ut is not None:   # adapter fully inside the GEMM: T = A Ut^T computed per tile (B2 = Vs must be given, A2 not)
+        a.Ut, a.T_out, a.Tt_out = ptr(Ut), ptr(T_out), ptr(Tt_out)
+        a.ldt = Tt_out.shape[1] if Tt_out is not None else 0
     if scratch is not None:   # zero-initialised uint8 tensor of gemm_scratch_bytes(): enables the stream-K kernel
         a.scratch, a.scratch_bytes = ptr(scratch), scratch.numel() * scratch.element_size()
     a.M = M if M is not None else A.shape[0]
@@ -141,7 +146,7 @@ def gemm(A, B, out, *, epi, bias=None, A2=None, B2=None, C2=None, aux=None, rows
     a.A, a.lda = ptr(A), lda or A.shape[1]
     a.B, a.ldb = ptr(B), ldb or B.shape[1]
     a.A2, a.B2 = ptr(A2), ptr(B2)
-    a.Rp = A2.shape[1] if A2 is not None else 0
+    a.Rp = A2.shape[1] if A2 is not None else (B2.shape[1] if B2 is not None else 0)
     a.bias, a.epi = ptr(bias), epi
     a.C, a.ldc = ptr(out), ldc or out.shape[-1]
     a.C2, a.aux, a.rowscale = ptr(C2), ptr(aux), ptr(rowscale)

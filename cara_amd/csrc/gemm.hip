@@ -282,6 +282,151 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? 4
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same 128x128x32 kernel with the WHOLE adapter inside (cara_gemm_args::Ut): besides its 128 x 128 outputs
+// every workgroup accumulates T[128 rows, 32] = A_rows . Ut^T on the operand tiles it streams anyway (a 2-KiB
+// slab of Ut per K step: +12 % staged bytes, +25 % MFMAs in a loop that waits on staging), rounds T to bf16 into
+// the LDS image the K-extension step reads, and the tiles of column 0 write T / Tt out for the backward.  The
+// separate cara_skinny_xu pass (a full re-read of A, a launch, a dependency) is gone.
+// ---------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
+  constexpr int TBM = 128;
+  constexpr int A_BYTES = TBM * BK32 * 2, U_BYTES = 32 * BK32 * 2;
+  constexpr int SLOT = A_BYTES + B32_BYTES + U_BYTES;   // 18 KiB; two slots = 36 KiB, still 4 workgroups per CU
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  int tm, tn;
+  if (gm <= 1) {
+    tm = tile / tiles_n;
+    tn = tile - tm * tiles_n;
+  } else {
+    const int tiles_m = nwg / tiles_n;
+    const int per_group = gm * tiles_n;
+    const int gid = tile / per_group, rem = tile - gid * per_group;
+    const int first = gid * gm;
+    const int gsz = (tiles_m - first) < gm ? (tiles_m - first) : gm;
+    tn = rem / gsz;
+    tm = first + (rem - tn * gsz);
+  }
+  const int m0 = tm * TBM, n0 = tn * BN;
+  const bf16* __restrict__ A = static_cast<const bf16*>(p.A);
+  const bf16* __restrict__ B = static_cast<const bf16*>(p.B);
+  const bf16* __restrict__ Ut = static_cast<const bf16*>(p.Ut);
+  f32x4 acc[4][4], accg[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    accg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // the 32 x 32 slab of Ut of one K step = two 1-KiB pieces (16 rows x 64 B), issued by waves 0 and 1
+  auto stage_u = [&](int k0, char* dst) {
+    if (wave < 2) {
+      const int r = wave * 16 + (lane >> 2);
+      const int cg = (lane & 3) ^ (((r >> 3) & 1) * 3);
+      glds16(Ut + (size_t)r * p.K + k0 + cg * 8, dst + wave * 1024);
+    }
+  };
+  const int nk = p.K / BK32;
+  stage_tile32<TBM, 4>(A, p.lda, m0, p.M - 1, 0, smem, wave, lane);
+  stage_tile32<BN, 4>(B, p.ldb, n0, p.N - 1, 0, smem + A_BYTES, wave, lane);
+  stage_u(0, smem + A_BYTES + B32_BYTES);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    char* sA = smem + cur * SLOT;
+    if (kt + 1 < nk) {
+      char* nA = smem + (cur ^ 1) * SLOT;
+      stage_tile32<TBM, 4>(A, p.lda, m0, p.M - 1, (kt + 1) * BK32, nA, wave, lane);
+      stage_tile32<BN, 4>(B, p.ldb, n0, p.N - 1, (kt + 1) * BK32, nA + A_BYTES, wave, lane);
+      stage_u((kt + 1) * BK32, nA + A_BYTES + B32_BYTES);
+    }
+    const char* sB = sA + A_BYTES;
+    const char* sU = sB + B32_BYTES;
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sA + swz32(wr * 64 + i * 16 + fr, fq));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sB + swz32(wc * 64 + j * 16 + fr, fq));
+    const bf16x8 bu = *reinterpret_cast<const bf16x8*>(sU + swz32(wc * 16 + fr, fq));   // this wave's 16 columns of T
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      accg[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bu, accg[i], 0, 0, 0);
+    }
+    cur ^= 1;
+  }
+  // T tile (rows wr*64 .., columns wc*16 ..) -> bf16 -> the A image of the extension step; column-0 tiles also
+  // write it (and its transpose) to global for the backward's transposed skinny products
+  __syncthreads();
+  {
+    bf16* T = static_cast<bf16*>(p.T_out);
+    bf16* Tt = static_cast<bf16*>(p.Tt_out);
+    const int col = wc * 16 + fr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row0 = wr * 64 + i * 16 + fq * 4;
+      bf16x4 tv = {(bf16)accg[i][0], (bf16)accg[i][1], (bf16)accg[i][2], (bf16)accg[i][3]};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *reinterpret_cast<bf16*>(smem + swz32(row0 + r, col >> 3) + (col & 7) * 2) = tv[r];
+      if (tn == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (m0 + row0 + r < p.M) T[(size_t)(m0 + row0 + r) * 32 + col] = tv[r];
+        if (Tt) {
+          if (m0 + row0 + 4 <= p.M) {
+            *reinterpret_cast<bf16x4*>(Tt + (size_t)col * p.ldt + m0 + row0) = tv;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (m0 + row0 + r < p.M) Tt[(size_t)col * p.ldt + m0 + row0 + r] = tv[r];
+          }
+        }
+      }
+    }
+  }
+  stage_ext32<BN, 4>(static_cast<const bf16*>(p.B2), 32, n0, p.N - 1, 0, smem + A_BYTES, tid);
+  __syncthreads();
+  mma_tile32<4>(smem, smem + A_BYTES, acc, wr, wc, lane);
+  // epilogue: two 32-row halves through a wave-private [32][64] fp32 image
+  constexpr int HALF = 32;
+  __syncthreads();
+  float* stg = reinterpret_cast<float*>(smem) + wave * (HALF * 64);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[half * 2 + i][j][r];
+    epilogue_rows<EPI, HALF>(p, stg, m0 + wr * 64 + half * HALF, n0 + wc * 64, lane);
+  }
+}
+
+static int group_m(int tiles_n);
+
+template <int EPI>
+int launch32ft(const cara_gemm_args* a, hipStream_t st) {
+  const int tiles_n = (a->N + BN - 1) / BN;
+  const int gm = group_m(tiles_n);
+  const int nwg = ((a->M + 127) / 128) * tiles_n;
+  // consumers read Tt in whole 32-row steps: keep columns [M, roundup32(M)) zero, as cara_skinny_xu does
+  const int m32 = (a->M + 31) / 32 * 32;
+  if (a->Tt_out && m32 > a->M && m32 <= a->ldt &&
+      hipMemset2DAsync(static_cast<bf16*>(a->Tt_out) + a->M, (size_t)a->ldt * 2, 0, (size_t)(m32 - a->M) * 2, 32, st) != hipSuccess)
+    return CARA_E_LAUNCH;
+  hipLaunchKernelGGL((gemm32ft_kernel<EPI>), dim3(nwg), dim3(256), 2 * (128 * BK32 * 2 + B32_BYTES + 32 * BK32 * 2), st, *a, tiles_n, nwg, gm);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
 // CARA_GEMM_BM=64 selects the 64-row tile (A/B only).  Measured same-box in the real step: 64-row
 // tiles everywhere 14.07 ms, 64 rows only for the N <= 768 products 13.3 ms, 128 rows 12.2 ms -- the
 // better balance over 256 CUs does not pay for the lower FLOP per staged byte, so 128 is the default.
@@ -389,11 +534,23 @@ extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % BK) != 0) return CARA_E_ARG;
   if (a->lda < a->K || a->ldb < a->K || (a->lda & 7) || (a->ldb & 7) || a->ldc < a->N) return CARA_E_ARG;
   if (!(a->Rp == 0 || a->Rp == 32 || a->Rp == 64)) return CARA_E_ARG;
-  if (a->Rp && (!a->A2 || !a->B2)) return CARA_E_ARG;
+  if (a->Rp && ((!a->A2 && !a->Ut) || !a->B2)) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a->epi == CARA_EPI_GELU && !a->C2) return CARA_E_ARG;
   if (a->epi == CARA_EPI_RESID && (!a->aux || (a->rowscale && a->rows_per_sample <= 0))) return CARA_E_ARG;
   if (a->epi == CARA_EPI_DGELU && !a->aux) return CARA_E_ARG;
+  if (a->Ut) {   // whole adapter inside the GEMM: default kernel family, Rp = 32, T produced here
+    if (a->A2 || !a->B2 || a->Rp != 32 || !a->T_out || a->batch > 1 || (a->K % BK32) || (a->Tt_out && (a->ldt < a->M || (a->ldt & 7))))
+      return CARA_E_ARG;
+    switch (a->epi) {
+      case CARA_EPI_BF16: return launch32ft<CARA_EPI_BF16>(a, st);
+      case CARA_EPI_F32: return launch32ft<CARA_EPI_F32>(a, st);
+      case CARA_EPI_GELU: return launch32ft<CARA_EPI_GELU>(a, st);
+      case CARA_EPI_RESID: return launch32ft<CARA_EPI_RESID>(a, st);
+      case CARA_EPI_DGELU: return launch32ft<CARA_EPI_DGELU>(a, st);
+      default: return CARA_E_ARG;
+    }
+  }
   if (a->batch > 1) {   // batched products: the default kernel family only, plain epilogues
     if (a->A2 || a->aux || a->C2 || !(a->epi == CARA_EPI_F32 || a->epi == CARA_EPI_BF16) || a->batch > 65535) return CARA_E_ARG;
     return a->epi == CARA_EPI_F32 ? launch32<CARA_EPI_F32>(a, st) : launch32<CARA_EPI_BF16>(a, st);

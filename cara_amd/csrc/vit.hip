@@ -182,6 +182,21 @@ bool fuse_xu(const cara_geom* g) {
   return v != 0 && g->Rp == 32 && (g->dim == 768 || g->dim == 1024 || g->dim == 256);   // what cara_layernorm_*_xu take
 }
 
+// CARA_FUSE_GEMM_T=0 keeps T = X U (forward proj / fc2) and G' = dY Vs (backward qkv / fc1) as separate
+// cara_skinny_xu passes instead of computing them inside the GEMM that consumes them (cara_gemm_args::Ut).
+// Only with the default GEMM family (no CARA_GEMM_TILE / CARA_GEMM_SK / CARA_GEMM_BM / CARA_GEMM_BK override).
+// Bit 0: forward (default on), bit 1: backward (default off -- measured: the transposed skinny products then fork
+// after the dX GEMM instead of running under it, and the step gets 0.35 ms longer).
+bool fuse_gemm_t(int Mr, int Rp, bool backward) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CARA_FUSE_GEMM_T");
+    v = e ? atoi(e) : 1;
+    if (getenv("CARA_GEMM_TILE") || getenv("CARA_GEMM_SK") || getenv("CARA_GEMM_BM") || getenv("CARA_GEMM_BK")) v = 0;
+  }
+  return (v & (backward ? 2 : 1)) != 0 && Rp == 32 && Mr >= 1024;
+}
+
 // stream-K scratch of the workspace in use (set on entry of cara_vit_forward / _backward: one
 // workspace per stream, as for the side stream above)
 char* g_sk_scratch = nullptr;
@@ -197,8 +212,10 @@ int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char*
             bool have_T = false) {
   bf16* T = reinterpret_cast<bf16*>(ws + lw.T[L.slot]);
   bf16* Tt = reinterpret_cast<bf16*>(ws + lw.Tt[L.slot]);
-  if (!have_T) TRY(cara_skinny_xu(X, ldx, L.Ut, T, Tt, ldt, Mr, L.in, Rp, st));
-  a.A = X; a.lda = ldx; a.B = L.W; a.ldb = L.in; a.A2 = T; a.B2 = L.Vs; a.Rp = Rp;
+  const bool inside = !have_T && fuse_gemm_t(Mr, Rp, false);   // T computed by the GEMM itself
+  if (!have_T && !inside) TRY(cara_skinny_xu(X, ldx, L.Ut, T, Tt, ldt, Mr, L.in, Rp, st));
+  a.A = X; a.lda = ldx; a.B = L.W; a.ldb = L.in; a.A2 = inside ? nullptr : T; a.B2 = L.Vs; a.Rp = Rp;
+  if (inside) { a.Ut = L.Ut; a.T_out = T; a.Tt_out = Tt; a.ldt = ldt; }
   a.M = Mr; a.N = L.out; a.K = L.in; a.bias = L.bias;
   if (a.ldc == 0) a.ldc = L.out;
   with_scratch(a);
@@ -213,7 +230,17 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
   bf16* G = reinterpret_cast<bf16*>(ws + W.G[L.slot]);
   bf16* Gt = reinterpret_cast<bf16*>(ws + W.Gt[L.slot]);
   // (have_G: the LayerNorm backward that produced dY already left G' and its transpose, cara_layernorm_bwd_xu)
-  if (!have_G) TRY(cara_skinny_xu(dY, lddy, L.Vst, G, Gt, ldt, Mr, L.out, Rp, st));
+  // inside: the dX GEMM computes G' = dY Vs itself (cara_gemm_args::Ut) and leaves G / Gt for the transposed
+  // skinny products, which therefore fork AFTER it (they still overlap whatever the main stream runs next)
+  const bool inside = !have_G && want_dx && fuse_gemm_t(Mr, Rp, true);
+  if (!have_G && !inside) TRY(cara_skinny_xu(dY, lddy, L.Vst, G, Gt, ldt, Mr, L.out, Rp, st));
+  if (inside) {
+    a.A = dY; a.lda = lddy; a.B = L.Wt; a.ldb = L.out; a.A2 = nullptr; a.B2 = L.U; a.Rp = Rp;
+    a.Ut = L.Vst; a.T_out = G; a.Tt_out = Gt; a.ldt = ldt;
+    a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
+    if (a.ldc == 0) a.ldc = L.in;
+    TRY(cara_gemm_bf16(&a, st));
+  }
   void* ts_stream = st;
   if (side_ready()) {   // fork: the side stream may start once G' exists
     if (hipEventRecord(g_side.fork[L.slot], static_cast<hipStream_t>(st)) != hipSuccess) return CARA_E_LAUNCH;
@@ -225,7 +252,7 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
                             dY, lddy, ws + lw.Tt[L.slot], ws + W.slabV[L.slot] + (size_t)layer * W.strideV[L.slot], L.out,
                             want_dc ? 1 : 0, ldt, Mr, Rp, ts_stream));
   if (side_ready() && hipEventRecord(g_side.join[L.slot], g_side.s) != hipSuccess) return CARA_E_LAUNCH;
-  if (want_dx) {
+  if (want_dx && !inside) {
     a.A = dY; a.lda = lddy; a.B = L.Wt; a.ldb = L.out; a.A2 = G; a.B2 = L.U; a.Rp = Rp;
     a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
     if (a.ldc == 0) a.ldc = L.in;

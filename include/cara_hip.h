@@ -60,6 +60,14 @@ typedef struct {
                                 /* (partial tiles + flags live there); NULL = one tile per workgroup.     */
   int batch;                    /* > 1: `batch` independent products in ONE launch; product z uses A, B,  */
   long long strideA, strideB, strideC;   /* C advanced by z * stride (elements); no A2/B2/aux/C2 then     */
+  /* Whole adapter inside the GEMM (Rp == 32, B2 set, A2 NULL): every tile also accumulates its rows of       */
+  /* T = A Ut^T (Ut bf16 [32, K], rows >= rank zero: the operand cara_skinny_xu takes), rounds it to bf16 and  */
+  /* uses it as the K-extension operand -- the separate skinny pass over A disappears.  The tiles of column   */
+  /* 0 also write T [M,32] and, if non-NULL, Tt [32,ldt] (for cara_tskinny_*).  Default kernel family only.   */
+  const void* Ut;
+  void* T_out;
+  void* Tt_out;
+  int ldt;
 } cara_gemm_args;
 int cara_gemm_bf16(const cara_gemm_args* a, void* stream);
 size_t cara_gemm_scratch_bytes(void);

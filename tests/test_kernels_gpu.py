@@ -96,6 +96,39 @@ def test_gemm_epilogues():
     close(dg, (A.double() @ B.double().t()) * ud.grad, 2 ** -8, 2e-3, "epi dgelu")
 
 
+@pytest.mark.parametrize("M,N,K,rank", [(12608, 768, 3072, 16), (12608, 768, 768, 8), (1500, 3072, 768, 32), (333, 300, 128, 16)])
+def test_gemm_with_adapter_inside(M, N, K, rank):
+    """cara_gemm_args.Ut: T = A Ut^T computed per tile inside the GEMM and used as the K-extension operand; must
+    agree with cara_skinny_xu + the ordinary K-extension, and leave T / Tt behind for the backward."""
+    Rp = 32
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    Ut = rnd(Rp, K, seed=3, scale=0.1)
+    Ut[rank:] = 0
+    Vs = rnd(N, Rp, seed=4, scale=0.3)
+    bias = rnd(N, seed=5, dtype=torch.float32)
+    ldt = (M + 31) // 32 * 32
+    T = torch.full((M, Rp), float("nan"), dtype=torch.bfloat16, device=DEV)
+    Tt = torch.full((Rp, ldt), float("nan"), dtype=torch.bfloat16, device=DEV)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    L().gemm(A, B, out, epi=L().EPI_F32, bias=bias, B2=Vs, Ut=Ut, T_out=T, Tt_out=Tt)
+    Tref = A.double() @ Ut.double().t()
+    close(T, Tref, 2 ** -8, 1e-3 * math.sqrt(K / 64), "T inside the GEMM")
+    assert torch.equal(Tt[:, :M], T.t()) and torch.count_nonzero(Tt[:, M:]) == 0 and torch.count_nonzero(T[:, rank:]) == 0
+    ref = A.double() @ B.double().t() + bias.double() + T.double() @ Vs.double().t()      # with the bf16 T it produced
+    close(out, ref, 1e-4, 1e-3 * math.sqrt(K / 64) + 2e-3, "gemm with the adapter inside")
+    T2 = torch.empty_like(T)
+    L().skinny_xu(A, Ut, T2)
+    out2 = torch.empty_like(out)
+    L().gemm(A, B, out2, epi=L().EPI_F32, bias=bias, A2=T2, B2=Vs)
+    # (the two T differ by one bf16 ulp where an fp32 sum sits on a rounding boundary: ~0.06 on values of ~10, times Vs)
+    close(out, out2.double(), 1e-3, 0.2, "vs skinny + K-extension")
+    # GELU epilogue through the same kernel
+    h, u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L().gemm(A, B, h, epi=L().EPI_GELU, bias=bias, B2=Vs, C2=u, Ut=Ut, T_out=T, Tt_out=Tt)
+    close(u, ref, 2 ** -8, 2e-3 * math.sqrt(K / 64) + 2e-3, "adapter inside, gelu u")
+    close(h, torch.nn.functional.gelu(ref), 2 ** -8, 2e-3 * math.sqrt(K / 64) + 2e-3, "adapter inside, gelu h")
+
+
 # ---- LDS-ring kernels (CARA_GEMM_TILE = 256: 256x256, one workgroup per CU; 1282: 128x256, two per CU) --------
 @pytest.mark.parametrize("tile", ["256", "1282", "bm256"])
 @pytest.mark.parametrize("M,N,K,Rp", [(12608, 768, 768, 32), (1500, 3072, 768, 64), (333, 300, 128, 32), (777, 640, 64, 0),
