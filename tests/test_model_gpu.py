@@ -158,9 +158,10 @@ def test_whole_model_with_persistent_gemm(monkeypatch):
         before = L.gemm_persistent_launches()
         logits = m(x.to(DEV))
         torch.nn.functional.cross_entropy(logits, y.to(DEV)).backward()
-        # patch embedding + 12 x (4 forward + 4 dX) products, minus the cls-row-only ones of the last block
-        # (proj, fc1, fc2 forward; fc2, fc1, proj dX run on 8 rows) and the first block's unused qkv dX... >= 80
-        assert (L.gemm_persistent_launches() - before >= 80) == (mode == "1")
+        # patch embedding + 12 x (2 forward + 4 dX) products -- forward proj / fc2 carry the adapter inside the
+        # GEMM (cara_gemm_args.Ut), which is its own kernel -- minus the cls-row-only ones of the last block and
+        # the first block's unused qkv dX: 68
+        assert (L.gemm_persistent_launches() - before >= 60) == (mode == "1")
         out[mode] = (logits.detach().float().cpu(), {n: getattr(m, n).grad.float().cpu() for n in O.CP_NAMES})
     r = rel(out["1"][0], out["0"][0])
     worst = max(rel(out["1"][1][n], out["0"][1][n]) for n in O.CP_NAMES)
