@@ -529,6 +529,97 @@ static bool use_bk32() {
   return v != 64;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Few-row products (the last block's cls-row-only proj / fc1 / fc2 and their dX: M = batch rows): one 128-row tile
+// per 128 columns is 6-24 workgroups each walking all of K (24-96 K steps back to back: 20-70 us of latency).
+// With caller scratch the K loop is cut into slabs that run as ONE batched launch of the default kernel (fp32
+// partial products into scratch), and a small finishing kernel adds the slabs in fixed order, the rank-R term
+// T Vs^T, the bias, and applies the epilogue.
+// ---------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void small_m_finish_kernel(const cara_gemm_args p, const float* __restrict__ slabs, const int nslab) {
+  const int n4 = (p.N + 3) / 4;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.M * n4) return;
+  const int m = idx / n4, n = (idx - m * n4) * 4;
+  const size_t slab_stride = (size_t)p.M * p.N;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool full = n + 4 <= p.N && (p.N & 3) == 0;
+  for (int s = 0; s < nslab; ++s) {
+    const float* src = slabs + s * slab_stride + (size_t)m * p.N + n;
+    if (full) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += t[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (n + k < p.N) v[k] += src[k];
+    }
+  }
+  if (p.Rp > 0) {   // the adapter term, straight from T [M,Rp] and Vs [N,Rp]
+    const bf16* t = static_cast<const bf16*>(p.A2) + (size_t)m * p.Rp;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (n + k >= p.N) continue;
+      const bf16* vs = static_cast<const bf16*>(p.B2) + (size_t)(n + k) * p.Rp;
+      float d = 0.f;
+      for (int r = 0; r < p.Rp; r += 8) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(t + r), b = *reinterpret_cast<const bf16x8*>(vs + r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d += (float)a[j] * (float)b[j];
+      }
+      v[k] += d;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] += (p.bias && n + k < p.N) ? p.bias[n + k] : 0.f;
+  const size_t o = (size_t)m * p.ldc + n;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (n + k >= p.N) continue;
+    if constexpr (EPI == CARA_EPI_F32) {
+      static_cast<float*>(p.C)[o + k] = v[k];
+    } else if constexpr (EPI == CARA_EPI_RESID) {
+      const float rs = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.f;
+      static_cast<float*>(p.C)[o + k] = static_cast<const float*>(p.aux)[o + k] + rs * v[k];
+    } else if constexpr (EPI == CARA_EPI_BF16) {
+      static_cast<bf16*>(p.C)[o + k] = (bf16)v[k];
+    } else if constexpr (EPI == CARA_EPI_GELU) {
+      static_cast<bf16*>(p.C2)[o + k] = (bf16)v[k];
+      static_cast<bf16*>(p.C)[o + k] = (bf16)gelu_erf(v[k]);
+    } else {
+      static_cast<bf16*>(p.C)[o + k] = (bf16)(v[k] * gelu_erf_grad((float)static_cast<const bf16*>(p.aux)[o + k]));
+    }
+  }
+}
+
+// K slabs of at least 128 columns, at most 16 of them; 0 = not worth it
+static int small_m_slabs(const cara_gemm_args* a) {
+  const char* e = getenv("CARA_GEMM_SMALL_M");   // 0 disables (A/B)
+  if (e && atoi(e) == 0) return 0;
+  if (a->M > 128 || a->K < 512 || !a->scratch || a->Ut || a->batch > 1) return 0;
+  int s = a->K / 128;
+  if (s > 16) s = 16;
+  while (s > 1 && (a->K % (s * 64)) != 0) --s;   // equal slabs, each a multiple of 64 columns
+  if (s < 2 || (size_t)s * a->M * a->N * sizeof(float) > a->scratch_bytes) return 0;
+  return s;
+}
+
+template <int EPI>
+static int launch_small_m(const cara_gemm_args* a, int nslab, hipStream_t st) {
+  cara_gemm_args d = {};
+  d.A = a->A; d.lda = a->lda; d.B = a->B; d.ldb = a->ldb; d.M = a->M; d.N = a->N; d.K = a->K / nslab;
+  d.epi = CARA_EPI_F32; d.C = a->scratch; d.ldc = a->N;
+  d.batch = nslab; d.strideA = d.K; d.strideB = d.K; d.strideC = (long long)a->M * a->N;
+  const int rc = launch32<CARA_EPI_F32>(&d, st);
+  if (rc != CARA_OK) return rc;
+  const int n4 = (a->N + 3) / 4;
+  hipLaunchKernelGGL((small_m_finish_kernel<EPI>), dim3((a->M * n4 + 255) / 256), dim3(256), 0, st, *a, static_cast<const float*>(a->scratch), nslab);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
 extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->B || !a->C) return CARA_E_ARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % BK) != 0) return CARA_E_ARG;
@@ -554,6 +645,16 @@ extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
   if (a->batch > 1) {   // batched products: the default kernel family only, plain epilogues
     if (a->A2 || a->aux || a->C2 || !(a->epi == CARA_EPI_F32 || a->epi == CARA_EPI_BF16) || a->batch > 65535) return CARA_E_ARG;
     return a->epi == CARA_EPI_F32 ? launch32<CARA_EPI_F32>(a, st) : launch32<CARA_EPI_BF16>(a, st);
+  }
+  if (const int nslab = small_m_slabs(a)) {
+    switch (a->epi) {
+      case CARA_EPI_BF16: return launch_small_m<CARA_EPI_BF16>(a, nslab, st);
+      case CARA_EPI_F32: return launch_small_m<CARA_EPI_F32>(a, nslab, st);
+      case CARA_EPI_GELU: return launch_small_m<CARA_EPI_GELU>(a, nslab, st);
+      case CARA_EPI_RESID: return launch_small_m<CARA_EPI_RESID>(a, nslab, st);
+      case CARA_EPI_DGELU: return launch_small_m<CARA_EPI_DGELU>(a, nslab, st);
+      default: return CARA_E_ARG;
+    }
   }
   const int tile = tile_choice(a);
   if (tile == 256) return cara_gemm256_dispatch(a, st);

@@ -129,6 +129,46 @@ def test_gemm_with_adapter_inside(M, N, K, rank):
     close(h, torch.nn.functional.gelu(ref), 2 ** -8, 2e-3 * math.sqrt(K / 64) + 2e-3, "adapter inside, gelu h")
 
 
+@pytest.mark.parametrize("M,N,K,Rp", [(64, 768, 3072, 32), (64, 3072, 768, 32), (64, 768, 768, 64), (17, 300, 2304, 0), (128, 768, 768, 32)])
+def test_gemm_few_rows_split_k(M, N, K, Rp):
+    """Few-row products with caller scratch: K slabs in one batched launch + a finishing kernel (bias, rank-R term,
+    epilogue).  Rows strided as the last block's cls rows are (row stride 5 * width)."""
+    sc = _sk_scratch()
+    before = L().gemm_persistent_launches()
+    stride = 5
+    Abig, B = rnd(M * stride, K, seed=1, scale=0.3), rnd(N, K, seed=2, scale=0.3)
+    A = Abig.view(M, stride * K)[:, :K]                     # row stride 5K
+    bias = rnd(N, seed=3, dtype=torch.float32)
+    A2 = rnd(M, Rp, seed=4) if Rp else None
+    B2 = rnd(N, Rp, seed=5, scale=0.3) if Rp else None
+    acc = A.double() @ B.double().t() + bias.double()
+    if Rp:
+        acc = acc + A2.double() @ B2.double().t()
+    kw = dict(bias=bias, A2=A2, B2=B2, scratch=sc, lda=stride * K, M=M, K=K)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    L().gemm(Abig, B, out, epi=L().EPI_F32, **kw)
+    close(out, acc, 1e-4, 2e-3 * math.sqrt(K / 64), "few rows f32")
+    h, u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L().gemm(Abig, B, h, epi=L().EPI_GELU, C2=u, **kw)
+    close(u, acc, 2 ** -8, 2e-3 * math.sqrt(K / 64), "few rows gelu u")
+    close(h, torch.nn.functional.gelu(acc), 2 ** -8, 2e-3 * math.sqrt(K / 64), "few rows gelu h")
+    # residual epilogue into a strided fp32 stream (ldc = 3N), per-row scale
+    xin = rnd(M, 3 * N, seed=6, dtype=torch.float32)
+    xo = xin.clone()
+    rs = (torch.arange(M, device=DEV) % 3).float() * 0.5 + 0.5
+    L().gemm(Abig, B, xo, epi=L().EPI_RESID, aux=xin, rowscale=rs, rows_per_sample=1, ldc=3 * N, N=N, **kw)
+    close(xo[:, :N], xin[:, :N].double() + rs.double()[:, None] * acc, 1e-5, 2e-3 * math.sqrt(K / 64), "few rows resid")
+    assert torch.equal(xo[:, N:], xin[:, N:])
+    dg = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    kw2 = dict(kw)
+    kw2["bias"] = None
+    L().gemm(Abig, B, dg, epi=L().EPI_DGELU, aux=u, **kw2)
+    ud = u.double().requires_grad_(True)
+    torch.nn.functional.gelu(ud).sum().backward()
+    close(dg, (acc - bias.double()) * ud.grad, 2 ** -8, 3e-3 * math.sqrt(K / 64), "few rows dgelu")
+    assert L().gemm_persistent_launches() == before          # not the persistent kernel: the split-K path
+
+
 # ---- LDS-ring kernels (CARA_GEMM_TILE = 256: 256x256, one workgroup per CU; 1282: 128x256, two per CU) --------
 @pytest.mark.parametrize("tile", ["256", "1282", "bm256"])
 @pytest.mark.parametrize("M,N,K,Rp", [(12608, 768, 768, 32), (1500, 3072, 768, 64), (333, 300, 128, 32), (777, 640, 64, 0),
