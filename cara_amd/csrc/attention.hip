@@ -66,6 +66,47 @@ __device__ __forceinline__ bf16x8 tr_frag_rm(const char* img, int cbase, int bas
 }
 
 // npad = N rounded up to a multiple of 32: the images hold npad rows (rows >= N duplicate row N-1)
+// Lane-constant byte offsets inside a 32-row block of a swizzled [rows][64] image (row stride 128 B): the swizzle
+// term ((row >> 1) & 7) only depends on the row's position inside its 32-row block, so the per-tile address of every
+// fragment is `block * 4096 + constant` -- computed once per kernel instead of ~10 VALU instructions per read
+// (rocprofv3 counted 2 300-2 450 VALU instructions per wave in these kernels, most of them address arithmetic
+// and mask selects: the matrix pipe was busy 8 % of a wave's life).
+struct RowOfs {   // ds_read_b128 row fragments: lane (ql = lane & 31, h = lane >> 5), K sub-step ks
+  int o[4];
+};
+__device__ __forceinline__ RowOfs row_ofs(int lane) {
+  const int ql = lane & 31, h = lane >> 5;
+  RowOfs r;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) r.o[ks] = ql * 128 + (((ks * 2 + h) ^ ((ql >> 1) & 7)) << 4);
+  return r;
+}
+struct TrOfs {    // the two ds_read_b64_tr_b16 of tr_frag_rm(img, cbase = dt*32, base = block*32 + st*16)
+  int lo[2][2], hi[2][2];
+};
+__device__ __forceinline__ TrOfs tr_ofs(int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  TrOfs t;
+#pragma unroll
+  for (int st = 0; st < 2; ++st)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int rl = st * 16 + 4 * (g >> 1) + (i >> 2);
+      const int chunk = ((dt * 32 + 16 * (g & 1)) >> 3) + ((i & 3) >> 1);
+      const int sub = (i & 1) * 8;
+      t.lo[st][dt] = rl * 128 + ((chunk ^ ((rl >> 1) & 7)) << 4) + sub;
+      t.hi[st][dt] = (rl + 8) * 128 + ((chunk ^ (((rl + 8) >> 1) & 7)) << 4) + sub;
+    }
+  return t;
+}
+__device__ __forceinline__ bf16x8 tr_frag_at(const char* blk, int lo, int hi) {
+  const s16x4 l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(blk + lo));
+  const s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(blk + hi));
+  const bf16x4 l4 = __builtin_bit_cast(bf16x4, l), h4 = __builtin_bit_cast(bf16x4, u);
+  bf16x8 o = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+  return o;
+}
+
 __device__ __forceinline__ void stage_rows_swz(const bf16* __restrict__ src, int ld, int N, char* img, int tid, int nthreads,
                                                int npad) {
   for (int idx = tid; idx < npad * 8; idx += nthreads) {
@@ -206,18 +247,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_long_kernel(const bf16* _
   for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qb + (size_t)qrow * ld + ks * 16 + h * 8);
   const int nkt = npad >> 5;
   const float c2 = scale * 1.4426950408889634f;
+  const RowOfs ro = row_ofs(lane);
+  const TrOfs to = tr_ofs(lane);
+  const int last_keys = N - (nkt - 1) * 32;   // valid keys of the last tile (only that tile needs a mask)
 
   auto score_tile = [&](int kt) {
     f32x16 t;
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] = 0.f;
+    const char* kb_ = Ks + kt * 4096;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + swz128(kt * 32 + ql, ks * 2 + h));
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(kb_ + ro.o[ks]);
       t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], t, 0, 0, 0);
     }
+    if (kt == nkt - 1) {   // S^T: row = key, column = query
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = (kt * 32 + crow(r, h)) < N ? t[r] : -3.0e38f;   // S^T: row = key, column = query
+      for (int r = 0; r < 16; ++r) t[r] = crow(r, h) < last_keys ? t[r] : -3.0e38f;
+    }
     return t;
   };
   // pass 1: row maximum, then (with the maximum known) the sum of exponentials, in the key order of pass 2
@@ -228,6 +275,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_long_kernel(const bf16* _
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, t[r]);
   }
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float mxc = mx * c2;
   float sum = 0.f;
   f32x16 o[2];
 #pragma unroll
@@ -239,15 +287,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_long_kernel(const bf16* _
     f32x16 t = score_tile(kt);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      t[r] = exp2f((t[r] - mx) * c2);
+      t[r] = __builtin_amdgcn_exp2f(t[r] * c2 - mxc);   // <= 0: raw v_exp_f32, no denormal fix-up code
       sum += t[r];
     }
+    const char* vb_ = Vs + kt * 4096;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       const bf16x8 pa = pack8(t, st);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const bf16x8 vf = tr_frag_rm(Vs, dt * 32, kt * 32 + st * 16, lane);
+        const bf16x8 vf = tr_frag_at(vb_, to.lo[st][dt], to.hi[st][dt]);
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vf, o[dt], 0, 0, 0);
       }
     }
