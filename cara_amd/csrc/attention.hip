@@ -381,36 +381,47 @@ __global__ __launch_bounds__(448, 2) void attn_bwd_dkv_kernel(const bf16* __rest
     for (int r = 0; r < 16; ++r) { dkt[dt][r] = 0.f; dvt[dt][r] = 0.f; }
 
   const int nqt = npad >> 5;
+  const RowOfs ro = row_ofs(lane);
+  const TrOfs to = tr_ofs(lane);
+  const int last_q = N - (nqt - 1) * 32;   // valid queries of the last tile (rows beyond are clamped duplicates)
   for (int qt = 0; qt < nqt; ++qt) {
     const int q0 = qt * 32;
+    const char* qblk = Qs + qt * 4096;
+    const char* dblk = dOs + qt * 4096;
     f32x16 sacc, pacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + swz128(q0 + kl, ks * 2 + h));
-      const bf16x8 da = *reinterpret_cast<const bf16x8*>(dOs + swz128(q0 + kl, ks * 2 + h));
+      const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qblk + ro.o[ks]);
+      const bf16x8 da = *reinterpret_cast<const bf16x8*>(dblk + ro.o[ks]);
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
       pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], pacc, 0, 0, 0);
     }
     // layout: column (lane & 31) = key, row = query q0 + crow(r, h).  Rows q >= N carry clamped
-    // duplicates of row N-1: force their P to zero.
+    // duplicates of row N-1: force their P to zero (last query tile only; an invalid key zeroes the whole lane).
     f32x16 p, ds;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int q = q0 + crow(r, h);
-      const float e = exp2f(sacc[r] * c2 - lse_s[q]);
-      const float pv = (kvalid && q < N) ? e : 0.f;
-      p[r] = pv;
-      ds[r] = pv * (pacc[r] - del_s[q]);
+    for (int g4 = 0; g4 < 4; ++g4) {   // registers 4*g4 .. +3 hold queries q0 + 8*g4 + 4h .. +3: one 16-byte LDS read each
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + q0 + 8 * g4 + 4 * h);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + q0 + 8 * g4 + 4 * h);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = 4 * g4 + k;
+        float e = __builtin_amdgcn_exp2f(sacc[r] * c2 - l4[k]);
+        if (qt == nqt - 1) e = crow(r, h) < last_q ? e : 0.f;
+        e = kvalid ? e : 0.f;
+        p[r] = e;
+        ds[r] = e * (pacc[r] - d4[k]);
+      }
     }
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       const bf16x8 pb = pack8(p, st), dsb = pack8(ds, st);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const bf16x8 doa = tr_frag_rm(dOs, dt * 32, q0 + st * 16, lane);
-        const bf16x8 qta = tr_frag_rm(Qs, dt * 32, q0 + st * 16, lane);
+        const bf16x8 doa = tr_frag_at(dblk, to.lo[st][dt], to.hi[st][dt]);
+        const bf16x8 qta = tr_frag_at(qblk, to.lo[st][dt], to.hi[st][dt]);
         dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa, pb, dvt[dt], 0, 0, 0);
         dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsb, dkt[dt], 0, 0, 0);
       }
@@ -485,31 +496,36 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
   const int nkt = npad >> 5;
+  const RowOfs ro = row_ofs(lane);
+  const TrOfs to = tr_ofs(lane);
+  const int last_keys = N - (nkt - 1) * 32;
   for (int kt = 0; kt < nkt; ++kt) {
+    const char* kblk = Ks + kt * 4096;
+    const char* vblk = Vs + kt * 4096;
     f32x16 sT, dpT;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sT[r] = 0.f; dpT[r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8 ka = *reinterpret_cast<const bf16x8*>(Ks + swz128(kt * 32 + ql, ks * 2 + h));
-      const bf16x8 va = *reinterpret_cast<const bf16x8*>(Vs + swz128(kt * 32 + ql, ks * 2 + h));
+      const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kblk + ro.o[ks]);
+      const bf16x8 va = *reinterpret_cast<const bf16x8*>(vblk + ro.o[ks]);
       sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], sT, 0, 0, 0);
       dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dpT, 0, 0, 0);
     }
-    // layout: column (lane & 31) = query, row = key kt*32 + crow(r, h)
+    // layout: column (lane & 31) = query, row = key kt*32 + crow(r, h); only the last tile has keys >= N
     f32x16 ds;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int key = kt * 32 + crow(r, h);
-      const float e = exp2f(sT[r] * c2 - lq);
-      ds[r] = key < N ? e * (dpT[r] - dl) : 0.f;
+      float e = __builtin_amdgcn_exp2f(sT[r] * c2 - lq);
+      if (kt == nkt - 1) e = crow(r, h) < last_keys ? e : 0.f;
+      ds[r] = e * (dpT[r] - dl);
     }
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       const bf16x8 a = pack8(ds, st);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const bf16x8 kf = tr_frag_rm(Ks, dt * 32, kt * 32 + st * 16, lane);
+        const bf16x8 kf = tr_frag_at(kblk, to.lo[st][dt], to.hi[st][dt]);
         dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf, dq[dt], 0, 0, 0);
       }
     }
