@@ -168,6 +168,37 @@ __device__ __forceinline__ void stage_tile32(const bf16* __restrict__ P, int ld,
   }
 }
 
+// The same with the row part of the address hoisted out of the K loop: off[t] = (clamped row) * ld * 2 + swizzled
+// chunk * 16 is a per-thread 32-bit byte offset computed once per tile, and a K step only adds the wave-uniform
+// k0 * 2 to the operand's base pointer (SGPR base + VGPR offset addressing: no vector arithmetic at all per piece).
+// rocprofv3 counted 1 460 VALU instructions per wave and tile in the bf16-epilogue kernel (3.6 per MFMA), about
+// two thirds of them this address arithmetic.  Needs the operand to span < 4 GiB (checked at dispatch).
+template <int ROWS, int NW = 4>
+struct TileOfs {
+  unsigned off[ROWS / (16 * NW)];
+};
+template <int ROWS, int NW = 4>
+__device__ __forceinline__ TileOfs<ROWS, NW> tile_ofs(int ld, int r0, int rmax, int wave, int lane) {
+  constexpr int PPW = ROWS / (16 * NW);
+  TileOfs<ROWS, NW> o;
+#pragma unroll
+  for (int t = 0; t < PPW; ++t) {
+    const int r = (wave * PPW + t) * 16 + (lane >> 2);
+    const int cg = (lane & 3) ^ (((r >> 3) & 1) * 3);
+    int gr = r0 + r;
+    gr = gr < rmax ? gr : rmax;
+    o.off[t] = (unsigned)gr * (unsigned)(ld * 2) + (unsigned)(cg * 16);
+  }
+  return o;
+}
+template <int ROWS, int NW = 4>
+__device__ __forceinline__ void stage_tile32_pre(const bf16* __restrict__ P, int k0, const TileOfs<ROWS, NW>& o, char* lds_tile, int wave) {
+  constexpr int PPW = ROWS / (16 * NW);
+  const char* base = reinterpret_cast<const char*>(P + k0);   // wave-uniform
+#pragma unroll
+  for (int t = 0; t < PPW; ++t) glds16(base + o.off[t], lds_tile + (wave * PPW + t) * 1024);
+}
+
 template <int MI>
 __device__ __forceinline__ void mma_tile32(const char* sA, const char* sB, f32x4 (&acc)[MI][4], int wr, int wc, int lane) {
   const int fr = lane & 15, fq = lane >> 4;
@@ -240,8 +271,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? 4
   // 4 = no epilogue stores (K loop + launch cost), 64 = K loop always reads K tile 0 (L2-resident operands)
   const int nk = (ablate & 32) ? 1 : p.K / BK32;
   const int kmul = (ablate & 64) ? 0 : BK32;
-  stage_tile32<TBM, NW>(A, p.lda, m0, p.M - 1, 0, smem, wave, lane);
-  stage_tile32<BN, NW>(B, p.ldb, n0, p.N - 1, 0, smem + A_BYTES, wave, lane);
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);   // wave-uniform copy: scalar LDS destinations
+  const TileOfs<TBM, NW> oA = tile_ofs<TBM, NW>(p.lda, m0, p.M - 1, wave, lane);
+  const TileOfs<BN, NW> oB = tile_ofs<BN, NW>(p.ldb, n0, p.N - 1, wave, lane);
+  stage_tile32_pre<TBM, NW>(A, 0, oA, smem, uwave);
+  stage_tile32_pre<BN, NW>(B, 0, oB, smem + A_BYTES, uwave);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -249,8 +283,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? 4
     char* sA = smem + cur * SLOT;
     if (kt + 1 < nk) {
       char* nA = smem + (cur ^ 1) * SLOT;
-      stage_tile32<TBM, NW>(A, p.lda, m0, p.M - 1, (kt + 1) * kmul, nA, wave, lane);
-      stage_tile32<BN, NW>(B, p.ldb, n0, p.N - 1, (kt + 1) * kmul, nA + A_BYTES, wave, lane);
+      stage_tile32_pre<TBM, NW>(A, (kt + 1) * kmul, oA, nA, uwave);
+      stage_tile32_pre<BN, NW>(B, (kt + 1) * kmul, oB, nA + A_BYTES, uwave);
     }
     mma_tile32<MI>(sA, sA + A_BYTES, acc, wr, wc, lane);
     cur ^= 1;
@@ -324,16 +358,17 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // the 32 x 32 slab of Ut of one K step = two 1-KiB pieces (16 rows x 64 B), issued by waves 0 and 1
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned offU = (unsigned)((wave & 1) * 16 + (lane >> 2)) * (unsigned)(p.K * 2) +
+                        (unsigned)((((lane & 3) ^ ((((lane >> 2) >> 3) & 1) * 3))) * 16);
   auto stage_u = [&](int k0, char* dst) {
-    if (wave < 2) {
-      const int r = wave * 16 + (lane >> 2);
-      const int cg = (lane & 3) ^ (((r >> 3) & 1) * 3);
-      glds16(Ut + (size_t)r * p.K + k0 + cg * 8, dst + wave * 1024);
-    }
+    if (uwave < 2) glds16(reinterpret_cast<const char*>(Ut + k0) + offU, dst + uwave * 1024);
   };
   const int nk = p.K / BK32;
-  stage_tile32<TBM, 4>(A, p.lda, m0, p.M - 1, 0, smem, wave, lane);
-  stage_tile32<BN, 4>(B, p.ldb, n0, p.N - 1, 0, smem + A_BYTES, wave, lane);
+  const TileOfs<TBM, 4> oA = tile_ofs<TBM, 4>(p.lda, m0, p.M - 1, wave, lane);
+  const TileOfs<BN, 4> oB = tile_ofs<BN, 4>(p.ldb, n0, p.N - 1, wave, lane);
+  stage_tile32_pre<TBM, 4>(A, 0, oA, smem, uwave);
+  stage_tile32_pre<BN, 4>(B, 0, oB, smem + A_BYTES, uwave);
   stage_u(0, smem + A_BYTES + B32_BYTES);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
@@ -342,8 +377,8 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
     char* sA = smem + cur * SLOT;
     if (kt + 1 < nk) {
       char* nA = smem + (cur ^ 1) * SLOT;
-      stage_tile32<TBM, 4>(A, p.lda, m0, p.M - 1, (kt + 1) * BK32, nA, wave, lane);
-      stage_tile32<BN, 4>(B, p.ldb, n0, p.N - 1, (kt + 1) * BK32, nA + A_BYTES, wave, lane);
+      stage_tile32_pre<TBM, 4>(A, (kt + 1) * BK32, oA, nA, uwave);
+      stage_tile32_pre<BN, 4>(B, (kt + 1) * BK32, oB, nA + A_BYTES, uwave);
       stage_u((kt + 1) * BK32, nA + A_BYTES + B32_BYTES);
     }
     const char* sB = sA + A_BYTES;
@@ -627,11 +662,13 @@ extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
   if (!(a->Rp == 0 || a->Rp == 32 || a->Rp == 64)) return CARA_E_ARG;
   if (a->Rp && ((!a->A2 && !a->Ut) || !a->B2)) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // the BK = 32 kernels address their operands with 32-bit byte offsets from the (batch-adjusted) base pointer
+  const bool small_ptrs = (unsigned long long)a->M * a->lda * 2 < (1ull << 32) && (unsigned long long)a->N * a->ldb * 2 < (1ull << 32);
   if (a->epi == CARA_EPI_GELU && !a->C2) return CARA_E_ARG;
   if (a->epi == CARA_EPI_RESID && (!a->aux || (a->rowscale && a->rows_per_sample <= 0))) return CARA_E_ARG;
   if (a->epi == CARA_EPI_DGELU && !a->aux) return CARA_E_ARG;
   if (a->Ut) {   // whole adapter inside the GEMM: default kernel family, Rp = 32, T produced here
-    if (a->A2 || !a->B2 || a->Rp != 32 || !a->T_out || a->batch > 1 || (a->K % BK32) || (a->Tt_out && (a->ldt < a->M || (a->ldt & 7))))
+    if (!small_ptrs || a->A2 || !a->B2 || a->Rp != 32 || !a->T_out || a->batch > 1 || (a->K % BK32) || (a->Tt_out && (a->ldt < a->M || (a->ldt & 7))))
       return CARA_E_ARG;
     switch (a->epi) {
       case CARA_EPI_BF16: return launch32ft<CARA_EPI_BF16>(a, st);
@@ -643,10 +680,10 @@ extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
     }
   }
   if (a->batch > 1) {   // batched products: the default kernel family only, plain epilogues
-    if (a->A2 || a->aux || a->C2 || !(a->epi == CARA_EPI_F32 || a->epi == CARA_EPI_BF16) || a->batch > 65535) return CARA_E_ARG;
+    if (!small_ptrs || a->A2 || a->aux || a->C2 || !(a->epi == CARA_EPI_F32 || a->epi == CARA_EPI_BF16) || a->batch > 65535) return CARA_E_ARG;
     return a->epi == CARA_EPI_F32 ? launch32<CARA_EPI_F32>(a, st) : launch32<CARA_EPI_BF16>(a, st);
   }
-  if (const int nslab = small_m_slabs(a)) {
+  if (const int nslab = small_ptrs ? small_m_slabs(a) : 0) {
     switch (a->epi) {
       case CARA_EPI_BF16: return launch_small_m<CARA_EPI_BF16>(a, nslab, st);
       case CARA_EPI_F32: return launch_small_m<CARA_EPI_F32>(a, nslab, st);
@@ -660,7 +697,7 @@ extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
   if (tile == 256) return cara_gemm256_dispatch(a, st);
   if (tile == 1282) return cara_gemm128x256_dispatch(a, st);   // 128 x 256
   if (use_stream_k(a)) return cara_gemm_sk_dispatch(a, st);
-  if (use_bk32()) {
+  if (use_bk32() && small_ptrs) {
     switch (a->epi) {
       case CARA_EPI_BF16: return launch32<CARA_EPI_BF16>(a, st);
       case CARA_EPI_F32: return launch32<CARA_EPI_F32>(a, st);
