@@ -82,6 +82,72 @@ __global__ __launch_bounds__(256, 4) void kloop(const char* __restrict__ src, fl
   if (s == 123.456f) out[blockIdx.x] = s;
 }
 
+// 256x128x32 step: 8 waves of 64x64, 24 KiB staged per step (3 pieces per wave), two workgroups per CU
+__global__ __launch_bounds__(512, 4) void kloop256(const char* __restrict__ src, float* __restrict__ out, int iters, size_t span) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int SLOT = 24576;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const char* base = src + ((size_t)blockIdx.x * 96 * 1024) % span;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto stage = [&](int it) {
+    char* buf = smem + (it & 1) * SLOT;
+    const char* s = base + (size_t)(it & 3) * SLOT;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const int q = wave * 3 + p;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + q * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(buf + q * 1024), 16, 0, 0);
+    }
+  };
+  stage(0);
+  for (int it = 0; it < iters; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    stage(it + 1);
+    const char* sA = smem + (it & 1) * SLOT;
+    const char* sB = sA + 16384;
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a[i] = *reinterpret_cast<const bf16x8*>(sA + swz32(wr * 64 + i * 16 + fr, fq));
+      b[i] = *reinterpret_cast<const bf16x8*>(sB + swz32(wc * 64 + i * 16 + fr, fq));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (s == 123.456f) out[blockIdx.x] = s;
+}
+
+void run256(int wpc, const char* src, float* out, size_t span) {
+  const int cus = 256, iters = 2000;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kloop256), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(kloop256, dim3(cus * wpc), dim3(512), 2 * 24576, 0, src, out, 50, span);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL(kloop256, dim3(cus * wpc), dim3(512), 2 * 24576, 0, src, out, iters, span);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double tf = 2.0 * 256 * 128 * 32 * (double)cus * wpc * iters / (ms * 1e-3) / 1e12;
+  printf("%-44s %d WG/CU: %6.3f us per K step per WG  -> %7.1f TF/s-equivalent\n", "the K loop at 256x128 (8 waves, 24 KiB/step)", wpc,
+         ms * 1e3 / iters, tf);
+}
+
 template <int MODE, int PF>
 void run(const char* name, int wpc, const char* src, float* out, size_t span) {
   const int cus = 256, iters = 2000;
@@ -116,5 +182,6 @@ int main() {
     run<9, 1>("stage, GEMM-like 64-B row segments", wpc, src, out, span);
     run<15, 1>("the K loop, GEMM-like 64-B row segments", wpc, src, out, span);
   }
+  for (int wpc : {1, 2, 3}) run256(wpc, src, out, span);
   return 0;
 }
