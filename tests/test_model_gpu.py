@@ -429,3 +429,27 @@ def test_baseline_configs_rank_variants(rank, batch):
     worst = max(rel(getattr(m, n).grad, gref[n]) for n in O.CP_NAMES)
     print(f"rank {rank}: worst CP-gradient rel-L2 {worst:.2e}")
     assert worst < 6e-2
+
+
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """bench.py's multi-rank plumbing on ONE GPU (CARA_BENCH_REHEARSAL=1: both ranks on cuda:0, gloo instead of RCCL):
+    rendezvous, per-rank shards, the flat-gradient all-reduce inside train_step, max-over-ranks timing, one JSON line
+    from rank 0 with the contract's keys.  Child processes, never an exec from this GPU-initialised one."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CARA_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
+    assert d["value"] > 0 and "cpu_baseline" not in d          # the CPU baseline is a rank-0, N = 1 leg
