@@ -30,7 +30,11 @@ struct Ws {
   size_t pack, patches, emb, head_wb, clsn, meanF, rstdF, x_last;
   LayerWs layer[64];
   // backward
-  size_t dx, dyb, dH, dXn, dAO, dQKV, G[4], Gt[4], slabs, dclsn, gscratch, gemm_scratch;
+  size_t dx, dXn, dAO, slabs, dclsn, gscratch, gemm_scratch;
+  // what the side stream reads (dY of the four linears, G' = dY Vs and its transpose) lives in a ring over the
+  // blocks, so that the main stream never has to wait for the side stream before overwriting it (see Side below)
+  int nring;
+  struct Ring { size_t dyb_fc2, dyb_proj, dH, dQKV, G[4], Gt[4]; } ring[64];
   size_t dU[4], dVs[4], dc[4];
   size_t slabU[4], slabV[4], strideU[4], strideV[4];   // per linear: depth regions of tskinny slabs
   // exact weight-dropout mode: merged weights of every layer (and their transposes), transposed activations, dense dW
@@ -42,6 +46,19 @@ struct Ws {
 };
 
 size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+
+// Ring depth of the backward buffers the side stream reads.  Default: one set per block, i.e. no reuse inside a
+// backward pass and therefore NO wait of the main stream on the side stream before the final reduction (a
+// hipStreamWaitEvent costs the main stream ~7.5 us even when the event completed long ago, tools/micro/sync_cost.hip;
+// ViT-B/16 at 64 x 197 tokens: 12 x 0.18 GB).  CARA_BWD_RING=n (1 <= n <= depth) trades memory for one wait per block.
+int bwd_ring(int depth) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CARA_BWD_RING");
+    v = e ? atoi(e) : 0;
+  }
+  return (v >= 1 && v <= depth) ? v : depth;
+}
 
 bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
   if (!g || !s || g->depth <= 0 || g->depth > 64 || g->dim % g->heads || g->dim / g->heads != 64) return false;
@@ -82,14 +99,19 @@ bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
     }
   }
   w->dx = c.take(M * D * 4);
-  w->dyb = c.take(M * D * 2);
-  w->dH = c.take(M * 4 * D * 2);
   w->dXn = c.take(M * D * 2);
   w->dAO = c.take(M * D * 2);
-  w->dQKV = c.take(M * 3 * D * 2);
-  for (int i = 0; i < 4; ++i) {   // one G' = dY Vs pair per linear: the side stream reads it while the next is written
-    w->G[i] = c.take(M * Rp * 2);
-    w->Gt[i] = c.take(Rp * ldt * 2);
+  w->nring = bwd_ring(g->depth);
+  for (int r = 0; r < w->nring; ++r) {
+    Ws::Ring& R = w->ring[r];
+    R.dyb_fc2 = c.take(M * D * 2);
+    R.dyb_proj = c.take(M * D * 2);
+    R.dH = c.take(M * 4 * D * 2);
+    R.dQKV = c.take(M * 3 * D * 2);
+    for (int i = 0; i < 4; ++i) {
+      R.G[i] = c.take(M * Rp * 2);
+      R.Gt[i] = c.take(Rp * ldt * 2);
+    }
   }
   w->slabs = 0;
   w->dclsn = c.take((size_t)s->B * D * 2);
@@ -138,7 +160,7 @@ bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
 struct Side {
   bool made = false, on = true;
   hipStream_t s = nullptr;
-  hipEvent_t fork[4], join[4];
+  hipEvent_t fork[4], join[64];   // join[l]: all side work of block l has finished (the side stream is in order)
 };
 Side g_side;
 
@@ -149,49 +171,69 @@ bool side_ready() {
     if (g_side.on) {
       if (hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking) != hipSuccess) g_side.on = false;
       for (int i = 0; i < 4 && g_side.on; ++i)
-        if (hipEventCreateWithFlags(&g_side.fork[i], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&g_side.join[i], hipEventDisableTiming) != hipSuccess)
-          g_side.on = false;
+        if (hipEventCreateWithFlags(&g_side.fork[i], hipEventDisableTiming) != hipSuccess) g_side.on = false;
+      for (int i = 0; i < 64 && g_side.on; ++i)
+        if (hipEventCreateWithFlags(&g_side.join[i], hipEventDisableTiming) != hipSuccess) g_side.on = false;
     }
     g_side.made = true;
   }
   return g_side.on;
 }
 
-// main stream: do not pass this point before the side work of linear `slot` has finished
-// The transposed skinny products of a linear whose G' is produced INSIDE its dX GEMM can only start after that GEMM;
-// run right away they would share the chip with the HBM-bound kernels that follow it (measured: +0.35 ms/step).
-// They are therefore parked and launched on the side stream just before the NEXT linear's dX GEMM starts, so that
-// "skinny products under a GEMM" is preserved, one GEMM later.  All their inputs live until the joins that
-// already guard the buffers (G'/dY per slot, saved activations per layer).
-struct PendingTs {
-  bool armed = false;
+// The transposed skinny products of the linears whose dY and G' exist, waiting for their fork.  Every fork is a
+// hipEventRecord on the main stream (3..5 us of idle chip each, tools/micro/sync_cost.hip), so CARA_BWD_FORK picks how
+// many there are per block: 4 = one per linear, just before its dX GEMM; 2 = one per branch (before the fc1 and
+// qkv dX GEMMs); 1 = one per block (before the qkv dX GEMM).  Block 0 always forks per linear: nothing follows it
+// that the products could hide under.
+struct TsJob {
   const bf16 *X, *dY, *Gt;
   const void* Tt;
   void *slabU, *slabV;
-  int ldx, lddy, in, out, want_dc, ldt, Mr, Rp, slot;
+  int ldx, lddy, in, out, want_dc, ldt, Mr, Rp;
 };
-PendingTs g_pending;
+struct TsQueue {
+  TsJob job[4];
+  int n = 0;
+};
+TsQueue g_jobs;
 
-int launch_pending(void* st) {
-  if (!g_pending.armed) return CARA_OK;
-  const PendingTs& q = g_pending;
+int fork_granularity() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CARA_BWD_FORK");
+    v = e ? atoi(e) : 4;
+    if (v != 1 && v != 2 && v != 4) v = 4;
+  }
+  return v;
+}
+bool flush_before(int slot, int layer) {   // slot: 0 qkv, 1 proj, 2 fc1, 3 fc2 (backward runs 3, 2, 1, 0)
+  const int gran = layer == 0 ? 4 : fork_granularity();
+  return gran == 4 || slot == 0 || (gran == 2 && slot == 2);
+}
+
+// launch the queued products on the side stream (main stream `st` when there is none); `layer_done`: this was the
+// last linear of block `layer`, its join event goes behind
+int flush_jobs(void* st, int layer, bool layer_done) {
   void* ts_stream = st;
-  if (side_ready()) {
-    if (hipEventRecord(g_side.fork[q.slot], static_cast<hipStream_t>(st)) != hipSuccess) return CARA_E_LAUNCH;
-    if (hipStreamWaitEvent(g_side.s, g_side.fork[q.slot], 0) != hipSuccess) return CARA_E_LAUNCH;
+  const bool side = side_ready();
+  if (side && g_jobs.n > 0) {
+    if (hipEventRecord(g_side.fork[0], static_cast<hipStream_t>(st)) != hipSuccess) return CARA_E_LAUNCH;
+    if (hipStreamWaitEvent(g_side.s, g_side.fork[0], 0) != hipSuccess) return CARA_E_LAUNCH;
     ts_stream = g_side.s;
   }
-  TRY(cara_tskinny_partial2(q.X, q.ldx, q.Gt, q.slabU, q.in, q.dY, q.lddy, q.Tt, q.slabV, q.out, q.want_dc, q.ldt, q.Mr, q.Rp, ts_stream));
-  if (side_ready() && hipEventRecord(g_side.join[q.slot], g_side.s) != hipSuccess) return CARA_E_LAUNCH;
-  g_pending.armed = false;
+  for (int i = 0; i < g_jobs.n; ++i) {
+    const TsJob& q = g_jobs.job[i];
+    TRY(cara_tskinny_partial2(q.X, q.ldx, q.Gt, q.slabU, q.in, q.dY, q.lddy, q.Tt, q.slabV, q.out, q.want_dc, q.ldt, q.Mr, q.Rp, ts_stream));
+  }
+  g_jobs.n = 0;
+  if (side && layer_done && hipEventRecord(g_side.join[layer], g_side.s) != hipSuccess) return CARA_E_LAUNCH;
   return CARA_OK;
 }
 
-int side_join(int slot, void* stream) {
-  if (g_pending.armed && g_pending.slot == slot) TRY(launch_pending(stream));   // (its join event must exist first)
+// main stream: do not pass this point before all side work of block `layer` has finished
+int side_join(int layer, void* stream) {
   if (!side_ready()) return CARA_OK;
-  return hipStreamWaitEvent(static_cast<hipStream_t>(stream), g_side.join[slot], 0) == hipSuccess ? CARA_OK : CARA_E_LAUNCH;
+  return hipStreamWaitEvent(static_cast<hipStream_t>(stream), g_side.join[layer], 0) == hipSuccess ? CARA_OK : CARA_E_LAUNCH;
 }
 
 struct Lin {  // one adapted linear of one layer
@@ -256,34 +298,32 @@ int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char*
 // (row stride ldx):
 //   G' = dY Vs ; dX = [dY | G'] [W^T | U]^T (optional) ; dU = X^T G' ; dVs = dY^T T ; dc = colsum dY
 int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int Mr, int Rp, int ldt, char* ws, const Ws& W,
-            const LayerWs& lw, int layer, bool want_dx, cara_gemm_args a, bool want_dc, void* st, bool have_G = false) {
-  bf16* G = reinterpret_cast<bf16*>(ws + W.G[L.slot]);
-  bf16* Gt = reinterpret_cast<bf16*>(ws + W.Gt[L.slot]);
+            const Ws::Ring& R, const LayerWs& lw, int layer, bool want_dx, cara_gemm_args a, bool want_dc, void* st,
+            bool have_G = false) {
+  bf16* G = reinterpret_cast<bf16*>(ws + R.G[L.slot]);
+  bf16* Gt = reinterpret_cast<bf16*>(ws + R.Gt[L.slot]);
   void* slabU = ws + W.slabU[L.slot] + (size_t)layer * W.strideU[L.slot];
   void* slabV = ws + W.slabV[L.slot] + (size_t)layer * W.strideV[L.slot];
   // (have_G: the LayerNorm backward that produced dY already left G' and its transpose, cara_layernorm_bwd_xu)
   // inside: the dX GEMM computes G' = dY Vs itself (cara_gemm_args::Ut) and leaves G / Gt behind
   const bool inside = !have_G && want_dx && fuse_gemm_t(Mr, Rp, true);
   if (!have_G && !inside) TRY(cara_skinny_xu(dY, lddy, L.Vst, G, Gt, ldt, Mr, L.out, Rp, st));
-  TRY(launch_pending(st));   // the previous linear's parked products start under THIS linear's GEMM
+  // partial slabs on the side stream; their fixed-order sums run once per linear after the layer loop
+  const TsJob job{X, dY, Gt, ws + lw.Tt[L.slot], slabU, slabV, ldx, lddy, L.in, L.out, want_dc ? 1 : 0, ldt, Mr, Rp};
+  const bool last = L.slot == 0;   // a block's backward ends with qkv
   if (inside) {
+    if (flush_before(L.slot, layer)) TRY(flush_jobs(st, layer, false));   // earlier linears' products run under this GEMM
     a.A = dY; a.lda = lddy; a.B = L.Wt; a.ldb = L.out; a.A2 = nullptr; a.B2 = L.U; a.Rp = Rp;
     a.Ut = L.Vst; a.T_out = G; a.Tt_out = Gt; a.ldt = ldt;
     a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
     if (a.ldc == 0) a.ldc = L.in;
     TRY(cara_gemm_bf16(&a, st));
-    g_pending = PendingTs{true, X, dY, Gt, ws + lw.Tt[L.slot], slabU, slabV, ldx, lddy, L.in, L.out, want_dc ? 1 : 0, ldt, Mr, Rp, L.slot};
+    g_jobs.job[g_jobs.n++] = job;   // its G' exists only behind the GEMM
+    if (last) TRY(flush_jobs(st, layer, true));
     return CARA_OK;
   }
-  void* ts_stream = st;
-  if (side_ready()) {   // fork: the side stream may start once G' exists
-    if (hipEventRecord(g_side.fork[L.slot], static_cast<hipStream_t>(st)) != hipSuccess) return CARA_E_LAUNCH;
-    if (hipStreamWaitEvent(g_side.s, g_side.fork[L.slot], 0) != hipSuccess) return CARA_E_LAUNCH;
-    ts_stream = g_side.s;
-  }
-  // partial slabs now; their fixed-order sums run once per linear after the layer loop
-  TRY(cara_tskinny_partial2(X, ldx, Gt, slabU, L.in, dY, lddy, ws + lw.Tt[L.slot], slabV, L.out, want_dc ? 1 : 0, ldt, Mr, Rp, ts_stream));
-  if (side_ready() && hipEventRecord(g_side.join[L.slot], g_side.s) != hipSuccess) return CARA_E_LAUNCH;
+  g_jobs.job[g_jobs.n++] = job;
+  if (flush_before(L.slot, layer)) TRY(flush_jobs(st, layer, last));   // fork: G' exists, the dX GEMM comes next
   if (want_dx) {
     a.A = dY; a.lda = lddy; a.B = L.Wt; a.ldb = L.out; a.A2 = G; a.B2 = L.U; a.Rp = Rp;
     a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
@@ -370,7 +410,8 @@ void make_lins(const cara_geom* g, const cara_vit_weights* w, const char* pack, 
 // stream the kernel runs on.  Diagnostic state, off by default.
 struct Prof {
   bool on = false;
-  int n = 0;
+  int every = 1;   // bracket the layers l with l % every == 0
+  long n = 0;      // brackets recorded since the hook was switched on (ring of 64)
   hipEvent_t ev[64][3];
   bool made = false;
 };
@@ -420,6 +461,7 @@ extern "C" int cara_profile_fc1(int enable) {
     g_prof.made = true;
   }
   g_prof.on = enable != 0;
+  g_prof.every = enable > 0 ? enable : 1;
   g_prof.n = 0;
   return CARA_OK;
 }
@@ -433,16 +475,17 @@ extern "C" int cara_profile_fc1_read(float* avg_ms, int* launches) {
 extern "C" int cara_profile_fc1_read2(float* avg_ms, float* marker_ms, int* launches) {
   if (!avg_ms || !marker_ms || !launches || !g_prof.made || g_prof.n == 0) return CARA_E_ARG;
   double tot = 0, gap = 0;
-  for (int i = 0; i < g_prof.n; ++i) {
+  const int cnt = g_prof.n < 64 ? (int)g_prof.n : 64;
+  for (int i = 0; i < cnt; ++i) {
     float ms = 0.f, g = 0.f;
     if (hipEventElapsedTime(&ms, g_prof.ev[i][0], g_prof.ev[i][1]) != hipSuccess) return CARA_E_LAUNCH;
     if (hipEventElapsedTime(&g, g_prof.ev[i][1], g_prof.ev[i][2]) != hipSuccess) return CARA_E_LAUNCH;
     tot += ms;
     gap += g;
   }
-  *marker_ms = (float)(gap / g_prof.n);
-  *avg_ms = (float)((tot - gap) / g_prof.n);
-  *launches = g_prof.n;
+  *marker_ms = (float)(gap / cnt);
+  *avg_ms = (float)((tot - gap) / cnt);
+  *launches = cnt;
   return CARA_OK;
 }
 
@@ -533,7 +576,7 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
     e.epi = CARA_EPI_GELU; e.C = ws + lw.h; e.C2 = ws + lw.u;
     if (ex) {
       TRY(lin_fwd_exact(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, ws, W, l, s, e, stream));
-    } else if (g_prof.on && !cls_only) {
+    } else if (g_prof.on && !cls_only && l % g_prof.every == 0) {
       // T first, so that the bracket holds exactly one kernel: the fc1 GEMM
       bf16* T = reinterpret_cast<bf16*>(ws + lw.T[2]);
       if (!fx) TRY(cara_skinny_xu(ws + lw.xn2, D, lin[2].Ut, T, ws + lw.Tt[2], W.ldt, M, D, Rp, stream));
@@ -541,11 +584,12 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
       a2.A = ws + lw.xn2; a2.lda = D; a2.B = lin[2].W; a2.ldb = D; a2.A2 = T; a2.B2 = lin[2].Vs; a2.Rp = Rp;
       a2.M = M; a2.N = 4 * D; a2.K = D; a2.bias = lin[2].bias; a2.ldc = 4 * D;
       with_scratch(a2);
-      hipEventRecord(g_prof.ev[l][0], static_cast<hipStream_t>(stream));
+      hipEvent_t* ev = g_prof.ev[g_prof.n % 64];
+      hipEventRecord(ev[0], static_cast<hipStream_t>(stream));
       TRY(cara_gemm_bf16(&a2, stream));
-      hipEventRecord(g_prof.ev[l][1], static_cast<hipStream_t>(stream));
-      hipEventRecord(g_prof.ev[l][2], static_cast<hipStream_t>(stream));   // empty bracket: the markers' own cost
-      g_prof.n = l + 1;
+      hipEventRecord(ev[1], static_cast<hipStream_t>(stream));
+      hipEventRecord(ev[2], static_cast<hipStream_t>(stream));   // empty bracket: the markers' own cost
+      ++g_prof.n;
     } else {
       TRY(lin_fwd(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, W.ldt, ws, lw, e, stream, fx));
     }
@@ -576,7 +620,8 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
   cara_pack_layout pl;
   TRY(cara_pack_offsets(g, &pl));
   float* dx = reinterpret_cast<float*>(ws + W.dx);
-  bf16* dyb = reinterpret_cast<bf16*>(ws + W.dyb);
+  bf16* dyb = reinterpret_cast<bf16*>(ws + W.ring[(g->depth - 1) % W.nring].dyb_fc2);   // dY of the last block's fc2
+  g_jobs.n = 0;
   TRY(cara_head_backward(dlogits, ws + W.clsn, head_w, dhead_w, dhead_b, ws + W.dclsn, B, s->num_classes, D, stream));
   // gradient enters the token stream only through the cls rows
   if (hipMemsetAsync(dx, 0, (size_t)M * D * 4, hs) != hipSuccess) return CARA_E_LAUNCH;
@@ -599,55 +644,58 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     const int Mr = cls_only ? B : M;
     const int ldr = cls_only ? N * D : D;
     const int rps = cls_only ? 1 : N;
+    // this block's ring slot of side-stream inputs (its dyb_fc2 and G'[3] were written by the block above)
+    const Ws::Ring& R = W.ring[l % W.nring];
+    bf16* dyb = reinterpret_cast<bf16*>(ws + R.dyb_fc2);
+    bf16* dyp = reinterpret_cast<bf16*>(ws + R.dyb_proj);
+    bf16* dH = reinterpret_cast<bf16*>(ws + R.dH);
+    bf16* dQKV = reinterpret_cast<bf16*>(ws + R.dQKV);
     // ---- mlp branch: dY = drop_path scale * dx (already in dyb) ----
     cara_gemm_args e = {};
-    e.epi = CARA_EPI_DGELU; e.C = ws + W.dH; e.aux = ws + lw.u;
-    TRY(side_join(2, stream));   // the previous block's fc1 products still read dH / G'[2]
+    e.epi = CARA_EPI_DGELU; e.C = dH; e.aux = ws + lw.u;
     if (ex) TRY(lin_bwd_exact(lin[3], dyb, reinterpret_cast<bf16*>(ws + lw.h), Mr, Rp, ws, W, l, s, true, e, true, stream));
-    else TRY(lin_bwd(lin[3], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, W.ldt, ws, W, lw, l, true, e, true, stream,
+    else TRY(lin_bwd(lin[3], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, W.ldt, ws, W, R, lw, l, true, e, true, stream,
                      have_G_fc2));
     have_G_fc2 = false;
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
-    if (ex) TRY(lin_bwd_exact(lin[2], reinterpret_cast<bf16*>(ws + W.dH), reinterpret_cast<bf16*>(ws + lw.xn2), Mr, Rp, ws, W, l, s, true, e,
-                              true, stream));
-    else TRY(lin_bwd(lin[2], reinterpret_cast<bf16*>(ws + W.dH), 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, W.ldt, ws, W,
-                     lw, l, true, e, true, stream));
-    TRY(side_join(3, stream));   // fc2's products read dyb, which this LayerNorm backward overwrites
-    // dyb = dY of this block's proj: its G' = dY Vs comes out of the same kernel
+    if (ex) TRY(lin_bwd_exact(lin[2], dH, reinterpret_cast<bf16*>(ws + lw.xn2), Mr, Rp, ws, W, l, s, true, e, true, stream));
+    else TRY(lin_bwd(lin[2], dH, 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, W.ldt, ws, W, R, lw, l, true, e, true, stream));
+    // dyp = dY of this block's proj: its G' = dY Vs comes out of the same kernel
     if (fx)
       TRY(cara_layernorm_bwd_xu(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_mid), ldr, w->ln2_g + (size_t)l * D,
-                                reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyb, dp1,
-                                rps, Mr, D, lin[1].Vst, g->rank, Rp, ws + W.G[1], ws + W.Gt[1], W.ldt, stream));
+                                reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyp, dp1,
+                                rps, Mr, D, lin[1].Vst, g->rank, Rp, ws + R.G[1], ws + R.Gt[1], W.ldt, stream));
     else
       TRY(cara_layernorm_bwd(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_mid), ldr, w->ln2_g + (size_t)l * D,
-                             reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyb, dp1, rps,
+                             reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyp, dp1, rps,
                              Mr, D, stream));
     // ---- attention branch ----
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dAO; e.ldc = ldr;
     if (cls_only && hipMemsetAsync(ws + W.dAO, 0, (size_t)M * D * 2, hs) != hipSuccess) return CARA_E_LAUNCH;
-    if (ex) TRY(lin_bwd_exact(lin[1], dyb, reinterpret_cast<bf16*>(ws + lw.ao), Mr, Rp, ws, W, l, s, true, e, true, stream));
-    else TRY(lin_bwd(lin[1], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, W, lw, l, true, e, true, stream, fx));
-    TRY(side_join(0, stream));   // the previous block's qkv products still read dQKV / G'[0]
-    TRY(cara_attention_bwd(ws + lw.qkv, ws + lw.ao, ws + W.dAO, reinterpret_cast<float*>(ws + lw.lse), ws + W.dQKV, B, N,
+    if (ex) TRY(lin_bwd_exact(lin[1], dyp, reinterpret_cast<bf16*>(ws + lw.ao), Mr, Rp, ws, W, l, s, true, e, true, stream));
+    else TRY(lin_bwd(lin[1], dyp, ldr, reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, W, R, lw, l, true, e, true, stream, fx));
+    TRY(cara_attention_bwd(ws + lw.qkv, ws + lw.ao, ws + W.dAO, reinterpret_cast<float*>(ws + lw.lse), dQKV, B, N,
                            g->heads, att_scale, stream));
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
     // block 0 has nothing trainable upstream of it: its dX GEMM and LayerNorm backward are skipped
-    if (ex) TRY(lin_bwd_exact(lin[0], reinterpret_cast<bf16*>(ws + W.dQKV), reinterpret_cast<bf16*>(ws + lw.xn1), M, Rp, ws, W, l, s, l > 0, e,
-                              false, stream));
-    else TRY(lin_bwd(lin[0], reinterpret_cast<bf16*>(ws + W.dQKV), 3 * D, reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, W.ldt, ws, W,
-                     lw, l, l > 0, e, false, stream));
-    TRY(side_join(1, stream));   // proj's products read dyb, which the next LayerNorm backward overwrites
+    if (ex) TRY(lin_bwd_exact(lin[0], dQKV, reinterpret_cast<bf16*>(ws + lw.xn1), M, Rp, ws, W, l, s, l > 0, e, false, stream));
+    else TRY(lin_bwd(lin[0], dQKV, 3 * D, reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, W.ldt, ws, W, R, lw, l, l > 0, e, false, stream));
     if (l > 0) {
+      // the LayerNorm backward below starts to fill the ring slot of block l - 1: its previous user, block
+      // l - 1 + nring, must be through with it (never the case with one slot per block)
+      const Ws::Ring& Rb = W.ring[(l - 1) % W.nring];
+      if (!ex && l - 1 + W.nring < g->depth) TRY(side_join(l - 1 + W.nring, stream));
+      bf16* dyb = reinterpret_cast<bf16*>(ws + Rb.dyb_fc2);
       if (fx) {
         // dyb = dY of fc2 of the block BELOW (all M rows there: only the last block runs on cls rows)
         Lin below[4];
         make_lins(g, w, ws + W.pack, pl, l - 1, below);
         TRY(cara_layernorm_bwd_xu(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_in), D, w->ln1_g + (size_t)l * D,
                                   reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), dx, dx, dyb,
-                                  dp_prev, N, M, D, below[3].Vst, g->rank, Rp, ws + W.G[3], ws + W.Gt[3], W.ldt, stream));
+                                  dp_prev, N, M, D, below[3].Vst, g->rank, Rp, ws + Rb.G[3], ws + Rb.Gt[3], W.ldt, stream));
         have_G_fc2 = true;
       } else {
         TRY(cara_layernorm_bwd(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_in), D, w->ln1_g + (size_t)l * D,
@@ -656,8 +704,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
       }
     }
   }
-  TRY(launch_pending(stream));
-  for (int i = 0; i < 4; ++i) TRY(side_join(i, stream));   // all slabs written
+  if (!ex) TRY(side_join(0, stream));   // all slabs written (block 0's join is the last record of the in-order side stream)
   if (!ex) {   // (the exact mode wrote dU / dVs / dc of every layer directly)
     const int ins[4] = {D, D, D, 4 * D}, outs[4] = {3 * D, D, 4 * D, D};
     const int L = g->depth;

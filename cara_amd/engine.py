@@ -198,7 +198,13 @@ class CaraEngine:
         rates = [float(getattr(b.drop_path, "drop_prob", 0.0) or 0.0) for b in model.blocks]
         if not any(r > 0 for r in rates):
             return None
-        keep = 1.0 - torch.tensor(rates, device=dev).reshape(-1, 1, 1)
+        # the keep probabilities stay on the device: a host -> device copy here would make the host wait for the
+        # previous step's kernels at the top of every step (and leave the GPU idle until the queue refills)
+        key = (tuple(rates), str(dev))
+        if self.__dict__.get("_keep_key") != key:
+            self._keep = 1.0 - torch.tensor(rates, device=dev).reshape(-1, 1, 1)
+            self._keep_key = key
+        keep = self._keep
         return ((keep + torch.rand(len(rates), 2, B, device=dev)).floor_() / keep).contiguous()
 
     def forward(self, images, droppath: Optional[torch.Tensor] = None):

@@ -259,9 +259,11 @@ int cara_head_backward(const float* dlogits, const void* xn_bf16, const float* h
                        float* dhead_b, void* dxn_bf16, int B, int classes, int D, void* stream);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */
-/* Bracket the fc1 forward GEMM of every layer (the dominant kernel) with HIP events recorded on
- * the compute stream inside cara_vit_forward; read the average duration of the last forward's
- * launches after synchronising.  Process-global diagnostic state; off by default.              */
+/* Bracket the fc1 forward GEMM (the dominant kernel) of the layers l with l % enable == 0 (enable = 1: every
+ * layer; 0: off) with HIP events recorded on the compute stream inside cara_vit_forward; read the average
+ * duration of the last (up to 64) bracketed launches after synchronising.  Every bracket idles the chip for
+ * ~15 us (three event records), so a timed run brackets a few layers per step, not all.  Process-global
+ * diagnostic state; off by default.                                                                        */
 int cara_profile_fc1(int enable);
 int cara_profile_fc1_read(float* avg_ms, int* launches);   /* host pointers */
 /* The same with the markers' own cost made visible: every bracket is followed by an EMPTY bracket (two event
