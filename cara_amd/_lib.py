@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("CARA_LIB_PATH") or os.path.join(_HERE, "libcara_hip.s
 
 # every symbol include/cara_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "cara_abi_version", "cara_build_arch", "cara_gemm_bf16", "cara_gemm_scratch_bytes", "cara_debug_gemm_persistent_launches", "cara_skinny_xu",
+    "cara_abi_version", "cara_build_arch", "cara_gemm_bf16", "cara_pack_b_panels", "cara_gemm_scratch_bytes", "cara_debug_gemm_persistent_launches", "cara_skinny_xu",
     "cara_tskinny_scratch_bytes", "cara_tskinny_xtg", "cara_tskinny_partial", "cara_tskinny_partial2", "cara_tskinny_reduce", "cara_layernorm_fwd", "cara_layernorm_bwd", "cara_layernorm_fwd_xu", "cara_layernorm_bwd_xu",
     "cara_attention_fwd", "cara_attention_bwd", "cara_im2col_patches", "cara_assemble_tokens",
     "cara_cross_entropy", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_transpose_bf16_ld", "cara_pack_offsets",
@@ -36,7 +36,8 @@ class GemmArgs(C.Structure):
                 ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int),
                 ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
                 ("batch", C.c_int), ("strideA", C.c_longlong), ("strideB", C.c_longlong), ("strideC", C.c_longlong),
-                ("Ut", C.c_void_p), ("T_out", C.c_void_p), ("Tt_out", C.c_void_p), ("ldt", C.c_int)]
+                ("Ut", C.c_void_p), ("T_out", C.c_void_p), ("Tt_out", C.c_void_p), ("ldt", C.c_int),
+                ("Bp", C.c_void_p)]
 
 
 class Geom(C.Structure):
@@ -71,7 +72,8 @@ class VitWeights(C.Structure):
         "ln1_g", "ln1_b", "ln2_g", "ln2_b",
         "qkv_w", "qkv_wt", "qkv_b", "proj_w", "proj_wt", "proj_b",
         "fc1_w", "fc1_wt", "fc1_b", "fc2_w", "fc2_wt", "fc2_b",
-        "norm_g", "norm_b")]
+        "norm_g", "norm_b",
+        "qkv_wp", "qkv_wtp", "proj_wp", "proj_wtp", "fc1_wp", "fc1_wtp", "fc2_wp", "fc2_wtp")]
 
 
 class VitShape(C.Structure):
@@ -133,8 +135,9 @@ def stream() -> C.c_void_p:
 
 def gemm(A, B, out, *, epi, bias=None, A2=None, B2=None, C2=None, aux=None, rowscale=None,
          rows_per_sample=0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, scratch=None, Ut=None, T_out=None,
-         Tt_out=None):
+         Tt_out=None, Bp=None):
     a = GemmArgs()
+    a.Bp = ptr(Bp)   # optional K-panel-major image of B (pack_b_panels)
     if Ut is not None:   # adapter fully inside the GEMM: T = A Ut^T computed per tile (B2 = Vs must be given, A2 not)
         a.Ut, a.T_out, a.Tt_out = ptr(Ut), ptr(T_out), ptr(Tt_out)
         a.ldt = Tt_out.shape[1] if Tt_out is not None else 0
@@ -152,6 +155,14 @@ def gemm(A, B, out, *, epi, bias=None, A2=None, B2=None, C2=None, aux=None, rows
     a.C2, a.aux, a.rowscale = ptr(C2), ptr(aux), ptr(rowscale)
     a.rows_per_sample = rows_per_sample
     check(lib().cara_gemm_bf16(C.byref(a), stream()), "cara_gemm_bf16")
+    return out
+
+
+def pack_b_panels(B):
+    """bf16 [N, K] -> its K-panel-major image [K/32, N, 32] (cara_gemm_args::Bp)."""
+    N, K = B.shape
+    out = torch.empty(K // 32, N, 32, dtype=torch.bfloat16, device=B.device)
+    check(lib().cara_pack_b_panels(ptr(B), B.stride(0), N, K, ptr(out), stream()), "cara_pack_b_panels")
     return out
 
 

@@ -260,7 +260,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? 4
   // batched launch (blockIdx.y = product index): advance the operand pointers and the output offset
   const size_t zb = p.batch > 1 ? blockIdx.y : 0;
   const bf16* __restrict__ A = static_cast<const bf16*>(p.A) + zb * p.strideA;
-  const bf16* __restrict__ B = static_cast<const bf16*>(p.B) + zb * p.strideB;
+  // B from its K-panel-major image when there is one: row stride 64 B inside a panel, N * 32 elements per K step
+  const bool packed = p.Bp != nullptr;
+  const bf16* __restrict__ B = packed ? static_cast<const bf16*>(p.Bp) : static_cast<const bf16*>(p.B) + zb * p.strideB;
   const size_t coff = zb * p.strideC;
   f32x4 acc[MI][4];
 #pragma unroll
@@ -273,7 +275,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? 4
   const int kmul = (ablate & 64) ? 0 : BK32;
   const int uwave = __builtin_amdgcn_readfirstlane(wave);   // wave-uniform copy: scalar LDS destinations
   const TileOfs<TBM, NW> oA = tile_ofs<TBM, NW>(p.lda, m0, p.M - 1, wave, lane);
-  const TileOfs<BN, NW> oB = tile_ofs<BN, NW>(p.ldb, n0, p.N - 1, wave, lane);
+  const TileOfs<BN, NW> oB = tile_ofs<BN, NW>(packed ? BK32 : p.ldb, n0, p.N - 1, wave, lane);
+  const int kmulB = (ablate & 64) ? 0 : (packed ? p.N * BK32 : BK32);
   stage_tile32_pre<TBM, NW>(A, 0, oA, smem, uwave);
   stage_tile32_pre<BN, NW>(B, 0, oB, smem + A_BYTES, uwave);
   int cur = 0;
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? 4
     if (kt + 1 < nk) {
       char* nA = smem + (cur ^ 1) * SLOT;
       stage_tile32_pre<TBM, NW>(A, (kt + 1) * kmul, oA, nA, uwave);
-      stage_tile32_pre<BN, NW>(B, (kt + 1) * kmul, oB, nA + A_BYTES, uwave);
+      stage_tile32_pre<BN, NW>(B, (kt + 1) * kmulB, oB, nA + A_BYTES, uwave);
     }
     mma_tile32<MI>(sA, sA + A_BYTES, acc, wr, wc, lane);
     cur ^= 1;
@@ -348,7 +351,9 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
   }
   const int m0 = tm * TBM, n0 = tn * BN;
   const bf16* __restrict__ A = static_cast<const bf16*>(p.A);
-  const bf16* __restrict__ B = static_cast<const bf16*>(p.B);
+  const bool packed = p.Bp != nullptr;   // K-panel-major image of B (cara_gemm_args::Bp)
+  const bf16* __restrict__ B = static_cast<const bf16*>(packed ? p.Bp : p.B);
+  const int kmulB = packed ? p.N * BK32 : BK32;
   const bf16* __restrict__ Ut = static_cast<const bf16*>(p.Ut);
   f32x4 acc[4][4], accg[4];
 #pragma unroll
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
   };
   const int nk = p.K / BK32;
   const TileOfs<TBM, 4> oA = tile_ofs<TBM, 4>(p.lda, m0, p.M - 1, wave, lane);
-  const TileOfs<BN, 4> oB = tile_ofs<BN, 4>(p.ldb, n0, p.N - 1, wave, lane);
+  const TileOfs<BN, 4> oB = tile_ofs<BN, 4>(packed ? BK32 : p.ldb, n0, p.N - 1, wave, lane);
   stage_tile32_pre<TBM, 4>(A, 0, oA, smem, uwave);
   stage_tile32_pre<BN, 4>(B, 0, oB, smem + A_BYTES, uwave);
   stage_u(0, smem + A_BYTES + B32_BYTES);
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
     if (kt + 1 < nk) {
       char* nA = smem + (cur ^ 1) * SLOT;
       stage_tile32_pre<TBM, 4>(A, (kt + 1) * BK32, oA, nA, uwave);
-      stage_tile32_pre<BN, 4>(B, (kt + 1) * BK32, oB, nA + A_BYTES, uwave);
+      stage_tile32_pre<BN, 4>(B, (kt + 1) * kmulB, oB, nA + A_BYTES, uwave);
       stage_u((kt + 1) * BK32, nA + A_BYTES + B32_BYTES);
     }
     const char* sB = sA + A_BYTES;
@@ -655,6 +660,25 @@ static int launch_small_m(const cara_gemm_args* a, int nslab, hipStream_t st) {
   return CARA_OK;
 }
 
+// B [N, K] row-major -> K-panel-major [K/32][N][32] (cara_gemm_args::Bp): one 16-byte chunk per thread
+__global__ __launch_bounds__(256) void pack_b_panels_kernel(const bf16* __restrict__ B, int ldb, int N, int K, bf16* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)N * (K / 8);
+  if (i >= total) return;
+  const size_t panel = i / ((size_t)N * 4), rem = i - panel * (size_t)N * 4;
+  const size_t n = rem >> 2, c = rem & 3;
+  *reinterpret_cast<uint4*>(out + i * 8) = *reinterpret_cast<const uint4*>(B + n * ldb + panel * 32 + c * 8);
+}
+
+extern "C" int cara_pack_b_panels(const void* B, int ldb, int N, int K, void* out, void* stream) {
+  if (!B || !out || N <= 0 || K <= 0 || (K % 32) || ldb < K || (ldb & 7)) return CARA_E_ARG;
+  const size_t total = (size_t)N * (K / 8);
+  hipLaunchKernelGGL(pack_b_panels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const bf16*>(B), ldb, N, K, static_cast<bf16*>(out));
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
 extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->B || !a->C) return CARA_E_ARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % BK) != 0) return CARA_E_ARG;
@@ -680,7 +704,7 @@ extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
     }
   }
   if (a->batch > 1) {   // batched products: the default kernel family only, plain epilogues
-    if (!small_ptrs || a->A2 || a->aux || a->C2 || !(a->epi == CARA_EPI_F32 || a->epi == CARA_EPI_BF16) || a->batch > 65535) return CARA_E_ARG;
+    if (!small_ptrs || a->A2 || a->aux || a->C2 || a->Bp || !(a->epi == CARA_EPI_F32 || a->epi == CARA_EPI_BF16) || a->batch > 65535) return CARA_E_ARG;
     return a->epi == CARA_EPI_F32 ? launch32<CARA_EPI_F32>(a, st) : launch32<CARA_EPI_BF16>(a, st);
   }
   if (const int nslab = small_ptrs ? small_m_slabs(a) : 0) {

@@ -241,6 +241,7 @@ struct Lin {  // one adapted linear of one layer
   const bf16 *Ut, *U, *Vs, *Vst;
   const float* bias;
   int in, out, slot;
+  const bf16 *Wp = nullptr, *Wtp = nullptr;   // K-panel-major images of W / Wt (cara_gemm_args::Bp), or null
 };
 
 // CARA_FUSE_XU=0 keeps the K = dim adapter contractions (T = LN(x) U of qkv / fc1, G' = dY Vs of proj / fc2) as
@@ -286,7 +287,7 @@ int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char*
   bf16* Tt = reinterpret_cast<bf16*>(ws + lw.Tt[L.slot]);
   const bool inside = !have_T && fuse_gemm_t(Mr, Rp, false);   // T computed by the GEMM itself
   if (!have_T && !inside) TRY(cara_skinny_xu(X, ldx, L.Ut, T, Tt, ldt, Mr, L.in, Rp, st));
-  a.A = X; a.lda = ldx; a.B = L.W; a.ldb = L.in; a.A2 = inside ? nullptr : T; a.B2 = L.Vs; a.Rp = Rp;
+  a.A = X; a.lda = ldx; a.B = L.W; a.Bp = L.Wp; a.ldb = L.in; a.A2 = inside ? nullptr : T; a.B2 = L.Vs; a.Rp = Rp;
   if (inside) { a.Ut = L.Ut; a.T_out = T; a.Tt_out = Tt; a.ldt = ldt; }
   a.M = Mr; a.N = L.out; a.K = L.in; a.bias = L.bias;
   if (a.ldc == 0) a.ldc = L.out;
@@ -313,7 +314,7 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
   const bool last = L.slot == 0;   // a block's backward ends with qkv
   if (inside) {
     if (flush_before(L.slot, layer)) TRY(flush_jobs(st, layer, false));   // earlier linears' products run under this GEMM
-    a.A = dY; a.lda = lddy; a.B = L.Wt; a.ldb = L.out; a.A2 = nullptr; a.B2 = L.U; a.Rp = Rp;
+    a.A = dY; a.lda = lddy; a.B = L.Wt; a.Bp = L.Wtp; a.ldb = L.out; a.A2 = nullptr; a.B2 = L.U; a.Rp = Rp;
     a.Ut = L.Vst; a.T_out = G; a.Tt_out = Gt; a.ldt = ldt;
     a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
     if (a.ldc == 0) a.ldc = L.in;
@@ -325,7 +326,7 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
   g_jobs.job[g_jobs.n++] = job;
   if (flush_before(L.slot, layer)) TRY(flush_jobs(st, layer, last));   // fork: G' exists, the dX GEMM comes next
   if (want_dx) {
-    a.A = dY; a.lda = lddy; a.B = L.Wt; a.ldb = L.out; a.A2 = G; a.B2 = L.U; a.Rp = Rp;
+    a.A = dY; a.lda = lddy; a.B = L.Wt; a.Bp = L.Wtp; a.ldb = L.out; a.A2 = G; a.B2 = L.U; a.Rp = Rp;
     a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
     if (a.ldc == 0) a.ldc = L.in;
     with_scratch(a);
@@ -403,6 +404,16 @@ void make_lins(const cara_geom* g, const cara_vit_weights* w, const char* pack, 
                reinterpret_cast<const float*>(pk + pl.bias_fc1), (int)D, (int)(4 * D), 2};
   out[3] = Lin{B(w->fc2_w, l * 4 * D * D), B(w->fc2_wt, l * 4 * D * D), P(pl.Ut_fc2), P(pl.U_fc2), P(pl.Vs_fc2), P(pl.Vst_fc2),
                reinterpret_cast<const float*>(pk + pl.bias_fc2), (int)(4 * D), (int)D, 3};
+  // CARA_GEMM_PACKED=0: stage the weights from their row-major images (A/B measurements)
+  static const bool use_packed = [] { const char* e = getenv("CARA_GEMM_PACKED"); return !(e && atoi(e) == 0); }();
+  if (use_packed) {
+    const void* wp[4][2] = {{w->qkv_wp, w->qkv_wtp}, {w->proj_wp, w->proj_wtp}, {w->fc1_wp, w->fc1_wtp}, {w->fc2_wp, w->fc2_wtp}};
+    for (int i = 0; i < 4; ++i) {
+      const size_t elems = (size_t)l * out[i].in * out[i].out;
+      if (wp[i][0]) out[i].Wp = B(wp[i][0], elems);
+      if (wp[i][1]) out[i].Wtp = B(wp[i][1], elems);
+    }
+  }
 }
 
 // Optional HIP-event bracket around the dominant kernel (the fc1 forward GEMM, one per layer) so
@@ -581,7 +592,7 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
       bf16* T = reinterpret_cast<bf16*>(ws + lw.T[2]);
       if (!fx) TRY(cara_skinny_xu(ws + lw.xn2, D, lin[2].Ut, T, ws + lw.Tt[2], W.ldt, M, D, Rp, stream));
       cara_gemm_args a2 = e;
-      a2.A = ws + lw.xn2; a2.lda = D; a2.B = lin[2].W; a2.ldb = D; a2.A2 = T; a2.B2 = lin[2].Vs; a2.Rp = Rp;
+      a2.A = ws + lw.xn2; a2.lda = D; a2.B = lin[2].W; a2.Bp = lin[2].Wp; a2.ldb = D; a2.A2 = T; a2.B2 = lin[2].Vs; a2.Rp = Rp;
       a2.M = M; a2.N = 4 * D; a2.K = D; a2.bias = lin[2].bias; a2.ldc = 4 * D;
       with_scratch(a2);
       hipEvent_t* ev = g_prof.ev[g_prof.n % 64];

@@ -82,13 +82,17 @@ class CaraEngine:
             return torch.stack([t.detach().to(dev, torch.float32) for t in ts]).contiguous()
 
         def bf16_pair(ws, out_f, in_f):
+            """-> W, W^T row-major and both once more as K-panel-major images (the layout the GEMMs stage from)."""
             src = f32(ws)  # [depth, out, in]
             w = torch.empty(depth, out_f, in_f, dtype=torch.bfloat16, device=dev)
             wt = torch.empty(depth, in_f, out_f, dtype=torch.bfloat16, device=dev)
+            wp, wtp = torch.empty_like(w), torch.empty_like(wt)
             check(lib.cara_f32_to_bf16(ptr(src), ptr(w), C.c_size_t(src.numel()), stream()), "cara_f32_to_bf16")
             for l in range(depth):
                 check(lib.cara_transpose_bf16(ptr(w[l]), ptr(wt[l]), out_f, in_f, stream()), "cara_transpose_bf16")
-            return w, wt
+                check(lib.cara_pack_b_panels(ptr(w[l]), in_f, out_f, in_f, ptr(wp[l]), stream()), "cara_pack_b_panels")
+                check(lib.cara_pack_b_panels(ptr(wt[l]), out_f, in_f, out_f, ptr(wtp[l]), stream()), "cara_pack_b_panels")
+            return w, wt, wp, wtp
 
         t = {}
         pw = model.patch_embed.proj.weight.detach().to(dev, torch.float32).reshape(D, -1).contiguous()
@@ -99,10 +103,10 @@ class CaraEngine:
         t["pos"] = model.pos_embed.detach().to(dev, torch.float32).reshape(-1, D).contiguous()
         t["ln1_g"], t["ln1_b"] = f32([b.norm1.weight for b in blocks]), f32([b.norm1.bias for b in blocks])
         t["ln2_g"], t["ln2_b"] = f32([b.norm2.weight for b in blocks]), f32([b.norm2.bias for b in blocks])
-        t["qkv_w"], t["qkv_wt"] = bf16_pair([b.attn.qkv.weight for b in blocks], 3 * D, D)
-        t["proj_w"], t["proj_wt"] = bf16_pair([b.attn.proj.weight for b in blocks], D, D)
-        t["fc1_w"], t["fc1_wt"] = bf16_pair([b.mlp.fc1.weight for b in blocks], 4 * D, D)
-        t["fc2_w"], t["fc2_wt"] = bf16_pair([b.mlp.fc2.weight for b in blocks], D, 4 * D)
+        t["qkv_w"], t["qkv_wt"], t["qkv_wp"], t["qkv_wtp"] = bf16_pair([b.attn.qkv.weight for b in blocks], 3 * D, D)
+        t["proj_w"], t["proj_wt"], t["proj_wp"], t["proj_wtp"] = bf16_pair([b.attn.proj.weight for b in blocks], D, D)
+        t["fc1_w"], t["fc1_wt"], t["fc1_wp"], t["fc1_wtp"] = bf16_pair([b.mlp.fc1.weight for b in blocks], 4 * D, D)
+        t["fc2_w"], t["fc2_wt"], t["fc2_wp"], t["fc2_wtp"] = bf16_pair([b.mlp.fc2.weight for b in blocks], D, 4 * D)
         t["qkv_b"] = f32([b.attn.qkv.bias for b in blocks])
         t["proj_b"] = f32([b.attn.proj.bias for b in blocks])
         t["fc1_b"] = f32([b.mlp.fc1.bias for b in blocks])

@@ -68,8 +68,16 @@ typedef struct {
   void* T_out;
   void* Tt_out;
   int ldt;
+  /* Optional second image of B in K-PANEL-MAJOR layout (cara_pack_b_panels): bf16 [K/32][N][32], i.e. the 32     */
+  /* columns of K step t of ALL rows are contiguous, so the 128 x 32 operand tile of a K step is one 8-KiB run of  */
+  /* full cache lines instead of 128 half lines 2*ldb bytes apart (the L2 -> LDS path delivers ~30 % more tile     */
+  /* bytes per second that way, tools/micro/kloop_bw.hip).  Frozen weights are packed once at ingest.  The 32-     */
+  /* column-step kernels read it INSTEAD of B when non-NULL; B must still be valid (other kernel families).       */
+  const void* Bp;
 } cara_gemm_args;
 int cara_gemm_bf16(const cara_gemm_args* a, void* stream);
+/* B bf16 [N, K] (row stride ldb) -> out bf16 [K/32][N][32] (cara_gemm_args::Bp); K % 32 == 0 */
+int cara_pack_b_panels(const void* B, int ldb, int N, int K, void* out, void* stream);
 size_t cara_gemm_scratch_bytes(void);
 /* number of launches of the persistent 256x256 kernel so far in this process (tests assert the path taken) */
 long cara_debug_gemm_persistent_launches(void);
@@ -228,6 +236,9 @@ typedef struct {           /* frozen backbone (timm 0.4.12 VisionTransformer), d
   const void *fc1_w, *fc1_wt;   const float* fc1_b;    /* bf16 [depth,4dim,dim], [depth,dim,4dim] */
   const void *fc2_w, *fc2_wt;   const float* fc2_b;    /* bf16 [depth,dim,4dim], [depth,4dim,dim] */
   const float *norm_g, *norm_b; /* fp32 [dim]                                                    */
+  /* optional (NULL = unused): the eight matrices above once more as K-panel-major images, per layer
+   * [K/32][N][32] with N x K the shape of the row-major matrix (cara_pack_b_panels, cara_gemm_args::Bp) */
+  const void *qkv_wp, *qkv_wtp, *proj_wp, *proj_wtp, *fc1_wp, *fc1_wtp, *fc2_wp, *fc2_wtp;
 } cara_vit_weights;
 typedef struct {
   int B, img, patch, chans, tokens, num_classes;

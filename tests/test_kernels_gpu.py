@@ -129,6 +129,36 @@ def test_gemm_with_adapter_inside(M, N, K, rank):
     close(h, torch.nn.functional.gelu(ref), 2 ** -8, 2e-3 * math.sqrt(K / 64) + 2e-3, "adapter inside, gelu h")
 
 
+@pytest.mark.parametrize("M,N,K,Rp", [(12608, 768, 3072, 32), (1500, 3072, 768, 32), (333, 300, 128, 0), (4096, 2304, 768, 64)])
+def test_gemm_b_in_k_panel_major_layout(M, N, K, Rp):
+    """cara_gemm_args.Bp: the same B as [K/32][N][32] panels (cara_pack_b_panels).  Only the addresses the operand
+    tiles are fetched from change, so every result is BITWISE what the row-major image gives -- plain, with the
+    K-extension, with the adapter inside, ragged N."""
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    Bp = L().pack_b_panels(B)
+    assert torch.equal(Bp, B.view(N, K // 32, 32).permute(1, 0, 2).contiguous())
+    bias = rnd(N, seed=5, dtype=torch.float32)
+    kw = dict(epi=L().EPI_F32, bias=bias)
+    if Rp:
+        kw.update(A2=rnd(M, Rp, seed=3), B2=rnd(N, Rp, seed=4, scale=0.3))
+    o1 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    o2 = torch.full_like(o1, float("nan"))
+    L().gemm(A, B, o1, **kw)
+    L().gemm(A, B, o2, Bp=Bp, **kw)
+    assert torch.equal(o1, o2)
+    ref = A.double() @ B.double().t() + bias.double()
+    if Rp:
+        ref = ref + kw["A2"].double() @ kw["B2"].double().t()
+    close(o2, ref, 1e-4, 1e-3 * math.sqrt(K / 64) + 2e-3, "gemm with packed B")
+    if Rp == 32:   # adapter inside
+        Ut = rnd(32, K, seed=6, scale=0.1)
+        T1, T2 = (torch.empty(M, 32, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+        h1, h2, u1, u2 = (torch.empty(M, N, dtype=torch.bfloat16, device=DEV) for _ in range(4))
+        L().gemm(A, B, h1, epi=L().EPI_GELU, bias=bias, B2=kw["B2"], C2=u1, Ut=Ut, T_out=T1)
+        L().gemm(A, B, h2, epi=L().EPI_GELU, bias=bias, B2=kw["B2"], C2=u2, Ut=Ut, T_out=T2, Bp=Bp)
+        assert torch.equal(h1, h2) and torch.equal(u1, u2) and torch.equal(T1, T2)
+
+
 @pytest.mark.parametrize("M,N,K,Rp", [(64, 768, 3072, 32), (64, 3072, 768, 32), (64, 768, 768, 64), (17, 300, 2304, 0), (128, 768, 768, 32)])
 def test_gemm_few_rows_split_k(M, N, K, Rp):
     """Few-row products with caller scratch: K slabs in one batched launch + a finishing kernel (bias, rank-R term,

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--shape", action="append", default=[],
                     help="M,N,K[,epi] instead of the block shapes (repeatable), e.g. 4096,4096,768,bf16")
     ap.add_argument("--sk", action="store_true", help="give the GEMM stream-K scratch (persistent kernel)")
+    ap.add_argument("--packed", action="store_true", help="give the GEMM the K-panel-major image of B as well (Bp)")
     ap.add_argument("--blas", action="store_true",
                     help="also time torch.matmul (hipBLASLt, plain GEMM, no adapter columns, no epilogue) on the "
                          "same operands: a known-good ceiling for these shapes, measurement only")
@@ -51,6 +52,8 @@ def main():
         B2 = (torch.randn(N, args.rp, generator=g) * 0.02).bfloat16().to(dev)
         bias = torch.randn(N, generator=g).to(dev)
         kw = dict(A2=A2, B2=B2, bias=bias)
+        if args.packed:
+            kw["Bp"] = L.pack_b_panels(B)
         if args.sk:
             kw["scratch"] = scratch
         if epi == "bf16":

@@ -37,6 +37,9 @@ __global__ __launch_bounds__(256, 4) void kloop(const char* __restrict__ src, fl
       if (MODE & 8) {   // pieces 0-7: A rows, 8-15: B rows; row r of the tile, K step it: 64 B at r * 1536 + (it % 24) * 64
         const int r = (q & 7) * 16 + (lane >> 2);
         g = src + ((size_t)(blockIdx.x % 96) * 128 + (q >> 3) * 12288 + r) * 1536 + (it % 24) * 64 + (lane & 3) * 16;
+        // MODE bit 16: the B operand (pieces 8-15) is K-panel major, [K/32][N = 3072][32]: a tile's K step is 8 KiB contiguous
+        if ((MODE & 16) && q >= 8)
+          g = src + (40u << 20) + ((size_t)(it % 24) * 3072 + (blockIdx.x % 24) * 128) * 64 + (q & 7) * 1024 + lane * 16;
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(buf + q * 1024), 16, 0, 0);
@@ -148,6 +151,85 @@ void run256(int wpc, const char* src, float* out, size_t span) {
          ms * 1e3 / iters, tf);
 }
 
+
+// 128x128x64 step (BK = 64): 32 KiB per step, 8 pieces of 1 KiB per wave, 32 MFMAs per wave; double buffer = 64 KiB
+// per workgroup.  SEG = 0: 1-KiB contiguous pieces; SEG = 1: GEMM-like, a piece is 8 rows x 128 B (full cache lines)
+// of a row-major [rows][3072 B] operand.
+template <int SEG>
+__global__ __launch_bounds__(256, 2) void kloop64(const char* __restrict__ src, float* __restrict__ out, int iters, size_t span) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int SLOT = 32768;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const char* base = src + ((size_t)blockIdx.x * 128 * 1024) % span;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto stage = [&](int it) {
+    char* buf = smem + (it & 1) * SLOT;
+    const char* s = base + (size_t)(it & 3) * SLOT;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int q = wave * 8 + p;   // pieces 0-15: A rows (8 rows each), 16-31: B rows
+      const char* g = s + q * 1024 + lane * 16;
+      if (SEG) {
+        const int r = (q & 15) * 8 + (lane >> 3);
+        g = src + ((size_t)(blockIdx.x % 96) * 128 + (q >> 4) * 12288 + r) * 3072 + (it % 24) * 128 + (lane & 7) * 16;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(buf + q * 1024), 16, 0, 0);
+    }
+  };
+  stage(0);
+  for (int it = 0; it < iters; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    stage(it + 1);
+    const char* sA = smem + (it & 1) * SLOT;
+    const char* sB = sA + 16384;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = *reinterpret_cast<const bf16x8*>(sA + (wr * 64 + i * 16 + fr) * 128 + (((kk * 4 + fq) ^ (fr & 7)) << 4));
+        b[i] = *reinterpret_cast<const bf16x8*>(sB + (wc * 64 + i * 16 + fr) * 128 + (((kk * 4 + fq) ^ (fr & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (s == 123.456f) out[blockIdx.x] = s;
+}
+
+template <int SEG>
+void run64(int wpc, const char* src, float* out, size_t span) {
+  const int cus = 256, iters = 1000;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kloop64<SEG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(kloop64<SEG>, dim3(cus * wpc), dim3(256), 2 * 32768, 0, src, out, 50, span);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL(kloop64<SEG>, dim3(cus * wpc), dim3(256), 2 * 32768, 0, src, out, iters, span);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double tf = 2.0 * 128 * 128 * 64 * (double)cus * wpc * iters / (ms * 1e-3) / 1e12;
+  printf("%-44s %d WG/CU: %6.3f us per K step per WG  -> %7.1f TF/s-equivalent\n",
+         SEG ? "the K loop at 128x128x64, 128-B row segments" : "the K loop at 128x128x64, contiguous pieces", wpc, ms * 1e3 / iters, tf);
+}
+
 template <int MODE, int PF>
 void run(const char* name, int wpc, const char* src, float* out, size_t span) {
   const int cus = 256, iters = 2000;
@@ -169,9 +251,11 @@ void run(const char* name, int wpc, const char* src, float* out, size_t span) {
 }
 
 int main() {
-  const size_t span = 48u << 20;
+  const size_t span = 96u << 20;
   char* src; float* out;
   CK(hipMalloc(&src, span + (1 << 20))); CK(hipMemset(src, 0x3c, span + (1 << 20))); CK(hipMalloc(&out, 1 << 20));
+  for (int wpc : {1, 2}) { run64<0>(wpc, src, out, span); run64<1>(wpc, src, out, span); }
+  for (int wpc : {3}) { run<7, 1>("stage + frag reads + MFMA (the K loop)", wpc, src, out, span); run<15, 1>("the K loop, GEMM-like 64-B row segments", wpc, src, out, span); }
   for (int wpc : {1, 2, 4}) {
     run<1, 1>("stage", wpc, src, out, span);
     run<3, 1>("stage + frag reads", wpc, src, out, span);
@@ -181,6 +265,7 @@ int main() {
     run<7, 2>("the K loop, 2 K steps of prefetch", wpc, src, out, span);
     run<9, 1>("stage, GEMM-like 64-B row segments", wpc, src, out, span);
     run<15, 1>("the K loop, GEMM-like 64-B row segments", wpc, src, out, span);
+    run<31, 1>("the K loop, A row segments + B K-panel major", wpc, src, out, span);
   }
   for (int wpc : {1, 2, 3}) run256(wpc, src, out, span);
   return 0;
