@@ -37,7 +37,7 @@ class GemmArgs(C.Structure):
                 ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
                 ("batch", C.c_int), ("strideA", C.c_longlong), ("strideB", C.c_longlong), ("strideC", C.c_longlong),
                 ("Ut", C.c_void_p), ("T_out", C.c_void_p), ("Tt_out", C.c_void_p), ("ldt", C.c_int),
-                ("Bp", C.c_void_p)]
+                ("Bp", C.c_void_p), ("a_panels", C.c_int), ("c_panels", C.c_int)]
 
 
 class Geom(C.Structure):
@@ -135,9 +135,10 @@ def stream() -> C.c_void_p:
 
 def gemm(A, B, out, *, epi, bias=None, A2=None, B2=None, C2=None, aux=None, rowscale=None,
          rows_per_sample=0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, scratch=None, Ut=None, T_out=None,
-         Tt_out=None, Bp=None):
+         Tt_out=None, Bp=None, a_panels=0, c_panels=0):
     a = GemmArgs()
     a.Bp = ptr(Bp)   # optional K-panel-major image of B (pack_b_panels)
+    a.a_panels, a.c_panels = a_panels, c_panels   # A given / C written as [K/32][P][32] panels
     if Ut is not None:   # adapter fully inside the GEMM: T = A Ut^T computed per tile (B2 = Vs must be given, A2 not)
         a.Ut, a.T_out, a.Tt_out = ptr(Ut), ptr(T_out), ptr(Tt_out)
         a.ldt = Tt_out.shape[1] if Tt_out is not None else 0
@@ -174,15 +175,24 @@ def gemm_persistent_launches() -> int:
     return int(lib().cara_debug_gemm_persistent_launches())
 
 
-def skinny_xu(X, Ut, T, Tt=None):
-    M, K = X.shape
+def skinny_xu(X, Ut, T, Tt=None, panels=False):
+    """panels: X is the K-panel-major image [K/32, M, 32] of the [M, K] operand (ldx = -M)."""
+    M, K = (X.shape[1], X.shape[0] * 32) if panels else X.shape
     Rp = Ut.shape[0]
     ldt = Tt.shape[1] if Tt is not None else 0
-    check(lib().cara_skinny_xu(ptr(X), K, ptr(Ut), ptr(T), ptr(Tt), ldt, M, K, Rp, stream()), "cara_skinny_xu")
+    check(lib().cara_skinny_xu(ptr(X), -M if panels else K, ptr(Ut), ptr(T), ptr(Tt), ldt, M, K, Rp, stream()), "cara_skinny_xu")
     return T
 
 
-def tskinny_xtg(X, Gt, D, colsum=None, M=None):
+def tskinny_xtg(X, Gt, D, colsum=None, M=None, panels=False):
+    """panels: X is the K-panel-major image [K1/32, M, 32] of the [M, K1] operand (ldx = -M)."""
+    if panels:
+        K1, M = X.shape[0] * 32, X.shape[1]
+        nbytes = lib().cara_tskinny_scratch_bytes(M, K1, Gt.shape[0])
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
+        check(lib().cara_tskinny_xtg(ptr(X), -M, ptr(Gt), Gt.shape[1], ptr(D), ptr(colsum), ptr(scratch),
+                                     M, K1, Gt.shape[0], stream()), "cara_tskinny_xtg")
+        return D
     M = M if M is not None else X.shape[0]
     K1 = X.shape[1]
     Rp = Gt.shape[0]

@@ -274,9 +274,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? 4
   const int nk = (ablate & 32) ? 1 : p.K / BK32;
   const int kmul = (ablate & 64) ? 0 : BK32;
   const int uwave = __builtin_amdgcn_readfirstlane(wave);   // wave-uniform copy: scalar LDS destinations
-  const TileOfs<TBM, NW> oA = tile_ofs<TBM, NW>(p.lda, m0, p.M - 1, wave, lane);
+  const TileOfs<TBM, NW> oA = tile_ofs<TBM, NW>(p.a_panels ? BK32 : p.lda, m0, p.M - 1, wave, lane);
   const TileOfs<BN, NW> oB = tile_ofs<BN, NW>(packed ? BK32 : p.ldb, n0, p.N - 1, wave, lane);
   const int kmulB = (ablate & 64) ? 0 : (packed ? p.N * BK32 : BK32);
+  const int kmulA = p.a_panels ? ((ablate & 64) ? 0 : p.a_panels * BK32) : kmul;   // K-panel-major A: a_panels rows per panel
   stage_tile32_pre<TBM, NW>(A, 0, oA, smem, uwave);
   stage_tile32_pre<BN, NW>(B, 0, oB, smem + A_BYTES, uwave);
   int cur = 0;
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? 4
     char* sA = smem + cur * SLOT;
     if (kt + 1 < nk) {
       char* nA = smem + (cur ^ 1) * SLOT;
-      stage_tile32_pre<TBM, NW>(A, (kt + 1) * kmul, oA, nA, uwave);
+      stage_tile32_pre<TBM, NW>(A, (kt + 1) * kmulA, oA, nA, uwave);
       stage_tile32_pre<BN, NW>(B, (kt + 1) * kmulB, oB, nA + A_BYTES, uwave);
     }
     mma_tile32<MI>(sA, sA + A_BYTES, acc, wr, wc, lane);
@@ -370,7 +371,8 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
     if (uwave < 2) glds16(reinterpret_cast<const char*>(Ut + k0) + offU, dst + uwave * 1024);
   };
   const int nk = p.K / BK32;
-  const TileOfs<TBM, 4> oA = tile_ofs<TBM, 4>(p.lda, m0, p.M - 1, wave, lane);
+  const TileOfs<TBM, 4> oA = tile_ofs<TBM, 4>(p.a_panels ? BK32 : p.lda, m0, p.M - 1, wave, lane);
+  const int kmulA = p.a_panels ? p.a_panels * BK32 : BK32;
   const TileOfs<BN, 4> oB = tile_ofs<BN, 4>(packed ? BK32 : p.ldb, n0, p.N - 1, wave, lane);
   stage_tile32_pre<TBM, 4>(A, 0, oA, smem, uwave);
   stage_tile32_pre<BN, 4>(B, 0, oB, smem + A_BYTES, uwave);
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
     char* sA = smem + cur * SLOT;
     if (kt + 1 < nk) {
       char* nA = smem + (cur ^ 1) * SLOT;
-      stage_tile32_pre<TBM, 4>(A, (kt + 1) * BK32, oA, nA, uwave);
+      stage_tile32_pre<TBM, 4>(A, (kt + 1) * kmulA, oA, nA, uwave);
       stage_tile32_pre<BN, 4>(B, (kt + 1) * kmulB, oB, nA + A_BYTES, uwave);
       stage_u((kt + 1) * BK32, nA + A_BYTES + B32_BYTES);
     }
@@ -682,12 +684,19 @@ extern "C" int cara_pack_b_panels(const void* B, int ldb, int N, int K, void* ou
 extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->B || !a->C) return CARA_E_ARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % BK) != 0) return CARA_E_ARG;
-  if (a->lda < a->K || a->ldb < a->K || (a->lda & 7) || (a->ldb & 7) || a->ldc < a->N) return CARA_E_ARG;
+  if ((!a->a_panels && (a->lda < a->K || (a->lda & 7))) || a->ldb < a->K || (a->ldb & 7) || a->ldc < a->N) return CARA_E_ARG;
+  const bool panels = a->a_panels || a->c_panels;
+  if (panels) {   // K-panel-major activations: default kernel family, bf16 outputs
+    if (a->a_panels < 0 || a->c_panels < 0 || (a->a_panels && a->a_panels < a->M) || (a->c_panels && a->c_panels < a->M) || (a->K % BK32))
+      return CARA_E_ARG;
+    if (a->c_panels && ((a->N & 31) || !(a->epi == CARA_EPI_BF16 || a->epi == CARA_EPI_GELU || a->epi == CARA_EPI_DGELU))) return CARA_E_ARG;
+    if (a->batch > 1 || a->M <= 128) return CARA_E_ARG;
+  }
   if (!(a->Rp == 0 || a->Rp == 32 || a->Rp == 64)) return CARA_E_ARG;
   if (a->Rp && ((!a->A2 && !a->Ut) || !a->B2)) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // the BK = 32 kernels address their operands with 32-bit byte offsets from the (batch-adjusted) base pointer
-  const bool small_ptrs = (unsigned long long)a->M * a->lda * 2 < (1ull << 32) && (unsigned long long)a->N * a->ldb * 2 < (1ull << 32);
+  const bool small_ptrs = (unsigned long long)a->M * (a->a_panels ? 32 : a->lda) * 2 < (1ull << 32) && (unsigned long long)a->N * a->ldb * 2 < (1ull << 32);
   if (a->epi == CARA_EPI_GELU && !a->C2) return CARA_E_ARG;
   if (a->epi == CARA_EPI_RESID && (!a->aux || (a->rowscale && a->rows_per_sample <= 0))) return CARA_E_ARG;
   if (a->epi == CARA_EPI_DGELU && !a->aux) return CARA_E_ARG;
@@ -718,6 +727,7 @@ extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
     }
   }
   const int tile = tile_choice(a);
+  if (panels && (tile == 256 || tile == 1282 || use_stream_k(a) || !use_bk32() || !small_ptrs || bm_choice(a) != 128)) return CARA_E_ARG;
   if (tile == 256) return cara_gemm256_dispatch(a, st);
   if (tile == 1282) return cara_gemm128x256_dispatch(a, st);   // 128 x 256
   if (use_stream_k(a)) return cara_gemm_sk_dispatch(a, st);

@@ -85,7 +85,9 @@ __device__ __forceinline__ void epilogue_rows(const cara_gemm_args& p, const flo
 #pragma unroll
         for (int k = 0; k < 8; ++k) out[k] = (bf16)(v[k] * gelu_erf_grad((float)u[k]));
       }
-      bf16* dst = static_cast<bf16*>(p.C) + o + coff;
+      // C as K-panel-major [N/32][c_panels][32] (the next GEMM's A operand): the 8 columns stay inside one panel
+      bf16* dst = p.c_panels ? static_cast<bf16*>(p.C) + ((size_t)(n >> 5) * p.c_panels + m) * 32 + (n & 31)
+                             : static_cast<bf16*>(p.C) + o + coff;
       if (vec) {
         *reinterpret_cast<bf16x8*>(dst) = out;
         if constexpr (EPI == CARA_EPI_GELU) *reinterpret_cast<bf16x8*>(static_cast<bf16*>(p.C2) + o) = out2;

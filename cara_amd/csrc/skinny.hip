@@ -40,11 +40,17 @@ __global__ __launch_bounds__(1024) void skinny_xu_sliced_kernel(const bf16* __re
     for (int j = 0; j < NT; ++j) u[ks][j] = *reinterpret_cast<const bf16x8*>(Ut + (size_t)(j * 16 + fr) * K + k0 + ks * 32);
   const int mblk = blockIdx.x * (16 * XU_GROUPS);
   bf16x8 a[KS], an[KS];
+  // ldx < 0: X is K-panel-major, [K/32][-ldx rows][32] (cara_gemm_args::c_panels): element (r, k0 + 32 ks) sits at
+  // ((wave * KS + ks) * rows + r) * 32 + fq * 8 -- a wave's load is one contiguous KiB
+  const size_t prow = ldx < 0 ? (size_t)(-ldx) : 0;
+  auto xptr = [&](int r, int ks) {
+    return prow ? X + ((size_t)(wave * KS + ks) * prow + r) * 32 + fq * 8 : X + (size_t)r * ldx + k0 + ks * 32;
+  };
   {
     int r = mblk + fr;
     r = r < M ? r : M - 1;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(X + (size_t)r * ldx + k0 + ks * 32);
+    for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(xptr(r, ks));
   }
 #pragma unroll
   for (int g = 0; g < XU_GROUPS; ++g) {
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(1024) void skinny_xu_sliced_kernel(const bf16* __re
       int r = m0 + 16 + fr;
       r = r < M ? r : M - 1;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) an[ks] = *reinterpret_cast<const bf16x8*>(X + (size_t)r * ldx + k0 + ks * 32);
+      for (int ks = 0; ks < KS; ++ks) an[ks] = *reinterpret_cast<const bf16x8*>(xptr(r, ks));
     }
     f32x4 acc[NT];
 #pragma unroll
@@ -111,13 +117,15 @@ __global__ __launch_bounds__(256) void skinny_xu_kernel(const bf16* __restrict__
   for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   int r0 = m0 + fr;
   r0 = r0 < M ? r0 : M - 1;
-  const bf16* xa = X + (size_t)r0 * ldx + fq * 8;
+  // ldx < 0: X is K-panel-major, [K/32][-ldx rows][32]: K step ks of row r0 sits at (ks * rows + r0) * 32
+  const bf16* xa = ldx < 0 ? X + (size_t)r0 * 32 + fq * 8 : X + (size_t)r0 * ldx + fq * 8;
+  const size_t kstride = ldx < 0 ? (size_t)(-ldx) * 32 : 32;
   const bf16* ub = Ut + (size_t)fr * K + fq * 8;
   const int nks = K >> 5;
   // wave w takes k-steps w, w+4, ...: the four waves read adjacent 64-B pieces of each row
 #pragma unroll 6
   for (int ks = wave; ks < nks; ks += 4) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(xa + ks * 32);
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(xa + ks * kstride);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const bf16x8 b = *reinterpret_cast<const bf16x8*>(ub + (size_t)j * 16 * K + ks * 32);
@@ -189,12 +197,15 @@ __device__ __forceinline__ void ts_issue(const bf16* __restrict__ X, int ldx, co
                                          int ldg, int i0, int m0, int M, char* stage, int lane) {
   // X tile: piece q = rows 8q..8q+7; lane -> row 8q + lane/8, 16-B slot lane%8 holding global
   // chunk (lane%8) ^ q  (reader of row group fq = q reads chunk c ^ fq: bank-conflict free)
+  // ldx < 0: X is K-panel-major, [K1/32][-ldx rows][32]: chunk cg of the 64 columns = panel i0/32 + cg/4, 16-B piece cg%4
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     int m = m0 + q * 8 + (lane >> 3);
     m = m < M ? m : M - 1;
     const int cg = (lane & 7) ^ q;
-    glds16(X + (size_t)m * ldx + i0 + cg * 8, stage + q * 1024);
+    const bf16* src = ldx < 0 ? X + ((size_t)((i0 >> 5) + (cg >> 2)) * (size_t)(-ldx) + m) * 32 + (cg & 3) * 8
+                              : X + (size_t)m * ldx + i0 + cg * 8;
+    glds16(src, stage + q * 1024);
   }
   // Gt tile: [Rp][32 m] bf16, 64-B rows; piece p = rows 16p..16p+15, lane -> row lane/4, chunk lane%4
 #pragma unroll
@@ -363,7 +374,10 @@ __global__ void tskinny_reduce_kernel(const char* __restrict__ slabs_base, size_
 
 extern "C" int cara_skinny_xu(const void* X, int ldx, const void* Ut, void* T, void* Tt, int ldt,
                               int M, int K, int Rp, void* stream) {
-  if (!X || !Ut || !T || M <= 0 || K <= 0 || (K & 31) || (ldx & 7) || ldx < K) return CARA_E_ARG;
+  if (!X || !Ut || !T || M <= 0 || K <= 0 || (K & 31)) return CARA_E_ARG;
+  // ldx < 0: X is K-panel-major with -ldx >= M rows per panel (sliced kernel only)
+  const bool xpanels = ldx < 0;
+  if (xpanels ? -ldx < M : ((ldx & 7) || ldx < K)) return CARA_E_ARG;
   if (Tt && (ldt < M || (ldt & 7))) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // consumers (cara_tskinny_*) read Tt in whole 32-row steps: keep columns [M, roundup32(M)) zero even
@@ -403,7 +417,8 @@ extern "C" size_t cara_tskinny_scratch_bytes(int M, int K1, int Rp) {
 
 namespace {
 bool ts_args_ok(const void* X, int ldx, const void* Gt, int ldg, void* slabs, int M, int K1, int Rp) {
-  if (!X || !Gt || !slabs || M <= 0 || K1 <= 0 || (K1 % TS_COLS) || (ldx & 7) || ldx < K1) return false;
+  if (!X || !Gt || !slabs || M <= 0 || K1 <= 0 || (K1 % TS_COLS)) return false;
+  if (ldx < 0 ? -ldx < M : ((ldx & 7) || ldx < K1)) return false;   // ldx < 0: K-panel-major X, -ldx rows per panel
   // Gt rows must be readable (and zero) up to the next multiple of 32 rows of M
   if ((ldg & 7) || ldg < ((M + 31) / 32) * 32) return false;
   return Rp == 32 || Rp == 64;

@@ -270,6 +270,22 @@ bool fuse_gemm_t(int Mr, int Rp, bool backward) {
   return (v & (backward ? 2 : 1)) != 0 && Rp == 32 && Mr >= 1024;
 }
 
+// CARA_PANEL_ACTS=0 keeps every activation row-major.  Default: the activations that only GEMMs and the skinny
+// products read -- h = gelu(fc1) and dH = d(fc1 output) -- are written K-panel-major ([K/32][M][32],
+// cara_gemm_args::c_panels) by the GEMM that produces them, so that the GEMM that consumes them stages whole
+// cache lines (tools/micro/kloop_bw.hip: +34 % operand bytes per second on top of the packed weights).
+// Default GEMM family only, not in the exact-dropout mode, not on the cls-row-only last block.
+bool panel_acts(int Mr, const cara_vit_shape* s) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CARA_PANEL_ACTS");
+    v = e ? atoi(e) : 1;
+  }
+  // (the kernel-family overrides are read per call, as cara_gemm_bf16 reads them: tests switch them at run time)
+  if (getenv("CARA_GEMM_TILE") || getenv("CARA_GEMM_SK") || getenv("CARA_GEMM_BM") || getenv("CARA_GEMM_BK")) return false;
+  return v != 0 && !s->wd_exact && Mr >= 1024;
+}
+
 // stream-K scratch of the workspace in use (set on entry of cara_vit_forward / _backward: one
 // workspace per stream, as for the side stream above)
 char* g_sk_scratch = nullptr;
@@ -278,7 +294,7 @@ void with_scratch(cara_gemm_args& a) {
   a.scratch_bytes = g_sk_scratch ? cara_gemm_scratch_bytes() : 0;
 }
 
-// forward of one adapted linear on Mr rows of X (row stride ldx): T = X U ;
+// forward of one adapted linear on Mr rows of X (row stride ldx; ldx < 0: K-panel-major, -ldx rows per panel): T = X U ;
 // C = [X | T] [W | Vs]^T + bias -> epilogue (a.ldc == 0: dense output)
 // (have_T: the LayerNorm that produced X already left T = X U and its transpose, cara_layernorm_fwd_xu)
 int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char* ws, const LayerWs& lw, cara_gemm_args a, void* st,
@@ -288,6 +304,7 @@ int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char*
   const bool inside = !have_T && fuse_gemm_t(Mr, Rp, false);   // T computed by the GEMM itself
   if (!have_T && !inside) TRY(cara_skinny_xu(X, ldx, L.Ut, T, Tt, ldt, Mr, L.in, Rp, st));
   a.A = X; a.lda = ldx; a.B = L.W; a.Bp = L.Wp; a.ldb = L.in; a.A2 = inside ? nullptr : T; a.B2 = L.Vs; a.Rp = Rp;
+  if (ldx < 0) { a.a_panels = -ldx; a.lda = 0; }   // (ldx < 0: X is K-panel-major with -ldx rows per panel, as in cara_skinny_xu)
   if (inside) { a.Ut = L.Ut; a.T_out = T; a.Tt_out = Tt; a.ldt = ldt; }
   a.M = Mr; a.N = L.out; a.K = L.in; a.bias = L.bias;
   if (a.ldc == 0) a.ldc = L.out;
@@ -296,7 +313,7 @@ int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char*
 }
 
 // backward of one adapted linear given dY (bf16, Mr rows, row stride lddy) and its saved input X
-// (row stride ldx):
+// (row stride ldx; a negative stride = K-panel-major with that many rows per panel):
 //   G' = dY Vs ; dX = [dY | G'] [W^T | U]^T (optional) ; dU = X^T G' ; dVs = dY^T T ; dc = colsum dY
 int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int Mr, int Rp, int ldt, char* ws, const Ws& W,
             const Ws::Ring& R, const LayerWs& lw, int layer, bool want_dx, cara_gemm_args a, bool want_dc, void* st,
@@ -315,6 +332,7 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
   if (inside) {
     if (flush_before(L.slot, layer)) TRY(flush_jobs(st, layer, false));   // earlier linears' products run under this GEMM
     a.A = dY; a.lda = lddy; a.B = L.Wt; a.Bp = L.Wtp; a.ldb = L.out; a.A2 = nullptr; a.B2 = L.U; a.Rp = Rp;
+    if (lddy < 0) { a.a_panels = -lddy; a.lda = 0; }
     a.Ut = L.Vst; a.T_out = G; a.Tt_out = Gt; a.ldt = ldt;
     a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
     if (a.ldc == 0) a.ldc = L.in;
@@ -327,6 +345,7 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
   if (flush_before(L.slot, layer)) TRY(flush_jobs(st, layer, last));   // fork: G' exists, the dX GEMM comes next
   if (want_dx) {
     a.A = dY; a.lda = lddy; a.B = L.Wt; a.Bp = L.Wtp; a.ldb = L.out; a.A2 = G; a.B2 = L.U; a.Rp = Rp;
+    if (lddy < 0) { a.a_panels = -lddy; a.lda = 0; }
     a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
     if (a.ldc == 0) a.ldc = L.in;
     with_scratch(a);
@@ -585,6 +604,8 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
                              reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), Mr, D, s->eps, stream));
     e = {};
     e.epi = CARA_EPI_GELU; e.C = ws + lw.h; e.C2 = ws + lw.u;
+    const bool pa = panel_acts(Mr, s);   // h (and dH in the backward) K-panel-major
+    if (pa) { e.c_panels = Mr; e.ldc = 4 * D; }
     if (ex) {
       TRY(lin_fwd_exact(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, ws, W, l, s, e, stream));
     } else if (g_prof.on && !cls_only && l % g_prof.every == 0) {
@@ -607,7 +628,7 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
     e = {};
     e.epi = CARA_EPI_RESID; e.C = x_out; e.aux = x_mid; e.rowscale = dp2; e.rows_per_sample = rps; e.ldc = ldr;
     if (ex) TRY(lin_fwd_exact(lin[3], reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, ws, W, l, s, e, stream));
-    else TRY(lin_fwd(lin[3], reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, W.ldt, ws, lw, e, stream));
+    else TRY(lin_fwd(lin[3], reinterpret_cast<bf16*>(ws + lw.h), pa ? -Mr : 4 * D, Mr, Rp, W.ldt, ws, lw, e, stream));
   }
   // norm -> cls token -> head  (LayerNorm is per token, so only the cls rows are normalised)
   TRY(cara_layernorm_fwd(reinterpret_cast<float*>(ws + W.x_last), (long)N * D, w->norm_g, w->norm_b, ws + W.clsn,
@@ -664,14 +685,16 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     // ---- mlp branch: dY = drop_path scale * dx (already in dyb) ----
     cara_gemm_args e = {};
     e.epi = CARA_EPI_DGELU; e.C = dH; e.aux = ws + lw.u;
+    const bool pa = panel_acts(Mr, s);   // h was written K-panel-major by the forward; dH is, here
+    if (pa) { e.c_panels = Mr; e.ldc = 4 * D; }
     if (ex) TRY(lin_bwd_exact(lin[3], dyb, reinterpret_cast<bf16*>(ws + lw.h), Mr, Rp, ws, W, l, s, true, e, true, stream));
-    else TRY(lin_bwd(lin[3], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, W.ldt, ws, W, R, lw, l, true, e, true, stream,
+    else TRY(lin_bwd(lin[3], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.h), pa ? -Mr : 4 * D, Mr, Rp, W.ldt, ws, W, R, lw, l, true, e, true, stream,
                      have_G_fc2));
     have_G_fc2 = false;
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
     if (ex) TRY(lin_bwd_exact(lin[2], dH, reinterpret_cast<bf16*>(ws + lw.xn2), Mr, Rp, ws, W, l, s, true, e, true, stream));
-    else TRY(lin_bwd(lin[2], dH, 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, W.ldt, ws, W, R, lw, l, true, e, true, stream));
+    else TRY(lin_bwd(lin[2], dH, pa ? -Mr : 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, W.ldt, ws, W, R, lw, l, true, e, true, stream));
     // dyp = dY of this block's proj: its G' = dY Vs comes out of the same kernel
     if (fx)
       TRY(cara_layernorm_bwd_xu(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_mid), ldr, w->ln2_g + (size_t)l * D,

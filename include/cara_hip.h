@@ -74,6 +74,11 @@ typedef struct {
   /* bytes per second that way, tools/micro/kloop_bw.hip).  Frozen weights are packed once at ingest.  The 32-     */
   /* column-step kernels read it INSTEAD of B when non-NULL; B must still be valid (other kernel families).       */
   const void* Bp;
+  /* Activations in the same K-panel-major layout (bf16 only, default kernel family only: M > 128, no batch, no     */
+  /* scratch-selected kernels).  a_panels = P > 0: A is [K/32][P][32] (P >= M rows per panel), lda is ignored.      */
+  /* c_panels = P > 0 (bf16 epilogues): C is WRITTEN as [N/32][P][32] -- the A operand of the next GEMM, the X of   */
+  /* cara_skinny_xu / cara_tskinny_* with ldx = -P -- while C2 / aux keep the row-major ldc.  N % 32 == 0 then.     */
+  int a_panels, c_panels;
 } cara_gemm_args;
 int cara_gemm_bf16(const cara_gemm_args* a, void* stream);
 /* B bf16 [N, K] (row stride ldb) -> out bf16 [K/32][N][32] (cara_gemm_args::Bp); K % 32 == 0 */
@@ -84,7 +89,9 @@ long cara_debug_gemm_persistent_launches(void);
 
 /* ---- skinny adapter contractions (HBM-bound) --------------------------------------------- */
 /* T[M,Rp] = X[M,K] * Ut[Rp,K]^T, bf16 out, also written transposed Tt[Rp,ldt] when Tt != NULL
- * (ldt >= M, multiple of 8).  Forward: T = X U; backward: G' = dY Vs.  K % 32 == 0.            */
+ * (ldt >= M, multiple of 8).  Forward: T = X U; backward: G' = dY Vs.  K % 32 == 0.
+ * In this function and in cara_tskinny_*, a NEGATIVE ldx says that X is K-panel-major: bf16 [K/32][-ldx][32]
+ * with -ldx >= M rows per panel (what a GEMM with cara_gemm_args::c_panels = -ldx wrote).                  */
 int cara_skinny_xu(const void* X, int ldx, const void* Ut, void* T, void* Tt, int ldt,
                    int M, int K, int Rp, void* stream);
 /* D[K1,Rp] (fp32) = sum_m X[m,K1] * G[m,Rp]  given Gt[Rp,ldg] (= G transposed, bf16); optional

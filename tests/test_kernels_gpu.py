@@ -159,6 +159,68 @@ def test_gemm_b_in_k_panel_major_layout(M, N, K, Rp):
         assert torch.equal(h1, h2) and torch.equal(u1, u2) and torch.equal(T1, T2)
 
 
+def _panels(X):
+    """[M, K] -> K-panel-major [K/32, M, 32]"""
+    M, K = X.shape
+    return X.view(M, K // 32, 32).permute(1, 0, 2).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K", [(12608, 3072, 768), (12608, 768, 3072), (1000, 768, 2304)])
+def test_gemm_activations_in_k_panel_major_layout(M, N, K):
+    """cara_gemm_args.a_panels / c_panels: A read from, C written as, [K/32][M][32] panels.  Addresses only: every
+    output is BITWISE the row-major result (re-laid), for the plain, GELU, GELU' and adapter-inside forms."""
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    Ap, Bp = _panels(A), L().pack_b_panels(B)
+    A2, B2 = rnd(M, 32, seed=3), rnd(N, 32, seed=4, scale=0.3)
+    bias = rnd(N, seed=5, dtype=torch.float32)
+    o1, o2 = (torch.empty(M, N, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    op = torch.full((N // 32, M, 32), float("nan"), dtype=torch.bfloat16, device=DEV)
+    L().gemm(A, B, o1, epi=L().EPI_BF16, bias=bias, A2=A2, B2=B2, Bp=Bp)
+    L().gemm(Ap, B, o2, epi=L().EPI_BF16, bias=bias, A2=A2, B2=B2, Bp=Bp, a_panels=M, M=M, K=K, lda=K)
+    assert torch.equal(o1, o2)
+    L().gemm(Ap, B, op, epi=L().EPI_BF16, bias=bias, A2=A2, B2=B2, Bp=Bp, a_panels=M, c_panels=M, M=M, K=K, lda=K, ldc=N)
+    assert torch.equal(op, _panels(o1))
+    # GELU: h as panels, u row-major; GELU': aux row-major, output as panels
+    h1, u1, u2 = (torch.empty(M, N, dtype=torch.bfloat16, device=DEV) for _ in range(3))
+    L().gemm(A, B, h1, epi=L().EPI_GELU, bias=bias, A2=A2, B2=B2, C2=u1)
+    L().gemm(A, B, op, epi=L().EPI_GELU, bias=bias, A2=A2, B2=B2, C2=u2, c_panels=M, ldc=N)
+    assert torch.equal(op, _panels(h1)) and torch.equal(u1, u2)
+    L().gemm(A, B, o1, epi=L().EPI_DGELU, A2=A2, B2=B2, aux=u1)
+    L().gemm(Ap, B, op, epi=L().EPI_DGELU, A2=A2, B2=B2, aux=u1, a_panels=M, c_panels=M, M=M, K=K, lda=K, ldc=N)
+    assert torch.equal(op, _panels(o1))
+    # adapter inside the GEMM on a panel-major A
+    Ut = rnd(32, K, seed=6, scale=0.1)
+    T1, T2 = (torch.empty(M, 32, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    f1, f2 = (torch.empty(M, N, dtype=torch.float32, device=DEV) for _ in range(2))
+    L().gemm(A, B, f1, epi=L().EPI_F32, bias=bias, B2=B2, Ut=Ut, T_out=T1)
+    L().gemm(Ap, B, f2, epi=L().EPI_F32, bias=bias, B2=B2, Ut=Ut, T_out=T2, Bp=Bp, a_panels=M, M=M, K=K, lda=K)
+    assert torch.equal(f1, f2) and torch.equal(T1, T2)
+    # refused where the layout is not implemented: few rows (the split-K path), fp32 output as panels
+    with pytest.raises(L().CaraError):
+        L().gemm(Ap[:, :64], B, o2[:64], epi=L().EPI_BF16, a_panels=64, M=64, K=K, lda=K)
+    with pytest.raises(L().CaraError):
+        L().gemm(A, B, f1, epi=L().EPI_F32, c_panels=M)
+
+
+@pytest.mark.parametrize("M,K", [(12608, 3072), (12608, 768), (1000, 2304), (2000, 4096), (50, 1024)])
+def test_skinny_products_on_k_panel_major_operands(M, K):
+    """cara_skinny_xu / cara_tskinny_xtg with ldx = -M: the same products, bitwise, from the panel image of X."""
+    X = rnd(M, K, seed=1)
+    Xp = _panels(X)
+    Ut = rnd(32, K, seed=2, scale=0.1)
+    ldt = (M + 31) // 32 * 32
+    T1, T2 = (torch.empty(M, 32, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    Tt1, Tt2 = (torch.zeros(32, ldt, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    L().skinny_xu(X, Ut, T1, Tt1)
+    L().skinny_xu(Xp, Ut, T2, Tt2, panels=True)
+    assert torch.equal(T1, T2) and torch.equal(Tt1, Tt2)
+    D1, D2 = (torch.empty(K, 32, dtype=torch.float32, device=DEV) for _ in range(2))
+    c1, c2 = (torch.empty(K, dtype=torch.float32, device=DEV) for _ in range(2))
+    L().tskinny_xtg(X, Tt1, D1, c1)
+    L().tskinny_xtg(Xp, Tt1, D2, c2, panels=True)
+    assert torch.equal(D1, D2) and torch.equal(c1, c2)
+
+
 @pytest.mark.parametrize("M,N,K,Rp", [(64, 768, 3072, 32), (64, 3072, 768, 32), (64, 768, 768, 64), (17, 300, 2304, 0), (128, 768, 768, 32)])
 def test_gemm_few_rows_split_k(M, N, K, Rp):
     """Few-row products with caller scratch: K slabs in one batched launch + a finishing kernel (bias, rank-R term,

@@ -40,6 +40,9 @@ __global__ __launch_bounds__(256, 4) void kloop(const char* __restrict__ src, fl
         // MODE bit 16: the B operand (pieces 8-15) is K-panel major, [K/32][N = 3072][32]: a tile's K step is 8 KiB contiguous
         if ((MODE & 16) && q >= 8)
           g = src + (40u << 20) + ((size_t)(it % 24) * 3072 + (blockIdx.x % 24) * 128) * 64 + (q & 7) * 1024 + lane * 16;
+        // MODE bit 32: the A operand K-panel major as well, [K/32][M = 12608][32]
+        if ((MODE & 32) && q < 8)
+          g = src + ((size_t)(it % 24) * 12608 + (blockIdx.x % 96) * 128) * 64 + (q & 7) * 1024 + lane * 16;
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(buf + q * 1024), 16, 0, 0);
@@ -266,6 +269,7 @@ int main() {
     run<9, 1>("stage, GEMM-like 64-B row segments", wpc, src, out, span);
     run<15, 1>("the K loop, GEMM-like 64-B row segments", wpc, src, out, span);
     run<31, 1>("the K loop, A row segments + B K-panel major", wpc, src, out, span);
+    run<63, 1>("the K loop, A and B K-panel major", wpc, src, out, span);
   }
   for (int wpc : {1, 2, 3}) run256(wpc, src, out, span);
   return 0;
