@@ -24,6 +24,20 @@ struct XuLds {
   bf16 y[16 * LDY];
   float part[XU_WAVES][2][64 * 4];
 };
+// the block's 16 staged bf16 rows -> K-panel-major global image [C/32][yp][32]: a wave writes one panel's 16 rows
+// (16 x 64 B = one contiguous KiB of full cache lines) per instruction, instead of each row's 8-byte pieces
+// scattered over C/32 panels.  Call after the rows are complete (a __syncthreads() away from the staging).
+template <int V4>
+__device__ __forceinline__ void panel_store(const XuLds<V4>& L, bf16* __restrict__ y, const int yp, const int row_base, const int M) {
+  constexpr int C = V4 * 256, LDY = XuLds<V4>::LDY;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = lane >> 2, chunk = lane & 3;
+  if (row_base + row >= M) return;
+#pragma unroll
+  for (int p = wave; p < C / 32; p += XU_WAVES)
+    *reinterpret_cast<bf16x8*>(y + ((size_t)p * yp + row_base + row) * 32 + chunk * 8) =
+        *reinterpret_cast<const bf16x8*>(L.y + row * LDY + p * 32 + chunk * 8);
+}
 template <int V4>
 __device__ __forceinline__ void block_contract(XuLds<V4>& L, const bf16* __restrict__ Ut, bf16* __restrict__ T,
                                                bf16* __restrict__ Tt, const int ldt, const int row_base, const int M) {
@@ -73,7 +87,7 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_fwd_kernel(const 
                                                      bf16* __restrict__ y, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int M, float eps,
                                                      const bf16* __restrict__ Ut, int rank, int Rp, bf16* __restrict__ T,
-                                                     bf16* __restrict__ Tt, int ldt) {
+                                                     bf16* __restrict__ Tt, int ldt, const int yp) {
   constexpr int C = V4 * 256;
   constexpr int RPW = XU ? XU_ROWS : 1;
   const int lane = threadIdx.x & 63;
@@ -105,7 +119,9 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_fwd_kernel(const 
     const float4 b = *reinterpret_cast<const float4*>(beta + c0);
     bf16x4 o = {(bf16)((v[i].x - mu) * rs * g.x + b.x), (bf16)((v[i].y - mu) * rs * g.y + b.y),
                 (bf16)((v[i].z - mu) * rs * g.z + b.z), (bf16)((v[i].w - mu) * rs * g.w + b.w)};
-    *reinterpret_cast<bf16x4*>(yr + c0) = o;
+    // yp > 0: y as K-panel-major [C/32][yp][32] (the A operand layout of the GEMM that reads it)
+    if (!(XU && yp))   // (fused kernels write the panel image from the staged rows, panel_store)
+      *reinterpret_cast<bf16x4*>(yp ? y + ((size_t)(c0 >> 5) * yp + row) * 32 + (c0 & 31) : yr + c0) = o;
     yb[i] = o;
   }
   if (lane == 0) {
@@ -118,7 +134,13 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_fwd_kernel(const 
       *reinterpret_cast<bf16x4*>(L.y + (row - blockIdx.x * 16) * XuLds<V4>::LDY + i * 256 + lane * 4) = yb[i];
   }
   }
-  if constexpr (XU) block_contract<V4>(L, Ut, T, Tt, ldt, blockIdx.x * 16, M);   // T = LN(x) U of the next linear
+  if constexpr (XU) {
+    if (yp) {
+      __syncthreads();
+      panel_store<V4>(L, y, yp, blockIdx.x * 16, M);
+    }
+    block_contract<V4>(L, Ut, T, Tt, ldt, blockIdx.x * 16, M);   // T = LN(x) U of the next linear
+  }
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mu) * rstd
@@ -132,7 +154,7 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_bwd_kernel(const 
                                                      const float* __restrict__ rowscale,
                                                      int rows_per_sample, int M,
                                                      const bf16* __restrict__ Vst, int rank, int Rp, bf16* __restrict__ G,
-                                                     bf16* __restrict__ Gt, int ldt) {
+                                                     bf16* __restrict__ Gt, int ldt, const int yp) {
   constexpr int C = V4 * 256;
   constexpr int RPW = XU ? XU_ROWS : 1;
   const int lane = threadIdx.x & 63;
@@ -172,7 +194,7 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_bwd_kernel(const 
     }
     *reinterpret_cast<float4*>(dor + c0) = o;
     bf16x4 b = {(bf16)(o.x * sc), (bf16)(o.y * sc), (bf16)(o.z * sc), (bf16)(o.w * sc)};
-    if (db) *reinterpret_cast<bf16x4*>(db + c0) = b;
+    if (db && !(XU && yp)) *reinterpret_cast<bf16x4*>(yp ? dyb + ((size_t)(c0 >> 5) * yp + row) * 32 + (c0 & 31) : db + c0) = b;
     yb[i] = b;
   }
   if constexpr (XU) {
@@ -181,7 +203,13 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_bwd_kernel(const 
       *reinterpret_cast<bf16x4*>(L.y + (row - blockIdx.x * 16) * XuLds<V4>::LDY + i * 256 + lane * 4) = yb[i];
   }
   }
-  if constexpr (XU) block_contract<V4>(L, Vst, G, Gt, ldt, blockIdx.x * 16, M);   // G' = dY Vs of the linear below
+  if constexpr (XU) {
+    if (yp) {
+      __syncthreads();
+      panel_store<V4>(L, dyb, yp, blockIdx.x * 16, M);
+    }
+    block_contract<V4>(L, Vst, G, Gt, ldt, blockIdx.x * 16, M);   // G' = dY Vs of the linear below
+  }
 }
 
 // images fp32 [B,C,Hi,Wi] -> patch rows bf16 [B*gh*gw, C*p*p], column = (c*p + py)*p + px
@@ -336,14 +364,15 @@ int xu_pad(const XuArgs& a, int M, hipStream_t st) {
 }
 
 int ln_fwd_launch(const float* x, long ldx, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M,
-                  int C, float eps, const XuArgs& a, void* stream) {
+                  int C, float eps, const XuArgs& a, void* stream, int yp = 0) {
   if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0 || ldx < C || (ldx & 3) || !xu_ok(a, M, C)) return CARA_E_ARG;
+  if (yp && yp < M) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (xu_pad(a, M, st) != CARA_OK) return CARA_E_LAUNCH;
   const int rows_per_block = a.Ut ? 16 : 4;
   const dim3 grid((M + rows_per_block - 1) / rows_per_block), block(a.Ut ? XU_WAVES * 64 : 256);
 #define LNF(V, X) hipLaunchKernelGGL((ln_fwd_kernel<V, X>), grid, block, 0, st, x, ldx, gamma, beta, (bf16*)y, mean, rstd, M, eps, \
-                                     a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt)
+                                     a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp)
   if (a.Ut) {
     if (C == 768) LNF(3, true);
     else if (C == 1024) LNF(4, true);
@@ -359,15 +388,16 @@ int ln_fwd_launch(const float* x, long ldx, const float* gamma, const float* bet
 
 int ln_bwd_launch(const void* dy, const float* x, long ldx, const float* gamma, const float* mean, const float* rstd,
                   const float* dx_in, float* dx_out, void* dyb, const float* rowscale, int rows_per_sample, int M, int C,
-                  const XuArgs& a, void* stream) {
+                  const XuArgs& a, void* stream, int yp = 0) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx_out || M <= 0 || ldx < C || (ldx & 3) || !xu_ok(a, M, C)) return CARA_E_ARG;
+  if (yp && (yp < M || !dyb)) return CARA_E_ARG;
   if (rowscale && rows_per_sample <= 0) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (xu_pad(a, M, st) != CARA_OK) return CARA_E_LAUNCH;
   const int rows_per_block = a.Ut ? 16 : 4;
   const dim3 grid((M + rows_per_block - 1) / rows_per_block), block(a.Ut ? XU_WAVES * 64 : 256);
 #define LNB(V, X) hipLaunchKernelGGL((ln_bwd_kernel<V, X>), grid, block, 0, st, (const bf16*)dy, x, ldx, gamma, mean, rstd, \
-                                     dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M, a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt)
+                                     dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M, a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp)
   if (a.Ut) {
     if (C == 768) LNB(3, true);
     else if (C == 1024) LNB(4, true);
@@ -406,6 +436,25 @@ extern "C" int cara_layernorm_bwd_xu(const void* dy, const float* x, long ldx, c
   if (!Vst) return CARA_E_ARG;
   return ln_bwd_launch(dy, x, ldx, gamma, mean, rstd, dx_in, dx_out, dyb, rowscale, rows_per_sample, M, C,
                        XuArgs{static_cast<const bf16*>(Vst), rank, Rp, static_cast<bf16*>(G), static_cast<bf16*>(Gt), ldt}, stream);
+}
+// The general forms: Ut may be NULL (no fused contraction), and the bf16 output (y, resp. dyb) can be written
+// K-panel-major -- [C/32][panels][32], panels >= M rows per panel -- the layout cara_gemm_args::a_panels reads.
+extern "C" int cara_layernorm_fwd_ex(const float* x, long ldx, const float* gamma, const float* beta, void* y,
+                                     float* mean, float* rstd, int M, int C, float eps, const void* Ut, int rank, int Rp,
+                                     void* T, void* Tt, int ldt, int y_panels, void* stream) {
+  if (y_panels < 0) return CARA_E_ARG;
+  const XuArgs a = Ut ? XuArgs{static_cast<const bf16*>(Ut), rank, Rp, static_cast<bf16*>(T), static_cast<bf16*>(Tt), ldt}
+                      : XuArgs{nullptr, 0, 0, nullptr, nullptr, 0};
+  return ln_fwd_launch(x, ldx, gamma, beta, y, mean, rstd, M, C, eps, a, stream, y_panels);
+}
+extern "C" int cara_layernorm_bwd_ex(const void* dy, const float* x, long ldx, const float* gamma, const float* mean,
+                                     const float* rstd, const float* dx_in, float* dx_out, void* dyb, const float* rowscale,
+                                     int rows_per_sample, int M, int C, const void* Vst, int rank, int Rp, void* G, void* Gt,
+                                     int ldt, int dyb_panels, void* stream) {
+  if (dyb_panels < 0) return CARA_E_ARG;
+  const XuArgs a = Vst ? XuArgs{static_cast<const bf16*>(Vst), rank, Rp, static_cast<bf16*>(G), static_cast<bf16*>(Gt), ldt}
+                       : XuArgs{nullptr, 0, 0, nullptr, nullptr, 0};
+  return ln_bwd_launch(dy, x, ldx, gamma, mean, rstd, dx_in, dx_out, dyb, rowscale, rows_per_sample, M, C, a, stream, dyb_panels);
 }
 
 extern "C" int cara_im2col_patches(const float* img, void* patches, int B, int C, int Hi, int Wi, int p, void* stream) {

@@ -275,15 +275,19 @@ bool fuse_gemm_t(int Mr, int Rp, bool backward) {
 // cara_gemm_args::c_panels) by the GEMM that produces them, so that the GEMM that consumes them stages whole
 // cache lines (tools/micro/kloop_bw.hip: +34 % operand bytes per second on top of the packed weights).
 // Default GEMM family only, not in the exact-dropout mode, not on the cls-row-only last block.
-bool panel_acts(int Mr, const cara_vit_shape* s) {
+// `what`: 1 = h / dH (written by GEMM epilogues), 2 = xn1 / xn2 (LayerNorm forward), 4 = the dY of fc2 / proj
+// (LayerNorm backward); CARA_PANEL_ACTS is the mask of the groups that use the layout.
+bool panel_acts(int Mr, const cara_vit_shape* s, int what = 1) {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("CARA_PANEL_ACTS");
-    v = e ? atoi(e) : 1;
+    // default 5: measured same-box 10.56 ms (0) -> 10.37 (1) -> 10.18-10.38 (5); the LayerNorm-forward group costs
+    // 0.25 ms (3: 10.52-10.62) although the GEMMs reading xn1 / xn2 gain 5-8 us each when timed alone
+    v = e ? atoi(e) : 5;
   }
   // (the kernel-family overrides are read per call, as cara_gemm_bf16 reads them: tests switch them at run time)
   if (getenv("CARA_GEMM_TILE") || getenv("CARA_GEMM_SK") || getenv("CARA_GEMM_BM") || getenv("CARA_GEMM_BK")) return false;
-  return v != 0 && !s->wd_exact && Mr >= 1024;
+  return (v & what) != 0 && !s->wd_exact && Mr >= 1024;
 }
 
 // stream-K scratch of the workspace in use (set on entry of cara_vit_forward / _backward: one
@@ -578,42 +582,36 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
     // x = x + drop_path(attn(norm1(x)))
     const bool ex = s->wd_exact != 0;   // exact weight-dropout mode: plain GEMMs on the merged weights
     const bool fx = fuse_xu(g) && !ex;
-    if (fx)
-      TRY(cara_layernorm_fwd_xu(x_in, D, w->ln1_g + (size_t)l * D, w->ln1_b + (size_t)l * D, ws + lw.xn1,
-                                reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), M, D, s->eps,
-                                lin[0].Ut, g->rank, Rp, ws + lw.T[0], ws + lw.Tt[0], W.ldt, stream));
-    else
-      TRY(cara_layernorm_fwd(x_in, D, w->ln1_g + (size_t)l * D, w->ln1_b + (size_t)l * D, ws + lw.xn1,
-                             reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), M, D, s->eps, stream));
+    // K-panel-major activations (panel_acts): pa_x for what all M token rows produce (xn1), pa for the Mr rows of
+    // the proj / MLP half of the block (xn2, h)
+    const bool pa_x = panel_acts(M, s, 2), pa = panel_acts(Mr, s, 1), pa_n = panel_acts(Mr, s, 2);
+    TRY(cara_layernorm_fwd_ex(x_in, D, w->ln1_g + (size_t)l * D, w->ln1_b + (size_t)l * D, ws + lw.xn1,
+                              reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), M, D, s->eps,
+                              fx ? lin[0].Ut : nullptr, g->rank, Rp, ws + lw.T[0], ws + lw.Tt[0], W.ldt, pa_x ? M : 0, stream));
     cara_gemm_args e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + lw.qkv;
     if (ex) TRY(lin_fwd_exact(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, ws, W, l, s, e, stream));
-    else TRY(lin_fwd(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, W.ldt, ws, lw, e, stream, fx));
+    else TRY(lin_fwd(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), pa_x ? -M : D, M, Rp, W.ldt, ws, lw, e, stream, fx));
     TRY(cara_attention_fwd(ws + lw.qkv, ws + lw.ao, reinterpret_cast<float*>(ws + lw.lse), B, N, g->heads, att_scale, stream));
     e = {};
     e.epi = CARA_EPI_RESID; e.C = x_mid; e.aux = x_in; e.rowscale = dp1; e.rows_per_sample = rps; e.ldc = ldr;
     if (ex) TRY(lin_fwd_exact(lin[1], reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, ws, W, l, s, e, stream));
     else TRY(lin_fwd(lin[1], reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, lw, e, stream));
     // x = x + drop_path(mlp(norm2(x)))
-    if (fx)
-      TRY(cara_layernorm_fwd_xu(x_mid, ldr, w->ln2_g + (size_t)l * D, w->ln2_b + (size_t)l * D, ws + lw.xn2,
-                                reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), Mr, D, s->eps,
-                                lin[2].Ut, g->rank, Rp, ws + lw.T[2], ws + lw.Tt[2], W.ldt, stream));
-    else
-      TRY(cara_layernorm_fwd(x_mid, ldr, w->ln2_g + (size_t)l * D, w->ln2_b + (size_t)l * D, ws + lw.xn2,
-                             reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), Mr, D, s->eps, stream));
+    TRY(cara_layernorm_fwd_ex(x_mid, ldr, w->ln2_g + (size_t)l * D, w->ln2_b + (size_t)l * D, ws + lw.xn2,
+                              reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), Mr, D, s->eps,
+                              fx ? lin[2].Ut : nullptr, g->rank, Rp, ws + lw.T[2], ws + lw.Tt[2], W.ldt, pa_n ? Mr : 0, stream));
     e = {};
     e.epi = CARA_EPI_GELU; e.C = ws + lw.h; e.C2 = ws + lw.u;
-    const bool pa = panel_acts(Mr, s);   // h (and dH in the backward) K-panel-major
-    if (pa) { e.c_panels = Mr; e.ldc = 4 * D; }
+    if (pa) { e.c_panels = Mr; e.ldc = 4 * D; }   // h (and dH in the backward) K-panel-major
     if (ex) {
       TRY(lin_fwd_exact(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, ws, W, l, s, e, stream));
     } else if (g_prof.on && !cls_only && l % g_prof.every == 0) {
       // T first, so that the bracket holds exactly one kernel: the fc1 GEMM
       bf16* T = reinterpret_cast<bf16*>(ws + lw.T[2]);
-      if (!fx) TRY(cara_skinny_xu(ws + lw.xn2, D, lin[2].Ut, T, ws + lw.Tt[2], W.ldt, M, D, Rp, stream));
+      if (!fx) TRY(cara_skinny_xu(ws + lw.xn2, pa_n ? -M : D, lin[2].Ut, T, ws + lw.Tt[2], W.ldt, M, D, Rp, stream));
       cara_gemm_args a2 = e;
-      a2.A = ws + lw.xn2; a2.lda = D; a2.B = lin[2].W; a2.Bp = lin[2].Wp; a2.ldb = D; a2.A2 = T; a2.B2 = lin[2].Vs; a2.Rp = Rp;
+      a2.A = ws + lw.xn2; a2.lda = D; a2.a_panels = pa_n ? M : 0; a2.B = lin[2].W; a2.Bp = lin[2].Wp; a2.ldb = D; a2.A2 = T; a2.B2 = lin[2].Vs; a2.Rp = Rp;
       a2.M = M; a2.N = 4 * D; a2.K = D; a2.bias = lin[2].bias; a2.ldc = 4 * D;
       with_scratch(a2);
       hipEvent_t* ev = g_prof.ev[g_prof.n % 64];
@@ -623,7 +621,7 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
       hipEventRecord(ev[2], static_cast<hipStream_t>(stream));   // empty bracket: the markers' own cost
       ++g_prof.n;
     } else {
-      TRY(lin_fwd(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, W.ldt, ws, lw, e, stream, fx));
+      TRY(lin_fwd(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), pa_n ? -Mr : D, Mr, Rp, W.ldt, ws, lw, e, stream, fx));
     }
     e = {};
     e.epi = CARA_EPI_RESID; e.C = x_out; e.aux = x_mid; e.rowscale = dp2; e.rows_per_sample = rps; e.ldc = ldr;
@@ -685,57 +683,52 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     // ---- mlp branch: dY = drop_path scale * dx (already in dyb) ----
     cara_gemm_args e = {};
     e.epi = CARA_EPI_DGELU; e.C = dH; e.aux = ws + lw.u;
-    const bool pa = panel_acts(Mr, s);   // h was written K-panel-major by the forward; dH is, here
+    // K-panel-major activations, as the forward wrote them (xn1: pa_x; xn2, h: pa) and as the kernels here write
+    // theirs: dH and dyp (pa), dyb of the block below (pa_x).  This block's own dyb came from the block above --
+    // panels -- except in the last block, where the final norm's backward left it row-major on the cls rows.
+    const bool pa_x = panel_acts(M, s, 2), pa = panel_acts(Mr, s, 1), pa_n = panel_acts(Mr, s, 2);
+    const bool pa_dp = panel_acts(Mr, s, 4), pa_dx = panel_acts(M, s, 4);   // dyp here; dyb of the block below
+    const bool pa_dyb = pa_dx && l < g->depth - 1;
     if (pa) { e.c_panels = Mr; e.ldc = 4 * D; }
     if (ex) TRY(lin_bwd_exact(lin[3], dyb, reinterpret_cast<bf16*>(ws + lw.h), Mr, Rp, ws, W, l, s, true, e, true, stream));
-    else TRY(lin_bwd(lin[3], dyb, ldr, reinterpret_cast<bf16*>(ws + lw.h), pa ? -Mr : 4 * D, Mr, Rp, W.ldt, ws, W, R, lw, l, true, e, true, stream,
+    else TRY(lin_bwd(lin[3], dyb, pa_dyb ? -M : ldr, reinterpret_cast<bf16*>(ws + lw.h), pa ? -Mr : 4 * D, Mr, Rp, W.ldt, ws, W, R, lw, l, true, e, true, stream,
                      have_G_fc2));
     have_G_fc2 = false;
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
     if (ex) TRY(lin_bwd_exact(lin[2], dH, reinterpret_cast<bf16*>(ws + lw.xn2), Mr, Rp, ws, W, l, s, true, e, true, stream));
-    else TRY(lin_bwd(lin[2], dH, pa ? -Mr : 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, W.ldt, ws, W, R, lw, l, true, e, true, stream));
+    else TRY(lin_bwd(lin[2], dH, pa ? -Mr : 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), pa_n ? -Mr : D, Mr, Rp, W.ldt, ws, W, R, lw, l, true, e, true, stream));
     // dyp = dY of this block's proj: its G' = dY Vs comes out of the same kernel
-    if (fx)
-      TRY(cara_layernorm_bwd_xu(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_mid), ldr, w->ln2_g + (size_t)l * D,
-                                reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyp, dp1,
-                                rps, Mr, D, lin[1].Vst, g->rank, Rp, ws + R.G[1], ws + R.Gt[1], W.ldt, stream));
-    else
-      TRY(cara_layernorm_bwd(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_mid), ldr, w->ln2_g + (size_t)l * D,
-                             reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyp, dp1, rps,
-                             Mr, D, stream));
+    TRY(cara_layernorm_bwd_ex(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_mid), ldr, w->ln2_g + (size_t)l * D,
+                              reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyp, dp1,
+                              rps, Mr, D, fx ? lin[1].Vst : nullptr, g->rank, Rp, ws + R.G[1], ws + R.Gt[1], W.ldt, pa_dp ? Mr : 0, stream));
     // ---- attention branch ----
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dAO; e.ldc = ldr;
     if (cls_only && hipMemsetAsync(ws + W.dAO, 0, (size_t)M * D * 2, hs) != hipSuccess) return CARA_E_LAUNCH;
     if (ex) TRY(lin_bwd_exact(lin[1], dyp, reinterpret_cast<bf16*>(ws + lw.ao), Mr, Rp, ws, W, l, s, true, e, true, stream));
-    else TRY(lin_bwd(lin[1], dyp, ldr, reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, W, R, lw, l, true, e, true, stream, fx));
+    else TRY(lin_bwd(lin[1], dyp, pa_dp ? -Mr : ldr, reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, W, R, lw, l, true, e, true, stream, fx));
     TRY(cara_attention_bwd(ws + lw.qkv, ws + lw.ao, ws + W.dAO, reinterpret_cast<float*>(ws + lw.lse), dQKV, B, N,
                            g->heads, att_scale, stream));
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
     // block 0 has nothing trainable upstream of it: its dX GEMM and LayerNorm backward are skipped
     if (ex) TRY(lin_bwd_exact(lin[0], dQKV, reinterpret_cast<bf16*>(ws + lw.xn1), M, Rp, ws, W, l, s, l > 0, e, false, stream));
-    else TRY(lin_bwd(lin[0], dQKV, 3 * D, reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, W.ldt, ws, W, R, lw, l, l > 0, e, false, stream));
+    else TRY(lin_bwd(lin[0], dQKV, 3 * D, reinterpret_cast<bf16*>(ws + lw.xn1), pa_x ? -M : D, M, Rp, W.ldt, ws, W, R, lw, l, l > 0, e, false, stream));
     if (l > 0) {
       // the LayerNorm backward below starts to fill the ring slot of block l - 1: its previous user, block
       // l - 1 + nring, must be through with it (never the case with one slot per block)
       const Ws::Ring& Rb = W.ring[(l - 1) % W.nring];
       if (!ex && l - 1 + W.nring < g->depth) TRY(side_join(l - 1 + W.nring, stream));
       bf16* dyb = reinterpret_cast<bf16*>(ws + Rb.dyb_fc2);
-      if (fx) {
-        // dyb = dY of fc2 of the block BELOW (all M rows there: only the last block runs on cls rows)
-        Lin below[4];
-        make_lins(g, w, ws + W.pack, pl, l - 1, below);
-        TRY(cara_layernorm_bwd_xu(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_in), D, w->ln1_g + (size_t)l * D,
-                                  reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), dx, dx, dyb,
-                                  dp_prev, N, M, D, below[3].Vst, g->rank, Rp, ws + Rb.G[3], ws + Rb.Gt[3], W.ldt, stream));
-        have_G_fc2 = true;
-      } else {
-        TRY(cara_layernorm_bwd(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_in), D, w->ln1_g + (size_t)l * D,
-                               reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), dx, dx, dyb,
-                               dp_prev, N, M, D, stream));
-      }
+      // dyb = dY of fc2 of the block BELOW (all M rows there: only the last block runs on cls rows)
+      Lin below[4];
+      make_lins(g, w, ws + W.pack, pl, l - 1, below);
+      TRY(cara_layernorm_bwd_ex(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_in), D, w->ln1_g + (size_t)l * D,
+                                reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), dx, dx, dyb,
+                                dp_prev, N, M, D, fx ? below[3].Vst : nullptr, g->rank, Rp, ws + Rb.G[3], ws + Rb.Gt[3], W.ldt,
+                                pa_dx ? M : 0, stream));
+      have_G_fc2 = fx;
     }
   }
   if (!ex) TRY(side_join(0, stream));   // all slabs written (block 0's join is the last record of the in-order side stream)

@@ -140,6 +140,17 @@ int cara_layernorm_bwd_xu(const void* dy, const float* x, long ldx, const float*
                           const float* mean, const float* rstd, const float* dx_in, float* dx_out,
                           void* dyb, const float* rowscale, int rows_per_sample, int M, int C,
                           const void* Vst, int rank, int Rp, void* G, void* Gt, int ldt, void* stream);
+/* The general forms: Ut / Vst may be NULL (no fused product), and the bf16 output (y, resp. dyb) is written
+ * K-panel-major -- [C/32][panels][32] with panels >= M rows per panel, the layout cara_gemm_args::a_panels
+ * and a negative ldx of the skinny products read -- when y_panels / dyb_panels > 0 (0 = row-major).        */
+int cara_layernorm_fwd_ex(const float* x, long ldx, const float* gamma, const float* beta, void* y,
+                          float* mean, float* rstd, int M, int C, float eps, const void* Ut, int rank,
+                          int Rp, void* T, void* Tt, int ldt, int y_panels, void* stream);
+int cara_layernorm_bwd_ex(const void* dy, const float* x, long ldx, const float* gamma,
+                          const float* mean, const float* rstd, const float* dx_in, float* dx_out,
+                          void* dyb, const float* rowscale, int rows_per_sample, int M, int C,
+                          const void* Vst, int rank, int Rp, void* G, void* Gt, int ldt, int dyb_panels,
+                          void* stream);
 
 /* ---- attention (cara.py:43-48; softmax(q k^T * scale) v per head) ------------------------- */
 /* qkv bf16 [B*N, 3*H*64] with column k*H*64 + h*64 + d (k = q,k,v): exactly the layout

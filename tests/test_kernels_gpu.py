@@ -483,6 +483,43 @@ def test_layernorm_fused_adapter_contraction(M, C_, rank, Rp):
     assert torch.equal(Gt[:, :M], G.t()) and torch.count_nonzero(Gt[:, M:]) == 0
 
 
+@pytest.mark.parametrize("M,C_,fused", [(12608, 768, True), (333, 768, False), (197, 1024, True), (70, 256, False)])
+def test_layernorm_outputs_in_k_panel_major_layout(M, C_, fused):
+    """cara_layernorm_fwd_ex / _bwd_ex with y_panels / dyb_panels = M: the bf16 outputs land as [C/32][M][32] panels,
+    bitwise the row-major values; statistics, dx and the fused skinny products are untouched."""
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+    x = rnd(M, C_, seed=1, scale=2.0, dtype=torch.float32) + 0.5
+    g = 1 + 0.1 * rnd(C_, seed=2, dtype=torch.float32)
+    b = 0.1 * rnd(C_, seed=3, dtype=torch.float32)
+    Ut = rnd(32, C_, seed=6, scale=0.1)
+    ldt = (M + 31) // 32 * 32
+    up = p(Ut) if fused else None
+    y1 = torch.empty(M, C_, dtype=torch.bfloat16, device=DEV)
+    y2 = torch.full((C_ // 32, M, 32), float("nan"), dtype=torch.bfloat16, device=DEV)
+    mean, rstd, mean2, rstd2 = (torch.empty(M, device=DEV) for _ in range(4))
+    T1, T2 = (torch.zeros(M, 32, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    Tt1, Tt2 = (torch.zeros(32, ldt, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    L().check(lib.cara_layernorm_fwd_ex(p(x), C.c_long(C_), p(g), p(b), p(y1), p(mean), p(rstd), M, C_, C.c_float(1e-6),
+                                        up, 32, 32, p(T1), p(Tt1), ldt, 0, st()), "ln fwd ex")
+    L().check(lib.cara_layernorm_fwd_ex(p(x), C.c_long(C_), p(g), p(b), p(y2), p(mean2), p(rstd2), M, C_, C.c_float(1e-6),
+                                        up, 32, 32, p(T2), p(Tt2), ldt, M, st()), "ln fwd ex panels")
+    assert torch.equal(y2, _panels(y1)) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    assert torch.equal(T1, T2) and torch.equal(Tt1, Tt2)
+    dy = rnd(M, C_, seed=4)
+    dx_in = rnd(M, C_, seed=5, dtype=torch.float32)
+    dx1, dx2 = torch.empty(M, C_, device=DEV), torch.empty(M, C_, device=DEV)
+    d1 = torch.empty(M, C_, dtype=torch.bfloat16, device=DEV)
+    d2 = torch.full((C_ // 32, M, 32), float("nan"), dtype=torch.bfloat16, device=DEV)
+    rps = 7
+    rs = (torch.arange((M + rps - 1) // rps, device=DEV) % 3).float() * 0.5 + 0.5
+    L().check(lib.cara_layernorm_bwd_ex(p(dy), p(x), C.c_long(C_), p(g), p(mean), p(rstd), p(dx_in), p(dx1), p(d1), p(rs),
+                                        rps, M, C_, up, 32, 32, p(T1), p(Tt1), ldt, 0, st()), "ln bwd ex")
+    L().check(lib.cara_layernorm_bwd_ex(p(dy), p(x), C.c_long(C_), p(g), p(mean), p(rstd), p(dx_in), p(dx2), p(d2), p(rs),
+                                        rps, M, C_, up, 32, 32, p(T2), p(Tt2), ldt, M, st()), "ln bwd ex panels")
+    assert torch.equal(d2, _panels(d1)) and torch.equal(dx1, dx2) and torch.equal(T1, T2) and torch.equal(Tt1, Tt2)
+
+
 def test_layernorm_strided_cls_rows():
     """Final norm: only the cls row of each sample (row stride tokens*C)."""
     lib = L().lib()

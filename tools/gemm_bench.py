@@ -29,6 +29,7 @@ def main():
                     help="M,N,K[,epi] instead of the block shapes (repeatable), e.g. 4096,4096,768,bf16")
     ap.add_argument("--sk", action="store_true", help="give the GEMM stream-K scratch (persistent kernel)")
     ap.add_argument("--packed", action="store_true", help="give the GEMM the K-panel-major image of B as well (Bp)")
+    ap.add_argument("--apanels", action="store_true", help="A in K-panel-major layout as well (a_panels)")
     ap.add_argument("--blas", action="store_true",
                     help="also time torch.matmul (hipBLASLt, plain GEMM, no adapter columns, no epilogue) on the "
                          "same operands: a known-good ceiling for these shapes, measurement only")
@@ -54,6 +55,10 @@ def main():
         kw = dict(A2=A2, B2=B2, bias=bias)
         if args.packed:
             kw["Bp"] = L.pack_b_panels(B)
+        Arow = A
+        if args.apanels:
+            A = A.view(M, K // 32, 32).permute(1, 0, 2).contiguous()
+            kw.update(a_panels=M, M=M, K=K, lda=K)
         if args.sk:
             kw["scratch"] = scratch
         if epi == "bf16":
@@ -87,11 +92,11 @@ def main():
         if args.blas:
             Bt = B.t()
             for _ in range(3):
-                torch.matmul(A, Bt)
+                torch.matmul(Arow, Bt)
             torch.cuda.synchronize()
             e0.record()
             for _ in range(args.iters):
-                torch.matmul(A, Bt)
+                torch.matmul(Arow, Bt)
             e1.record()
             torch.cuda.synchronize()
             ub = e0.elapsed_time(e1) * 1e3 / args.iters
