@@ -79,7 +79,7 @@ class VitWeights(C.Structure):
 class VitShape(C.Structure):
     _fields_ = [("B", C.c_int), ("img", C.c_int), ("patch", C.c_int), ("chans", C.c_int),
                 ("tokens", C.c_int), ("num_classes", C.c_int), ("eps", C.c_float),
-                ("wd_exact", C.c_int), ("wd_p", C.c_float), ("wd_seed", C.c_uint)]
+                ("wd_exact", C.c_int), ("wd_p", C.c_float), ("wd_seed", C.c_uint), ("inference", C.c_int)]
 
 
 class CaraError(RuntimeError):

@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256) void small_m_finish_kernel(const cara_gemm_arg
     } else if constexpr (EPI == CARA_EPI_BF16) {
       static_cast<bf16*>(p.C)[o + k] = (bf16)v[k];
     } else if constexpr (EPI == CARA_EPI_GELU) {
-      static_cast<bf16*>(p.C2)[o + k] = (bf16)v[k];
+      if (p.C2) static_cast<bf16*>(p.C2)[o + k] = (bf16)v[k];
       static_cast<bf16*>(p.C)[o + k] = (bf16)gelu_erf(v[k]);
     } else {
       static_cast<bf16*>(p.C)[o + k] = (bf16)(v[k] * gelu_erf_grad((float)static_cast<const bf16*>(p.aux)[o + k]));
@@ -697,7 +697,8 @@ extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   // the BK = 32 kernels address their operands with 32-bit byte offsets from the (batch-adjusted) base pointer
   const bool small_ptrs = (unsigned long long)a->M * (a->a_panels ? 32 : a->lda) * 2 < (1ull << 32) && (unsigned long long)a->N * a->ldb * 2 < (1ull << 32);
-  if (a->epi == CARA_EPI_GELU && !a->C2) return CARA_E_ARG;
+  // (CARA_EPI_GELU with C2 == NULL: the pre-activation is not kept -- default kernel family and the few-row path only)
+  if (a->epi == CARA_EPI_GELU && !a->C2 && (tile_choice(a) != 0 || use_stream_k(a) || !use_bk32())) return CARA_E_ARG;
   if (a->epi == CARA_EPI_RESID && (!a->aux || (a->rowscale && a->rows_per_sample <= 0))) return CARA_E_ARG;
   if (a->epi == CARA_EPI_DGELU && !a->aux) return CARA_E_ARG;
   if (a->Ut) {   // whole adapter inside the GEMM: default kernel family, Rp = 32, T produced here

@@ -90,13 +90,17 @@ __device__ __forceinline__ void epilogue_rows(const cara_gemm_args& p, const flo
                              : static_cast<bf16*>(p.C) + o + coff;
       if (vec) {
         *reinterpret_cast<bf16x8*>(dst) = out;
-        if constexpr (EPI == CARA_EPI_GELU) *reinterpret_cast<bf16x8*>(static_cast<bf16*>(p.C2) + o) = out2;
+        if constexpr (EPI == CARA_EPI_GELU) {
+          if (p.C2) *reinterpret_cast<bf16x8*>(static_cast<bf16*>(p.C2) + o) = out2;   // (NULL: inference, u is not kept)
+        }
       } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (n + k < p.N) {
             dst[k] = out[k];
-            if constexpr (EPI == CARA_EPI_GELU) (static_cast<bf16*>(p.C2) + o)[k] = out2[k];
+            if constexpr (EPI == CARA_EPI_GELU) {
+              if (p.C2) (static_cast<bf16*>(p.C2) + o)[k] = out2[k];
+            }
           }
       }
     }

@@ -582,6 +582,9 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
     // x = x + drop_path(attn(norm1(x)))
     const bool ex = s->wd_exact != 0;   // exact weight-dropout mode: plain GEMMs on the merged weights
     const bool fx = fuse_xu(g) && !ex;
+    // no backward will follow (cara_vit_shape::inference): do not keep what only it reads.  Only with the default
+    // GEMM family (the others insist on both GELU outputs).
+    const bool inference = s->inference != 0 && !ex && !getenv("CARA_GEMM_TILE") && !getenv("CARA_GEMM_SK") && !getenv("CARA_GEMM_BK");
     // K-panel-major activations (panel_acts): pa_x for what all M token rows produce (xn1), pa for the Mr rows of
     // the proj / MLP half of the block (xn2, h)
     const bool pa_x = panel_acts(M, s, 2), pa = panel_acts(Mr, s, 1), pa_n = panel_acts(Mr, s, 2);
@@ -602,7 +605,8 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
                               reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), Mr, D, s->eps,
                               fx ? lin[2].Ut : nullptr, g->rank, Rp, ws + lw.T[2], ws + lw.Tt[2], W.ldt, pa_n ? Mr : 0, stream));
     e = {};
-    e.epi = CARA_EPI_GELU; e.C = ws + lw.h; e.C2 = ws + lw.u;
+    e.epi = CARA_EPI_GELU; e.C = ws + lw.h;
+    e.C2 = inference ? nullptr : ws + lw.u;   // the pre-activation is only read by the backward (gelu')
     if (pa) { e.c_panels = Mr; e.ldc = 4 * D; }   // h (and dH in the backward) K-panel-major
     if (ex) {
       TRY(lin_fwd_exact(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, ws, W, l, s, e, stream));

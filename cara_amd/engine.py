@@ -27,7 +27,8 @@ class _VitFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eng, images, droppath, head_w, head_b, *cp):
-        logits = eng._run_forward(images, droppath, head_w, head_b, cp)
+        # (grad mode is always off in here: CaraEngine.forward noted beforehand whether a backward can follow)
+        logits = eng._run_forward(images, droppath, head_w, head_b, cp, need_backward=eng._need_backward)
         ctx.eng, ctx.droppath, ctx.shape_key = eng, droppath, eng._last_key
         ctx.save_for_backward(head_w, *cp)
         return logits
@@ -59,6 +60,7 @@ class CaraEngine:
         self._last_key = None
         self._fwd_serial = 0
         self._bwd_ready = -1
+        self._need_backward = True
         self._flat_grad = None
         self._grad_views = None
         from .modules import FactorPack
@@ -150,7 +152,7 @@ class CaraEngine:
         return L.CpPtrs(*[ptr(t) for t in cp])
 
     # ------------------------------------------------------------------ forward / backward
-    def _run_forward(self, images, droppath, head_w, head_b, cp):
+    def _run_forward(self, images, droppath, head_w, head_b, cp, need_backward=True):
         model = self._model()
         if images.ndim != 4 or images.shape[2] != images.shape[3]:
             raise CaraError("images must be [B, C, H, H]")
@@ -164,13 +166,15 @@ class CaraEngine:
         if use_exact:
             st["shape"].wd_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if self.weight_dropout_seed is None \
                 else int(self.weight_dropout_seed)
+        # eval / no_grad: nothing the backward alone reads is kept (cara_vit_shape::inference)
+        st["shape"].inference = 0 if need_backward else 1
         cps = self._cp_ptrs([t.detach().contiguous() for t in cp])
         logits = torch.empty_like(st["logits"])
         check(L.lib().cara_vit_forward(C.byref(st["geom"]), C.byref(st["shape"]), C.byref(self._ingested[1]), C.byref(cps),
                                        ptr(head_w.detach().contiguous()), ptr(head_b.detach().contiguous()), ptr(images),
                                        ptr(droppath), ptr(st["ws"]), ptr(logits), stream()), "cara_vit_forward")
         self._fwd_serial += 1
-        self._bwd_ready = self._fwd_serial
+        self._bwd_ready = self._fwd_serial if need_backward else -1
         return logits
 
     def _grad_buffers(self, model, dev):
@@ -223,7 +227,9 @@ class CaraEngine:
         cp = [getattr(model, "CP_" + n) for n in L.CP_FIELDS]
         if model.head.weight.device != images.device or cp[0].device != images.device:
             raise CaraError("model parameters and images must be on the same device")
-        return _VitFn.apply(self, images, droppath, model.head.weight, model.head.bias, *cp)
+        params = [model.head.weight, model.head.bias, *cp]
+        self._need_backward = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _VitFn.apply(self, images, droppath, *params)
 
     # ------------------------------------------------------------------ fused train step
     def trainable_parameters(self):

@@ -50,7 +50,7 @@ typedef struct {
   const float* bias;            /* fp32 [N] or NULL */
   int epi;
   void* C;  int ldc;
-  void* C2;                     /* CARA_EPI_GELU only (same ldc) */
+  void* C2;                     /* CARA_EPI_GELU only (same ldc); NULL = the pre-activation is not kept */
   const void* aux;              /* CARA_EPI_RESID: fp32 [M,ldc]; CARA_EPI_DGELU: bf16 [M,ldc] */
   const float* rowscale;        /* CARA_EPI_RESID: fp32 [M / rows_per_sample] or NULL (=1) */
   int rows_per_sample;
@@ -269,6 +269,10 @@ typedef struct {
   int wd_exact;
   float wd_p;
   unsigned wd_seed;
+  /* 1: no backward will follow this forward (eval / no_grad).  The forward then skips what only the backward
+   * reads -- the bf16 pre-activation of fc1 (77 MB per block at bs 64), T^T of the adapter products -- and
+   * cara_vit_backward on that workspace is an error until a forward with inference = 0 has run.            */
+  int inference;
 } cara_vit_shape;
 size_t cara_vit_workspace_bytes(const cara_geom* g, const cara_vit_shape* s);
 /* images fp32 [B,chans,img,img]; droppath fp32 [depth,2,B] per-sample branch multipliers

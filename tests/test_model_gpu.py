@@ -258,6 +258,25 @@ def test_zero_init_known_answer_bitwise():
     assert rel(outs[0], base) < 1e-2 and torch.equal(outs[0].argmax(1).cpu(), base.argmax(1))
 
 
+def test_inference_forward_keeps_nothing_for_backward():
+    """Under no_grad the forward runs with cara_vit_shape.inference = 1 (no pre-activation kept): the logits are
+    bitwise those of the training-capable forward, and a backward cannot be started from it."""
+    from oracle import cara_oracle as O
+    from cara_amd._lib import CaraError
+    w = O.synthetic_backbone(depth=3)
+    cp = O.synthetic_cp(rank=16)
+    x, _ = O.synthetic_batch(batch=8)       # 8 x 197 rows: the full-size GEMM path, not the few-row one
+    m = build(w, cp, 16, 0.1, 3, 224).eval()
+    eng = m._cara_engine
+    a = m(x.to(DEV))                         # grad mode on: everything kept
+    assert eng._bwd_ready == eng._fwd_serial
+    with torch.no_grad():
+        b = m(x.to(DEV))
+    assert eng._bwd_ready == -1 and torch.equal(a.detach(), b)
+    with pytest.raises(CaraError):
+        a.sum().backward()                   # the workspace now holds the inference forward
+
+
 def test_drop_path_masks_and_train_mode():
     from oracle import cara_oracle as O
     w = O.synthetic_backbone(depth=3)
