@@ -173,6 +173,9 @@ __device__ __forceinline__ void stage_tile32(const bf16* __restrict__ P, int ld,
 // k0 * 2 to the operand's base pointer (SGPR base + VGPR offset addressing: no vector arithmetic at all per piece).
 // rocprofv3 counted 1 460 VALU instructions per wave and tile in the bf16-epilogue kernel (3.6 per MFMA), about
 // two thirds of them this address arithmetic.  Needs the operand to span < 4 GiB (checked at dispatch).
+#ifndef CARA_G32_WGS
+#define CARA_G32_WGS 4   // workgroups per CU the 128x128x32 kernel is compiled for
+#endif
 template <int ROWS, int NW = 4>
 struct TileOfs {
   unsigned off[ROWS / (16 * NW)];
@@ -229,7 +232,7 @@ __device__ __forceinline__ void stage_ext32(const bf16* __restrict__ P, int Rp, 
 // NW = waves per workgroup (NW/2 along M x 2 along N): 4, or 8 with MI = 2 for a 128-row tile made of
 // 32x64 wave tiles (more resident waves per CU)
 template <int EPI, int MI, int NW = 4>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? 4 : 6)) void gemm32_kernel(const cara_gemm_args p, const int tiles_n,
+__global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? CARA_G32_WGS : 6)) void gemm32_kernel(const cara_gemm_args p, const int tiles_n,
                                                                                           const int nwg, const int gm, const int ablate) {
   constexpr int TBM = MI * 16 * (NW / 2);
   constexpr int A_BYTES = TBM * BK32 * 2;
