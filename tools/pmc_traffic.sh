@@ -4,3 +4,5 @@ export TMPDIR=/tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_fetch.log 2>&1 || echo fetch pass failed
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_write.log 2>&1 || echo write pass failed
 ls gpurun_out/pmc_fetch/*/ gpurun_out/pmc_write/*/ | head
+python3 tools/pmc_summarize.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_traffic_fc1.json > gpurun_out/pmc_traffic_summary.txt 2>&1; cat gpurun_out/pmc_traffic_summary.txt
+rm -rf gpurun_out/pmc_fetch/*/*kernel_trace.csv gpurun_out/pmc_write/*/*kernel_trace.csv
