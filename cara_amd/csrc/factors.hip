@@ -104,10 +104,28 @@ __global__ __launch_bounds__(256) void prep_bias_kernel(PackDims g, cara_cp cp, 
 // gradient scatter (A.4).  All layer inputs are fp32 [depth, rows, Rp]; only r < rank is read.
 // ---------------------------------------------------------------------------------------------
 
+// Two launches.  Stage 1 runs the four independent reductions side by side in ONE grid (block ranges), with the
+// long row sums cut into GS_SPLIT partials so that no thread walks more than ~24 rows; stage 2 sums the partials in
+// a fixed order (bitwise reproducible, no float atomics).  As five back-to-back launches of 36..144 blocks whose
+// threads walked 96..150 rows each, the same arithmetic took 210 us per step -- all of it latency.
+//   scratch: pa3 [3L][H][R], pa4 [3L][hd][R], zvp [L][GS_SPLIT][R], zp [12L][GS_SPLIT][R]
+constexpr int GS_SPLIT = 4;
+struct GradScratch {
+  float *pa3, *pa4, *zvp, *zp;
+};
+__host__ __device__ inline GradScratch grad_scratch(float* sc, int L, int H, int hd, int R) {
+  GradScratch g;
+  g.pa3 = sc;
+  g.pa4 = g.pa3 + (size_t)3 * L * H * R;
+  g.zvp = g.pa4 + (size_t)3 * L * hd * R;
+  g.zp = g.zvp + (size_t)L * GS_SPLIT * R;
+  return g;
+}
+
 // (a) outputs indexed (j, r) that sum over layers: dA2, dP3, dP2, bias grads
-__global__ __launch_bounds__(256) void grad_rowwise_kernel(PackDims g, cara_cp cp, cara_layer_grads lg, cara_cp out) {
+__device__ __forceinline__ void grad_rowwise(const PackDims& g, const cara_cp& cp, const cara_layer_grads& lg, const cara_cp& out,
+                                             const int e) {
   const int R = g.rank, Rp = g.Rp, dim = g.dim, L = g.depth;
-  const int e = blockIdx.x * 256 + threadIdx.x;
   if (e < dim * R) {
     const int j = e / R, r = e - j * R;
     float a2 = 0.f, p3 = 0.f, p2 = 0.f;
@@ -142,18 +160,19 @@ __global__ __launch_bounds__(256) void grad_rowwise_kernel(PackDims g, cara_cp c
   }
 }
 
-// (b) column reductions Z[l, slot, r] = sum_rows W[row, r] * F[row, r], written (unscaled by the
-// lambda) into the dA1 / dP1 rows; slots per layer: 0-2 qkv(k), 3 proj, 4-7 fc1(a), 8-11 fc2(a)
-__global__ __launch_bounds__(256) void grad_colred_kernel(PackDims g, cara_cp cp, cara_layer_grads lg, cara_cp out) {
-  __shared__ float red[256];
+// (b) column reductions Z[l, slot, r] = sum_rows W[row, r] * F[row, r] (slots per layer: 0-2 qkv(k), 3 proj,
+// 4-7 fc1(a), 8-11 fc2(a)), and (b') zv[l, r] = sum_c dVs_fc2[l, c, r] * P3[c, r] as slot 12: one block per
+// (layer, slot, split) sums its quarter of the rows -> zp / zvp partials
+__device__ __forceinline__ void grad_colred_part(const PackDims& g, const cara_cp& cp, const cara_layer_grads& lg, const GradScratch& sc,
+                                                 const int l, const int slot, const int split, float* red) {
   const int R = g.rank, Rp = g.Rp, dim = g.dim;
-  const int l = blockIdx.x / 12, slot = blockIdx.x - l * 12;
   const int r = threadIdx.x % 32, part = threadIdx.x / 32;  // 8 row partitions; R <= 64 -> loop over r groups
+  const int row0 = (int)((long)dim * split / GS_SPLIT), row1 = (int)((long)dim * (split + 1) / GS_SPLIT);
   for (int rb = 0; rb < R; rb += 32) {
     const int rr = rb + r;
     float z = 0.f;
     if (rr < R) {
-      for (int row = part; row < dim; row += 8) {
+      for (int row = row0 + part; row < row1; row += 8) {
         float w, f;
         if (slot < 3) {
           const int hh = row / g.hd, d = row - hh * g.hd;
@@ -165,9 +184,12 @@ __global__ __launch_bounds__(256) void grad_colred_kernel(PackDims g, cara_cp cp
         } else if (slot < 8) {
           w = lg.dVs_fc1[((size_t)l * 4 * dim + (slot - 4) * dim + row) * Rp + rr];
           f = g.s * cp.P2[row * R + rr];
-        } else {
+        } else if (slot < 12) {
           w = lg.dU_fc2[((size_t)l * 4 * dim + (slot - 8) * dim + row) * Rp + rr];
           f = cp.P2[row * R + rr];
+        } else {
+          w = lg.dVs_fc2[((size_t)l * dim + row) * Rp + rr];
+          f = cp.P3[row * R + rr];
         }
         z += w * f;
       }
@@ -177,96 +199,117 @@ __global__ __launch_bounds__(256) void grad_colred_kernel(PackDims g, cara_cp cp
     if (part == 0 && rr < R) {
       float s = 0.f;
       for (int p = 0; p < 8; ++p) s += red[p * 32 + r];
-      if (slot < 3) out.A1[(3 * l + slot) * R + rr] = s;
-      else if (slot == 3) out.P1[(9 * l) * R + rr] = s;
-      else out.P1[(9 * l + 1 + (slot - 4)) * R + rr] = s;   // 4..7 -> 9l+1..4 ; 8..11 -> 9l+5..8
+      if (slot < 12) sc.zp[((size_t)(l * 12 + slot) * GS_SPLIT + split) * R + rr] = s;
+      else sc.zvp[((size_t)l * GS_SPLIT + split) * R + rr] = s;
     }
     __syncthreads();
   }
 }
 
-// (c) dA3[hh, r] and dA4[d, r]: one block per (layer, k) writes its partial (already multiplied by
-// A1[3l+k, r]) into scratch; the final kernel sums the 3*depth partials in a fixed order.
-//   scratch layout: pa3 [3L][H][R], pa4 [3L][hd][R], zv [L][R]
-__global__ __launch_bounds__(256) void grad_a34_partial_kernel(PackDims g, cara_cp cp, cara_layer_grads lg,
-                                                               float* __restrict__ scratch) {
-  const int R = g.rank, Rp = g.Rp, dim = g.dim, H = g.heads, hd = g.hd, L = g.depth;
-  const int lk = blockIdx.x, l = lk / 3, k = lk - 3 * l;
+// (c) dA3[hh, r] and dA4[d, r]: partials per (layer, k), already multiplied by A1[3l+k, r]; piece 0 of a (layer, k)
+// does pa3, pieces 1..4 a quarter of pa4 each
+__device__ __forceinline__ void grad_a34_part(const PackDims& g, const cara_cp& cp, const cara_layer_grads& lg, const GradScratch& sc,
+                                              const int lk, const int piece) {
+  const int R = g.rank, Rp = g.Rp, dim = g.dim, H = g.heads, hd = g.hd;
+  const int l = lk / 3, k = lk - 3 * l;
   const float* W = lg.dVs_qkv + ((size_t)l * 3 * dim + (size_t)k * dim) * Rp;   // [H*hd, Rp]
-  float* pa3 = scratch + (size_t)lk * H * R;
-  float* pa4 = scratch + (size_t)3 * L * H * R + (size_t)lk * hd * R;
-  for (int e = threadIdx.x; e < H * R; e += 256) {
-    const int hh = e / R, r = e - hh * R;
-    float in = 0.f;
-    for (int d = 0; d < hd; ++d) in += W[(size_t)(hh * hd + d) * Rp + r] * cp.A4[d * R + r];
-    pa3[e] = cp.A1[lk * R + r] * in;
-  }
-  for (int e = threadIdx.x; e < hd * R; e += 256) {
-    const int d = e / R, r = e - d * R;
-    float in = 0.f;
-    for (int hh = 0; hh < H; ++hh) in += W[(size_t)(hh * hd + d) * Rp + r] * cp.A3[hh * R + r];
-    pa4[e] = cp.A1[lk * R + r] * in;
+  if (piece == 0) {
+    float* pa3 = sc.pa3 + (size_t)lk * H * R;
+    for (int e = threadIdx.x; e < H * R; e += 256) {
+      const int hh = e / R, r = e - hh * R;
+      float in = 0.f;
+      for (int d = 0; d < hd; ++d) in += W[(size_t)(hh * hd + d) * Rp + r] * cp.A4[d * R + r];
+      pa3[e] = cp.A1[lk * R + r] * in;
+    }
+  } else {
+    float* pa4 = sc.pa4 + (size_t)lk * hd * R;
+    const int n = hd * R, e0 = (int)((long)n * (piece - 1) / 4), e1 = (int)((long)n * piece / 4);
+    for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+      const int d = e / R, r = e - d * R;
+      float in = 0.f;
+      for (int hh = 0; hh < H; ++hh) in += W[(size_t)(hh * hd + d) * Rp + r] * cp.A3[hh * R + r];
+      pa4[e] = cp.A1[lk * R + r] * in;
+    }
   }
 }
 
-// zv[l, r] = sum_c dVs_fc2[l, c, r] * P3[c, r]   (the R2-gradient carried by fc2's output factor)
-__global__ __launch_bounds__(256) void grad_zv_kernel(PackDims g, cara_cp cp, cara_layer_grads lg, float* __restrict__ scratch) {
+// stage 1: block ranges [rowwise | colred + zv: L * 13 * GS_SPLIT | a34: 3L * 5]
+__global__ __launch_bounds__(256) void grad_stage1_kernel(PackDims g, cara_cp cp, cara_layer_grads lg, cara_cp out, float* __restrict__ scratch,
+                                                          int nb_row) {
   __shared__ float red[256];
-  const int R = g.rank, Rp = g.Rp, dim = g.dim, H = g.heads, hd = g.hd, L = g.depth;
-  float* zv = scratch + (size_t)3 * L * (H + hd) * R;
-  const int l = blockIdx.x;
-  const int r = threadIdx.x % 32, part = threadIdx.x / 32;
-  for (int rb = 0; rb < R; rb += 32) {
-    const int rr = rb + r;
-    float v = 0.f;
-    if (rr < R)
-      for (int c = part; c < dim; c += 8) v += lg.dVs_fc2[((size_t)l * dim + c) * Rp + rr] * cp.P3[c * R + rr];
-    red[threadIdx.x] = v;
-    __syncthreads();
-    if (part == 0 && rr < R) {
-      float s = 0.f;
-      for (int p = 0; p < 8; ++p) s += red[p * 32 + r];
-      zv[l * R + rr] = s;
-    }
-    __syncthreads();
+  const GradScratch sc = grad_scratch(scratch, g.depth, g.heads, g.hd, g.rank);
+  int b = blockIdx.x;
+  if (b < nb_row) {
+    grad_rowwise(g, cp, lg, out, b * 256 + threadIdx.x);
+    return;
   }
+  b -= nb_row;
+  const int nb_col = g.depth * 13 * GS_SPLIT;
+  if (b < nb_col) {
+    const int split = b % GS_SPLIT, ls = b / GS_SPLIT;
+    grad_colred_part(g, cp, lg, sc, ls / 13, ls % 13, split, red);
+    return;
+  }
+  b -= nb_col;
+  grad_a34_part(g, cp, lg, sc, b / 5, b % 5);
 }
 
-// (d) finish: dA3/dA4 from the partials, lambda gradients, then scale the Z rows by the lambda.
-//   dR1 = sum A1 (.) Z ; dR2 = sum over the R2-carrying P1 rows (9l .. 9l+4) of P1 (.) Z + s * sum_l zv
-__global__ __launch_bounds__(256) void grad_finish_kernel(PackDims g, cara_cp cp, const float* __restrict__ scratch, cara_cp out) {
+// stage 2.  Blocks [0, nb_a): dA3 / dA4 = s R1 (.) sum of the 3L partials.  Last block: Z = sum of the splits,
+// the lambda gradients  dR1 = sum A1 (.) Z ;  dR2 = sum over the R2-carrying P1 rows (9l .. 9l+4) of P1 (.) Z
+// + s * sum_l zv ,  and the Z rows scaled by their lambda into dA1 / dP1.
+__global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp, float* __restrict__ scratch, cara_cp out, int nb_a) {
   const int R = g.rank, H = g.heads, hd = g.hd, L = g.depth;
-  const float* pa3 = scratch;
-  const float* pa4 = scratch + (size_t)3 * L * H * R;
-  const float* zv = scratch + (size_t)3 * L * (H + hd) * R;
-  for (int e = threadIdx.x; e < (H + hd) * R; e += 256) {
-    const bool is3 = e < H * R;
-    const int e2 = is3 ? e : e - H * R;
-    const int r = e2 % R;
-    const int per = is3 ? H * R : hd * R;
-    const float* p = is3 ? pa3 : pa4;
-    float acc = 0.f;
-    for (int lk = 0; lk < 3 * L; ++lk) acc += p[(size_t)lk * per + e2];
-    (is3 ? out.A3 : out.A4)[e2] = g.s * cp.R1[r] * acc;
-  }
-  for (int rr = threadIdx.x; rr < R; rr += 256) {
-    float d1 = 0.f, d2 = 0.f;
-    for (int l = 0; l < L; ++l) d2 += zv[l * R + rr];
-    d2 *= g.s;
-    for (int row = 0; row < 3 * L; ++row) {
-      const float z = out.A1[row * R + rr];
-      d1 += cp.A1[row * R + rr] * z;
-      out.A1[row * R + rr] = cp.R1[rr] * z;
+  const GradScratch sc = grad_scratch(scratch, L, H, hd, R);
+  if ((int)blockIdx.x < nb_a) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < (H + hd) * R) {
+      const bool is3 = e < H * R;
+      const int e2 = is3 ? e : e - H * R;
+      const int r = e2 % R;
+      const int per = is3 ? H * R : hd * R;
+      const float* p = is3 ? sc.pa3 : sc.pa4;
+      float acc = 0.f;
+      for (int lk = 0; lk < 3 * L; ++lk) acc += p[(size_t)lk * per + e2];
+      (is3 ? out.A3 : out.A4)[e2] = g.s * cp.R1[r] * acc;
     }
-    for (int row = 0; row < 9 * L; ++row) {
-      if (row % 9 < 5) {
-        const float z = out.P1[row * R + rr];
-        d2 += cp.P1[row * R + rr] * z;
-        out.P1[row * R + rr] = cp.R2[rr] * z;
+    return;
+  }
+  __shared__ float red1[256], red2[256];
+  const int r = threadIdx.x % 64, qg = threadIdx.x / 64;   // R <= 64; four groups walk the 12L (layer, slot) pairs
+  float d1 = 0.f, d2 = 0.f;
+  if (r < R) {
+    for (int q = qg; q < 12 * L; q += 4) {
+      const float* zp = sc.zp + (size_t)q * GS_SPLIT * R + r;
+      float z = 0.f;
+#pragma unroll
+      for (int sp = 0; sp < GS_SPLIT; ++sp) z += zp[sp * R];
+      const int l = q / 12, slot = q - 12 * l;
+      if (slot < 3) {
+        const int row = 3 * l + slot;
+        d1 += cp.A1[row * R + r] * z;
+        out.A1[row * R + r] = cp.R1[r] * z;
+      } else {
+        const int row = 9 * l + (slot - 3);   // 3 -> 9l ; 4..7 -> 9l+1..4 ; 8..11 -> 9l+5..8
+        if (slot < 8) {
+          d2 += cp.P1[row * R + r] * z;
+          out.P1[row * R + r] = cp.R2[r] * z;
+        } else {
+          out.P1[row * R + r] = z;
+        }
       }
     }
-    out.R1[rr] = d1;
-    out.R2[rr] = d2;
+    if (qg == 0) {
+      float zv = 0.f;
+      for (int i = 0; i < L * GS_SPLIT; ++i) zv += sc.zvp[(size_t)i * R + r];
+      d2 += g.s * zv;
+    }
+  }
+  red1[threadIdx.x] = d1;
+  red2[threadIdx.x] = d2;
+  __syncthreads();
+  if (qg == 0 && r < R) {
+    out.R1[r] = (red1[r] + red1[64 + r]) + (red1[128 + r] + red1[192 + r]);
+    out.R2[r] = (red2[r] + red2[64 + r]) + (red2[128 + r] + red2[192 + r]);
   }
 }
 
@@ -317,7 +360,7 @@ extern "C" int cara_factor_prep(const cara_geom* g, const cara_cp* cp, const flo
 extern "C" size_t cara_factor_grad_scratch_bytes(const cara_geom* g) {
   if (!geom_ok(g)) return 0;
   const size_t L = g->depth, R = g->rank, H = g->heads, hd = g->dim / g->heads;
-  return (3 * L * (H + hd) * R + L * R) * sizeof(float);
+  return (3 * L * (H + hd) * R + L * GS_SPLIT * R + 12 * L * GS_SPLIT * R) * sizeof(float);
 }
 
 extern "C" int cara_factor_grad_reduce(const cara_geom* g, const cara_cp* cp, const cara_layer_grads* lg,
@@ -329,16 +372,12 @@ extern "C" int cara_factor_grad_reduce(const cara_geom* g, const cara_cp* cp, co
   hipStream_t st = static_cast<hipStream_t>(stream);
   const PackDims d = dims_of(g);
   const int n1 = g->dim * g->rank > 4 * g->dim ? g->dim * g->rank : 4 * g->dim;
-  hipLaunchKernelGGL(grad_rowwise_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, d, *cp, *lg, *grads);
-  CARA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(grad_colred_kernel, dim3(g->depth * 12), dim3(256), 0, st, d, *cp, *lg, *grads);
-  CARA_CHECK_LAUNCH();
+  const int nb_row = (n1 + 255) / 256, nb_col = g->depth * 13 * GS_SPLIT, nb_a34 = 3 * g->depth * 5;
   float* sc = static_cast<float*>(scratch);
-  hipLaunchKernelGGL(grad_a34_partial_kernel, dim3(3 * g->depth), dim3(256), 0, st, d, *cp, *lg, sc);
+  hipLaunchKernelGGL(grad_stage1_kernel, dim3(nb_row + nb_col + nb_a34), dim3(256), 0, st, d, *cp, *lg, *grads, sc, nb_row);
   CARA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(grad_zv_kernel, dim3(g->depth), dim3(256), 0, st, d, *cp, *lg, sc);
-  CARA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(grad_finish_kernel, dim3(1), dim3(256), 0, st, d, *cp, sc, *grads);
+  const int nb_a = ((g->heads + g->dim / g->heads) * g->rank + 255) / 256;
+  hipLaunchKernelGGL(grad_stage2_kernel, dim3(nb_a + 1), dim3(256), 0, st, d, *cp, sc, *grads, nb_a);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }

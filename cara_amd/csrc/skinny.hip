@@ -370,7 +370,56 @@ __global__ void tskinny_reduce_kernel(const char* __restrict__ slabs_base, size_
   }
 }
 
+// several reductions in ONE launch (grid.z = problem): the 8 + 6 slab sums at the end of a backward pass are 10 us
+// each as separate launches, almost all of it launch latency
+struct TsReduceTable {
+  cara_ts_reduce p[CARA_TS_REDUCE_MAX];
+  int nchunks[CARA_TS_REDUCE_MAX];
+};
+__global__ void tskinny_reduce_many_kernel(const TsReduceTable t) {
+  const cara_ts_reduce& q = t.p[blockIdx.z];
+  if ((int)blockIdx.y >= q.batch) return;
+  const int K1 = q.K1, Rp = q.Rp, nchunks = t.nchunks[blockIdx.z];
+  const int colblocks = K1 / TS_COLS;
+  const int nblk = colblocks * nchunks;
+  const float* slabs = reinterpret_cast<const float*>(static_cast<const char*>(q.slabs) + (size_t)blockIdx.y * q.slab_stride);
+  const float* cs_slabs = slabs + (size_t)nblk * TS_COLS * Rp;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = K1 * Rp;
+  if (idx < total) {
+    const int i = idx / Rp, r = idx - i * Rp;
+    const int cb = i / TS_COLS, il = i - cb * TS_COLS;
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += slabs[((size_t)(c * colblocks + cb) * TS_COLS + il) * Rp + r];
+    q.D[(size_t)blockIdx.y * total + idx] = s;
+  }
+  if (q.colsum && idx < K1) {
+    const int cb = idx / TS_COLS, il = idx - cb * TS_COLS;
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += cs_slabs[(size_t)(c * colblocks + cb) * TS_COLS + il];
+    q.colsum[(size_t)blockIdx.y * K1 + idx] = s;
+  }
+}
+
 }  // namespace
+
+extern "C" int cara_tskinny_reduce_many(const cara_ts_reduce* probs, int n, void* stream) {
+  if (!probs || n <= 0 || n > CARA_TS_REDUCE_MAX) return CARA_E_ARG;
+  TsReduceTable t;
+  int maxblocks = 0, maxbatch = 0;
+  for (int i = 0; i < n; ++i) {
+    const cara_ts_reduce& q = probs[i];
+    if (!q.slabs || !q.D || q.batch <= 0 || q.M <= 0 || q.K1 <= 0 || (q.K1 % TS_COLS) || !(q.Rp == 32 || q.Rp == 64)) return CARA_E_ARG;
+    t.p[i] = q;
+    t.nchunks[i] = ts_chunks(q.M, q.K1);
+    const int blocks = (q.K1 * q.Rp + 255) / 256;
+    maxblocks = blocks > maxblocks ? blocks : maxblocks;
+    maxbatch = q.batch > maxbatch ? q.batch : maxbatch;
+  }
+  hipLaunchKernelGGL(tskinny_reduce_many_kernel, dim3(maxblocks, maxbatch, n), dim3(256), 0, static_cast<hipStream_t>(stream), t);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
 
 extern "C" int cara_skinny_xu(const void* X, int ldx, const void* Ut, void* T, void* Tt, int ldt,
                               int M, int K, int Rp, void* stream) {

@@ -113,6 +113,13 @@ int cara_tskinny_partial2(const void* Xa, int ldxa, const void* Gta, void* slabs
                           int ldg, int M, int Rp, void* stream);
 int cara_tskinny_reduce(const void* slabs, size_t slab_stride, float* D, float* colsum, int batch,
                         int M, int K1, int Rp, void* stream);
+/* Up to CARA_TS_REDUCE_MAX of those reductions in ONE launch (each entry = the arguments of cara_tskinny_reduce). */
+#define CARA_TS_REDUCE_MAX 16
+typedef struct {
+  const void* slabs; size_t slab_stride; float* D; float* colsum;   /* colsum may be NULL */
+  int batch, M, K1, Rp;
+} cara_ts_reduce;
+int cara_tskinny_reduce_many(const cara_ts_reduce* probs, int n, void* stream);
 
 /* ---- LayerNorm (eps inside the sqrt, biased variance; timm Block norm1/norm2/norm) ------- */
 /* y bf16 [M,C] = (x - mean) * rstd * gamma + beta; saves mean, rstd fp32 [M].  x fp32 rows with

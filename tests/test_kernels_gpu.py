@@ -407,6 +407,41 @@ def test_tskinny(M, K1, Rp):
     assert torch.equal(D, D2), "tskinny must be bitwise reproducible (fixed-order slab sum)"
 
 
+def test_tskinny_reductions_in_one_launch():
+    """cara_tskinny_reduce_many: several slab reductions of different shapes (and layer counts) in one launch give
+    bitwise what one cara_tskinny_reduce launch per product gives."""
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+
+    class Red(C.Structure):
+        _fields_ = [("slabs", C.c_void_p), ("slab_stride", C.c_size_t), ("D", C.c_void_p), ("colsum", C.c_void_p),
+                    ("batch", C.c_int), ("M", C.c_int), ("K1", C.c_int), ("Rp", C.c_int)]
+
+    lib.cara_tskinny_scratch_bytes.restype = C.c_size_t
+    probs, keep = [], []
+    for (M, K1, batch, want_cs, seed) in [(3000, 768, 3, False, 1), (3000, 3072, 3, True, 2), (64, 768, 1, True, 3), (500, 2304, 2, False, 4)]:
+        nb = int(lib.cara_tskinny_scratch_bytes(M, K1, 32))
+        stride = (nb + 255) // 256 * 256
+        slabs = torch.zeros(batch * stride, dtype=torch.uint8, device=DEV)
+        ldg = (M + 31) // 32 * 32
+        for b in range(batch):
+            X = rnd(M, K1, seed=10 * seed + b)
+            Gt = torch.zeros(32, ldg, dtype=torch.bfloat16, device=DEV)
+            Gt[:, :M] = rnd(M, 32, seed=20 * seed + b, scale=0.5).t()
+            L().check(lib.cara_tskinny_partial(p(X), K1, p(Gt), ldg, C.c_void_p(slabs.data_ptr() + b * stride), 1 if want_cs else 0,
+                                               M, K1, 32, st()), "partial")
+        D1, D2 = (torch.full((batch, K1, 32), float("nan"), device=DEV) for _ in range(2))
+        c1, c2 = (torch.full((batch, K1), float("nan"), device=DEV) for _ in range(2))
+        L().check(lib.cara_tskinny_reduce(p(slabs), C.c_size_t(stride), p(D1), p(c1) if want_cs else None, batch, M, K1, 32, st()), "reduce")
+        probs.append(Red(slabs.data_ptr(), stride, D2.data_ptr(), c2.data_ptr() if want_cs else None, batch, M, K1, 32))
+        keep.append((D1, D2, c1, c2, want_cs, slabs))
+    arr = (Red * len(probs))(*probs)
+    L().check(lib.cara_tskinny_reduce_many(arr, len(probs), st()), "reduce_many")
+    for D1, D2, c1, c2, want_cs, _ in keep:
+        assert torch.equal(D1, D2) and (not want_cs or torch.equal(c1, c2))
+    assert lib.cara_tskinny_reduce_many(arr, 17, st()) != 0      # more than CARA_TS_REDUCE_MAX entries
+
+
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,C_", [(12608, 768), (64, 768), (33, 1024)])
 def test_layernorm_fwd_bwd(M, C_):
