@@ -345,6 +345,23 @@ __global__ __launch_bounds__(256) void tskinny_kernel(const TsProblem p0, const 
   }
 }
 
+// sum of n values `stride` floats apart, in a FIXED order that keeps four loads in flight: four interleaved partial
+// sums, then (s0 + s1) + (s2 + s3)
+__device__ __forceinline__ float strided_sum4(const float* __restrict__ p, const size_t stride, const int n) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = 0;
+  for (; c + 4 <= n; c += 4) {
+    s0 += p[(size_t)c * stride];
+    s1 += p[(size_t)(c + 1) * stride];
+    s2 += p[(size_t)(c + 2) * stride];
+    s3 += p[(size_t)(c + 3) * stride];
+  }
+  if (c < n) s0 += p[(size_t)c * stride];
+  if (c + 1 < n) s1 += p[(size_t)(c + 1) * stride];
+  if (c + 2 < n) s2 += p[(size_t)(c + 2) * stride];
+  return (s0 + s1) + (s2 + s3);
+}
+
 // D[b][i][r] = sum_chunk slab[b][chunk*colblocks + i/64][i%64][r]   (fixed order); grid.y = batch
 __global__ void tskinny_reduce_kernel(const char* __restrict__ slabs_base, size_t slab_stride,
                                       float* __restrict__ D, float* __restrict__ colsum, int K1, int Rp,
@@ -358,14 +375,12 @@ __global__ void tskinny_reduce_kernel(const char* __restrict__ slabs_base, size_
   if (idx < total) {
     const int i = idx / Rp, r = idx - i * Rp;
     const int cb = i / TS_COLS, il = i - cb * TS_COLS;
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += slabs[((size_t)(c * colblocks + cb) * TS_COLS + il) * Rp + r];
+    const float s = strided_sum4(slabs + ((size_t)cb * TS_COLS + il) * Rp + r, (size_t)colblocks * TS_COLS * Rp, nchunks);
     D[(size_t)blockIdx.y * total + idx] = s;
   }
   if (colsum && idx < K1) {
     const int cb = idx / TS_COLS, il = idx - cb * TS_COLS;
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += cs_slabs[(size_t)(c * colblocks + cb) * TS_COLS + il];
+    const float s = strided_sum4(cs_slabs + (size_t)cb * TS_COLS + il, (size_t)colblocks * TS_COLS, nchunks);
     colsum[(size_t)blockIdx.y * K1 + idx] = s;
   }
 }
@@ -389,14 +404,12 @@ __global__ void tskinny_reduce_many_kernel(const TsReduceTable t) {
   if (idx < total) {
     const int i = idx / Rp, r = idx - i * Rp;
     const int cb = i / TS_COLS, il = i - cb * TS_COLS;
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += slabs[((size_t)(c * colblocks + cb) * TS_COLS + il) * Rp + r];
+    const float s = strided_sum4(slabs + ((size_t)cb * TS_COLS + il) * Rp + r, (size_t)colblocks * TS_COLS * Rp, nchunks);
     q.D[(size_t)blockIdx.y * total + idx] = s;
   }
   if (q.colsum && idx < K1) {
     const int cb = idx / TS_COLS, il = idx - cb * TS_COLS;
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += cs_slabs[(size_t)(c * colblocks + cb) * TS_COLS + il];
+    const float s = strided_sum4(cs_slabs + (size_t)cb * TS_COLS + il, (size_t)colblocks * TS_COLS, nchunks);
     q.colsum[(size_t)blockIdx.y * K1 + idx] = s;
   }
 }
