@@ -19,6 +19,7 @@
 
 #include "common.h"
 #include "gemm_epilogue.h"
+#include "tskinny_body.h"
 
 namespace {
 
@@ -231,13 +232,13 @@ __device__ __forceinline__ void stage_ext32(const bf16* __restrict__ P, int Rp, 
 // 2 -> 64x128 tile (24 KiB LDS, 6 workgroups/CU, twice the tiles: used for the N = 768 products)
 // NW = waves per workgroup (NW/2 along M x 2 along N): 4, or 8 with MI = 2 for a 128-row tile made of
 // 32x64 wave tiles (more resident waves per CU)
-template <int EPI, int MI, int NW = 4>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? CARA_G32_WGS : 6)) void gemm32_kernel(const cara_gemm_args p, const int tiles_n,
-                                                                                          const int nwg, const int gm, const int ablate) {
+// one workgroup's tile; `block` = its index among the nwg tiles of the product, `zb` = product index of a batched launch
+template <int EPI, int MI, int NW>
+__device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int tiles_n, const int nwg, const int gm, const int ablate,
+                                            const int block, const size_t zb_in, char* smem) {
   constexpr int TBM = MI * 16 * (NW / 2);
   constexpr int A_BYTES = TBM * BK32 * 2;
   constexpr int SLOT = A_BYTES + B32_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   // Tile order: each XCD gets a contiguous run of logical tile indices (xcd_remap); inside the run
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? C
   // ~128 tiles an XCD keeps in flight touch about sqrt(128)+sqrt(128) operand panels instead of
   // 5 + tiles_n -- rocprofv3 FETCH_SIZE showed 9x re-fetch on the N = 3072 products with the plain
   // row-major order (their W panels alone exceed the XCD's 4 MiB L2).
-  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int tile = xcd_remap(block, nwg);
   int tm, tn;
   if (gm <= 1) {
     tm = tile / tiles_n;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? C
   }
   const int m0 = tm * TBM, n0 = tn * BN;
   // batched launch (blockIdx.y = product index): advance the operand pointers and the output offset
-  const size_t zb = p.batch > 1 ? blockIdx.y : 0;
+  const size_t zb = p.batch > 1 ? zb_in : 0;
   const bf16* __restrict__ A = static_cast<const bf16*>(p.A) + zb * p.strideA;
   // B from its K-panel-major image when there is one: row stride 64 B inside a panel, N * 32 elements per K step
   const bool packed = p.Bp != nullptr;
@@ -320,6 +321,34 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? C
 #pragma unroll
         for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[half * (MI / NPASS) + i][j][r];
     epilogue_rows<EPI, HALF>(p, stg, m0 + wr * (MI * 16) + half * HALF, n0 + wc * 64, lane, coff);
+  }
+}
+
+template <int EPI, int MI, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? CARA_G32_WGS : 6)) void gemm32_kernel(const cara_gemm_args p, const int tiles_n,
+                                                                                          const int nwg, const int gm, const int ablate) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm32_body<EPI, MI, NW>(p, tiles_n, nwg, gm, ablate, blockIdx.x, blockIdx.y, smem);
+}
+
+// The dX GEMM of a linear and the two transposed skinny products of the SAME linear (dU = X^T G', dVs = dY^T T) in
+// one grid: blocks [0, nts) are tskinny blocks (HBM-bound, one LDS stage per wave), the rest GEMM tiles (MFMA-bound).
+// The products used to run on a side stream under the GEMM, which costs a fork (an event record = 3..7 us of idle
+// chip, 44 of them per backward pass) and overlaps only as well as two queues happen to interleave; as one launch
+// there is no event at all and the dispatcher mixes the two kinds of workgroup on every CU.  Needs Rp = 32 products
+// (84 VGPRs; the Rp = 64 form needs 136) and 36 KiB of LDS per workgroup (still four per CU).
+template <int EPI, bool COLSUM>
+__global__ __launch_bounds__(256, 4) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
+                                                           const TsProblem t0, const TsProblem t1, const int ldg, const int Mts, const int nts,
+                                                           const int ts_first) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // (ts_first: the GEMM tiles start at a multiple of 8 so that blockIdx % 8, the XCD, is what xcd_remap assumes)
+  const int b = blockIdx.x, nts8 = (nts + 7) & ~7;
+  if (ts_first ? b < nts8 : b >= nwg) {
+    const int tb = ts_first ? b : b - nwg;
+    if (tb < nts) tskinny_body<2, COLSUM, 1>(t0, t1, ldg, Mts, tb, smem);
+  } else {
+    gemm32_body<EPI, 4, 4>(p, tiles_n, nwg, gm, 0, ts_first ? b - nts8 : b, 0, smem);
   }
 }
 
@@ -499,10 +528,32 @@ static int group_m(int tiles_n) {
   return tiles_n >= 20 ? 8 : 1;
 }
 
+// the transposed skinny products a GEMM launch can carry (cara_gemm_with_tskinny)
+struct TsPair {
+  TsProblem a, b;
+  int ldg, M;
+  bool any_cs;
+};
+
 template <int EPI>
-int launch32(const cara_gemm_args* a, hipStream_t st) {
+int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr) {
   const int tiles_n = (a->N + BN - 1) / BN;
   const int gm = group_m(tiles_n);
+  if (ts) {   // default tile only (checked by the caller)
+    const int nwg = ((a->M + 127) / 128) * tiles_n, nts = ts->a.nblk + ts->b.nblk;
+    // the products' blocks go BEHIND the GEMM tiles (they fill the slots its last, partly filled round leaves free);
+    // CARA_TS_POS=0 puts them in front (A/B: 10.02 vs 9.95-9.98 ms/step; the side stream: 10.03-10.06)
+    const char* ep = getenv("CARA_TS_POS");
+    const int ts_first = ep && atoi(ep) == 0;
+    const int grid = nwg + (ts_first ? ((nts + 7) & ~7) : nts);
+    constexpr int LDS = TsRing<2, 1>::BLOCK_BYTES > 2 * (128 * BK32 * 2 + B32_BYTES) ? TsRing<2, 1>::BLOCK_BYTES : 2 * (128 * BK32 * 2 + B32_BYTES);
+    if (ts->any_cs)
+      hipLaunchKernelGGL((gemm32_ts_kernel<EPI, true>), dim3(grid), dim3(256), LDS, st, *a, tiles_n, nwg, gm, ts->a, ts->b, ts->ldg, ts->M, nts, ts_first);
+    else
+      hipLaunchKernelGGL((gemm32_ts_kernel<EPI, false>), dim3(grid), dim3(256), LDS, st, *a, tiles_n, nwg, gm, ts->a, ts->b, ts->ldg, ts->M, nts, ts_first);
+    CARA_CHECK_LAUNCH();
+    return CARA_OK;
+  }
   const char* ea = getenv("CARA_GEMM_ABLATE");
   const int ablate = ea ? atoi(ea) : 0;
   const int nb = a->batch > 1 ? a->batch : 1;
@@ -684,7 +735,22 @@ extern "C" int cara_pack_b_panels(const void* B, int ldb, int N, int K, void* ou
   return CARA_OK;
 }
 
-extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
+static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* ts);
+extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) { return gemm_bf16_impl(a, stream, nullptr); }
+
+extern "C" int cara_gemm_with_tskinny(const cara_gemm_args* a, const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
+                                      const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b, int ldg,
+                                      int M, int Rp, void* stream) {
+  if (Rp != 32 || !ts_args_ok(Xa, ldxa, Gta, ldg, slabs_a, M, K1a, Rp) || !ts_args_ok(Xb, ldxb, Gtb, ldg, slabs_b, M, K1b, Rp)) return CARA_E_ARG;
+  TsPair ts;
+  ts.a = ts_problem(Xa, ldxa, Gta, slabs_a, 0, M, K1a, Rp);
+  ts.b = ts_problem(Xb, ldxb, Gtb, slabs_b, want_colsum_b, M, K1b, Rp);
+  ts.ldg = ldg; ts.M = M; ts.any_cs = want_colsum_b != 0;
+  return gemm_bf16_impl(a, stream, &ts);
+}
+
+// ts != NULL: the launch also carries a pair of transposed skinny products; only the default 128 x 128 x 32 kernel can
+static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* ts) {
   if (!a || !a->A || !a->B || !a->C) return CARA_E_ARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % BK) != 0) return CARA_E_ARG;
   if ((!a->a_panels && (a->lda < a->K || (a->lda & 7))) || a->ldb < a->K || (a->ldb & 7) || a->ldc < a->N) return CARA_E_ARG;
@@ -704,6 +770,8 @@ extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
   if (a->epi == CARA_EPI_GELU && !a->C2 && (tile_choice(a) != 0 || use_stream_k(a) || !use_bk32())) return CARA_E_ARG;
   if (a->epi == CARA_EPI_RESID && (!a->aux || (a->rowscale && a->rows_per_sample <= 0))) return CARA_E_ARG;
   if (a->epi == CARA_EPI_DGELU && !a->aux) return CARA_E_ARG;
+  if (ts && (a->Ut || a->batch > 1 || a->M <= 128 || tile_choice(a) != 0 || use_stream_k(a) || !use_bk32() || !small_ptrs || bm_choice(a) != 128))
+    return CARA_E_ARG;
   if (a->Ut) {   // whole adapter inside the GEMM: default kernel family, Rp = 32, T produced here
     if (!small_ptrs || a->A2 || !a->B2 || a->Rp != 32 || !a->T_out || a->batch > 1 || (a->K % BK32) || (a->Tt_out && (a->ldt < a->M || (a->ldt & 7))))
       return CARA_E_ARG;
@@ -737,11 +805,11 @@ extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) {
   if (use_stream_k(a)) return cara_gemm_sk_dispatch(a, st);
   if (use_bk32() && small_ptrs) {
     switch (a->epi) {
-      case CARA_EPI_BF16: return launch32<CARA_EPI_BF16>(a, st);
-      case CARA_EPI_F32: return launch32<CARA_EPI_F32>(a, st);
-      case CARA_EPI_GELU: return launch32<CARA_EPI_GELU>(a, st);
-      case CARA_EPI_RESID: return launch32<CARA_EPI_RESID>(a, st);
-      case CARA_EPI_DGELU: return launch32<CARA_EPI_DGELU>(a, st);
+      case CARA_EPI_BF16: return launch32<CARA_EPI_BF16>(a, st, ts);
+      case CARA_EPI_F32: return launch32<CARA_EPI_F32>(a, st, ts);
+      case CARA_EPI_GELU: return launch32<CARA_EPI_GELU>(a, st, ts);
+      case CARA_EPI_RESID: return launch32<CARA_EPI_RESID>(a, st, ts);
+      case CARA_EPI_DGELU: return launch32<CARA_EPI_DGELU>(a, st, ts);
       default: return CARA_E_ARG;
     }
   }

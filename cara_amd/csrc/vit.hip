@@ -290,6 +290,18 @@ bool panel_acts(int Mr, const cara_vit_shape* s, int what = 1) {
   return (v & what) != 0 && !s->wd_exact && Mr >= 1024;
 }
 
+// CARA_FUSE_TS=0: the transposed skinny products of a linear go to the side stream (fork before its dX GEMM) instead
+// of riding in that GEMM's launch (cara_gemm_with_tskinny).  Default GEMM family, Rp = 32, full-size products only.
+bool fuse_ts(int Mr, int Rp) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CARA_FUSE_TS");
+    v = e ? atoi(e) : 1;
+  }
+  if (getenv("CARA_GEMM_TILE") || getenv("CARA_GEMM_SK") || getenv("CARA_GEMM_BM") || getenv("CARA_GEMM_BK")) return false;
+  return v != 0 && Rp == 32 && Mr >= 1024;
+}
+
 // stream-K scratch of the workspace in use (set on entry of cara_vit_forward / _backward: one
 // workspace per stream, as for the side stream above)
 char* g_sk_scratch = nullptr;
@@ -345,16 +357,23 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
     if (last) TRY(flush_jobs(st, layer, true));
     return CARA_OK;
   }
-  g_jobs.job[g_jobs.n++] = job;
-  if (flush_before(L.slot, layer)) TRY(flush_jobs(st, layer, last));   // fork: G' exists, the dX GEMM comes next
   if (want_dx) {
     a.A = dY; a.lda = lddy; a.B = L.Wt; a.Bp = L.Wtp; a.ldb = L.out; a.A2 = G; a.B2 = L.U; a.Rp = Rp;
     if (lddy < 0) { a.a_panels = -lddy; a.lda = 0; }
     a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
     if (a.ldc == 0) a.ldc = L.in;
     with_scratch(a);
-    TRY(cara_gemm_bf16(&a, st));
+    if (fuse_ts(Mr, Rp)) {
+      // the products ride in the dX GEMM's own launch: no side stream, no fork.  (A product still waiting in the
+      // queue -- none in this mode -- would go out first.)
+      if (g_jobs.n) TRY(flush_jobs(st, layer, false));
+      return cara_gemm_with_tskinny(&a, job.X, job.ldx, job.Gt, job.slabU, job.in, job.dY, job.lddy, job.Tt, job.slabV, job.out,
+                                    job.want_dc, job.ldt, job.Mr, job.Rp, st);
+    }
   }
+  g_jobs.job[g_jobs.n++] = job;
+  if (flush_before(L.slot, layer)) TRY(flush_jobs(st, layer, last));   // fork: G' exists, the dX GEMM comes next
+  if (want_dx) TRY(cara_gemm_bf16(&a, st));
   return CARA_OK;
 }
 

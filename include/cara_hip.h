@@ -111,6 +111,13 @@ int cara_tskinny_partial(const void* X, int ldx, const void* Gt, int ldg, void* 
 int cara_tskinny_partial2(const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
                           const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b,
                           int ldg, int M, int Rp, void* stream);
+/* cara_gemm_bf16(a) and cara_tskinny_partial2(...) of the SAME linear as ONE launch: the grid holds the GEMM's tiles
+ * and the products' blocks, so the HBM-bound products run under the MFMA-bound GEMM without a second stream (no
+ * event between the kernels before and after).  Default GEMM kernel family, M > 128, no batch / Ut; Rp == 32;
+ * CARA_E_ARG otherwise (callers then launch the two separately).  Results are bitwise those of the two calls.   */
+int cara_gemm_with_tskinny(const cara_gemm_args* a, const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
+                           const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b,
+                           int ldg, int M, int Rp, void* stream);
 int cara_tskinny_reduce(const void* slabs, size_t slab_stride, float* D, float* colsum, int batch,
                         int M, int K1, int Rp, void* stream);
 /* Up to CARA_TS_REDUCE_MAX of those reductions in ONE launch (each entry = the arguments of cara_tskinny_reduce). */

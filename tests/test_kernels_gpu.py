@@ -407,6 +407,54 @@ def test_tskinny(M, K1, Rp):
     assert torch.equal(D, D2), "tskinny must be bitwise reproducible (fixed-order slab sum)"
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(12608, 768, 3072, "bf16"), (12608, 3072, 768, "dgelu"), (1500, 768, 768, "bf16")])
+def test_gemm_carrying_the_transposed_skinny_products(M, N, K, epi, monkeypatch):
+    """cara_gemm_with_tskinny: the dX GEMM of a linear and its two transposed skinny products as ONE launch give
+    bitwise what cara_gemm_bf16 + cara_tskinny_partial2 give, with the products' blocks in front of or behind the tiles."""
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+    lib.cara_tskinny_scratch_bytes.restype = C.c_size_t
+    dY, Wt = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)          # dX = dY Wt^T: K = out features, N = in features
+    X = rnd(M, N, seed=3)
+    G, U = rnd(M, 32, seed=4, scale=0.5), rnd(N, 32, seed=5, scale=0.3)
+    ldg = (M + 31) // 32 * 32
+    Gt, Tt = (torch.zeros(32, ldg, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    Gt[:, :M] = G.t()
+    Tt[:, :M] = rnd(M, 32, seed=6, scale=0.5).t()
+    aux = rnd(M, N, seed=7)
+
+    def run(fused):
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        sa = torch.zeros(int(lib.cara_tskinny_scratch_bytes(M, N, 32)), dtype=torch.uint8, device=DEV)
+        sb = torch.zeros(int(lib.cara_tskinny_scratch_bytes(M, K, 32)), dtype=torch.uint8, device=DEV)
+        a = L().GemmArgs()
+        a.A, a.lda, a.B, a.ldb, a.A2, a.B2, a.Rp = p(dY), K, p(Wt), K, p(G), p(U), 32
+        a.M, a.N, a.K, a.C, a.ldc = M, N, K, p(out), N
+        a.epi = L().EPI_DGELU if epi == "dgelu" else L().EPI_BF16
+        a.aux = p(aux) if epi == "dgelu" else None
+        ts = (p(X), N, p(Gt), p(sa), N, p(dY), K, p(Tt), p(sb), K, 1, ldg, M, 32, st())
+        if fused:
+            L().check(lib.cara_gemm_with_tskinny(C.byref(a), *ts), "cara_gemm_with_tskinny")
+        else:
+            L().check(lib.cara_gemm_bf16(C.byref(a), st()), "gemm")
+            L().check(lib.cara_tskinny_partial2(*ts), "partial2")
+        return out, sa, sb
+
+    ref = run(False)
+    for pos in ("0", "1"):
+        monkeypatch.setenv("CARA_TS_POS", pos)
+        got = run(True)
+        assert all(torch.equal(x, y) for x, y in zip(ref, got)), f"CARA_TS_POS={pos}"
+    # not fusable: few rows
+    a = L().GemmArgs()
+    a.A, a.lda, a.B, a.ldb, a.M, a.N, a.K, a.ldc = p(dY), K, p(Wt), K, 64, N, K, N
+    out = torch.empty(64, N, dtype=torch.bfloat16, device=DEV)
+    a.C, a.epi = p(out), L().EPI_BF16
+    sa = torch.zeros(int(lib.cara_tskinny_scratch_bytes(64, N, 32)), dtype=torch.uint8, device=DEV)
+    sb = torch.zeros(int(lib.cara_tskinny_scratch_bytes(64, K, 32)), dtype=torch.uint8, device=DEV)
+    assert lib.cara_gemm_with_tskinny(C.byref(a), p(X), N, p(Gt), p(sa), N, p(dY), K, p(Tt), p(sb), K, 0, ldg, 64, 32, st()) != 0
+
+
 def test_tskinny_reductions_in_one_launch():
     """cara_tskinny_reduce_many: several slab reductions of different shapes (and layer counts) in one launch give
     bitwise what one cara_tskinny_reduce launch per product gives."""
