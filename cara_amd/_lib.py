@@ -42,14 +42,30 @@ class GemmArgs(C.Structure):
 
 class Geom(C.Structure):
     _fields_ = [("depth", C.c_int), ("dim", C.c_int), ("heads", C.c_int), ("rank", C.c_int),
-                ("Rp", C.c_int), ("scale", C.c_float)]
+                ("Rp", C.c_int), ("scale", C.c_float), ("cp_length", C.c_int)]
 
 
 CP_FIELDS = ("A1", "A2", "A3", "A4", "P1", "P2", "P3", "R1", "R2", "bias1", "bias2", "bias3")
 
 
+def cp_fields(cp_length: int = 4):
+    """Names (without the CP_ prefix) of the CP tensors of a QKV tensorisation of order `cp_length`, in the order
+    the engine passes them around: order 3 has no A4, order 5 has an A5 (dim_experiment.py:264-295)."""
+    if cp_length == 3:
+        return tuple(n for n in CP_FIELDS if n != "A4")
+    if cp_length == 5:
+        return CP_FIELDS[:4] + ("A5",) + CP_FIELDS[4:]
+    return CP_FIELDS
+
+
+def cp_ptrs(fields, tensors):
+    """cara_cp from tensors given in `fields` order (missing members stay NULL)."""
+    return CpPtrs(**{n: ptr(t) for n, t in zip(fields, tensors)})
+
+
 class CpPtrs(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in CP_FIELDS]
+    """the 12 tensors of the default (order-4) tensorisation in CP_FIELDS order, then A5 (order 5 only)"""
+    _fields_ = [(n, C.c_void_p) for n in CP_FIELDS] + [("A5", C.c_void_p)]
 
 
 class PackLayout(C.Structure):

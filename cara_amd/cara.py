@@ -54,10 +54,59 @@ def _is(obj, *classes) -> bool:
     return any(type(obj) is c for c in classes)  # exact-type dispatch, like cara.py:110,147,157
 
 
-def set_cara(model: nn.Module, rank: int, scale: float, l_mu: float, l_std: float, _root=None) -> None:
-    """Declare + initialise the CP tensors on the ViT and walk its children (``cara.py:98-166``)."""
+def set_cara(model: nn.Module, rank: int, scale: float, l_mu: float, l_std: float, _root=None, cp_length: int = 4) -> None:
+    """Declare + initialise the CP tensors on the ViT and walk its children (``cara.py:98-166``).
+
+    ``cp_length`` selects the order of the QKV tensorisation as ``image_classification/dim_experiment.py:264-295``
+    (``set_CP``) does: 4 is ``src/cara``'s; 3 = ``[3L, dim, dim]`` (A3 ``[dim, R]``, no A4); 5 =
+    ``[L, 3, dim, heads, dim/heads]`` (A1 ``[L, R]``, A2 ``[3, R]``, A3 ``[dim, R]``, A4 ``[heads, R]``, A5
+    ``[dim/heads, R]``; ``attn_idx`` then advances by 1 per block, ``:334``).  Same initialisers in the same order."""
     root = _root
-    if _is(model, _vit.VisionTransformer):
+    if _is(model, _vit.VisionTransformer) and cp_length in (3, 5):
+        root = model
+        dim, heads, depth = model.embed_dim, model.blocks[0].attn.num_heads, len(model.blocks)
+        if cp_length == 5:   # dim_experiment.py:266-276
+            model.CP_A1 = nn.Parameter(th.empty([depth, rank]), requires_grad=True)
+            model.CP_A2 = nn.Parameter(th.empty([3, rank]), requires_grad=True)
+            model.CP_A3 = nn.Parameter(th.empty([dim, rank]), requires_grad=True)
+            model.CP_A4 = nn.Parameter(th.empty([heads, rank]), requires_grad=True)
+            model.CP_A5 = nn.Parameter(th.empty([dim // heads, rank]), requires_grad=True)
+            nn.init.xavier_normal_(model.CP_A1)
+            nn.init.orthogonal_(model.CP_A2)
+            nn.init.zeros_(model.CP_A3)
+            nn.init.orthogonal_(model.CP_A4)
+            nn.init.orthogonal_(model.CP_A5)
+        else:                # dim_experiment.py:286-292
+            model.CP_A1 = nn.Parameter(th.empty([3 * depth, rank]), requires_grad=True)
+            model.CP_A2 = nn.Parameter(th.empty([dim, rank]), requires_grad=True)
+            model.CP_A3 = nn.Parameter(th.empty([dim, rank]), requires_grad=True)
+            nn.init.xavier_normal_(model.CP_A1)
+            nn.init.zeros_(model.CP_A2)
+            nn.init.orthogonal_(model.CP_A3)
+        model.CP_P1 = nn.Parameter(th.empty([9 * depth, rank]), requires_grad=True)
+        model.CP_P2 = nn.Parameter(th.empty([dim, rank]), requires_grad=True)
+        model.CP_P3 = nn.Parameter(th.empty([dim, rank]), requires_grad=True)
+        model.CP_R1 = nn.Parameter(th.empty([rank]), requires_grad=True)
+        model.CP_R2 = nn.Parameter(th.empty([rank]), requires_grad=True)
+        model.CP_bias1 = nn.Parameter(th.empty([dim]), requires_grad=True)
+        model.CP_bias2 = nn.Parameter(th.empty([dim * 4]), requires_grad=True)
+        model.CP_bias3 = nn.Parameter(th.empty([dim]), requires_grad=True)
+        nn.init.xavier_normal_(model.CP_P1)
+        nn.init.zeros_(model.CP_P2)
+        nn.init.orthogonal_(model.CP_P3)
+        if l_std != 0.0:
+            nn.init.normal_(model.CP_R1, mean=l_mu, std=l_std)
+            nn.init.normal_(model.CP_R2, mean=l_mu, std=l_std)
+        elif l_mu == 1.0 and l_std == 0.0:
+            nn.init.ones_(model.CP_R1)
+            nn.init.ones_(model.CP_R2)
+        nn.init.zeros_(model.CP_bias1)
+        nn.init.zeros_(model.CP_bias2)
+        nn.init.zeros_(model.CP_bias3)
+        model.idx = 0
+        model.attn_idx = 0
+        model.cp_l = cp_length
+    elif _is(model, _vit.VisionTransformer):
         root = model
         dim, heads, depth = model.embed_dim, model.blocks[0].attn.num_heads, len(model.blocks)
         model.CP_A1 = nn.Parameter(th.empty([3 * depth, rank]), requires_grad=True)
@@ -102,7 +151,7 @@ def set_cara(model: nn.Module, rank: int, scale: float, l_mu: float, l_std: floa
             child.idx = root.idx
             child.attn_idx = root.attn_idx
             root.idx += 1
-            root.attn_idx += 3
+            root.attn_idx += 1 if cp_length == 5 else 3   # dim_experiment.py:334
             child.__dict__["_cara_owner"] = weakref.ref(root)
             setattr(child, "forward", cp_attn.__get__(child, child.__class__))  # noqa: B010
         elif _is(child, _vit.Mlp):
@@ -114,7 +163,7 @@ def set_cara(model: nn.Module, rank: int, scale: float, l_mu: float, l_std: floa
             child.__dict__["_cara_owner"] = weakref.ref(root)
             setattr(child, "forward", cp_mlp.__get__(child, child.__class__))  # noqa: B010
         elif len(list(child.children())) != 0:
-            set_cara(child, rank, scale, l_mu, l_std, _root=root)
+            set_cara(child, rank, scale, l_mu, l_std, _root=root, cp_length=cp_length)
 
 
 def cara(config: Dict[str, Any]) -> th.nn.Module:
@@ -129,9 +178,18 @@ def cara(config: Dict[str, Any]) -> th.nn.Module:
                         "build one with cara_amd.create_model(...)")
     if not (1 <= int(rank) <= 64):
         raise CaraError("rank must be in 1..64 (the K-extension is padded to 32 or 64 columns)")
+    # optional sixth key, the `cp_length` of image_classification/dim_experiment.py (its `--dims`): order of the QKV
+    # tensorisation.  4 (default) is src/cara's; 3 and 5 are rank-R in (in, out) too and run on the same kernels.
+    # 2 parametrises each projection as a sum of R DENSE dim x dim matrices: not an adapter the factored path can run.
+    cp_length = int(config.get("cp_length", 4))
+    if cp_length == 2:
+        raise CaraError("cp_length 2 is a sum of `rank` dense dim x dim matrices per projection (dim_experiment.py:203-207), "
+                        "not low-rank in (in, out): the factored HIP path cannot run it")
+    if cp_length not in (3, 4, 5):
+        raise CaraError("cp_length must be 3, 4 or 5")
     global global_model
     global_model = model
-    set_cara(model, rank, scale, l_mu, l_std)
+    set_cara(model, rank, scale, l_mu, l_std, cp_length=cp_length)
     from .engine import CaraEngine
-    model.__dict__["_cara_engine"] = CaraEngine(model, rank=int(rank), scale=float(scale))
+    model.__dict__["_cara_engine"] = CaraEngine(model, rank=int(rank), scale=float(scale), cp_length=cp_length)
     return model

@@ -10,7 +10,22 @@ namespace {
 struct PackDims {
   int depth, dim, heads, hd, rank, Rp;
   float s;
+  int cpl;   // order of the QKV tensorisation: 3, 4 or 5 (cara_geom::cp_length)
 };
+
+// The QKV adapter of block l, projection k, in factored form for every supported order (cara_geom::cp_length):
+//   dW_k[e, o] = sum_r  R1[r] * qkv_coef(l, k, r) * qkv_in(e, r) * qkv_out(o, r)
+__device__ __forceinline__ float qkv_coef(const PackDims& g, const cara_cp& cp, int l, int k, int r) {
+  return g.cpl == 5 ? cp.A1[l * g.rank + r] * cp.A2[k * g.rank + r] : cp.A1[(3 * l + k) * g.rank + r];
+}
+__device__ __forceinline__ float qkv_in(const PackDims& g, const cara_cp& cp, int e, int r) {
+  return (g.cpl == 5 ? cp.A3 : cp.A2)[e * g.rank + r];
+}
+__device__ __forceinline__ float qkv_out(const PackDims& g, const cara_cp& cp, int o, int r) {
+  if (g.cpl == 3) return cp.A3[o * g.rank + r];
+  const int hh = o / g.hd, d = o - hh * g.hd;
+  return g.cpl == 5 ? cp.A4[hh * g.rank + r] * cp.A5[d * g.rank + r] : cp.A3[hh * g.rank + r] * cp.A4[d * g.rank + r];
+}
 
 // logical matrices of one layer, in pack order
 enum { M_U_QKV, M_VS_QKV, M_U_PROJ, M_VS_PROJ, M_U_FC1, M_VS_FC1, M_U_FC2, M_VS_FC2, M_COUNT };
@@ -27,10 +42,10 @@ __device__ __forceinline__ float factor_value(const PackDims& g, const cara_cp& 
   if (r >= g.rank) return 0.f;
   const int R = g.rank, dim = g.dim;
   switch (m) {
-    case M_U_QKV: return cp.A2[row * R + r];
+    case M_U_QKV: return qkv_in(g, cp, row, r);
     case M_VS_QKV: {
-      const int k = row / dim, c = row - k * dim, hh = c / g.hd, d = c - hh * g.hd;
-      return g.s * cp.R1[r] * cp.A1[(3 * l + k) * R + r] * cp.A3[hh * R + r] * cp.A4[d * R + r];
+      const int k = row / dim, c = row - k * dim;
+      return g.s * cp.R1[r] * qkv_coef(g, cp, l, k, r) * qkv_out(g, cp, c, r);
     }
     case M_U_PROJ: case M_U_FC1: return cp.P3[row * R + r];
     case M_VS_PROJ: return g.s * cp.R2[r] * cp.P1[(9 * l) * R + r] * cp.P2[row * R + r];
@@ -128,10 +143,12 @@ __device__ __forceinline__ void grad_rowwise(const PackDims& g, const cara_cp& c
   const int R = g.rank, Rp = g.Rp, dim = g.dim, L = g.depth;
   if (e < dim * R) {
     const int j = e / R, r = e - j * R;
-    float a2 = 0.f, p3 = 0.f, p2 = 0.f;
+    float a2 = 0.f, p3 = 0.f, p2 = 0.f, a3o = 0.f;
     const float sr2 = g.s * cp.R2[r];
     for (int l = 0; l < L; ++l) {
       a2 += lg.dU_qkv[((size_t)l * dim + j) * Rp + r];
+      if (g.cpl == 3)   // order 3: the out factor A3 [dim, R] is a plain row-wise sum over blocks and projections
+        for (int k = 0; k < 3; ++k) a3o += cp.A1[(3 * l + k) * R + r] * lg.dVs_qkv[((size_t)l * 3 * dim + k * dim + j) * Rp + r];
       p3 += lg.dU_proj[((size_t)l * dim + j) * Rp + r] + lg.dU_fc1[((size_t)l * dim + j) * Rp + r] +
             sr2 * lg.dVs_fc2[((size_t)l * dim + j) * Rp + r];
       p2 += sr2 * cp.P1[(9 * l) * R + r] * lg.dVs_proj[((size_t)l * dim + j) * Rp + r];
@@ -140,7 +157,8 @@ __device__ __forceinline__ void grad_rowwise(const PackDims& g, const cara_cp& c
         p2 += cp.P1[(9 * l + 5 + a) * R + r] * lg.dU_fc2[((size_t)l * 4 * dim + a * dim + j) * Rp + r];
       }
     }
-    out.A2[e] = a2;
+    (g.cpl == 5 ? out.A3 : out.A2)[e] = a2;   // gradient of the in factor
+    if (g.cpl == 3) out.A3[e] = g.s * cp.R1[r] * a3o;
     out.P3[e] = p3;
     out.P2[e] = p2;
   }
@@ -175,9 +193,8 @@ __device__ __forceinline__ void grad_colred_part(const PackDims& g, const cara_c
       for (int row = row0 + part; row < row1; row += 8) {
         float w, f;
         if (slot < 3) {
-          const int hh = row / g.hd, d = row - hh * g.hd;
           w = lg.dVs_qkv[((size_t)l * 3 * dim + slot * dim + row) * Rp + rr];
-          f = g.s * cp.A3[hh * R + rr] * cp.A4[d * R + rr];
+          f = g.s * qkv_out(g, cp, row, rr);
         } else if (slot == 3) {
           w = lg.dVs_proj[((size_t)l * dim + row) * Rp + rr];
           f = g.s * cp.P2[row * R + rr];
@@ -212,14 +229,17 @@ __device__ __forceinline__ void grad_a34_part(const PackDims& g, const cara_cp& 
                                               const int lk, const int piece) {
   const int R = g.rank, Rp = g.Rp, dim = g.dim, H = g.heads, hd = g.hd;
   const int l = lk / 3, k = lk - 3 * l;
+  if (g.cpl == 3) return;   // no head / head-dim factors (grad_rowwise did A3)
   const float* W = lg.dVs_qkv + ((size_t)l * 3 * dim + (size_t)k * dim) * Rp;   // [H*hd, Rp]
+  const float* Fh = g.cpl == 5 ? cp.A4 : cp.A3;   // head factor [H, R]
+  const float* Fd = g.cpl == 5 ? cp.A5 : cp.A4;   // head-dim factor [hd, R]
   if (piece == 0) {
     float* pa3 = sc.pa3 + (size_t)lk * H * R;
     for (int e = threadIdx.x; e < H * R; e += 256) {
       const int hh = e / R, r = e - hh * R;
       float in = 0.f;
-      for (int d = 0; d < hd; ++d) in += W[(size_t)(hh * hd + d) * Rp + r] * cp.A4[d * R + r];
-      pa3[e] = cp.A1[lk * R + r] * in;
+      for (int d = 0; d < hd; ++d) in += W[(size_t)(hh * hd + d) * Rp + r] * Fd[d * R + r];
+      pa3[e] = qkv_coef(g, cp, l, k, r) * in;
     }
   } else {
     float* pa4 = sc.pa4 + (size_t)lk * hd * R;
@@ -227,8 +247,8 @@ __device__ __forceinline__ void grad_a34_part(const PackDims& g, const cara_cp& 
     for (int e = e0 + threadIdx.x; e < e1; e += 256) {
       const int d = e / R, r = e - d * R;
       float in = 0.f;
-      for (int hh = 0; hh < H; ++hh) in += W[(size_t)(hh * hd + d) * Rp + r] * cp.A3[hh * R + r];
-      pa4[e] = cp.A1[lk * R + r] * in;
+      for (int hh = 0; hh < H; ++hh) in += W[(size_t)(hh * hd + d) * Rp + r] * Fh[hh * R + r];
+      pa4[e] = qkv_coef(g, cp, l, k, r) * in;
     }
   }
 }
@@ -262,7 +282,7 @@ __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp
   const GradScratch sc = grad_scratch(scratch, L, H, hd, R);
   if ((int)blockIdx.x < nb_a) {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e < (H + hd) * R) {
+    if (g.cpl != 3 && e < (H + hd) * R) {
       const bool is3 = e < H * R;
       const int e2 = is3 ? e : e - H * R;
       const int r = e2 % R;
@@ -270,13 +290,16 @@ __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp
       const float* p = is3 ? sc.pa3 : sc.pa4;
       float acc = 0.f;
       for (int lk = 0; lk < 3 * L; ++lk) acc += p[(size_t)lk * per + e2];
-      (is3 ? out.A3 : out.A4)[e2] = g.s * cp.R1[r] * acc;
+      float* o3 = g.cpl == 5 ? out.A4 : out.A3;   // head factor
+      float* o4 = g.cpl == 5 ? out.A5 : out.A4;   // head-dim factor
+      (is3 ? o3 : o4)[e2] = g.s * cp.R1[r] * acc;
     }
     return;
   }
   __shared__ float red1[256], red2[256];
   const int r = threadIdx.x % 64, qg = threadIdx.x / 64;   // R <= 64; four groups walk the 12L (layer, slot) pairs
-  float d1 = 0.f, d2 = 0.f;
+  __shared__ float red3[3][256];
+  float d1 = 0.f, d2 = 0.f, dk[3] = {0.f, 0.f, 0.f};
   if (r < R) {
     for (int q = qg; q < 12 * L; q += 4) {
       const float* zp = sc.zp + (size_t)q * GS_SPLIT * R + r;
@@ -285,6 +308,7 @@ __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp
       for (int sp = 0; sp < GS_SPLIT; ++sp) z += zp[sp * R];
       const int l = q / 12, slot = q - 12 * l;
       if (slot < 3) {
+        if (g.cpl == 5) continue;   // order 5: A1 [depth, R] and A2 [3, R] mix the three projections, below
         const int row = 3 * l + slot;
         d1 += cp.A1[row * R + r] * z;
         out.A1[row * R + r] = cp.R1[r] * z;
@@ -298,6 +322,23 @@ __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp
         }
       }
     }
+    if (g.cpl == 5) {
+      // dA1[l] = R1 sum_k A2[k] Z[l,k] ;  dA2[k] = R1 sum_l A1[l] Z[l,k] ;  dR1 = sum_{l,k} A1[l] A2[k] Z[l,k]
+      for (int l = qg; l < L; l += 4) {
+        float a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float* zp = sc.zp + (size_t)(l * 12 + k) * GS_SPLIT * R + r;
+          float z = 0.f;
+#pragma unroll
+          for (int sp = 0; sp < GS_SPLIT; ++sp) z += zp[sp * R];
+          a1 += cp.A2[k * R + r] * z;
+          dk[k] += cp.A1[l * R + r] * z;
+        }
+        out.A1[l * R + r] = cp.R1[r] * a1;
+        d1 += cp.A1[l * R + r] * a1;
+      }
+    }
     if (qg == 0) {
       float zv = 0.f;
       for (int i = 0; i < L * GS_SPLIT; ++i) zv += sc.zvp[(size_t)i * R + r];
@@ -306,10 +347,17 @@ __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp
   }
   red1[threadIdx.x] = d1;
   red2[threadIdx.x] = d2;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) red3[k][threadIdx.x] = dk[k];
   __syncthreads();
   if (qg == 0 && r < R) {
     out.R1[r] = (red1[r] + red1[64 + r]) + (red1[128 + r] + red1[192 + r]);
     out.R2[r] = (red2[r] + red2[64 + r]) + (red2[128 + r] + red2[192 + r]);
+    if (g.cpl == 5) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        out.A2[k * R + r] = cp.R1[r] * ((red3[k][r] + red3[k][64 + r]) + (red3[k][128 + r] + red3[k][192 + r]));
+    }
   }
 }
 
@@ -317,14 +365,18 @@ PackDims dims_of(const cara_geom* g) {
   PackDims d;
   d.depth = g->depth; d.dim = g->dim; d.heads = g->heads; d.hd = g->dim / g->heads;
   d.rank = g->rank; d.Rp = g->Rp; d.s = g->scale;
+  d.cpl = g->cp_length == 0 ? 4 : g->cp_length;
   return d;
 }
 bool geom_ok(const cara_geom* g) {
   return g && g->depth > 0 && g->dim > 0 && g->heads > 0 && g->dim % g->heads == 0 && g->rank > 0 &&
-         g->rank <= g->Rp && (g->Rp == 32 || g->Rp == 64);
+         g->rank <= g->Rp && (g->Rp == 32 || g->Rp == 64) &&
+         (g->cp_length == 0 || g->cp_length == 3 || g->cp_length == 4 || g->cp_length == 5);
 }
-bool cp_ok(const cara_cp* c) {
-  return c && c->A1 && c->A2 && c->A3 && c->A4 && c->P1 && c->P2 && c->P3 && c->R1 && c->R2 && c->bias1 && c->bias2 && c->bias3;
+bool cp_ok(const cara_geom* g, const cara_cp* c) {
+  if (!(c && c->A1 && c->A2 && c->A3 && c->P1 && c->P2 && c->P3 && c->R1 && c->R2 && c->bias1 && c->bias2 && c->bias3)) return false;
+  if (g->cp_length != 3 && !c->A4) return false;   // order 3 has no fourth factor
+  return g->cp_length != 5 || c->A5 != nullptr;
 }
 
 }  // namespace
@@ -344,7 +396,7 @@ extern "C" int cara_pack_offsets(const cara_geom* g, cara_pack_layout* out) {
 
 extern "C" int cara_factor_prep(const cara_geom* g, const cara_cp* cp, const float* base_bias_proj,
                                 const float* base_bias_fc1, const float* base_bias_fc2, void* pack, void* stream) {
-  if (!geom_ok(g) || !cp_ok(cp) || !base_bias_proj || !base_bias_fc1 || !base_bias_fc2 || !pack) return CARA_E_ARG;
+  if (!geom_ok(g) || !cp_ok(g, cp) || !base_bias_proj || !base_bias_fc1 || !base_bias_fc2 || !pack) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const PackDims d = dims_of(g);
   const PackOffsets po = make_offsets(g->dim, g->Rp);
@@ -365,7 +417,7 @@ extern "C" size_t cara_factor_grad_scratch_bytes(const cara_geom* g) {
 
 extern "C" int cara_factor_grad_reduce(const cara_geom* g, const cara_cp* cp, const cara_layer_grads* lg,
                                        const cara_cp* grads, void* scratch, void* stream) {
-  if (!geom_ok(g) || !cp_ok(cp) || !cp_ok(grads) || !lg || !scratch) return CARA_E_ARG;
+  if (!geom_ok(g) || !cp_ok(g, cp) || !cp_ok(g, grads) || !lg || !scratch) return CARA_E_ARG;
   if (!lg->dU_qkv || !lg->dVs_qkv || !lg->dU_proj || !lg->dVs_proj || !lg->dU_fc1 || !lg->dVs_fc1 || !lg->dU_fc2 ||
       !lg->dVs_fc2 || !lg->dc_proj || !lg->dc_fc1 || !lg->dc_fc2)
     return CARA_E_ARG;

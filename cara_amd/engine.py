@@ -40,13 +40,16 @@ class _VitFn(torch.autograd.Function):
         if eng._last_key != ctx.shape_key or eng._fwd_serial != eng._bwd_ready:
             raise CaraError("backward must follow its own forward: the activation workspace holds one step")
         g = eng._run_backward(dlogits, ctx.droppath, head_w, cp)
-        return (None, None, None, g["head_w"], g["head_b"], *[g[n] for n in L.CP_FIELDS])
+        return (None, None, None, g["head_w"], g["head_b"], *[g[n] for n in eng.cp_fields])
 
 
 class CaraEngine:
-    def __init__(self, model, rank: int, scale: float):
+    def __init__(self, model, rank: int, scale: float, cp_length: int = 4):
         self._model = weakref.ref(model)
         self.rank, self.Rp, self.scale = rank, _rp(rank), scale
+        # order of the QKV tensorisation (dim_experiment.py:188-207): 4 = src/cara's; 3 and 5 run on the same kernels
+        self.cp_length = int(cp_length)
+        self.cp_fields = L.cp_fields(self.cp_length)
         # Dropout(0.1) on the materialised dW (cara.py:35,57,81,92).  "off": factored adapters, no weight-space
         # dropout (the fast default; a mask on dW's elements does not factor).  "exact": train-mode forwards run on
         # W_eff = W + keep/(1-p) dW with a fresh mask per step and the adapter gradients come from the dense
@@ -132,7 +135,8 @@ class CaraEngine:
         st = self._ws.get(key)
         if st is None:
             pe = model.patch_embed
-            geom = L.Geom(len(model.blocks), model.embed_dim, model.blocks[0].attn.num_heads, self.rank, self.Rp, self.scale)
+            geom = L.Geom(len(model.blocks), model.embed_dim, model.blocks[0].attn.num_heads, self.rank, self.Rp, self.scale,
+                          self.cp_length)
             # (sized with the exact-mode regions when that mode is selected; a call with wd_exact = 0 on the same
             # workspace -- eval -- simply does not touch them)
             shape = L.VitShape(B, img, pe.patch_size[0], model.in_chans, (img // pe.patch_size[0]) ** 2 + 1, ncls,
@@ -149,7 +153,7 @@ class CaraEngine:
         return st
 
     def _cp_ptrs(self, cp):
-        return L.CpPtrs(*[ptr(t) for t in cp])
+        return L.cp_ptrs(self.cp_fields, cp)
 
     # ------------------------------------------------------------------ forward / backward
     def _run_forward(self, images, droppath, head_w, head_b, cp, need_backward=True):
@@ -178,7 +182,7 @@ class CaraEngine:
         return logits
 
     def _grad_buffers(self, model, dev):
-        names = [(n, getattr(model, "CP_" + n)) for n in L.CP_FIELDS] + [("head_w", model.head.weight), ("head_b", model.head.bias)]
+        names = [(n, getattr(model, "CP_" + n)) for n in self.cp_fields] + [("head_w", model.head.weight), ("head_b", model.head.bias)]
         sizes = [p.numel() for _, p in names]
         if self._flat_grad is None or self._flat_grad.numel() != sum(sizes) or self._flat_grad.device != dev:
             from .dist import flat_views
@@ -190,7 +194,7 @@ class CaraEngine:
         st = self._ws[self._last_key]
         g = self._grad_buffers(model, dlogits.device)
         cps = self._cp_ptrs([t.detach().contiguous() for t in cp])
-        gps = L.CpPtrs(*[ptr(g[n]) for n in L.CP_FIELDS])
+        gps = L.cp_ptrs(self.cp_fields, [g[n] for n in self.cp_fields])
         check(L.lib().cara_vit_backward(C.byref(st["geom"]), C.byref(st["shape"]), C.byref(self._ingested[1]), C.byref(cps),
                                         ptr(head_w.detach().contiguous()), ptr(dlogits.contiguous().float()), ptr(droppath),
                                         ptr(st["ws"]), C.byref(gps), ptr(g["head_w"]), ptr(g["head_b"]), stream()),
@@ -224,7 +228,7 @@ class CaraEngine:
             raise CaraError("the classifier head must be a Linear (num_classes > 0)")
         if droppath is None:
             droppath = self.draw_droppath(model, images.shape[0], images.device)
-        cp = [getattr(model, "CP_" + n) for n in L.CP_FIELDS]
+        cp = [getattr(model, "CP_" + n) for n in self.cp_fields]
         if model.head.weight.device != images.device or cp[0].device != images.device:
             raise CaraError("model parameters and images must be on the same device")
         params = [model.head.weight, model.head.bias, *cp]
@@ -235,7 +239,7 @@ class CaraEngine:
     def trainable_parameters(self):
         """The selection rule of vit_cp.py:175-183: names containing "CP" or "head"."""
         model = self._model()
-        return [getattr(model, "CP_" + n) for n in L.CP_FIELDS] + [model.head.weight, model.head.bias]
+        return [getattr(model, "CP_" + n) for n in self.cp_fields] + [model.head.weight, model.head.bias]
 
     def train_step(self, images, labels, optimizer=None, group=None, droppath: Optional[torch.Tensor] = None):
         """One fine-tuning step of vit_cp.py:45-50 without autograd bookkeeping:
@@ -250,7 +254,7 @@ class CaraEngine:
         dev = images.device
         if droppath is None:
             droppath = self.draw_droppath(model, images.shape[0], dev)
-        cp = [getattr(model, "CP_" + n) for n in L.CP_FIELDS]
+        cp = [getattr(model, "CP_" + n) for n in self.cp_fields]
         hw, hb = model.head.weight, model.head.bias
         with torch.no_grad():
             logits = self._run_forward(images, droppath, hw, hb, cp)
@@ -263,7 +267,7 @@ class CaraEngine:
             check(L.lib().cara_cross_entropy(ptr(logits), ptr(labels.contiguous()), ptr(self._loss_buf), ptr(self._dlogits),
                                              B, ncls, stream()), "cara_cross_entropy")
             g = self._run_backward(self._dlogits, droppath, hw, cp)
-            for n, p in zip(list(L.CP_FIELDS) + ["head_w", "head_b"], cp + [hw, hb]):
+            for n, p in zip(list(self.cp_fields) + ["head_w", "head_b"], cp + [hw, hb]):
                 if p.grad is None or p.grad.data_ptr() != g[n].data_ptr():
                     p.grad = g[n]
             # the only data-path collective of a step: one RCCL all-reduce over xGMI of the flat buffer
@@ -286,7 +290,7 @@ class CaraEngine:
             raise CaraError("cara_amd runs on the GPU only (no CPU fallback)")
         if x.ndim != 3 or x.shape[2] != model.embed_dim or x.shape[1] > 224:
             raise CaraError("module-level forward expects x of shape [B, N <= 224, embed_dim]")
-        return model, [getattr(model, "CP_" + n) for n in L.CP_FIELDS]
+        return model, [getattr(model, "CP_" + n) for n in self.cp_fields]
 
     def attn_forward(self, child, x):
         from .modules import AttnFn

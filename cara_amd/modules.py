@@ -29,17 +29,18 @@ class FactorPack:
         self.geom = None
 
     def get(self, model, dev):
-        cp = [getattr(model, "CP_" + n) for n in L.CP_FIELDS]
+        cp = [getattr(model, "CP_" + n) for n in self.eng.cp_fields]
         sig = tuple((p.data_ptr(), p._version) for p in cp) + (str(dev),)
         if sig != self.sig:
             eng = self.eng
             t, _ = eng._weights(model, dev)
-            geom = L.Geom(len(model.blocks), model.embed_dim, model.blocks[0].attn.num_heads, eng.rank, eng.Rp, eng.scale)
+            geom = L.Geom(len(model.blocks), model.embed_dim, model.blocks[0].attn.num_heads, eng.rank, eng.Rp, eng.scale,
+                          eng.cp_length)
             lay = L.PackLayout()
             check(L.lib().cara_pack_offsets(C.byref(geom), C.byref(lay)), "cara_pack_offsets")
             if self.pack is None or self.pack.numel() != lay.total or self.pack.device != dev:
                 self.pack = torch.zeros(lay.total, dtype=torch.uint8, device=dev)
-            cps = L.CpPtrs(*[ptr(p.detach().contiguous()) for p in cp])
+            cps = L.cp_ptrs(eng.cp_fields, [p.detach().contiguous() for p in cp])
             check(L.lib().cara_factor_prep(C.byref(geom), C.byref(cps), ptr(t["proj_b"]), ptr(t["fc1_b"]), ptr(t["fc2_b"]),
                                            ptr(self.pack), stream()), "cara_factor_prep")
             self.sig, self.lay, self.geom = sig, lay, geom
@@ -101,11 +102,11 @@ def _scatter(eng, model, dev, layer, pieces):
     b = bufs[key]
     for k, v in pieces.items():
         b[k][layer].copy_(v)
-    cp = [getattr(model, "CP_" + n).detach().contiguous() for n in L.CP_FIELDS]
+    cp = [getattr(model, "CP_" + n).detach().contiguous() for n in eng.cp_fields]
     grads = [torch.empty_like(p) for p in cp]
     lg = L.LayerGrads(*[ptr(b[n]) for n, _ in L.LayerGrads._fields_])
-    check(L.lib().cara_factor_grad_reduce(C.byref(geom), C.byref(L.CpPtrs(*[ptr(p) for p in cp])), C.byref(lg),
-                                          C.byref(L.CpPtrs(*[ptr(g) for g in grads])), ptr(b["scratch"]), stream()),
+    check(L.lib().cara_factor_grad_reduce(C.byref(geom), C.byref(L.cp_ptrs(eng.cp_fields, cp)), C.byref(lg),
+                                          C.byref(L.cp_ptrs(eng.cp_fields, grads)), ptr(b["scratch"]), stream()),
           "cara_factor_grad_reduce")
     for k in pieces:
         b[k][layer].zero_()

@@ -198,10 +198,21 @@ int cara_transpose_bf16_ld(const void* src, long lds, void* dst, long ldd, int r
 typedef struct {
   int depth, dim, heads, rank, Rp;
   float scale;                       /* child.s, cara.py:149,159 */
+  /* Order of the CP tensorisation of the QKV adapter (image_classification/dim_experiment.py:188-207,264-295).
+   * 0 or 4 (src/cara, the default): dW[k,e,h,d] = sum_r R1 A1[3l+k] A2[e] A3[h] A4[d],  A1 [3 depth,R], A2 [dim,R],
+   *         A3 [heads,R], A4 [dim/heads,R].
+   * 3: dW[k,e,o] = sum_r R1 A1[3l+k] A2[e] A3[o],  A3 [dim,R], no A4.
+   * 5: dW[k,e,h,d] = sum_r R1 A1[l] A2[k] A3[e] A4[h] A5[d],  A1 [depth,R], A2 [3,R], A3 [dim,R], A4 [heads,R],
+   *    A5 [dim/heads,R].
+   * All three are rank-R in (in, out) and run on the same factored kernels; only the factor pack and the
+   * gradient scatter differ.  (cp_length 2 is a sum of R dense dim x dim matrices, not low-rank: not supported.) */
+  int cp_length;
 } cara_geom;
-/* Pointers to the 12 CP tensors (fp32, shapes of cara.py:112-125) or to their gradients.      */
+/* Pointers to the CP tensors (fp32, shapes of cara.py:112-125 for cp_length 4) or to their gradients.
+ * A4 is unused for cp_length 3, A5 only used for cp_length 5 (NULL otherwise).                               */
 typedef struct {
   float *A1, *A2, *A3, *A4, *P1, *P2, *P3, *R1, *R2, *bias1, *bias2, *bias3;
+  float *A5;
 } cara_cp;
 /* Per-layer operand pack written by cara_factor_prep (bf16 unless noted), l = 0..depth-1:
  *   Ut_* [Rp,in] (U transposed, K-contiguous), U_* [in,Rp], Vs_* [out,Rp], Vst_* [Rp,out]

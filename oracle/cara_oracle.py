@@ -247,24 +247,46 @@ CP_NAMES = ("CP_A1", "CP_A2", "CP_A3", "CP_A4", "CP_P1", "CP_P2", "CP_P3", "CP_R
             "CP_bias1", "CP_bias2", "CP_bias3")
 
 
-def cp_shapes(rank: int, dim: int = 768, heads: int = 12, depth: int = 12) -> Dict[str, Tuple[int, ...]]:
-    """Shapes of ``src/cara/cara.py:112-125`` (dim/heads/depth generalised; reference = 768/12/12)."""
-    return {
-        "CP_A1": (3 * depth, rank), "CP_A2": (dim, rank), "CP_A3": (heads, rank),
-        "CP_A4": (dim // heads, rank), "CP_P1": (9 * depth, rank), "CP_P2": (dim, rank),
-        "CP_P3": (dim, rank), "CP_R1": (rank,), "CP_R2": (rank,),
-        "CP_bias1": (dim,), "CP_bias2": (4 * dim,), "CP_bias3": (dim,),
-    }
+def cp_length_of(cp) -> int:
+    """Order of the QKV tensorisation a CP dict carries (``image_classification/dim_experiment.py:264-295``):
+    5 has a CP_A5, 3 has no CP_A4, 4 is ``src/cara``'s."""
+    return 5 if "CP_A5" in cp else (4 if "CP_A4" in cp else 3)
 
 
-def init_cp_params(rank: int, l_mu: float, l_std: float, dim=768, heads=12, depth=12) -> Dict[str, torch.Tensor]:
+def cp_shapes(rank: int, dim: int = 768, heads: int = 12, depth: int = 12, cp_length: int = 4) -> Dict[str, Tuple[int, ...]]:
+    """Shapes of ``src/cara/cara.py:112-125`` (dim/heads/depth generalised; reference = 768/12/12); for
+    ``cp_length`` 3 / 5 those of ``dim_experiment.py:286-288`` / ``:266-270``."""
+    if cp_length == 5:
+        a = {"CP_A1": (depth, rank), "CP_A2": (3, rank), "CP_A3": (dim, rank), "CP_A4": (heads, rank),
+             "CP_A5": (dim // heads, rank)}
+    elif cp_length == 3:
+        a = {"CP_A1": (3 * depth, rank), "CP_A2": (dim, rank), "CP_A3": (dim, rank)}
+    else:
+        a = {"CP_A1": (3 * depth, rank), "CP_A2": (dim, rank), "CP_A3": (heads, rank), "CP_A4": (dim // heads, rank)}
+    a.update({"CP_P1": (9 * depth, rank), "CP_P2": (dim, rank),
+              "CP_P3": (dim, rank), "CP_R1": (rank,), "CP_R2": (rank,),
+              "CP_bias1": (dim,), "CP_bias2": (4 * dim,), "CP_bias3": (dim,)})
+    return a
+
+
+def init_cp_params(rank: int, l_mu: float, l_std: float, dim=768, heads=12, depth=12, cp_length: int = 4) -> Dict[str, torch.Tensor]:
     """Initialisation of ``src/cara/cara.py:127-142``; consumes the global torch RNG in the same
-    order (A1, A3, A4, P1, P3, R1, R2; zeros consume nothing)."""
-    p = {k: torch.empty(*s) for k, s in cp_shapes(rank, dim, heads, depth).items()}
+    order (A1, A3, A4, P1, P3, R1, R2; zeros consume nothing).  ``cp_length`` 3 / 5: the initialisers of
+    ``dim_experiment.py:289-292`` / ``:271-276``, in that order."""
+    p = {k: torch.empty(*s) for k, s in cp_shapes(rank, dim, heads, depth, cp_length).items()}
     nn.init.xavier_normal_(p["CP_A1"])
-    nn.init.zeros_(p["CP_A2"])
-    nn.init.orthogonal_(p["CP_A3"])
-    nn.init.orthogonal_(p["CP_A4"])
+    if cp_length == 5:
+        nn.init.orthogonal_(p["CP_A2"])
+        nn.init.zeros_(p["CP_A3"])
+        nn.init.orthogonal_(p["CP_A4"])
+        nn.init.orthogonal_(p["CP_A5"])
+    elif cp_length == 3:
+        nn.init.zeros_(p["CP_A2"])
+        nn.init.orthogonal_(p["CP_A3"])
+    else:
+        nn.init.zeros_(p["CP_A2"])
+        nn.init.orthogonal_(p["CP_A3"])
+        nn.init.orthogonal_(p["CP_A4"])
     nn.init.xavier_normal_(p["CP_P1"])
     nn.init.zeros_(p["CP_P2"])
     nn.init.orthogonal_(p["CP_P3"])
@@ -280,6 +302,24 @@ def init_cp_params(rank: int, l_mu: float, l_std: float, dim=768, heads=12, dept
     return p
 
 
+def qkv_adapter_tensor(cp, attn_idx: int) -> torch.Tensor:
+    """The materialised QKV adapter [3, in, out] of one block, for every order of tensorisation
+    (``dim_experiment.py:188-207``).  ``attn_idx`` is always the order-4 walk index 3 * block; the order-5 form, whose
+    own walk advances by 1 per block (``:334``), takes row ``attn_idx // 3`` of its CP_A1."""
+    n = cp_length_of(cp)
+    if n == 5:   # :189-194
+        f1 = cp["CP_A1"][attn_idx // 3:attn_idx // 3 + 1]
+        t = cp_to_tensor((cp["CP_R1"], (f1, cp["CP_A2"], cp["CP_A3"], cp["CP_A4"], cp["CP_A5"]))).squeeze(0)
+        K, E, H, D = t.shape
+        return t.reshape(K, E, H * D)
+    f1 = cp["CP_A1"][attn_idx:attn_idx + 3]
+    if n == 3:   # :200-202
+        return cp_to_tensor((cp["CP_R1"], (f1, cp["CP_A2"], cp["CP_A3"])))
+    t = cp_to_tensor((cp["CP_R1"], (f1, cp["CP_A2"], cp["CP_A3"], cp["CP_A4"])))   # src/cara/cara.py:26-34
+    K, E, H, D = t.shape
+    return t.reshape(K, E, H * D)
+
+
 def attn_as_written(x, cp, qkv_w, qkv_b, proj_w, proj_b, *, attn_idx: int, idx: int, s: float,
                     num_heads: int, scale: float, dp=None):
     """``cp_attn`` (``src/cara/cara.py:15-60``) over explicit tensors.  ``dp`` is the
@@ -290,9 +330,7 @@ def attn_as_written(x, cp, qkv_w, qkv_b, proj_w, proj_b, *, attn_idx: int, idx: 
     B, N, C = x.shape
     hd = C // num_heads
     qkv = F.linear(x, qkv_w, qkv_b)
-    t = cp_to_tensor((cp["CP_R1"], (cp["CP_A1"][attn_idx:attn_idx + 3], cp["CP_A2"], cp["CP_A3"], cp["CP_A4"])))
-    K, E, H, D = t.shape
-    t = t.reshape(K, E, H * D)
+    t = qkv_adapter_tensor(cp, attn_idx)
     delta = torch.einsum("bnd,kde->kbne", x, dp_qkv(t))
     delta = delta.reshape(3, B, N, num_heads, hd).permute(0, 1, 3, 2, 4)
     qkv = qkv.reshape(B, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
@@ -435,12 +473,16 @@ def build_factored(cp: Dict[str, torch.Tensor], s: float, depth: int = 12, heads
     Table of SURVEY.md A.3 (derived from ``src/cara/cara.py:26-34,51-58,72-82,87-93``)."""
     out = []
     idxs = block_indices(depth)
-    kr_a = khatri_rao(cp["CP_A3"], cp["CP_A4"])  # [dim, R], row h*hd+d
+    n = cp_length_of(cp)
+    # out factor [dim, R] (row h*hd+d) and in factor [dim, R] of the QKV adapter, per order of tensorisation
+    kr_a = cp["CP_A3"] if n == 3 else (khatri_rao(cp["CP_A4"], cp["CP_A5"]) if n == 5 else khatri_rao(cp["CP_A3"], cp["CP_A4"]))
+    u_qkv = cp["CP_A3"] if n == 5 else cp["CP_A2"]
     for l in range(depth):
         a_idx, a_aidx, m_idx = idxs[l]
-        g_qkv = cp["CP_R1"].unsqueeze(0) * cp["CP_A1"][a_aidx:a_aidx + 3]  # [3,R]
+        coef = cp["CP_A1"][l:l + 1] * cp["CP_A2"] if n == 5 else cp["CP_A1"][a_aidx:a_aidx + 3]   # [3,R]
+        g_qkv = cp["CP_R1"].unsqueeze(0) * coef  # [3,R]
         v_qkv = (g_qkv.unsqueeze(1) * kr_a.unsqueeze(0)).reshape(-1, kr_a.shape[1]) * s  # [3*dim,R]
-        qkv = (cp["CP_A2"], v_qkv, None)
+        qkv = (u_qkv, v_qkv, None)
         proj = (cp["CP_P3"], s * (cp["CP_R2"] * cp["CP_P1"][a_idx]).unsqueeze(0) * cp["CP_P2"], s * cp["CP_bias1"])
         fc1 = (cp["CP_P3"], s * cp["CP_R2"].unsqueeze(0) * khatri_rao(cp["CP_P1"][m_idx:m_idx + 4], cp["CP_P2"]),
                s * cp["CP_bias2"])
@@ -509,18 +551,19 @@ def synthetic_backbone(depth=12, dim=768, heads=12, num_classes=100, img=224, pa
 
 
 def synthetic_cp(rank=16, l_mu=1.5, l_std=0.1, seed=14, seed_nz=3, dim=768, heads=12, depth=12,
-                 nonzero_std=0.05) -> Dict[str, torch.Tensor]:
+                 nonzero_std=0.05, cp_length: int = 4) -> Dict[str, torch.Tensor]:
     """CP init per ``cara.py:127-142`` under ``torch.manual_seed(seed)`` (cifar hyper-params of
     ``vtab_config.py:2-8``), then CP_A2/CP_P2 ~ N(0, nonzero_std) and small biases so the
     adapter term is non-zero.  Restores the caller's global RNG state."""
     state = torch.get_rng_state()
     try:
         torch.manual_seed(seed)
-        cp = init_cp_params(rank, l_mu, l_std, dim, heads, depth)
+        cp = init_cp_params(rank, l_mu, l_std, dim, heads, depth, cp_length)
     finally:
         torch.set_rng_state(state)
     g = torch.Generator(device="cpu").manual_seed(seed_nz)
-    cp["CP_A2"] = torch.randn(cp["CP_A2"].shape, generator=g) * nonzero_std
+    zero_init = "CP_A3" if cp_length == 5 else "CP_A2"    # the factor the reference initialises to zero
+    cp[zero_init] = torch.randn(cp[zero_init].shape, generator=g) * nonzero_std
     cp["CP_P2"] = torch.randn(cp["CP_P2"].shape, generator=g) * nonzero_std
     for k in ("CP_bias1", "CP_bias2", "CP_bias3"):
         cp[k] = torch.randn(cp[k].shape, generator=g) * 0.02

@@ -89,6 +89,30 @@ def test_init_matches_reference_draws(rank):
     assert th.equal(m.CP_P3.detach()[:8], th.from_numpy(G[f"init_r{rank}_CP_P3_rows0_8"]))
 
 
+@pytest.mark.parametrize("cp_length", [3, 5])
+def test_other_orders_of_the_qkv_tensorisation(cp_length):
+    """config["cp_length"] = the `--dims` of image_classification/dim_experiment.py: parameter names, shapes, zero
+    factor and index walk of its set_CP (:264-295, :330-336); order 2 is refused with the reason."""
+    cfg = _cfg(depth=3)
+    cfg["cp_length"] = cp_length
+    vit = cara(cfg)
+    shapes = {n: tuple(p.shape) for n, p in vit.named_parameters() if n.startswith("CP_A")}
+    if cp_length == 5:
+        assert shapes == {"CP_A1": (3, 32), "CP_A2": (3, 32), "CP_A3": (768, 32), "CP_A4": (12, 32), "CP_A5": (64, 32)}
+        assert th.count_nonzero(vit.CP_A3) == 0 and th.count_nonzero(vit.CP_A2) > 0
+        assert [b.attn.attn_idx for b in vit.blocks] == [0, 1, 2] and vit.attn_idx == 3
+    else:
+        assert shapes == {"CP_A1": (9, 32), "CP_A2": (768, 32), "CP_A3": (768, 32)}
+        assert th.count_nonzero(vit.CP_A2) == 0
+        assert [b.attn.attn_idx for b in vit.blocks] == [0, 3, 6]
+    assert [b.attn.idx for b in vit.blocks] == [0, 9, 18] and vit.idx == 27 and vit.cp_l == cp_length
+    assert vit._cara_engine.cp_fields == _lib.cp_fields(cp_length)
+    cfg2 = _cfg(depth=2)
+    cfg2["cp_length"] = 2
+    with pytest.raises(CaraError, match="dense"):
+        cara(cfg2)
+
+
 def test_state_dict_roundtrip_and_reset_classifier():
     m = cara(_cfg(depth=2))
     m.reset_classifier(100)

@@ -30,15 +30,16 @@ def rel(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-def build(w, cp, rank, scale, depth, img, num_classes=100, drop_path_rate=0.1, name="vit_base_patch16_224_in21k"):
+def build(w, cp, rank, scale, depth, img, num_classes=100, drop_path_rate=0.1, name="vit_base_patch16_224_in21k", cp_length=4):
     from cara_amd import cara, create_model
     m = create_model(name, drop_path_rate=drop_path_rate, depth=depth, img_size=img, num_classes=num_classes)
-    m = cara({"model": m, "rank": rank, "scale": scale, "l_mu": 1.5, "l_std": 0.1})
+    m = cara({"model": m, "rank": rank, "scale": scale, "l_mu": 1.5, "l_std": 0.1, "cp_length": cp_length})
     sd = dict(w)
     sd.update(cp)
     # the reference hard-codes 36 / 108 rows (cara.py:112,118 = 3 / 9 per block at depth 12); this
     # build sizes them 3*depth / 9*depth, and a shallower test model only ever reads its own rows
-    sd["CP_A1"], sd["CP_P1"] = cp["CP_A1"][:3 * depth], cp["CP_P1"][:9 * depth]
+    # (order 5: one CP_A1 row per block, dim_experiment.py:266)
+    sd["CP_A1"], sd["CP_P1"] = cp["CP_A1"][:(1 if cp_length == 5 else 3) * depth], cp["CP_P1"][:9 * depth]
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not missing and not unexpected, (missing, unexpected)
     return m.to(DEV)
@@ -275,6 +276,39 @@ def test_inference_forward_keeps_nothing_for_backward():
     assert eng._bwd_ready == -1 and torch.equal(a.detach(), b)
     with pytest.raises(CaraError):
         a.sum().backward()                   # the workspace now holds the inference forward
+
+
+@pytest.mark.parametrize("cp_length", [3, 5])
+def test_other_orders_of_the_qkv_tensorisation_against_oracle(cp_length):
+    """cp_length 3 and 5 of image_classification/dim_experiment.py (QKV adapter as an order-3 / order-5 CP tensor):
+    same kernels, another factor pack and gradient scatter.  Logits against the fp32 as-written oracle within the
+    bf16 rounding model, every CP gradient (A1..A3 / A1..A5 included) against autograd of the as-written form."""
+    from oracle import cara_oracle as O
+    depth, rank, B = 3, 16, 8
+    w = O.synthetic_backbone(depth=depth)
+    cp = O.synthetic_cp(rank=rank, cp_length=cp_length)
+    x, y = O.synthetic_batch(batch=B)
+    m = build(w, cp, rank, 0.1, depth, 224, drop_path_rate=0.0, cp_length=cp_length).train()
+    assert m._cara_engine.cp_length == cp_length and ("CP_A5" in dict(m.named_parameters())) == (cp_length == 5)
+    assert ("CP_A4" in dict(m.named_parameters())) == (cp_length != 3)
+    logits = m(x.to(DEV))
+    loss = torch.nn.functional.cross_entropy(logits, y.to(DEV))
+    loss.backward()
+    cpo = {k: (v[:(1 if cp_length == 5 else 3) * depth] if k == "CP_A1" else (v[:9 * depth] if k == "CP_P1" else v)) for k, v in cp.items()}
+    head = {"weight": w["head.weight"], "bias": w["head.bias"]}
+    rloss, rlogits, rg = O.train_step_as_written(x, y, w, cpo, head, s=0.1, depth=depth)
+    with torch.no_grad():
+        sim = O.vit_cara_forward(x, w, cpo, s=0.1, depth=depth, factored=True, bf16_sim=True)
+    e = rel(logits.detach(), rlogits)
+    print(f"cp_length {cp_length}: logits rel {e:.2e} (bf16 model {rel(sim, rlogits):.2e})")
+    assert e < 1.5 * max(rel(sim, rlogits), 4e-3) and e < 1.5e-2
+    for k in cpo:
+        gk = getattr(m, k).grad
+        assert gk is not None and torch.isfinite(gk).all(), k
+        if rg[k].norm() > 0:
+            ek = rel(gk, rg[k])
+            print(f"  d{k}: rel {ek:.2e}")
+            assert ek < 6e-2, (k, ek)
 
 
 def test_drop_path_masks_and_train_mode():

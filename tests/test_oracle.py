@@ -86,6 +86,27 @@ def test_factored_equals_as_written(case12):
     assert torch.allclose(fac.float(), t("full_logits"), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("cp_length", [3, 5])
+def test_other_orders_of_the_qkv_tensorisation_factor_the_same_way(cp_length):
+    """dim_experiment.py's order-3 and order-5 QKV tensorisations are rank-R in (in, out) as well: the factored form the
+    kernels run equals the materialised einsum of the script in fp64, logits and every CP gradient."""
+    import torch
+    w = {k: v.double() for k, v in O.synthetic_backbone(depth=2).items()}
+    cp = {k: v.double() for k, v in O.synthetic_cp(rank=8, depth=2, cp_length=cp_length).items()}
+    assert O.cp_length_of(cp) == cp_length
+    x, y = O.synthetic_batch(batch=2)
+    outs = []
+    for factored in (False, True):
+        cpv = {k: v.clone().requires_grad_(True) for k, v in cp.items()}
+        logits = O.vit_cara_forward(x.double(), w, cpv, s=0.1, depth=2, factored=factored)
+        torch.nn.functional.cross_entropy(logits, y).backward()
+        outs.append((logits.detach(), {k: v.grad for k, v in cpv.items()}))
+    assert torch.allclose(outs[0][0], outs[1][0], atol=1e-10)
+    for k in cp:
+        assert torch.allclose(outs[0][1][k], outs[1][1][k], atol=1e-10), k
+        assert k in ("CP_bias1", "CP_bias2", "CP_bias3") or outs[0][1][k].abs().max() > 0, k
+
+
 def test_train_mode_rng_order(case12):
     """Dropout(0.1) on each materialised dW + DropPath, drawn in the reference's order."""
     R, L, S, w, cp, _ = case12
