@@ -300,7 +300,11 @@ typedef struct {
   int inference;
 } cara_vit_shape;
 size_t cara_vit_workspace_bytes(const cara_geom* g, const cara_vit_shape* s);
-/* images fp32 [B,chans,img,img]; droppath fp32 [depth,2,B] per-sample branch multipliers
+/* Threading: cara_vit_forward / cara_vit_backward keep a little process-global host state (the side stream and its
+ * events, the roofline bracket, the scratch of the workspace in use), so calls into them must not overlap in time
+ * from different host threads of one process; any number of streams / workspaces may be used one call after the
+ * other (data parallelism is one PROCESS per GPU).  Every other entry point of this header is stateless.
+ * images fp32 [B,chans,img,img]; droppath fp32 [depth,2,B] per-sample branch multipliers
  * (mask/keep_prob of timm DropPath) or NULL; head_w fp32 [classes,dim], head_b fp32 [classes];
  * logits fp32 [B,classes].  The workspace must be zero-filled once before its first use and
  * must not be touched between a forward and its backward.                                      */
