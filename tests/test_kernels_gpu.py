@@ -445,6 +445,20 @@ def test_gemm_carrying_the_transposed_skinny_products(M, N, K, epi, monkeypatch)
         monkeypatch.setenv("CARA_TS_POS", pos)
         got = run(True)
         assert all(torch.equal(x, y) for x, y in zip(ref, got)), f"CARA_TS_POS={pos}"
+    monkeypatch.delenv("CARA_TS_POS")
+    # the same with dY and X K-panel-major (a_panels on the GEMM, negative ld on the products) and packed weights
+    dYp, Xp, Wp = _panels(dY), _panels(X), L().pack_b_panels(Wt)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    sa = torch.zeros(int(lib.cara_tskinny_scratch_bytes(M, N, 32)), dtype=torch.uint8, device=DEV)
+    sb = torch.zeros(int(lib.cara_tskinny_scratch_bytes(M, K, 32)), dtype=torch.uint8, device=DEV)
+    a = L().GemmArgs()
+    a.A, a.lda, a.a_panels, a.B, a.ldb, a.Bp, a.A2, a.B2, a.Rp = p(dYp), 0, M, p(Wt), K, p(Wp), p(G), p(U), 32
+    a.M, a.N, a.K, a.C, a.ldc = M, N, K, p(out), N
+    a.epi = L().EPI_DGELU if epi == "dgelu" else L().EPI_BF16
+    a.aux = p(aux) if epi == "dgelu" else None
+    L().check(lib.cara_gemm_with_tskinny(C.byref(a), p(Xp), -M, p(Gt), p(sa), N, p(dYp), -M, p(Tt), p(sb), K, 1, ldg, M, 32, st()),
+              "cara_gemm_with_tskinny, panels")
+    assert all(torch.equal(x, y) for x, y in zip(ref, (out, sa, sb))), "panel-major operands"
     # not fusable: few rows
     a = L().GemmArgs()
     a.A, a.lda, a.B, a.ldb, a.M, a.N, a.K, a.ldc = p(dY), K, p(Wt), K, 64, N, K, N
