@@ -4,21 +4,33 @@
 One "step" = the reference's train step (/root/reference/image_classification/vit_cp.py:45-50):
 forward, mean cross-entropy, backward into the 12 CP tensors + head, (N > 1: one RCCL all-reduce
 of the flat gradient buffer), AdamW.  Synthetic data and random-init weights of the named
-architecture; inputs are resident in HBM before the timed region.
+architecture; inputs are resident in HBM before the timed region.  Train mode: DropPath 0.1 (per-rank
+random streams), factored adapters WITHOUT the reference's Dropout(0.1) on the materialised dW (that
+mode is ``--weight-dropout exact``, informational).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-``roofline`` (dominant kernel = the fc1 forward GEMM, timed with HIP events on the compute stream
-inside the timed region) and ``cpu_baseline`` (the oracle's as-written fp32 algorithm on the
-host cores, bounded sample, rank 0 at N = 1 only).
+With N > 1 and no WORLD_SIZE in the environment the script starts
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>`` as a CHILD process
+(before anything touches the GPU) and exits with its code; under torchrun it reads RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* itself.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
+``roofline``      the dominant kernel by measured time share (picked from a bracketed warm-up step), timed with
+                  HIP events on the compute stream INSIDE the timed region;
+``roofline_top``  the three kernel sites with the largest time share (name, algorithmic GFLOP, avg us, fraction
+                  of the 2.5 PFLOP/s dense bf16 MFMA peak), from bracketed steps after the timed region;
+``roofline_hbm``  the HBM-bound adapter-contraction / LayerNorm kernels in GB/s against 8 TB/s, same steps;
+``cpu_baseline``  the oracle's as-written fp32 algorithm on the host cores (SURVEY 8d protocol, bounded sample,
+                  rank 0 at N = 1 only).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -28,14 +40,53 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0      # HBM3E spec (6.3 TB/s is what a copy achieves), same guide
 # algorithmic GFLOP per image, SURVEY.md 8(d) / BASELINE.md section 3 (ViT-B/16, R=16)
 GF_PER_IMG = {"fwd": 36.06, "bwd": 38.18, "step": 74.24}
 # --model vit_large_patch16_384 (BASELINE.json configs[4], bs 32, rank 16): informational runs only, the
 # reported metric stays the ViT-B configuration
-# the roofline bracket (three HIP event records around the fc1 GEMM) idles the chip ~15 us per use: inside the
-# timed region it goes around the fc1 GEMM of every 6th block only (2 launches per ViT-B step, 4 per ViT-L step)
-PROFILE_EVERY = 6
 GF_PER_IMG_L384 = {"fwd": 389.39, "bwd": 428.47, "step": 817.87}
+# a bracket (three HIP event records) idles the chip ~15 us: inside the timed region only the dominant site is
+# bracketed, on every 6th block (2 launches per ViT-B step, 4 per ViT-L step)
+PROFILE_EVERY = 6
+
+SITES = ["qkv_fwd", "proj_fwd", "fc1_fwd", "fc2_fwd", "qkv_bwd", "proj_bwd", "fc1_bwd", "fc2_bwd", "attn_fwd", "attn_bwd",
+         "ln1_fwd", "ln2_fwd", "ln1_bwd", "ln2_bwd", "skinny_fwd", "skinny_bwd"]   # include/cara_hip.h CARA_SITE_*
+SITE_KERNEL = {
+    "qkv_fwd": "gemm32_kernel<BF16> (qkv forward, [xn1 | T][W | Vs]^T)",
+    "proj_fwd": "gemm32ft_kernel<RESID> (proj forward, T = X U inside)",
+    "fc1_fwd": "gemm32_kernel<GELU> (fc1 forward, two bf16 outputs u and gelu(u))",
+    "fc2_fwd": "gemm32ft_kernel<RESID> (fc2 forward, T = X U inside)",
+    "qkv_bwd": "gemm32_ts_kernel<BF16,false> (qkv dX + its dU / dVs products in one launch)",
+    "proj_bwd": "gemm32_ts_kernel<BF16,true> (proj dX + dU / dVs / dc)",
+    "fc1_bwd": "gemm32_ts_kernel<BF16,true> (fc1 dX + dU / dVs / dc)",
+    "fc2_bwd": "gemm32_ts_kernel<DGELU,true> (fc2 dX with gelu' epilogue + dU / dVs / dc)",
+    "attn_fwd": "attn_fwd_long_kernel<7>", "attn_bwd": "attn_bwd_dkv_kernel + attn_bwd_dq_kernel",
+    "ln1_fwd": "ln_fwd_kernel<XU> (LayerNorm 1 + T = LN(x) U of qkv)", "ln2_fwd": "ln_fwd_kernel<XU> (LayerNorm 2 + T of fc1)",
+    "ln1_bwd": "ln_bwd_kernel<XU> (LayerNorm 1 backward + G' of the fc2 below)", "ln2_bwd": "ln_bwd_kernel<XU> (LayerNorm 2 backward + G' of proj)",
+    "skinny_fwd": "skinny_xu_sliced_kernel (T = X U)", "skinny_bwd": "skinny_xu_sliced_kernel (G' = dY Vs of fc1 / qkv)",
+}
+
+
+def site_work(M, D, R, B, H, N):
+    """Algorithmic work per launch of every site: ('mfma', FLOP) or ('hbm', bytes).  R = the rank (not the padded Rp)."""
+    def fwd(i, o, t_inside):   # [X | T][W | Vs]^T, plus T = X U when the GEMM computes it
+        return 2.0 * M * o * (i + R) + (2.0 * M * i * R if t_inside else 0.0)
+
+    def bwd(i, o):             # dX = [dY | G'][W^T | U]^T plus the riding dU = X^T G', dVs = dY^T T
+        return 2.0 * M * i * (o + R) + 2.0 * M * R * (i + o)
+    att = 4.0 * B * H * N * N * 64
+    return {
+        "qkv_fwd": ("mfma", fwd(D, 3 * D, False)), "proj_fwd": ("mfma", fwd(D, D, True)),
+        "fc1_fwd": ("mfma", fwd(D, 4 * D, False)), "fc2_fwd": ("mfma", fwd(4 * D, D, True)),
+        "qkv_bwd": ("mfma", bwd(D, 3 * D)), "proj_bwd": ("mfma", bwd(D, D)), "fc1_bwd": ("mfma", bwd(D, 4 * D)), "fc2_bwd": ("mfma", bwd(4 * D, D)),
+        "attn_fwd": ("mfma", att), "attn_bwd": ("mfma", 2.5 * att),     # S, dP, dV, dK, dQ: five products of 2 B H N^2 64
+        # LayerNorm forward: read x fp32, write xn bf16; backward: read dy bf16 + x fp32 + dx fp32, write dx fp32 + dyb bf16
+        "ln1_fwd": ("hbm", M * D * 6.0), "ln2_fwd": ("hbm", M * D * 6.0), "ln1_bwd": ("hbm", M * D * 16.0), "ln2_bwd": ("hbm", M * D * 16.0),
+        # skinny contractions read their [M, K] operand once (bf16): forward K = D or 4 D (unused by default), backward
+        # the dY of fc1 (K = 4 D) and of qkv (K = 3 D) alternate -> mean
+        "skinny_fwd": ("hbm", M * 2.5 * D * 2.0), "skinny_bwd": ("hbm", M * 3.5 * D * 2.0),
+    }
 
 
 def build_model(rank, scale, num_classes, device, seed, name="vit_base_patch16_224_in21k"):
@@ -57,37 +108,91 @@ def build_model(rank, scale, num_classes, device, seed, name="vit_base_patch16_2
     return vit, trainable
 
 
-def cpu_baseline(rank, scale):
-    """The as-written reference algorithm (dense dW + second GEMM per linear, fp32 autograd, AdamW)
-    restated by the oracle, on the host cores.  Bounded: batch 16, 1 warm-up + 2 timed steps."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(scale):
+    """the as-written reference algorithm (dense dW + second GEMM per linear, fp32 autograd, AdamW)
+    restated by the oracle, on the host cores: config-1 shape (R = 8, bs 16) and the headline rank at bs 16
+    (bs 64 costs ~12 s per step: outside the bounded sample), 2 warm-ups + median of 5 timed train steps each,
+    plus the eval-forward rate.  Baseline only."""
     from oracle import cara_oracle as O
     # a 1-GPU box's CPU share is 16 cores; more threads than that only oversubscribes
     nthreads = min(16, os.cpu_count() or 1)
     torch.set_num_threads(nthreads)
-    bs = 16
     w = O.synthetic_backbone()
-    cp = O.synthetic_cp(rank=rank)
-    x, y = O.synthetic_batch(batch=bs)
-    head = {"weight": w["head.weight"].clone(), "bias": w["head.bias"].clone()}
-    params = [torch.nn.Parameter(v.clone()) for v in list(cp.values()) + list(head.values())]
-    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-4)
-    names = list(cp.keys())
-    times = []
-    for it in range(3):
-        t0 = time.perf_counter()
-        cpd = {n: p for n, p in zip(names, params[:len(names)])}
-        ww = dict(w)
-        ww["head.weight"], ww["head.bias"] = params[-2], params[-1]
-        logits = O.vit_cara_forward(x, ww, cpd, s=scale)
-        loss = torch.nn.functional.cross_entropy(logits, y)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        times.append(time.perf_counter() - t0)
-    dt = sum(times[1:]) / 2
-    return {"value": round(bs / dt, 3), "unit": "images/sec", "cores": nthreads, "kind": "port",
-            "sample": f"2 timed train steps (fwd+bwd+AdamW) of batch {bs}, rank {rank}, fp32, reference's as-written "
-                      f"dense-dW algorithm restated in oracle/cara_oracle.py; {dt:.2f} s/step"}
+    samples = {}
+    t_begin = time.perf_counter()
+    for label, rank, bs, warm, timed in (("cfg1_R8_bs16", 8, 16, 2, 5), ("headline_R16_bs16", 16, 16, 2, 5)):
+        cp = O.synthetic_cp(rank=rank)
+        x, y = O.synthetic_batch(batch=bs)
+        head = {"weight": w["head.weight"].clone(), "bias": w["head.bias"].clone()}
+        params = [torch.nn.Parameter(v.clone()) for v in list(cp.values()) + list(head.values())]
+        opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-4)
+        names = list(cp.keys())
+        times = []
+        for it in range(warm + timed):
+            if it >= warm and time.perf_counter() - t_begin > 75 and len(times) >= 3:
+                break   # bound the sample on a slow host
+            t0 = time.perf_counter()
+            cpd = {n: p for n, p in zip(names, params[:len(names)])}
+            ww = dict(w)
+            ww["head.weight"], ww["head.bias"] = params[-2], params[-1]
+            logits = O.vit_cara_forward(x, ww, cpd, s=scale)
+            loss = torch.nn.functional.cross_entropy(logits, y)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            if it >= warm:
+                times.append(time.perf_counter() - t0)
+        med = statistics.median(times)
+        samples[label] = {"images_per_sec": round(bs / med, 3), "s_per_step": round(med, 3), "timed_steps": len(times)}
+        if label.startswith("headline"):
+            with torch.no_grad():
+                cpd = {n: p.detach() for n, p in zip(names, params[:len(names)])}
+                O.vit_cara_forward(x, w, cpd, s=scale)
+                t0 = time.perf_counter()
+                O.vit_cara_forward(x, w, cpd, s=scale)
+                samples["eval_forward_R16_bs16"] = {"images_per_sec": round(bs / (time.perf_counter() - t0), 3)}
+    head = samples["headline_R16_bs16"]
+    return {"value": head["images_per_sec"], "unit": "images/sec", "cores": nthreads, "kind": "port",
+            "sample": f"median of {head['timed_steps']} train steps (fwd+bwd+AdamW) after 2 warm-ups, batch 16, rank 16, fp32, the "
+                      "reference's as-written dense-dW algorithm restated in oracle/cara_oracle.py (cara.py:15-95, vit_cp.py:45-50)",
+            "samples": samples, "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(),
+            "torch_parallel_info": " | ".join(l.strip() for l in torch.__config__.parallel_info().splitlines()[:4])}
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` without torchrun: start it ourselves, as a child, before any GPU call."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks through torch.distributed.run", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def read_sites(lib, names):
+    from cara_amd import _lib
+    out = {}
+    for n in names:
+        avg, mark, cnt = C.c_float(0), C.c_float(0), C.c_int(0)
+        _lib.check(lib.cara_profile_site_read(SITES.index(n), C.byref(avg), C.byref(mark), C.byref(cnt)), "cara_profile_site_read")
+        if cnt.value > 0:
+            out[n] = {"avg_ms": avg.value, "marker_ms": mark.value, "brackets": cnt.value}
+    return out
 
 
 def main():
@@ -105,35 +210,41 @@ def main():
                     help="vit_large_patch16_384 runs BASELINE.json configs[4] (use --batch 32); informational only")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearsal = os.environ.get("CARA_BENCH_REHEARSAL") == "1"
+    if args.gpus != world:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # CARA_BENCH_REHEARSAL=1: rehearse the multi-rank plumbing on a ONE-GPU box (all ranks on
         # cuda:0, gloo instead of RCCL).  Never used for reported numbers.
-        rehearsal = os.environ.get("CARA_BENCH_REHEARSAL") == "1"
         if rehearsal:
             local = 0
             dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if args.gpus != world:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE {world}: launch with torch.distributed.run", file=sys.stderr)
-        sys.exit(2)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
     from cara_amd import _lib
+    from cara_amd import dist as cdist
     lib = _lib.lib()
     scale, ncls = 0.1, 100
     large = args.model == "vit_large_patch16_384"
-    gf, img, tokens, dim = (GF_PER_IMG_L384, 384, 577, 1024) if large else (GF_PER_IMG, 224, 197, 768)
+    gf, img, tokens, dim, heads = (GF_PER_IMG_L384, 384, 577, 1024, 16) if large else (GF_PER_IMG, 224, 197, 768, 12)
     model, trainable = build_model(args.rank, scale, ncls, dev, seed=14, name=args.model)  # identical replicas on every rank
     eng = model._cara_engine
     eng.weight_dropout = args.weight_dropout
+    cdist.broadcast_parameters(trainable)   # replicas identical by construction; this makes it a fact (outside the timed region)
+    eng.seed_rank_streams(2024, rank)       # per-rank DropPath / weight-dropout masks
     try:
         opt = torch.optim.AdamW(trainable, lr=1e-3, weight_decay=1e-4, fused=True)
     except Exception:
@@ -142,15 +253,40 @@ def main():
     x = torch.randn(args.batch, 3, img, img, generator=gx).to(dev)
     y = torch.randint(0, ncls, (args.batch,), generator=gx).to(dev)
 
+    # how many ranks the collective really spans: all-reduce of a one
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, device="cpu" if rehearsal else dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+
     def step():
         return eng.train_step(x, y, opt)
 
-    for _ in range(args.warmup):
+    M = args.batch * tokens
+    work = site_work(M, dim, args.rank, args.batch, heads, tokens)
+    all_mask = (1 << len(SITES)) - 1
+    factored = args.weight_dropout == "off"
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    # last warm-up step with every site bracketed: which site has the largest time share?  (the exact mode runs
+    # its linears through other entry points; its GEMM sites then hold several kernels and are not reported)
+    dominant = "fc2_bwd"
+    if factored and args.warmup > 0:
+        _lib.check(lib.cara_profile_sites(C.c_ulonglong(all_mask), 1), "cara_profile_sites")
+        step()
+        torch.cuda.synchronize()
+        pre = read_sites(lib, SITES)
+        mf = {n: v for n, v in pre.items() if work[n][0] == "mfma"}
+        if mf:
+            dominant = max(mf, key=lambda n: mf[n]["avg_ms"] * mf[n]["brackets"])
+    elif args.warmup > 0:
         step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    _lib.check(lib.cara_profile_fc1(PROFILE_EVERY), "cara_profile_fc1")
+    _lib.check(lib.cara_profile_sites(C.c_ulonglong(1 << SITES.index(dominant)) if factored else C.c_ulonglong(0), PROFILE_EVERY),
+               "cara_profile_sites")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
@@ -162,20 +298,23 @@ def main():
         dist.barrier()
     wall = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1)
-    avg_ms, marker_ms, nl = C.c_float(0), C.c_float(0), C.c_int(0)
-    if args.weight_dropout == "off":
-        _lib.check(lib.cara_profile_fc1_read2(C.byref(avg_ms), C.byref(marker_ms), C.byref(nl)), "cara_profile_fc1_read2")
-    else:   # the informational exact mode runs its linears through other entry points: no bracket
-        avg_ms.value = float("nan")
-    lib.cara_profile_fc1(0)
-    t = torch.tensor([wall], device=dev, dtype=torch.float64)
+    dom = read_sites(lib, [dominant]).get(dominant) if factored else None
+    t = torch.tensor([wall], device="cpu" if (world > 1 and rehearsal) else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = t.item()
 
-    # forward-only rate (SURVEY 8d asks for it next to the train rate): eval mode, no autograd, same batch;
-    # outside the timed region above, rank 0's own clock
-    fwd_ms = None
+    # after the timed region, rank 0's own clock: (i) three steps with every site bracketed on every block ->
+    # roofline_top / roofline_hbm; (ii) the forward-only rate (SURVEY 8d asks for it next to the train rate)
+    post, fwd_ms = {}, None
+    if rank == 0 or world > 1:   # (every rank runs the bracketed steps: they contain the all-reduce)
+        if factored:
+            _lib.check(lib.cara_profile_sites(C.c_ulonglong(all_mask), 1), "cara_profile_sites")
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            post = read_sites(lib, SITES)
+    lib.cara_profile_sites(C.c_ulonglong(0), 1)
     if rank == 0:
         model.eval()
         with torch.no_grad():
@@ -194,17 +333,35 @@ def main():
     if rank == 0:
         ms_step = wall * 1e3 / args.steps
         ips = world * args.batch * args.steps / wall
-        M, D = args.batch * tokens, dim
-        fl_launch = 2.0 * M * (4 * D) * (D + args.rank)          # algorithmic: K = dim + rank (not the padded Rp)
-        ach = fl_launch / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value == avg_ms.value else 0.0
-        # HBM-side bytes per launch of that kernel from a committed rocprofv3 PMC run (separate
-        # FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 note of the microarch
-        # guide); only valid for the headline shape
+
+        def entry(n, v, per_step):
+            kind, amount = work[n]
+            us = v["avg_ms"] * 1e3
+            d = {"site": n, "kernel": SITE_KERNEL[n], "avg_launch_us": round(us, 2), "launches_per_step": per_step,
+                 "share_of_step": round(us * per_step / (ms_step * 1e3), 4)}
+            if kind == "mfma":
+                d.update(algorithmic_gflop=round(amount / 1e9, 2), achieved_tflops=round(amount / us / 1e6, 1),
+                         frac_of_mfma_peak=round(amount / us / 1e6 / PEAK_BF16_TFLOPS, 4))
+            else:
+                d.update(algorithmic_mb=round(amount / 1e6, 1), achieved_gbs=round(amount / us / 1e3, 1),
+                         frac_of_hbm_peak=round(amount / us / 1e3 / PEAK_HBM_GBS, 4))
+            return d
+        per_step = {n: v["brackets"] // 3 for n, v in post.items()}
+        ranked = sorted((n for n in post if work[n][0] == "mfma"), key=lambda n: -post[n]["avg_ms"] * per_step[n])
+        top = [entry(n, post[n], per_step[n]) for n in ranked[:3]]
+        hbm = [entry(n, post[n], per_step[n]) for n in post if work[n][0] == "hbm"]
+        if dom:
+            fl = work[dominant][1]
+            ach = fl / (dom["avg_ms"] * 1e-3) / 1e12
+        else:
+            fl, ach = 0.0, 0.0
+        # HBM-side bytes per launch of the dominant kernel from a committed rocprofv3 PMC run (separate FETCH_SIZE /
+        # WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 note of the microarch guide); headline shape only
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic_fc1.json")
+        tj = os.path.join(ROOT, "profiles", "pmc_traffic_by_site.json")
         if os.path.exists(tj) and args.batch == 64 and args.rank == 16 and not large:
             with open(tj) as fh:
-                traffic = json.load(fh).get("hbm_bytes_per_launch_corrected")
+                traffic = json.load(fh).get(dominant, {}).get("hbm_bytes_per_launch_corrected")
         out = {
             "metric": ("fine-tune images/sec ViT-L/16+CaRA r=16 @384, bs=32/GPU (BASELINE.json configs[4], informational)" if large
                        else "fine-tune images/sec ViT-B/16+CaRA r=16 @224, bs=64/GPU, 1/2/4/8 MI355X"),
@@ -216,9 +373,10 @@ def main():
                                     if large else
                                     f"ViT-B/16 + CaRA rank={args.rank}, synthetic 224x224, bs={args.batch}/GPU, bf16 "
                                     "(BASELINE.json configs[1]); fwd + CE + bwd + AdamW, drop-path 0.1, "
-                                    + ("factored adapters" if args.weight_dropout == "off" else
+                                    + ("factored adapters, no weight-space dropout" if factored else
                                        "EXACT weight-space dropout 0.1 (merged weights, dense dW; informational)")),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "ranks_in_allreduce": ranks_seen, "backend": ("gloo-rehearsal" if rehearsal else "rccl") if world > 1 else "none",
                        "step_algorithmic_gflop": round(gf["step"] * args.batch, 1),
                        "step_tflops_per_gpu": round(gf["step"] * args.batch / ms_step, 1),
                        "step_frac_of_mfma_peak": round(gf["step"] * args.batch / ms_step / PEAK_BF16_TFLOPS, 4),
@@ -228,12 +386,16 @@ def main():
                        "forward_frac_of_mfma_peak": round(gf["fwd"] * args.batch / fwd_ms / PEAK_BF16_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "kernel": f"gemm32_kernel<CARA_EPI_GELU> (fc1 forward, M={M} N={4 * D} K={D}+{args.rank}; the rocprofv3 name is gemm32_kernel<2>)",
-                         "avg_launch_ms": round(avg_ms.value, 4) if avg_ms.value == avg_ms.value else None, "launches_timed": nl.value,
-                         "event_marker_ms_subtracted": round(marker_ms.value, 4)},
+                         "kernel": f"{SITE_KERNEL[dominant]}; site {dominant}: the largest time share of the step among the "
+                                   f"bracketed sites; M={M}",
+                         "algorithmic_gflop_per_launch": round(fl / 1e9, 2),
+                         "avg_launch_ms": round(dom["avg_ms"], 4) if dom else None, "launches_timed": dom["brackets"] if dom else 0,
+                         "event_marker_ms_subtracted": round(dom["marker_ms"], 4) if dom else None},
+            "roofline_top": top,
+            "roofline_hbm": hbm,
         }
         if world == 1 and not args.no_cpu_baseline and not large:
-            out["cpu_baseline"] = cpu_baseline(args.rank, scale)
+            out["cpu_baseline"] = cpu_baseline(scale)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -17,12 +17,12 @@ LIB_PATH = os.environ.get("CARA_LIB_PATH") or os.path.join(_HERE, "libcara_hip.s
 
 # every symbol include/cara_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "cara_abi_version", "cara_build_arch", "cara_gemm_bf16", "cara_pack_b_panels", "cara_gemm_scratch_bytes", "cara_debug_gemm_persistent_launches", "cara_skinny_xu",
+    "cara_abi_version", "cara_build_arch", "cara_gemm_bf16", "cara_pack_b_panels", "cara_gemm_scratch_bytes", "cara_skinny_xu",
     "cara_tskinny_scratch_bytes", "cara_tskinny_xtg", "cara_tskinny_partial", "cara_tskinny_partial2", "cara_tskinny_reduce", "cara_tskinny_reduce_many", "cara_gemm_with_tskinny", "cara_layernorm_fwd", "cara_layernorm_bwd", "cara_layernorm_fwd_xu", "cara_layernorm_bwd_xu", "cara_layernorm_fwd_ex", "cara_layernorm_bwd_ex",
     "cara_attention_fwd", "cara_attention_bwd", "cara_im2col_patches", "cara_assemble_tokens",
     "cara_cross_entropy", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_transpose_bf16_ld", "cara_pack_offsets",
     "cara_weight_dropout_hash", "cara_materialize_merge", "cara_dropout_grad_scratch_bytes", "cara_dropout_grad_contract", "cara_colsum_scratch_bytes", "cara_colsum_bf16", "cara_factor_prep", "cara_factor_grad_scratch_bytes", "cara_factor_grad_reduce", "cara_vit_workspace_bytes", "cara_vit_forward",
-    "cara_vit_backward", "cara_head_backward", "cara_profile_fc1", "cara_profile_fc1_read", "cara_profile_fc1_read2", "cara_debug_tr_probe", "cara_debug_tr_frag",
+    "cara_vit_backward", "cara_head_backward", "cara_profile_sites", "cara_profile_site_read", "cara_debug_tr_probe", "cara_debug_tr_frag",
 )
 
 EPI_BF16, EPI_F32, EPI_GELU, EPI_RESID, EPI_DGELU = range(5)
@@ -123,7 +123,6 @@ def lib() -> C.CDLL:
             _lib.cara_weight_dropout_hash.restype = C.c_uint
             _lib.cara_dropout_grad_scratch_bytes.restype = C.c_size_t
             _lib.cara_colsum_scratch_bytes.restype = C.c_size_t
-            _lib.cara_debug_gemm_persistent_launches.restype = C.c_long
     return _lib
 
 
@@ -158,7 +157,7 @@ def gemm(A, B, out, *, epi, bias=None, A2=None, B2=None, C2=None, aux=None, rows
     if Ut is not None:   # adapter fully inside the GEMM: T = A Ut^T computed per tile (B2 = Vs must be given, A2 not)
         a.Ut, a.T_out, a.Tt_out = ptr(Ut), ptr(T_out), ptr(Tt_out)
         a.ldt = Tt_out.shape[1] if Tt_out is not None else 0
-    if scratch is not None:   # zero-initialised uint8 tensor of gemm_scratch_bytes(): enables the stream-K kernel
+    if scratch is not None:   # uint8 tensor of gemm_scratch_bytes(): few-row products run as batched split-K
         a.scratch, a.scratch_bytes = ptr(scratch), scratch.numel() * scratch.element_size()
     a.M = M if M is not None else A.shape[0]
     a.K = K if K is not None else A.shape[1]
@@ -185,10 +184,6 @@ def pack_b_panels(B):
 
 def gemm_scratch_bytes() -> int:
     return int(lib().cara_gemm_scratch_bytes())
-
-
-def gemm_persistent_launches() -> int:
-    return int(lib().cara_debug_gemm_persistent_launches())
 
 
 def skinny_xu(X, Ut, T, Tt=None, panels=False):

@@ -3,7 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libcara_hip.so
-SRCS="lib.hip gemm.hip gemm256.hip gemm_sk.hip skinny.hip norm_misc.hip attention.hip factors.hip dropout_exact.hip"
+SRCS="lib.hip gemm.hip skinny.hip norm_misc.hip attention.hip factors.hip dropout_exact.hip"
 [ -f vit.hip ] && SRCS="$SRCS vit.hip"
 OBJS=""
 mkdir -p build

@@ -9,12 +9,16 @@
 // second dense GEMM on a materialised dW.
 //
 // Structure: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 =
-// 4x4 v_mfma_f32_16x16x32_bf16 accumulators), BK = 64, two LDS buffers (64 KiB -> 2 blocks/CU),
+// 4x4 v_mfma_f32_16x16x32_bf16 accumulators), BK = 32, two LDS slots of A 128x32 + B 128x32 bf16
+// (32 KiB -> FOUR workgroups per CU: one's prologue / epilogue runs under the K loops of the others),
 // tiles staged by 16-byte global_load_lds (LDS-DMA, no VGPR round trip) issued one K-step ahead
-// of the MFMAs that consume them; one barrier per K-step.  LDS image is [row][64 bf16] with the
-// 16-byte chunk index XOR-swizzled by (row>>1)&7, applied on the global SOURCE address (the DMA
-// destination is lane-linear) and again on the ds_read_b128 address: conflict-free fragment reads.
+// of the MFMAs that consume them; one barrier per K-step.  LDS image is [row][32 bf16] with the
+// 16-byte chunk index XOR-swizzled, applied on the global SOURCE address (the DMA destination is
+// lane-linear) and again on the ds_read_b128 address: conflict-free fragment reads.
 // 1-D grid remapped so that each XCD's L2 sees a contiguous run of tiles.
+// (Other structures that were built and measured slower on this model's shapes -- a 64-deep double buffer,
+// 256x256 / 128x256 LDS-ring kernels, a persistent stream-K kernel -- live in tools/experimental/, outside the
+// library.)
 #include <stdlib.h>
 
 #include "common.h"
@@ -23,160 +27,19 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
-constexpr int LDS_BYTES = 4 * TILE_BYTES;      // [buf0: A,B][buf1: A,B]
+constexpr int BM = 128, BN = 128, BK = 64;   // (K granule the C ABI promises: K % 64 == 0)
 
-__device__ __forceinline__ int swz_off(int row, int chunk) {
-  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
-
-// Stage rows r0..r0+127 (clamped to rmax), columns k0..k0+63 of row-major P into a swizzled tile.
-// 16 one-KiB pieces (8 rows each); wave w issues pieces 4w..4w+3.
-__device__ __forceinline__ void stage_tile(const bf16* __restrict__ P, int ld, int r0, int rmax,
-                                           int k0, char* lds_tile, int wave, int lane) {
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int q = wave * 4 + t;
-    const int r = q * 8 + (lane >> 3);
-    const int cg = (lane & 7) ^ ((r >> 1) & 7);
-    int gr = r0 + r;
-    gr = gr < rmax ? gr : rmax;
-    glds16(P + (size_t)gr * ld + k0 + cg * 8, lds_tile + q * 1024);
-  }
-}
-
-// The K-extension operands are [rows, Rp] with Rp in {32, 64}: too narrow for lane-linear 1-KiB
-// pieces, so this single step per tile goes through registers.
-__device__ __forceinline__ void stage_ext(const bf16* __restrict__ P, int Rp, int r0, int rmax,
-                                          char* lds_tile, int tid) {
-  const int cpr = Rp >> 3;
-  for (int idx = tid; idx < 128 * cpr; idx += 256) {
-    const int r = idx / cpr, c = idx - r * cpr;
-    int gr = r0 + r;
-    gr = gr < rmax ? gr : rmax;
-    const uint4 v = *reinterpret_cast<const uint4*>(P + (size_t)gr * Rp + c * 8);
-    *reinterpret_cast<uint4*>(lds_tile + swz_off(r, c)) = v;
-  }
-}
-
-__device__ __forceinline__ void mma_tile(const char* sA, const char* sB, f32x4 (&acc)[4][4],
-                                         int wr, int wc, int lane, int ksub) {
-  const int fr = lane & 15, fq = lane >> 4;
-  for (int kk = 0; kk < ksub; ++kk) {
-    bf16x8 a[4], b[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      a[i] = *reinterpret_cast<const bf16x8*>(sA + swz_off(wr * 64 + i * 16 + fr, kk * 4 + fq));
-      b[i] = *reinterpret_cast<const bf16x8*>(sB + swz_off(wc * 64 + i * 16 + fr, kk * 4 + fq));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-  }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const cara_gemm_args p, const int tiles_n,
-                                                      const int nwg) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int tile = xcd_remap(blockIdx.x, nwg);
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const bf16* __restrict__ A = static_cast<const bf16*>(p.A);
-  const bf16* __restrict__ B = static_cast<const bf16*>(p.B);
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.K / BK;
-  stage_tile(A, p.lda, m0, p.M - 1, 0, smem, wave, lane);
-  stage_tile(B, p.ldb, n0, p.N - 1, 0, smem + TILE_BYTES, wave, lane);
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed (own DMA: vmcnt; other waves': barrier) and every wave has finished
-    // reading the other buffer (its MFMAs of step kt-1 are issued), so it may be refilled.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    char* sA = smem + cur * (2 * TILE_BYTES);
-    if (kt + 1 < nk) {
-      char* nA = smem + (cur ^ 1) * (2 * TILE_BYTES);
-      stage_tile(A, p.lda, m0, p.M - 1, (kt + 1) * BK, nA, wave, lane);
-      stage_tile(B, p.ldb, n0, p.N - 1, (kt + 1) * BK, nA + TILE_BYTES, wave, lane);
-    }
-    mma_tile(sA, sA + TILE_BYTES, acc, wr, wc, lane, BK / 32);
-    cur ^= 1;
-  }
-  if (p.Rp > 0) {
-    __syncthreads();
-    stage_ext(static_cast<const bf16*>(p.A2), p.Rp, m0, p.M - 1, smem, tid);
-    stage_ext(static_cast<const bf16*>(p.B2), p.Rp, n0, p.N - 1, smem + TILE_BYTES, tid);
-    __syncthreads();
-    mma_tile(smem, smem + TILE_BYTES, acc, wr, wc, lane, p.Rp >> 5);
-  }
-
-  // ---- epilogue ----
-  // The accumulators (C/D layout of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg) go
-  // through a wave-private fp32 image of the wave's 64x64 sub-tile in the now idle staging LDS, so
-  // that every global access of the epilogue (output, residual / pre-activation input, bias) is a
-  // 16-byte access on 128..256-byte contiguous row segments instead of 2-byte scatters.
-  __syncthreads();  // every wave is done reading the operand tiles
-  float* stg = reinterpret_cast<float*>(smem) + wave * (64 * 64);
-  {
-    const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[i][j][r];
-  }
-  epilogue_64x64<EPI>(p, stg, m0 + wr * 64, n0 + wc * 64, lane);
-}
-
-// ---------------------------------------------------------------------------------------------
-// 128x128x32 variant: 2 x (A 128x32 + B 128x32) bf16 = 32 KiB of LDS per workgroup, so FOUR
-// workgroups (16 waves) share a CU and one workgroup's prologue / epilogue overlaps the K-loops of
-// the others (the ablation in DESIGN.md section 7 attributes ~40 % of a GEMM to un-overlapped
-// prologue + epilogue).  Same staging, swizzle (64-byte rows) and epilogue, the latter in two
-// 32-row halves so that the fp32 image also fits the 32 KiB.
-// ---------------------------------------------------------------------------------------------
 constexpr int BK32 = 32;
 constexpr int B32_BYTES = BN * BK32 * 2;        // 8 KiB: the B tile (128 rows x 64 B)
 
 __device__ __forceinline__ int swz32(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 3) & 1) * 3)) << 4); }
 
-// ROWS x 64 B operand tile = ROWS/16 one-KiB pieces (16 rows each), spread over the 4 waves
-template <int ROWS, int NW = 4>
-__device__ __forceinline__ void stage_tile32(const bf16* __restrict__ P, int ld, int r0, int rmax, int k0, char* lds_tile,
-                                             int wave, int lane) {
-  constexpr int PPW = ROWS / (16 * NW);   // pieces per wave
-#pragma unroll
-  for (int t = 0; t < PPW; ++t) {
-    const int q = wave * PPW + t;
-    const int r = q * 16 + (lane >> 2);
-    const int cg = (lane & 3) ^ (((r >> 3) & 1) * 3);
-    int gr = r0 + r;
-    gr = gr < rmax ? gr : rmax;
-    glds16(P + (size_t)gr * ld + k0 + cg * 8, lds_tile + q * 1024);
-  }
-}
-
-// The same with the row part of the address hoisted out of the K loop: off[t] = (clamped row) * ld * 2 + swizzled
+// A ROWS x 64 B operand tile is ROWS/16 one-KiB LDS-DMA pieces (16 rows each), spread over the waves, with the
+// row part of the address hoisted out of the K loop: off[t] = (clamped row) * ld * 2 + swizzled
 // chunk * 16 is a per-thread 32-bit byte offset computed once per tile, and a K step only adds the wave-uniform
 // k0 * 2 to the operand's base pointer (SGPR base + VGPR offset addressing: no vector arithmetic at all per piece).
 // rocprofv3 counted 1 460 VALU instructions per wave and tile in the bf16-epilogue kernel (3.6 per MFMA), about
 // two thirds of them this address arithmetic.  Needs the operand to span < 4 GiB (checked at dispatch).
-#ifndef CARA_G32_WGS
-#define CARA_G32_WGS 4   // workgroups per CU the 128x128x32 kernel is compiled for
-#endif
 template <int ROWS, int NW = 4>
 struct TileOfs {
   unsigned off[ROWS / (16 * NW)];
@@ -234,7 +97,7 @@ __device__ __forceinline__ void stage_ext32(const bf16* __restrict__ P, int Rp, 
 // 32x64 wave tiles (more resident waves per CU)
 // one workgroup's tile; `block` = its index among the nwg tiles of the product, `zb` = product index of a batched launch
 template <int EPI, int MI, int NW>
-__device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int tiles_n, const int nwg, const int gm, const int ablate,
+__device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int tiles_n, const int nwg, const int gm,
                                             const int block, const size_t zb_in, char* smem) {
   constexpr int TBM = MI * 16 * (NW / 2);
   constexpr int A_BYTES = TBM * BK32 * 2;
@@ -273,15 +136,12 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // CARA_GEMM_ABLATE (timing diagnostics, results become wrong): 32 = one K step only (epilogue + launch cost),
-  // 4 = no epilogue stores (K loop + launch cost), 64 = K loop always reads K tile 0 (L2-resident operands)
-  const int nk = (ablate & 32) ? 1 : p.K / BK32;
-  const int kmul = (ablate & 64) ? 0 : BK32;
+  const int nk = p.K / BK32;
   const int uwave = __builtin_amdgcn_readfirstlane(wave);   // wave-uniform copy: scalar LDS destinations
   const TileOfs<TBM, NW> oA = tile_ofs<TBM, NW>(p.a_panels ? BK32 : p.lda, m0, p.M - 1, wave, lane);
   const TileOfs<BN, NW> oB = tile_ofs<BN, NW>(packed ? BK32 : p.ldb, n0, p.N - 1, wave, lane);
-  const int kmulB = (ablate & 64) ? 0 : (packed ? p.N * BK32 : BK32);
-  const int kmulA = p.a_panels ? ((ablate & 64) ? 0 : p.a_panels * BK32) : kmul;   // K-panel-major A: a_panels rows per panel
+  const int kmulB = packed ? p.N * BK32 : BK32;
+  const int kmulA = p.a_panels ? p.a_panels * BK32 : BK32;   // K-panel-major A: a_panels rows per panel
   stage_tile32_pre<TBM, NW>(A, 0, oA, smem, uwave);
   stage_tile32_pre<BN, NW>(B, 0, oB, smem + A_BYTES, uwave);
   int cur = 0;
@@ -304,7 +164,6 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
     __syncthreads();
     mma_tile32<MI>(smem, smem + A_BYTES, acc, wr, wc, lane);
   }
-  if ((ablate & 4) && acc[0][0][0] != 123.456f) return;
   // epilogue in NPASS passes of HALF rows: wave-private [HALF][64] fp32 image (8 waves x 4 row tiles: four
   // 16-row passes, so that the images fit the 48 KiB the K loop uses)
   constexpr int NPASS = (NW == 8 && MI == 4) ? 4 : 2;
@@ -324,11 +183,10 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
   }
 }
 
-template <int EPI, int MI, int NW = 4>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? CARA_G32_WGS : 6)) void gemm32_kernel(const cara_gemm_args p, const int tiles_n,
-                                                                                          const int nwg, const int gm, const int ablate) {
+template <int EPI>
+__global__ __launch_bounds__(256, 4) void gemm32_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm32_body<EPI, MI, NW>(p, tiles_n, nwg, gm, ablate, blockIdx.x, blockIdx.y, smem);
+  gemm32_body<EPI, 4, 4>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
 }
 
 // The dX GEMM of a linear and the two transposed skinny products of the SAME linear (dU = X^T G', dVs = dY^T T) in
@@ -339,16 +197,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? (MI == 4 ? 4 : 3) : (MI == 4 ? C
 // (84 VGPRs; the Rp = 64 form needs 136) and 36 KiB of LDS per workgroup (still four per CU).
 template <int EPI, bool COLSUM>
 __global__ __launch_bounds__(256, 4) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
-                                                           const TsProblem t0, const TsProblem t1, const int ldg, const int Mts, const int nts,
-                                                           const int ts_first) {
+                                                           const TsProblem t0, const TsProblem t1, const int ldg, const int Mts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // (ts_first: the GEMM tiles start at a multiple of 8 so that blockIdx % 8, the XCD, is what xcd_remap assumes)
-  const int b = blockIdx.x, nts8 = (nts + 7) & ~7;
-  if (ts_first ? b < nts8 : b >= nwg) {
-    const int tb = ts_first ? b : b - nwg;
-    if (tb < nts) tskinny_body<2, COLSUM, 1>(t0, t1, ldg, Mts, tb, smem);
+  // the products' blocks sit BEHIND the GEMM tiles: they fill the slots the GEMM's last, partly filled round leaves
+  // free (in front of the tiles: +0.05 ms per step; spread among them: +0.7 ms)
+  const int b = blockIdx.x;
+  if (b >= nwg) {
+    tskinny_body<2, COLSUM, 1>(t0, t1, ldg, Mts, b - nwg, smem);
   } else {
-    gemm32_body<EPI, 4, 4>(p, tiles_n, nwg, gm, 0, ts_first ? b - nts8 : b, 0, smem);
+    gemm32_body<EPI, 4, 4>(p, tiles_n, nwg, gm, b, 0, smem);
   }
 }
 
@@ -501,27 +358,8 @@ int launch32ft(const cara_gemm_args* a, hipStream_t st) {
   return CARA_OK;
 }
 
-// CARA_GEMM_BM=64 selects the 64-row tile (A/B only).  Measured same-box in the real step: 64-row
-// tiles everywhere 14.07 ms, 64 rows only for the N <= 768 products 13.3 ms, 128 rows 12.2 ms -- the
-// better balance over 256 CUs does not pay for the lower FLOP per staged byte, so 128 is the default.
-static int bm_choice(const cara_gemm_args* a) {
-  const char* e = getenv("CARA_GEMM_BM");   // read per call: tests and A/B runs switch it
-  const int forced = e ? atoi(e) : 0;
-  // 8 = 128-row tile with 8 waves; 256 = 256 x 128 tile, 8 waves of 64 x 64 (two workgroups per CU: 3/4 of the
-  // LDS-DMA bytes per flop of the 128 x 128 tile), only for products with at least 18 column tiles
-  if (forced == 256) return a->N >= 2304 && a->M >= 1024 ? 256 : 128;
-  if (forced == 2560) return 256;   // every shape (tests)
-  return forced == 64 ? 64 : (forced == 8 ? 8 : 128);
-}
-
-// rows per supertile; CARA_GEMM_GROUPM overrides (1 = plain row-major order)
+// rows per supertile (1 = plain row-major order)
 static int group_m(int tiles_n) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("CARA_GEMM_GROUPM");
-    forced = e ? atoi(e) : 0;
-  }
-  if (forced > 0) return forced;
   // measured with rocprofv3 FETCH_SIZE (x2 gfx950 correction), per launch, plain order -> groups of 8:
   // fc1 fwd (24 column tiles) 224 -> 133 MB, fc2 bwd 297 -> 207 MB, but the 6-column products
   // 82 -> 113 MB and qkv (18 columns) flat: group only when there are many column tiles
@@ -539,91 +377,25 @@ template <int EPI>
 int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr) {
   const int tiles_n = (a->N + BN - 1) / BN;
   const int gm = group_m(tiles_n);
-  if (ts) {   // default tile only (checked by the caller)
-    const int nwg = ((a->M + 127) / 128) * tiles_n, nts = ts->a.nblk + ts->b.nblk;
-    // the products' blocks go BEHIND the GEMM tiles (they fill the slots its last, partly filled round leaves free);
-    // CARA_TS_POS=0 puts them in front (A/B: 10.02 vs 9.95-9.98 ms/step; the side stream: 10.03-10.06)
-    const char* ep = getenv("CARA_TS_POS");
-    const int ts_first = ep && atoi(ep) == 0;
-    const int grid = nwg + (ts_first ? ((nts + 7) & ~7) : nts);
-    constexpr int LDS = TsRing<2, 1>::BLOCK_BYTES > 2 * (128 * BK32 * 2 + B32_BYTES) ? TsRing<2, 1>::BLOCK_BYTES : 2 * (128 * BK32 * 2 + B32_BYTES);
+  const int nwg = ((a->M + 127) / 128) * tiles_n;
+  constexpr int GEMM_LDS = 2 * (128 * BK32 * 2 + B32_BYTES);
+  if (ts) {
+    const int nts = ts->a.nblk + ts->b.nblk;
+    constexpr int LDS = TsRing<2, 1>::BLOCK_BYTES > GEMM_LDS ? TsRing<2, 1>::BLOCK_BYTES : GEMM_LDS;
     if (ts->any_cs)
-      hipLaunchKernelGGL((gemm32_ts_kernel<EPI, true>), dim3(grid), dim3(256), LDS, st, *a, tiles_n, nwg, gm, ts->a, ts->b, ts->ldg, ts->M, nts, ts_first);
+      hipLaunchKernelGGL((gemm32_ts_kernel<EPI, true>), dim3(nwg + nts), dim3(256), LDS, st, *a, tiles_n, nwg, gm, ts->a, ts->b, ts->ldg, ts->M);
     else
-      hipLaunchKernelGGL((gemm32_ts_kernel<EPI, false>), dim3(grid), dim3(256), LDS, st, *a, tiles_n, nwg, gm, ts->a, ts->b, ts->ldg, ts->M, nts, ts_first);
+      hipLaunchKernelGGL((gemm32_ts_kernel<EPI, false>), dim3(nwg + nts), dim3(256), LDS, st, *a, tiles_n, nwg, gm, ts->a, ts->b, ts->ldg, ts->M);
     CARA_CHECK_LAUNCH();
     return CARA_OK;
   }
-  const char* ea = getenv("CARA_GEMM_ABLATE");
-  const int ablate = ea ? atoi(ea) : 0;
   const int nb = a->batch > 1 ? a->batch : 1;
-  if (bm_choice(a) == 256) {
-    const int nwg = ((a->M + 255) / 256) * tiles_n;
-    hipLaunchKernelGGL((gemm32_kernel<EPI, 4, 8>), dim3(nwg, nb), dim3(512), 2 * (256 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm, ablate);
-  } else if (bm_choice(a) == 8) {
-    const int nwg = ((a->M + 127) / 128) * tiles_n;
-    hipLaunchKernelGGL((gemm32_kernel<EPI, 2, 8>), dim3(nwg, nb), dim3(512), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm, ablate);
-  } else if (bm_choice(a) == 64) {
-    const int nwg = ((a->M + 63) / 64) * tiles_n;
-    hipLaunchKernelGGL((gemm32_kernel<EPI, 2>), dim3(nwg, nb), dim3(256), 2 * (64 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm, ablate);
-  } else {
-    const int nwg = ((a->M + 127) / 128) * tiles_n;
-    hipLaunchKernelGGL((gemm32_kernel<EPI, 4>), dim3(nwg, nb), dim3(256), 2 * (128 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nwg, gm, ablate);
-  }
-  CARA_CHECK_LAUNCH();
-  return CARA_OK;
-}
-
-template <int EPI>
-int launch(const cara_gemm_args* a, hipStream_t st) {
-  const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
-  const int nwg = tiles_m * tiles_n;
-  hipLaunchKernelGGL(gemm_kernel<EPI>, dim3(nwg), dim3(256), LDS_BYTES, st, *a, tiles_n, nwg);
+  hipLaunchKernelGGL((gemm32_kernel<EPI>), dim3(nwg, nb), dim3(256), GEMM_LDS, st, *a, tiles_n, nwg, gm);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }
 
 }  // namespace
-
-int cara_gemm256_dispatch(const cara_gemm_args* a, hipStream_t st);      // gemm256.hip, 256 x 256 ring
-int cara_gemm128x256_dispatch(const cara_gemm_args* a, hipStream_t st);   // gemm256.hip, 128 x 256 ring, 2 workgroups per CU
-int cara_gemm_sk_dispatch(const cara_gemm_args* a, hipStream_t st);   // gemm_sk.hip
-
-// The persistent 256x256 kernel of gemm_sk.hip is OPT-IN (CARA_GEMM_SK=1 and caller scratch): its main loop
-// runs at twice the MFMA rate of the 128x128 kernels (half the LDS-DMA bytes per flop), but one workgroup per
-// CU means every CU writes its output tile at the same time while no MFMA runs, and on the shapes of this
-// model (K = 768..3072, 40-155 MB of output per product) that burst costs what the loop gains: same-box
-// block total 706 us vs 663 us for the default kernels.
-static bool use_stream_k(const cara_gemm_args* a) {
-  const char* e = getenv("CARA_GEMM_SK");   // read per call: tests switch it
-  const int v = e ? atoi(e) : 0;
-  if (v == 0 || !a->scratch || a->M < 1024 || a->N < 256) return false;
-  // its staging addresses are 32-bit byte offsets built with a 24-bit multiply
-  const unsigned long long abytes = (unsigned long long)a->M * a->lda * 2, bbytes = (unsigned long long)a->N * a->ldb * 2;
-  return a->M < (1 << 24) && a->N < (1 << 24) && a->lda < (1 << 22) && a->ldb < (1 << 22) && abytes < (1ull << 32) &&
-         bbytes < (1ull << 32);
-}
-
-// The 128x128 tile is the default for every shape: on the shapes of this model it is the fastest
-// of the structures measured so far.  CARA_GEMM_TILE=256 in the environment
-// selects the 256x256 LDS-ring kernel of gemm256.hip for A/B measurements.
-static int tile_choice(const cara_gemm_args* a) {
-  const char* e = getenv("CARA_GEMM_TILE");   // read per call: tests and A/B runs switch it
-  (void)a;
-  return e ? atoi(e) : 0;
-}
-
-// Default: the 32-deep, 4-workgroups-per-CU variant -- in the real train step it is 7 % faster
-// end to end than the 64-deep one (same-box A/B: 13.45 -> 12.53 ms/step) although the two tie
-// when a GEMM is timed alone.  CARA_GEMM_BK=64 selects the 64-deep kernel for A/B measurements.
-static bool use_bk32() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CARA_GEMM_BK");
-    v = e ? atoi(e) : 32;
-  }
-  return v != 64;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Few-row products (the last block's cls-row-only proj / fc1 / fc2 and their dX: M = batch rows): one 128-row tile
@@ -692,8 +464,6 @@ __global__ __launch_bounds__(256) void small_m_finish_kernel(const cara_gemm_arg
 
 // K slabs of at least 128 columns, at most 16 of them; 0 = not worth it
 static int small_m_slabs(const cara_gemm_args* a) {
-  const char* e = getenv("CARA_GEMM_SMALL_M");   // 0 disables (A/B)
-  if (e && atoi(e) == 0) return 0;
   if (a->M > 128 || a->K < 512 || !a->scratch || a->Ut || a->batch > 1) return 0;
   int s = a->K / 128;
   if (s > 16) s = 16;
@@ -755,8 +525,8 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % BK) != 0) return CARA_E_ARG;
   if ((!a->a_panels && (a->lda < a->K || (a->lda & 7))) || a->ldb < a->K || (a->ldb & 7) || a->ldc < a->N) return CARA_E_ARG;
   const bool panels = a->a_panels || a->c_panels;
-  if (panels) {   // K-panel-major activations: default kernel family, bf16 outputs
-    if (a->a_panels < 0 || a->c_panels < 0 || (a->a_panels && a->a_panels < a->M) || (a->c_panels && a->c_panels < a->M) || (a->K % BK32))
+  if (panels) {   // K-panel-major activations: bf16 outputs
+    if (a->a_panels < 0 || a->c_panels < 0 || (a->a_panels && a->a_panels < a->M) || (a->c_panels && a->c_panels < a->M))
       return CARA_E_ARG;
     if (a->c_panels && ((a->N & 31) || !(a->epi == CARA_EPI_BF16 || a->epi == CARA_EPI_GELU || a->epi == CARA_EPI_DGELU))) return CARA_E_ARG;
     if (a->batch > 1 || a->M <= 128) return CARA_E_ARG;
@@ -764,17 +534,14 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
   if (!(a->Rp == 0 || a->Rp == 32 || a->Rp == 64)) return CARA_E_ARG;
   if (a->Rp && ((!a->A2 && !a->Ut) || !a->B2)) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // the BK = 32 kernels address their operands with 32-bit byte offsets from the (batch-adjusted) base pointer
+  // operands are addressed with 32-bit byte offsets from the (batch-adjusted) base pointer
   const bool small_ptrs = (unsigned long long)a->M * (a->a_panels ? 32 : a->lda) * 2 < (1ull << 32) && (unsigned long long)a->N * a->ldb * 2 < (1ull << 32);
-  // (CARA_EPI_GELU with C2 == NULL: the pre-activation is not kept -- default kernel family and the few-row path only)
-  if (a->epi == CARA_EPI_GELU && !a->C2 && (tile_choice(a) != 0 || use_stream_k(a) || !use_bk32())) return CARA_E_ARG;
+  if (!small_ptrs) return CARA_E_ARG;
   if (a->epi == CARA_EPI_RESID && (!a->aux || (a->rowscale && a->rows_per_sample <= 0))) return CARA_E_ARG;
   if (a->epi == CARA_EPI_DGELU && !a->aux) return CARA_E_ARG;
-  if (ts && (a->Ut || a->batch > 1 || a->M <= 128 || tile_choice(a) != 0 || use_stream_k(a) || !use_bk32() || !small_ptrs || bm_choice(a) != 128))
-    return CARA_E_ARG;
-  if (a->Ut) {   // whole adapter inside the GEMM: default kernel family, Rp = 32, T produced here
-    if (!small_ptrs || a->A2 || !a->B2 || a->Rp != 32 || !a->T_out || a->batch > 1 || (a->K % BK32) || (a->Tt_out && (a->ldt < a->M || (a->ldt & 7))))
-      return CARA_E_ARG;
+  if (ts && (a->Ut || a->batch > 1 || a->M <= 128)) return CARA_E_ARG;
+  if (a->Ut) {   // whole adapter inside the GEMM: Rp = 32, T produced here
+    if (a->A2 || !a->B2 || a->Rp != 32 || !a->T_out || a->batch > 1 || (a->Tt_out && (a->ldt < a->M || (a->ldt & 7)))) return CARA_E_ARG;
     switch (a->epi) {
       case CARA_EPI_BF16: return launch32ft<CARA_EPI_BF16>(a, st);
       case CARA_EPI_F32: return launch32ft<CARA_EPI_F32>(a, st);
@@ -784,11 +551,11 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
       default: return CARA_E_ARG;
     }
   }
-  if (a->batch > 1) {   // batched products: the default kernel family only, plain epilogues
-    if (!small_ptrs || a->A2 || a->aux || a->C2 || a->Bp || !(a->epi == CARA_EPI_F32 || a->epi == CARA_EPI_BF16) || a->batch > 65535) return CARA_E_ARG;
+  if (a->batch > 1) {   // batched products: plain epilogues
+    if (a->A2 || a->aux || a->C2 || a->Bp || !(a->epi == CARA_EPI_F32 || a->epi == CARA_EPI_BF16) || a->batch > 65535) return CARA_E_ARG;
     return a->epi == CARA_EPI_F32 ? launch32<CARA_EPI_F32>(a, st) : launch32<CARA_EPI_BF16>(a, st);
   }
-  if (const int nslab = small_ptrs ? small_m_slabs(a) : 0) {
+  if (const int nslab = ts ? 0 : small_m_slabs(a)) {
     switch (a->epi) {
       case CARA_EPI_BF16: return launch_small_m<CARA_EPI_BF16>(a, nslab, st);
       case CARA_EPI_F32: return launch_small_m<CARA_EPI_F32>(a, nslab, st);
@@ -798,29 +565,15 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
       default: return CARA_E_ARG;
     }
   }
-  const int tile = tile_choice(a);
-  if (panels && (tile == 256 || tile == 1282 || use_stream_k(a) || !use_bk32() || !small_ptrs || bm_choice(a) != 128)) return CARA_E_ARG;
-  if (tile == 256) return cara_gemm256_dispatch(a, st);
-  if (tile == 1282) return cara_gemm128x256_dispatch(a, st);   // 128 x 256
-  if (use_stream_k(a)) return cara_gemm_sk_dispatch(a, st);
-  if (use_bk32() && small_ptrs) {
-    switch (a->epi) {
-      case CARA_EPI_BF16: return launch32<CARA_EPI_BF16>(a, st, ts);
-      case CARA_EPI_F32: return launch32<CARA_EPI_F32>(a, st, ts);
-      case CARA_EPI_GELU: return launch32<CARA_EPI_GELU>(a, st, ts);
-      case CARA_EPI_RESID: return launch32<CARA_EPI_RESID>(a, st, ts);
-      case CARA_EPI_DGELU: return launch32<CARA_EPI_DGELU>(a, st, ts);
-      default: return CARA_E_ARG;
-    }
-  }
   switch (a->epi) {
-    case CARA_EPI_BF16: return launch<CARA_EPI_BF16>(a, st);
-    case CARA_EPI_F32: return launch<CARA_EPI_F32>(a, st);
-    case CARA_EPI_GELU: return a->C2 ? launch<CARA_EPI_GELU>(a, st) : CARA_E_ARG;
-    case CARA_EPI_RESID:
-      if (!a->aux || (a->rowscale && a->rows_per_sample <= 0)) return CARA_E_ARG;
-      return launch<CARA_EPI_RESID>(a, st);
-    case CARA_EPI_DGELU: return a->aux ? launch<CARA_EPI_DGELU>(a, st) : CARA_E_ARG;
+    case CARA_EPI_BF16: return launch32<CARA_EPI_BF16>(a, st, ts);
+    case CARA_EPI_F32: return launch32<CARA_EPI_F32>(a, st, ts);
+    case CARA_EPI_GELU: return launch32<CARA_EPI_GELU>(a, st, ts);
+    case CARA_EPI_RESID: return launch32<CARA_EPI_RESID>(a, st, ts);
+    case CARA_EPI_DGELU: return launch32<CARA_EPI_DGELU>(a, st, ts);
     default: return CARA_E_ARG;
   }
 }
+
+// scratch for the few-row split-K path: up to 16 slabs of 128 rows x 4096 columns of fp32 partial products
+extern "C" size_t cara_gemm_scratch_bytes(void) { return (size_t)16 * 128 * 4096 * sizeof(float); }

@@ -31,10 +31,9 @@ struct Ws {
   LayerWs layer[64];
   // backward
   size_t dx, dXn, dAO, slabs, dclsn, gscratch, gemm_scratch;
-  // what the side stream reads (dY of the four linears, G' = dY Vs and its transpose) lives in a ring over the
-  // blocks, so that the main stream never has to wait for the side stream before overwriting it (see Side below)
-  int nring;
-  struct Ring { size_t dyb_fc2, dyb_proj, dH, dQKV, G[4], Gt[4]; } ring[64];
+  // dY of the four linears, G' = dY Vs and its transpose: one set, reused by every block (everything runs in
+  // stream order on the caller's stream)
+  struct Bwd { size_t dyb_fc2, dyb_proj, dH, dQKV, G[4], Gt[4]; } bwd;
   size_t dU[4], dVs[4], dc[4];
   size_t slabU[4], slabV[4], strideU[4], strideV[4];   // per linear: depth regions of tskinny slabs
   // exact weight-dropout mode: merged weights of every layer (and their transposes), transposed activations, dense dW
@@ -46,19 +45,6 @@ struct Ws {
 };
 
 size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
-
-// Ring depth of the backward buffers the side stream reads.  Default: one set per block, i.e. no reuse inside a
-// backward pass and therefore NO wait of the main stream on the side stream before the final reduction (a
-// hipStreamWaitEvent costs the main stream ~7.5 us even when the event completed long ago, tools/micro/sync_cost.hip;
-// ViT-B/16 at 64 x 197 tokens: 12 x 0.18 GB).  CARA_BWD_RING=n (1 <= n <= depth) trades memory for one wait per block.
-int bwd_ring(int depth) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CARA_BWD_RING");
-    v = e ? atoi(e) : 0;
-  }
-  return (v >= 1 && v <= depth) ? v : depth;
-}
 
 bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
   if (!g || !s || g->depth <= 0 || g->depth > 64 || g->dim % g->heads || g->dim / g->heads != 64) return false;
@@ -101,9 +87,8 @@ bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
   w->dx = c.take(M * D * 4);
   w->dXn = c.take(M * D * 2);
   w->dAO = c.take(M * D * 2);
-  w->nring = bwd_ring(g->depth);
-  for (int r = 0; r < w->nring; ++r) {
-    Ws::Ring& R = w->ring[r];
+  {
+    Ws::Bwd& R = w->bwd;
     R.dyb_fc2 = c.take(M * D * 2);
     R.dyb_proj = c.take(M * D * 2);
     R.dH = c.take(M * 4 * D * 2);
@@ -153,88 +138,40 @@ bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
     if (_st != CARA_OK) return _st; \
   } while (0)
 
-// Backward overlap: the two transposed skinny products of a linear (dU = X^T G', dVs = dY^T T) are
-// HBM-bound and independent of that linear's MFMA-bound dX GEMM, so they run on a side stream
-// (fork after G' is ready, join before any of their inputs is overwritten).  Process-global side
-// stream + events, created on first use; CARA_OVERLAP=0 keeps everything on the caller's stream.
-struct Side {
-  bool made = false, on = true;
-  hipStream_t s = nullptr;
-  hipEvent_t fork[4], join[64];   // join[l]: all side work of block l has finished (the side stream is in order)
+// Optional HIP-event brackets around the kernels of chosen call sites (cara_profile_sites), so that bench.py can
+// report average launch durations from INSIDE its timed region, on the stream the kernels run on.  Diagnostic
+// state, process-global, off by default; every bracket idles the chip ~15 us (three event records).
+struct Prof {
+  unsigned long long mask = 0;
+  int every = 1;   // bracket the layers l with l % every == 0
+  bool made = false;
+  long n[CARA_SITE_COUNT] = {};
+  hipEvent_t ev[CARA_SITE_COUNT][CARA_SITE_RING][3];
 };
-Side g_side;
+Prof g_prof;
 
-bool side_ready() {
-  if (!g_side.made) {
-    const char* e = getenv("CARA_OVERLAP");
-    g_side.on = !(e && atoi(e) == 0);
-    if (g_side.on) {
-      if (hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking) != hipSuccess) g_side.on = false;
-      for (int i = 0; i < 4 && g_side.on; ++i)
-        if (hipEventCreateWithFlags(&g_side.fork[i], hipEventDisableTiming) != hipSuccess) g_side.on = false;
-      for (int i = 0; i < 64 && g_side.on; ++i)
-        if (hipEventCreateWithFlags(&g_side.join[i], hipEventDisableTiming) != hipSuccess) g_side.on = false;
-    }
-    g_side.made = true;
-  }
-  return g_side.on;
-}
-
-// The transposed skinny products of the linears whose dY and G' exist, waiting for their fork.  Every fork is a
-// hipEventRecord on the main stream (3..5 us of idle chip each, tools/micro/sync_cost.hip), so CARA_BWD_FORK picks how
-// many there are per block: 4 = one per linear, just before its dX GEMM; 2 = one per branch (before the fc1 and
-// qkv dX GEMMs); 1 = one per block (before the qkv dX GEMM).  Block 0 always forks per linear: nothing follows it
-// that the products could hide under.
-struct TsJob {
-  const bf16 *X, *dY, *Gt;
-  const void* Tt;
-  void *slabU, *slabV;
-  int ldx, lddy, in, out, want_dc, ldt, Mr, Rp;
+// per-call context: what lin_fwd / lin_bwd need besides their operands (nothing here outlives the call)
+struct Ctx {
+  void* stream;
+  char* scratch;   // split-K scratch of the workspace in use (few-row products)
+  int layer;
+  bool full;       // this block runs on all token rows (not the cls-row-only last block)
 };
-struct TsQueue {
-  TsJob job[4];
-  int n = 0;
+
+struct SiteBracket {   // RAII: event 0 .. kernel(s) .. event 1, event 2 (an empty bracket: the markers' own cost)
+  hipEvent_t* ev = nullptr;
+  hipStream_t st;
+  SiteBracket(int site, const Ctx& cx) : st(static_cast<hipStream_t>(cx.stream)) {
+    if (!(g_prof.mask >> site & 1ull) || !cx.full || cx.layer % g_prof.every) return;
+    ev = g_prof.ev[site][g_prof.n[site]++ % CARA_SITE_RING];
+    (void)hipEventRecord(ev[0], st);
+  }
+  ~SiteBracket() {
+    if (!ev) return;
+    (void)hipEventRecord(ev[1], st);
+    (void)hipEventRecord(ev[2], st);
+  }
 };
-TsQueue g_jobs;
-
-int fork_granularity() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CARA_BWD_FORK");
-    v = e ? atoi(e) : 4;
-    if (v != 1 && v != 2 && v != 4) v = 4;
-  }
-  return v;
-}
-bool flush_before(int slot, int layer) {   // slot: 0 qkv, 1 proj, 2 fc1, 3 fc2 (backward runs 3, 2, 1, 0)
-  const int gran = layer == 0 ? 4 : fork_granularity();
-  return gran == 4 || slot == 0 || (gran == 2 && slot == 2);
-}
-
-// launch the queued products on the side stream (main stream `st` when there is none); `layer_done`: this was the
-// last linear of block `layer`, its join event goes behind
-int flush_jobs(void* st, int layer, bool layer_done) {
-  void* ts_stream = st;
-  const bool side = side_ready();
-  if (side && g_jobs.n > 0) {
-    if (hipEventRecord(g_side.fork[0], static_cast<hipStream_t>(st)) != hipSuccess) return CARA_E_LAUNCH;
-    if (hipStreamWaitEvent(g_side.s, g_side.fork[0], 0) != hipSuccess) return CARA_E_LAUNCH;
-    ts_stream = g_side.s;
-  }
-  for (int i = 0; i < g_jobs.n; ++i) {
-    const TsJob& q = g_jobs.job[i];
-    TRY(cara_tskinny_partial2(q.X, q.ldx, q.Gt, q.slabU, q.in, q.dY, q.lddy, q.Tt, q.slabV, q.out, q.want_dc, q.ldt, q.Mr, q.Rp, ts_stream));
-  }
-  g_jobs.n = 0;
-  if (side && layer_done && hipEventRecord(g_side.join[layer], g_side.s) != hipSuccess) return CARA_E_LAUNCH;
-  return CARA_OK;
-}
-
-// main stream: do not pass this point before all side work of block `layer` has finished
-int side_join(int layer, void* stream) {
-  if (!side_ready()) return CARA_OK;
-  return hipStreamWaitEvent(static_cast<hipStream_t>(stream), g_side.join[layer], 0) == hipSuccess ? CARA_OK : CARA_E_LAUNCH;
-}
 
 struct Lin {  // one adapted linear of one layer
   const bf16 *W, *Wt;
@@ -244,143 +181,117 @@ struct Lin {  // one adapted linear of one layer
   const bf16 *Wp = nullptr, *Wtp = nullptr;   // K-panel-major images of W / Wt (cara_gemm_args::Bp), or null
 };
 
+// A/B switches, read ONCE per process (tools/ab_env.sh); the defaults are what DESIGN.md reports.
+int env_once(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 // CARA_FUSE_XU=0 keeps the K = dim adapter contractions (T = LN(x) U of qkv / fc1, G' = dY Vs of proj / fc2) as
-// separate cara_skinny_xu passes instead of fusing them into the LayerNorm kernels (A/B measurements)
+// separate cara_skinny_xu passes instead of fusing them into the LayerNorm kernels
 bool fuse_xu(const cara_geom* g) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CARA_FUSE_XU");
-    v = e ? atoi(e) : 1;
-  }
+  static const int v = env_once("CARA_FUSE_XU", 1);
   return v != 0 && g->Rp == 32 && (g->dim == 768 || g->dim == 1024 || g->dim == 256);   // what cara_layernorm_*_xu take
 }
 
-// CARA_FUSE_GEMM_T=0 keeps T = X U (forward proj / fc2) and G' = dY Vs (backward qkv / fc1) as separate
-// cara_skinny_xu passes instead of computing them inside the GEMM that consumes them (cara_gemm_args::Ut).
-// Only with the default GEMM family (no CARA_GEMM_TILE / CARA_GEMM_SK / CARA_GEMM_BM / CARA_GEMM_BK override).
-// Bit 0: forward (default on), bit 1: backward (default off -- measured: the transposed skinny products then fork
-// after the dX GEMM instead of running under it, and the step gets 0.35 ms longer).
+// CARA_FUSE_GEMM_T: bit 0 (default on) computes T = X U of forward proj / fc2 inside the GEMM that consumes it
+// (cara_gemm_args::Ut) instead of a separate cara_skinny_xu pass; bit 1 (default off: measured slower) the same
+// for G' = dY Vs of the backward's qkv / fc1.
 bool fuse_gemm_t(int Mr, int Rp, bool backward) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CARA_FUSE_GEMM_T");
-    v = e ? atoi(e) : 1;
-    if (getenv("CARA_GEMM_TILE") || getenv("CARA_GEMM_SK") || getenv("CARA_GEMM_BM") || getenv("CARA_GEMM_BK")) v = 0;
-  }
+  static const int v = env_once("CARA_FUSE_GEMM_T", 1);
   return (v & (backward ? 2 : 1)) != 0 && Rp == 32 && Mr >= 1024;
 }
 
-// CARA_PANEL_ACTS=0 keeps every activation row-major.  Default: the activations that only GEMMs and the skinny
-// products read -- h = gelu(fc1) and dH = d(fc1 output) -- are written K-panel-major ([K/32][M][32],
-// cara_gemm_args::c_panels) by the GEMM that produces them, so that the GEMM that consumes them stages whole
-// cache lines (tools/micro/kloop_bw.hip: +34 % operand bytes per second on top of the packed weights).
-// Default GEMM family only, not in the exact-dropout mode, not on the cls-row-only last block.
-// `what`: 1 = h / dH (written by GEMM epilogues), 2 = xn1 / xn2 (LayerNorm forward), 4 = the dY of fc2 / proj
-// (LayerNorm backward); CARA_PANEL_ACTS is the mask of the groups that use the layout.
+// CARA_PANEL_ACTS = mask of the activation groups written K-panel-major ([K/32][M][32], cara_gemm_args::c_panels /
+// a_panels) so that the GEMM that consumes them stages whole cache lines: 1 = h / dH (written by GEMM epilogues),
+// 2 = xn1 / xn2 (LayerNorm forward), 4 = the dY of fc2 / proj (LayerNorm backward).  Default 5: group 2 costs
+// 0.2 ms per step although the GEMMs reading xn1 / xn2 gain 5-8 us each when timed alone.
+// Not in the exact-dropout mode, not on the cls-row-only last block.
 bool panel_acts(int Mr, const cara_vit_shape* s, int what = 1) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CARA_PANEL_ACTS");
-    // default 5: measured same-box 10.56 ms (0) -> 10.37 (1) -> 10.18-10.38 (5); the LayerNorm-forward group costs
-    // 0.25 ms (3: 10.52-10.62) although the GEMMs reading xn1 / xn2 gain 5-8 us each when timed alone
-    v = e ? atoi(e) : 5;
-  }
-  // (the kernel-family overrides are read per call, as cara_gemm_bf16 reads them: tests switch them at run time)
-  if (getenv("CARA_GEMM_TILE") || getenv("CARA_GEMM_SK") || getenv("CARA_GEMM_BM") || getenv("CARA_GEMM_BK")) return false;
+  static const int v = env_once("CARA_PANEL_ACTS", 5);
   return (v & what) != 0 && !s->wd_exact && Mr >= 1024;
 }
 
-// CARA_FUSE_TS=0: the transposed skinny products of a linear go to the side stream (fork before its dX GEMM) instead
-// of riding in that GEMM's launch (cara_gemm_with_tskinny).  Default GEMM family, Rp = 32, full-size products only.
+// CARA_FUSE_TS=0: the transposed skinny products of a linear run as their own launch behind its dX GEMM instead of
+// riding in that GEMM's launch (cara_gemm_with_tskinny).  Rp = 32, full-size products only.
 bool fuse_ts(int Mr, int Rp) {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CARA_FUSE_TS");
-    v = e ? atoi(e) : 1;
-  }
-  if (getenv("CARA_GEMM_TILE") || getenv("CARA_GEMM_SK") || getenv("CARA_GEMM_BM") || getenv("CARA_GEMM_BK")) return false;
+  static const int v = env_once("CARA_FUSE_TS", 1);
   return v != 0 && Rp == 32 && Mr >= 1024;
 }
 
-// stream-K scratch of the workspace in use (set on entry of cara_vit_forward / _backward: one
-// workspace per stream, as for the side stream above)
-char* g_sk_scratch = nullptr;
-void with_scratch(cara_gemm_args& a) {
-  a.scratch = g_sk_scratch;
-  a.scratch_bytes = g_sk_scratch ? cara_gemm_scratch_bytes() : 0;
+void with_scratch(cara_gemm_args& a, const Ctx& cx) {
+  a.scratch = cx.scratch;
+  a.scratch_bytes = cx.scratch ? cara_gemm_scratch_bytes() : 0;
 }
+
+constexpr int SITE_FWD[4] = {CARA_SITE_QKV_FWD, CARA_SITE_PROJ_FWD, CARA_SITE_FC1_FWD, CARA_SITE_FC2_FWD};
+constexpr int SITE_BWD[4] = {CARA_SITE_QKV_BWD, CARA_SITE_PROJ_BWD, CARA_SITE_FC1_BWD, CARA_SITE_FC2_BWD};
 
 // forward of one adapted linear on Mr rows of X (row stride ldx; ldx < 0: K-panel-major, -ldx rows per panel): T = X U ;
 // C = [X | T] [W | Vs]^T + bias -> epilogue (a.ldc == 0: dense output)
 // (have_T: the LayerNorm that produced X already left T = X U and its transpose, cara_layernorm_fwd_xu)
-int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char* ws, const LayerWs& lw, cara_gemm_args a, void* st,
+int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char* ws, const LayerWs& lw, cara_gemm_args a, const Ctx& cx,
             bool have_T = false) {
+  void* st = cx.stream;
   bf16* T = reinterpret_cast<bf16*>(ws + lw.T[L.slot]);
   bf16* Tt = reinterpret_cast<bf16*>(ws + lw.Tt[L.slot]);
   const bool inside = !have_T && fuse_gemm_t(Mr, Rp, false);   // T computed by the GEMM itself
-  if (!have_T && !inside) TRY(cara_skinny_xu(X, ldx, L.Ut, T, Tt, ldt, Mr, L.in, Rp, st));
+  if (!have_T && !inside) {
+    SiteBracket b(CARA_SITE_SKINNY_FWD, cx);
+    TRY(cara_skinny_xu(X, ldx, L.Ut, T, Tt, ldt, Mr, L.in, Rp, st));
+  }
   a.A = X; a.lda = ldx; a.B = L.W; a.Bp = L.Wp; a.ldb = L.in; a.A2 = inside ? nullptr : T; a.B2 = L.Vs; a.Rp = Rp;
   if (ldx < 0) { a.a_panels = -ldx; a.lda = 0; }   // (ldx < 0: X is K-panel-major with -ldx rows per panel, as in cara_skinny_xu)
   if (inside) { a.Ut = L.Ut; a.T_out = T; a.Tt_out = Tt; a.ldt = ldt; }
   a.M = Mr; a.N = L.out; a.K = L.in; a.bias = L.bias;
   if (a.ldc == 0) a.ldc = L.out;
-  with_scratch(a);
+  with_scratch(a, cx);
+  SiteBracket b(SITE_FWD[L.slot], cx);
   return cara_gemm_bf16(&a, st);
 }
 
 // backward of one adapted linear given dY (bf16, Mr rows, row stride lddy) and its saved input X
 // (row stride ldx; a negative stride = K-panel-major with that many rows per panel):
 //   G' = dY Vs ; dX = [dY | G'] [W^T | U]^T (optional) ; dU = X^T G' ; dVs = dY^T T ; dc = colsum dY
+// The two transposed skinny products ride in the launch of the dX GEMM when they can (cara_gemm_with_tskinny),
+// otherwise they are one launch of their own behind it, on the same stream.
 int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int Mr, int Rp, int ldt, char* ws, const Ws& W,
-            const Ws::Ring& R, const LayerWs& lw, int layer, bool want_dx, cara_gemm_args a, bool want_dc, void* st,
-            bool have_G = false) {
+            const LayerWs& lw, bool want_dx, cara_gemm_args a, bool want_dc, const Ctx& cx, bool have_G = false) {
+  void* st = cx.stream;
+  const Ws::Bwd& R = W.bwd;
   bf16* G = reinterpret_cast<bf16*>(ws + R.G[L.slot]);
   bf16* Gt = reinterpret_cast<bf16*>(ws + R.Gt[L.slot]);
-  void* slabU = ws + W.slabU[L.slot] + (size_t)layer * W.strideU[L.slot];
-  void* slabV = ws + W.slabV[L.slot] + (size_t)layer * W.strideV[L.slot];
+  void* slabU = ws + W.slabU[L.slot] + (size_t)cx.layer * W.strideU[L.slot];
+  void* slabV = ws + W.slabV[L.slot] + (size_t)cx.layer * W.strideV[L.slot];
+  const void* Tt = ws + lw.Tt[L.slot];
   // (have_G: the LayerNorm backward that produced dY already left G' and its transpose, cara_layernorm_bwd_xu)
   // inside: the dX GEMM computes G' = dY Vs itself (cara_gemm_args::Ut) and leaves G / Gt behind
   const bool inside = !have_G && want_dx && fuse_gemm_t(Mr, Rp, true);
-  if (!have_G && !inside) TRY(cara_skinny_xu(dY, lddy, L.Vst, G, Gt, ldt, Mr, L.out, Rp, st));
-  // partial slabs on the side stream; their fixed-order sums run once per linear after the layer loop
-  const TsJob job{X, dY, Gt, ws + lw.Tt[L.slot], slabU, slabV, ldx, lddy, L.in, L.out, want_dc ? 1 : 0, ldt, Mr, Rp};
-  const bool last = L.slot == 0;   // a block's backward ends with qkv
-  if (inside) {
-    if (flush_before(L.slot, layer)) TRY(flush_jobs(st, layer, false));   // earlier linears' products run under this GEMM
-    a.A = dY; a.lda = lddy; a.B = L.Wt; a.Bp = L.Wtp; a.ldb = L.out; a.A2 = nullptr; a.B2 = L.U; a.Rp = Rp;
-    if (lddy < 0) { a.a_panels = -lddy; a.lda = 0; }
-    a.Ut = L.Vst; a.T_out = G; a.Tt_out = Gt; a.ldt = ldt;
-    a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
-    if (a.ldc == 0) a.ldc = L.in;
-    TRY(cara_gemm_bf16(&a, st));
-    g_jobs.job[g_jobs.n++] = job;   // its G' exists only behind the GEMM
-    if (last) TRY(flush_jobs(st, layer, true));
-    return CARA_OK;
+  if (!have_G && !inside) {
+    SiteBracket b(CARA_SITE_SKINNY_BWD, cx);
+    TRY(cara_skinny_xu(dY, lddy, L.Vst, G, Gt, ldt, Mr, L.out, Rp, st));
   }
   if (want_dx) {
-    a.A = dY; a.lda = lddy; a.B = L.Wt; a.Bp = L.Wtp; a.ldb = L.out; a.A2 = G; a.B2 = L.U; a.Rp = Rp;
+    a.A = dY; a.lda = lddy; a.B = L.Wt; a.Bp = L.Wtp; a.ldb = L.out; a.A2 = inside ? nullptr : G; a.B2 = L.U; a.Rp = Rp;
     if (lddy < 0) { a.a_panels = -lddy; a.lda = 0; }
+    if (inside) { a.Ut = L.Vst; a.T_out = G; a.Tt_out = Gt; a.ldt = ldt; }
     a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
     if (a.ldc == 0) a.ldc = L.in;
-    with_scratch(a);
-    if (fuse_ts(Mr, Rp)) {
-      // the products ride in the dX GEMM's own launch: no side stream, no fork.  (A product still waiting in the
-      // queue -- none in this mode -- would go out first.)
-      if (g_jobs.n) TRY(flush_jobs(st, layer, false));
-      return cara_gemm_with_tskinny(&a, job.X, job.ldx, job.Gt, job.slabU, job.in, job.dY, job.lddy, job.Tt, job.slabV, job.out,
-                                    job.want_dc, job.ldt, job.Mr, job.Rp, st);
-    }
+    with_scratch(a, cx);
+    SiteBracket b(SITE_BWD[L.slot], cx);
+    if (!inside && fuse_ts(Mr, Rp))
+      return cara_gemm_with_tskinny(&a, X, ldx, Gt, slabU, L.in, dY, lddy, Tt, slabV, L.out, want_dc ? 1 : 0, ldt, Mr, Rp, st);
+    TRY(cara_gemm_bf16(&a, st));
   }
-  g_jobs.job[g_jobs.n++] = job;
-  if (flush_before(L.slot, layer)) TRY(flush_jobs(st, layer, last));   // fork: G' exists, the dX GEMM comes next
-  if (want_dx) TRY(cara_gemm_bf16(&a, st));
-  return CARA_OK;
+  return cara_tskinny_partial2(X, ldx, Gt, slabU, L.in, dY, lddy, Tt, slabV, L.out, want_dc ? 1 : 0, ldt, Mr, Rp, st);
 }
 
 // ---- exact weight-dropout mode (cara_vit_shape::wd_exact): plain GEMMs on W_eff = W + keep/(1-p) dW ----------
 // forward of one linear: materialise W_eff (and its transpose, for dX) of this layer, then C = X W_eff^T + bias
-int lin_fwd_exact(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, char* ws, const Ws& W, int layer, const cara_vit_shape* s,
-                  cara_gemm_args a, void* st) {
+int lin_fwd_exact(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, char* ws, const Ws& W, const cara_vit_shape* s,
+                  cara_gemm_args a, const Ctx& cx) {
+  void* st = cx.stream;
+  const int layer = cx.layer;
   const size_t wbytes = (size_t)L.out * L.in * 2;
   bf16* weff = reinterpret_cast<bf16*>(ws + W.weff[L.slot] + layer * wbytes);
   bf16* wefft = reinterpret_cast<bf16*>(ws + W.wefft[L.slot] + layer * wbytes);
@@ -389,14 +300,16 @@ int lin_fwd_exact(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, char* ws
   a.A = X; a.lda = ldx; a.B = weff; a.ldb = L.in; a.A2 = nullptr; a.B2 = nullptr; a.Rp = 0;
   a.M = Mr; a.N = L.out; a.K = L.in; a.bias = L.bias;
   if (a.ldc == 0) a.ldc = L.out;
-  with_scratch(a);
+  with_scratch(a, cx);
   return cara_gemm_bf16(&a, st);
 }
 
 // backward of one linear: dc = colsum dY; dW = dY^T X (dense, fp32) -> dU, dVs through the regenerated mask;
 // dX = dY W_eff (optional).  X and dY are dense [Mr, in] / [Mr, out] (the cls-row shortcut is off in this mode).
-int lin_bwd_exact(const Lin& L, const bf16* dY, const bf16* X, int Mr, int Rp, char* ws, const Ws& W, int layer,
-                  const cara_vit_shape* s, bool want_dx, cara_gemm_args a, bool want_dc, void* st) {
+int lin_bwd_exact(const Lin& L, const bf16* dY, const bf16* X, int Mr, int Rp, char* ws, const Ws& W,
+                  const cara_vit_shape* s, bool want_dx, cara_gemm_args a, bool want_dc, const Ctx& cx) {
+  void* st = cx.stream;
+  const int layer = cx.layer;
   hipStream_t hs = static_cast<hipStream_t>(st);
   const size_t wbytes = (size_t)L.out * L.in * 2;
   bf16* wefft = reinterpret_cast<bf16*>(ws + W.wefft[L.slot] + layer * wbytes);
@@ -427,7 +340,7 @@ int lin_bwd_exact(const Lin& L, const bf16* dY, const bf16* X, int Mr, int Rp, c
     a.A = dY; a.lda = L.out; a.B = wefft; a.ldb = L.out; a.A2 = nullptr; a.B2 = nullptr; a.Rp = 0;
     a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
     if (a.ldc == 0) a.ldc = L.in;
-    with_scratch(a);
+    with_scratch(a, cx);
     TRY(cara_gemm_bf16(&a, st));
   }
   return CARA_OK;
@@ -447,7 +360,7 @@ void make_lins(const cara_geom* g, const cara_vit_weights* w, const char* pack, 
   out[3] = Lin{B(w->fc2_w, l * 4 * D * D), B(w->fc2_wt, l * 4 * D * D), P(pl.Ut_fc2), P(pl.U_fc2), P(pl.Vs_fc2), P(pl.Vst_fc2),
                reinterpret_cast<const float*>(pk + pl.bias_fc2), (int)(4 * D), (int)D, 3};
   // CARA_GEMM_PACKED=0: stage the weights from their row-major images (A/B measurements)
-  static const bool use_packed = [] { const char* e = getenv("CARA_GEMM_PACKED"); return !(e && atoi(e) == 0); }();
+  static const bool use_packed = env_once("CARA_GEMM_PACKED", 1) != 0;
   if (use_packed) {
     const void* wp[4][2] = {{w->qkv_wp, w->qkv_wtp}, {w->proj_wp, w->proj_wtp}, {w->fc1_wp, w->fc1_wtp}, {w->fc2_wp, w->fc2_wtp}};
     for (int i = 0; i < 4; ++i) {
@@ -458,25 +371,9 @@ void make_lins(const cara_geom* g, const cara_vit_weights* w, const char* pack, 
   }
 }
 
-// Optional HIP-event bracket around the dominant kernel (the fc1 forward GEMM, one per layer) so
-// that bench.py can report its average launch duration from INSIDE the timed region, on the
-// stream the kernel runs on.  Diagnostic state, off by default.
-struct Prof {
-  bool on = false;
-  int every = 1;   // bracket the layers l with l % every == 0
-  long n = 0;      // brackets recorded since the hook was switched on (ring of 64)
-  hipEvent_t ev[64][3];
-  bool made = false;
-};
-Prof g_prof;
-
 // CARA_CLS_SHORTCUT=0 turns the exact last-block shortcut off (A/B measurements only)
 bool cls_shortcut_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CARA_CLS_SHORTCUT");
-    v = e ? atoi(e) : 1;
-  }
+  static const int v = env_once("CARA_CLS_SHORTCUT", 1);
   return v != 0;
 }
 
@@ -514,39 +411,39 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int cara_profile_fc1(int enable) {
-  if (enable && !g_prof.made) {
-    for (int i = 0; i < 64; ++i)
-      for (int j = 0; j < 3; ++j)
-        if (hipEventCreate(&g_prof.ev[i][j]) != hipSuccess) return CARA_E_LAUNCH;
+extern "C" int cara_profile_sites(unsigned long long mask, int every) {
+  if (mask && !g_prof.made) {
+    for (int i = 0; i < CARA_SITE_COUNT; ++i)
+      for (int k = 0; k < CARA_SITE_RING; ++k)
+        for (int j = 0; j < 3; ++j)
+          if (hipEventCreate(&g_prof.ev[i][k][j]) != hipSuccess) return CARA_E_LAUNCH;
     g_prof.made = true;
   }
-  g_prof.on = enable != 0;
-  g_prof.every = enable > 0 ? enable : 1;
-  g_prof.n = 0;
+  g_prof.mask = mask & ((1ull << CARA_SITE_COUNT) - 1);
+  g_prof.every = every > 0 ? every : 1;
+  for (int i = 0; i < CARA_SITE_COUNT; ++i) g_prof.n[i] = 0;
   return CARA_OK;
 }
 
-extern "C" int cara_profile_fc1_read(float* avg_ms, int* launches) {
-  float overhead = 0.f;
-  return cara_profile_fc1_read2(avg_ms, &overhead, launches);
-}
-// avg_ms = mean (event 0 -> event 1) around the kernel MINUS marker_ms = mean (event 1 -> event 2) with nothing
-// between: two event records in a row are ~8 us apart on this stack, and that gap is inside every bracket
-extern "C" int cara_profile_fc1_read2(float* avg_ms, float* marker_ms, int* launches) {
-  if (!avg_ms || !marker_ms || !launches || !g_prof.made || g_prof.n == 0) return CARA_E_ARG;
+// avg_ms = mean (event 0 -> event 1) around the site's kernel(s) MINUS marker_ms = mean (event 1 -> event 2) with
+// nothing between: two event records in a row are ~6-8 us apart on this stack, and that gap is inside every bracket
+extern "C" int cara_profile_site_read(int site, float* avg_ms, float* marker_ms, int* launches) {
+  if (site < 0 || site >= CARA_SITE_COUNT || !avg_ms || !marker_ms || !launches || !g_prof.made) return CARA_E_ARG;
+  const long n = g_prof.n[site];
+  *launches = 0;
+  if (n == 0) return CARA_OK;
   double tot = 0, gap = 0;
-  const int cnt = g_prof.n < 64 ? (int)g_prof.n : 64;
+  const int cnt = n < CARA_SITE_RING ? (int)n : CARA_SITE_RING;
   for (int i = 0; i < cnt; ++i) {
     float ms = 0.f, g = 0.f;
-    if (hipEventElapsedTime(&ms, g_prof.ev[i][0], g_prof.ev[i][1]) != hipSuccess) return CARA_E_LAUNCH;
-    if (hipEventElapsedTime(&g, g_prof.ev[i][1], g_prof.ev[i][2]) != hipSuccess) return CARA_E_LAUNCH;
+    if (hipEventElapsedTime(&ms, g_prof.ev[site][i][0], g_prof.ev[site][i][1]) != hipSuccess) return CARA_E_LAUNCH;
+    if (hipEventElapsedTime(&g, g_prof.ev[site][i][1], g_prof.ev[site][i][2]) != hipSuccess) return CARA_E_LAUNCH;
     tot += ms;
     gap += g;
   }
   *marker_ms = (float)(gap / cnt);
   *avg_ms = (float)((tot - gap) / cnt);
-  *launches = cnt;
+  *launches = (int)n;   // brackets recorded since cara_profile_sites(); the averages cover the last min(n, CARA_SITE_RING)
   return CARA_OK;
 }
 
@@ -583,8 +480,8 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
   cara_gemm_args a = {};
   a.A = ws + W.patches; a.lda = kp; a.B = w->patch_w; a.ldb = kp; a.M = B * P; a.N = D; a.K = kp;
   a.bias = w->patch_b; a.epi = CARA_EPI_F32; a.C = ws + W.emb; a.ldc = D;
-  g_sk_scratch = ws + W.gemm_scratch;
-  with_scratch(a);
+  Ctx cx{stream, ws + W.gemm_scratch, 0, false};
+  with_scratch(a, cx);
   TRY(cara_gemm_bf16(&a, stream));
   TRY(cara_assemble_tokens(reinterpret_cast<float*>(ws + W.emb), w->cls, w->pos,
                            reinterpret_cast<float*>(ws + W.layer[0].x_in), B, P, D, stream));
@@ -608,55 +505,50 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
     // x = x + drop_path(attn(norm1(x)))
     const bool ex = s->wd_exact != 0;   // exact weight-dropout mode: plain GEMMs on the merged weights
     const bool fx = fuse_xu(g) && !ex;
-    // no backward will follow (cara_vit_shape::inference): do not keep what only it reads.  Only with the default
-    // GEMM family (the others insist on both GELU outputs).
-    const bool inference = s->inference != 0 && !ex && !getenv("CARA_GEMM_TILE") && !getenv("CARA_GEMM_SK") && !getenv("CARA_GEMM_BK");
+    // no backward will follow (cara_vit_shape::inference): do not keep what only it reads
+    const bool inference = s->inference != 0 && !ex;
+    cx.layer = l;
+    cx.full = !cls_only;
+    Ctx cx_all = cx;   // qkv and attention always run on all token rows
+    cx_all.full = true;
     // K-panel-major activations (panel_acts): pa_x for what all M token rows produce (xn1), pa for the Mr rows of
     // the proj / MLP half of the block (xn2, h)
     const bool pa_x = panel_acts(M, s, 2), pa = panel_acts(Mr, s, 1), pa_n = panel_acts(Mr, s, 2);
-    TRY(cara_layernorm_fwd_ex(x_in, D, w->ln1_g + (size_t)l * D, w->ln1_b + (size_t)l * D, ws + lw.xn1,
-                              reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), M, D, s->eps,
-                              fx ? lin[0].Ut : nullptr, g->rank, Rp, ws + lw.T[0], ws + lw.Tt[0], W.ldt, pa_x ? M : 0, stream));
+    {
+      SiteBracket sb(CARA_SITE_LN1_FWD, cx_all);
+      TRY(cara_layernorm_fwd_ex(x_in, D, w->ln1_g + (size_t)l * D, w->ln1_b + (size_t)l * D, ws + lw.xn1,
+                                reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), M, D, s->eps,
+                                fx ? lin[0].Ut : nullptr, g->rank, Rp, ws + lw.T[0], ws + lw.Tt[0], W.ldt, pa_x ? M : 0, stream));
+    }
     cara_gemm_args e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + lw.qkv;
-    if (ex) TRY(lin_fwd_exact(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, ws, W, l, s, e, stream));
-    else TRY(lin_fwd(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), pa_x ? -M : D, M, Rp, W.ldt, ws, lw, e, stream, fx));
-    TRY(cara_attention_fwd(ws + lw.qkv, ws + lw.ao, reinterpret_cast<float*>(ws + lw.lse), B, N, g->heads, att_scale, stream));
+    if (ex) TRY(lin_fwd_exact(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, ws, W, s, e, cx_all));
+    else TRY(lin_fwd(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), pa_x ? -M : D, M, Rp, W.ldt, ws, lw, e, cx_all, fx));
+    {
+      SiteBracket sb(CARA_SITE_ATTN_FWD, cx_all);
+      TRY(cara_attention_fwd(ws + lw.qkv, ws + lw.ao, reinterpret_cast<float*>(ws + lw.lse), B, N, g->heads, att_scale, stream));
+    }
     e = {};
     e.epi = CARA_EPI_RESID; e.C = x_mid; e.aux = x_in; e.rowscale = dp1; e.rows_per_sample = rps; e.ldc = ldr;
-    if (ex) TRY(lin_fwd_exact(lin[1], reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, ws, W, l, s, e, stream));
-    else TRY(lin_fwd(lin[1], reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, lw, e, stream));
+    if (ex) TRY(lin_fwd_exact(lin[1], reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, ws, W, s, e, cx));
+    else TRY(lin_fwd(lin[1], reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, lw, e, cx));
     // x = x + drop_path(mlp(norm2(x)))
-    TRY(cara_layernorm_fwd_ex(x_mid, ldr, w->ln2_g + (size_t)l * D, w->ln2_b + (size_t)l * D, ws + lw.xn2,
-                              reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), Mr, D, s->eps,
-                              fx ? lin[2].Ut : nullptr, g->rank, Rp, ws + lw.T[2], ws + lw.Tt[2], W.ldt, pa_n ? Mr : 0, stream));
+    {
+      SiteBracket sb(CARA_SITE_LN2_FWD, cx);
+      TRY(cara_layernorm_fwd_ex(x_mid, ldr, w->ln2_g + (size_t)l * D, w->ln2_b + (size_t)l * D, ws + lw.xn2,
+                                reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), Mr, D, s->eps,
+                                fx ? lin[2].Ut : nullptr, g->rank, Rp, ws + lw.T[2], ws + lw.Tt[2], W.ldt, pa_n ? Mr : 0, stream));
+    }
     e = {};
     e.epi = CARA_EPI_GELU; e.C = ws + lw.h;
     e.C2 = inference ? nullptr : ws + lw.u;   // the pre-activation is only read by the backward (gelu')
     if (pa) { e.c_panels = Mr; e.ldc = 4 * D; }   // h (and dH in the backward) K-panel-major
-    if (ex) {
-      TRY(lin_fwd_exact(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, ws, W, l, s, e, stream));
-    } else if (g_prof.on && !cls_only && l % g_prof.every == 0) {
-      // T first, so that the bracket holds exactly one kernel: the fc1 GEMM
-      bf16* T = reinterpret_cast<bf16*>(ws + lw.T[2]);
-      if (!fx) TRY(cara_skinny_xu(ws + lw.xn2, pa_n ? -M : D, lin[2].Ut, T, ws + lw.Tt[2], W.ldt, M, D, Rp, stream));
-      cara_gemm_args a2 = e;
-      a2.A = ws + lw.xn2; a2.lda = D; a2.a_panels = pa_n ? M : 0; a2.B = lin[2].W; a2.Bp = lin[2].Wp; a2.ldb = D; a2.A2 = T; a2.B2 = lin[2].Vs; a2.Rp = Rp;
-      a2.M = M; a2.N = 4 * D; a2.K = D; a2.bias = lin[2].bias; a2.ldc = 4 * D;
-      with_scratch(a2);
-      hipEvent_t* ev = g_prof.ev[g_prof.n % 64];
-      hipEventRecord(ev[0], static_cast<hipStream_t>(stream));
-      TRY(cara_gemm_bf16(&a2, stream));
-      hipEventRecord(ev[1], static_cast<hipStream_t>(stream));
-      hipEventRecord(ev[2], static_cast<hipStream_t>(stream));   // empty bracket: the markers' own cost
-      ++g_prof.n;
-    } else {
-      TRY(lin_fwd(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), pa_n ? -Mr : D, Mr, Rp, W.ldt, ws, lw, e, stream, fx));
-    }
+    if (ex) TRY(lin_fwd_exact(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, ws, W, s, e, cx));
+    else TRY(lin_fwd(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), pa_n ? -Mr : D, Mr, Rp, W.ldt, ws, lw, e, cx, fx));
     e = {};
     e.epi = CARA_EPI_RESID; e.C = x_out; e.aux = x_mid; e.rowscale = dp2; e.rows_per_sample = rps; e.ldc = ldr;
-    if (ex) TRY(lin_fwd_exact(lin[3], reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, ws, W, l, s, e, stream));
-    else TRY(lin_fwd(lin[3], reinterpret_cast<bf16*>(ws + lw.h), pa ? -Mr : 4 * D, Mr, Rp, W.ldt, ws, lw, e, stream));
+    if (ex) TRY(lin_fwd_exact(lin[3], reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, ws, W, s, e, cx));
+    else TRY(lin_fwd(lin[3], reinterpret_cast<bf16*>(ws + lw.h), pa ? -Mr : 4 * D, Mr, Rp, W.ldt, ws, lw, e, cx));
   }
   // norm -> cls token -> head  (LayerNorm is per token, so only the cls rows are normalised)
   TRY(cara_layernorm_fwd(reinterpret_cast<float*>(ws + W.x_last), (long)N * D, w->norm_g, w->norm_b, ws + W.clsn,
@@ -673,15 +565,15 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
   Ws W;
   if (!layout(g, s, &W) || !w || !cp || !head_w || !dlogits || !workspace || !grads || !dhead_w || !dhead_b) return CARA_E_ARG;
   char* ws = static_cast<char*>(workspace);
-  g_sk_scratch = ws + W.gemm_scratch;
+  Ctx cx{stream, ws + W.gemm_scratch, 0, false};
   hipStream_t hs = static_cast<hipStream_t>(stream);
   const int D = g->dim, M = W.M, Rp = g->Rp, B = s->B, N = s->tokens;
   const float att_scale = 1.0f / sqrtf((float)(D / g->heads));
   cara_pack_layout pl;
   TRY(cara_pack_offsets(g, &pl));
   float* dx = reinterpret_cast<float*>(ws + W.dx);
-  bf16* dyb = reinterpret_cast<bf16*>(ws + W.ring[(g->depth - 1) % W.nring].dyb_fc2);   // dY of the last block's fc2
-  g_jobs.n = 0;
+  const Ws::Bwd& R = W.bwd;
+  bf16* dyb = reinterpret_cast<bf16*>(ws + R.dyb_fc2);   // dY of the last block's fc2
   TRY(cara_head_backward(dlogits, ws + W.clsn, head_w, dhead_w, dhead_b, ws + W.dclsn, B, s->num_classes, D, stream));
   // gradient enters the token stream only through the cls rows
   if (hipMemsetAsync(dx, 0, (size_t)M * D * 4, hs) != hipSuccess) return CARA_E_LAUNCH;
@@ -704,9 +596,11 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     const int Mr = cls_only ? B : M;
     const int ldr = cls_only ? N * D : D;
     const int rps = cls_only ? 1 : N;
-    // this block's ring slot of side-stream inputs (its dyb_fc2 and G'[3] were written by the block above)
-    const Ws::Ring& R = W.ring[l % W.nring];
-    bf16* dyb = reinterpret_cast<bf16*>(ws + R.dyb_fc2);
+    cx.layer = l;
+    cx.full = !cls_only;
+    Ctx cx_all = cx;   // attention and qkv always run on all token rows
+    cx_all.full = true;
+    // (dyb and G'[3] of this block's fc2 were written by the block above / the final norm's backward)
     bf16* dyp = reinterpret_cast<bf16*>(ws + R.dyb_proj);
     bf16* dH = reinterpret_cast<bf16*>(ws + R.dH);
     bf16* dQKV = reinterpret_cast<bf16*>(ws + R.dQKV);
@@ -720,48 +614,50 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     const bool pa_dp = panel_acts(Mr, s, 4), pa_dx = panel_acts(M, s, 4);   // dyp here; dyb of the block below
     const bool pa_dyb = pa_dx && l < g->depth - 1;
     if (pa) { e.c_panels = Mr; e.ldc = 4 * D; }
-    if (ex) TRY(lin_bwd_exact(lin[3], dyb, reinterpret_cast<bf16*>(ws + lw.h), Mr, Rp, ws, W, l, s, true, e, true, stream));
-    else TRY(lin_bwd(lin[3], dyb, pa_dyb ? -M : ldr, reinterpret_cast<bf16*>(ws + lw.h), pa ? -Mr : 4 * D, Mr, Rp, W.ldt, ws, W, R, lw, l, true, e, true, stream,
+    if (ex) TRY(lin_bwd_exact(lin[3], dyb, reinterpret_cast<bf16*>(ws + lw.h), Mr, Rp, ws, W, s, true, e, true, cx));
+    else TRY(lin_bwd(lin[3], dyb, pa_dyb ? -M : ldr, reinterpret_cast<bf16*>(ws + lw.h), pa ? -Mr : 4 * D, Mr, Rp, W.ldt, ws, W, lw, true, e, true, cx,
                      have_G_fc2));
     have_G_fc2 = false;
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
-    if (ex) TRY(lin_bwd_exact(lin[2], dH, reinterpret_cast<bf16*>(ws + lw.xn2), Mr, Rp, ws, W, l, s, true, e, true, stream));
-    else TRY(lin_bwd(lin[2], dH, pa ? -Mr : 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), pa_n ? -Mr : D, Mr, Rp, W.ldt, ws, W, R, lw, l, true, e, true, stream));
+    if (ex) TRY(lin_bwd_exact(lin[2], dH, reinterpret_cast<bf16*>(ws + lw.xn2), Mr, Rp, ws, W, s, true, e, true, cx));
+    else TRY(lin_bwd(lin[2], dH, pa ? -Mr : 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), pa_n ? -Mr : D, Mr, Rp, W.ldt, ws, W, lw, true, e, true, cx));
     // dyp = dY of this block's proj: its G' = dY Vs comes out of the same kernel
-    TRY(cara_layernorm_bwd_ex(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_mid), ldr, w->ln2_g + (size_t)l * D,
-                              reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyp, dp1,
-                              rps, Mr, D, fx ? lin[1].Vst : nullptr, g->rank, Rp, ws + R.G[1], ws + R.Gt[1], W.ldt, pa_dp ? Mr : 0, stream));
+    {
+      SiteBracket sb(CARA_SITE_LN2_BWD, cx);
+      TRY(cara_layernorm_bwd_ex(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_mid), ldr, w->ln2_g + (size_t)l * D,
+                                reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyp, dp1,
+                                rps, Mr, D, fx ? lin[1].Vst : nullptr, g->rank, Rp, ws + R.G[1], ws + R.Gt[1], W.ldt, pa_dp ? Mr : 0, stream));
+    }
     // ---- attention branch ----
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dAO; e.ldc = ldr;
     if (cls_only && hipMemsetAsync(ws + W.dAO, 0, (size_t)M * D * 2, hs) != hipSuccess) return CARA_E_LAUNCH;
-    if (ex) TRY(lin_bwd_exact(lin[1], dyp, reinterpret_cast<bf16*>(ws + lw.ao), Mr, Rp, ws, W, l, s, true, e, true, stream));
-    else TRY(lin_bwd(lin[1], dyp, pa_dp ? -Mr : ldr, reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, W, R, lw, l, true, e, true, stream, fx));
-    TRY(cara_attention_bwd(ws + lw.qkv, ws + lw.ao, ws + W.dAO, reinterpret_cast<float*>(ws + lw.lse), dQKV, B, N,
-                           g->heads, att_scale, stream));
+    if (ex) TRY(lin_bwd_exact(lin[1], dyp, reinterpret_cast<bf16*>(ws + lw.ao), Mr, Rp, ws, W, s, true, e, true, cx));
+    else TRY(lin_bwd(lin[1], dyp, pa_dp ? -Mr : ldr, reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, W, lw, true, e, true, cx, fx));
+    {
+      SiteBracket sb(CARA_SITE_ATTN_BWD, cx_all);
+      TRY(cara_attention_bwd(ws + lw.qkv, ws + lw.ao, ws + W.dAO, reinterpret_cast<float*>(ws + lw.lse), dQKV, B, N,
+                             g->heads, att_scale, stream));
+    }
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
     // block 0 has nothing trainable upstream of it: its dX GEMM and LayerNorm backward are skipped
-    if (ex) TRY(lin_bwd_exact(lin[0], dQKV, reinterpret_cast<bf16*>(ws + lw.xn1), M, Rp, ws, W, l, s, l > 0, e, false, stream));
-    else TRY(lin_bwd(lin[0], dQKV, 3 * D, reinterpret_cast<bf16*>(ws + lw.xn1), pa_x ? -M : D, M, Rp, W.ldt, ws, W, R, lw, l, l > 0, e, false, stream));
+    if (ex) TRY(lin_bwd_exact(lin[0], dQKV, reinterpret_cast<bf16*>(ws + lw.xn1), M, Rp, ws, W, s, l > 0, e, false, cx_all));
+    else TRY(lin_bwd(lin[0], dQKV, 3 * D, reinterpret_cast<bf16*>(ws + lw.xn1), pa_x ? -M : D, M, Rp, W.ldt, ws, W, lw, l > 0, e, false, cx_all));
     if (l > 0) {
-      // the LayerNorm backward below starts to fill the ring slot of block l - 1: its previous user, block
-      // l - 1 + nring, must be through with it (never the case with one slot per block)
-      const Ws::Ring& Rb = W.ring[(l - 1) % W.nring];
-      if (!ex && l - 1 + W.nring < g->depth) TRY(side_join(l - 1 + W.nring, stream));
-      bf16* dyb = reinterpret_cast<bf16*>(ws + Rb.dyb_fc2);
-      // dyb = dY of fc2 of the block BELOW (all M rows there: only the last block runs on cls rows)
+      // dyb = dY of fc2 of the block BELOW (all M rows there: only the last block runs on cls rows); this block's
+      // fc2 is through with the buffer (stream order)
       Lin below[4];
       make_lins(g, w, ws + W.pack, pl, l - 1, below);
+      SiteBracket sb(CARA_SITE_LN1_BWD, cx_all);
       TRY(cara_layernorm_bwd_ex(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_in), D, w->ln1_g + (size_t)l * D,
                                 reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), dx, dx, dyb,
-                                dp_prev, N, M, D, fx ? below[3].Vst : nullptr, g->rank, Rp, ws + Rb.G[3], ws + Rb.Gt[3], W.ldt,
+                                dp_prev, N, M, D, fx ? below[3].Vst : nullptr, g->rank, Rp, ws + R.G[3], ws + R.Gt[3], W.ldt,
                                 pa_dx ? M : 0, stream));
       have_G_fc2 = fx;
     }
   }
-  if (!ex) TRY(side_join(0, stream));   // all slabs written (block 0's join is the last record of the in-order side stream)
   if (!ex) {   // (the exact mode wrote dU / dVs / dc of every layer directly)
     const int ins[4] = {D, D, D, 4 * D}, outs[4] = {3 * D, D, 4 * D, D};
     const int L = g->depth;

@@ -66,6 +66,13 @@ class CaraEngine:
         self._need_backward = True
         self._flat_grad = None
         self._grad_views = None
+        # RNG streams of the stochastic parts (DropPath masks on the device, weight-dropout seeds on the host).
+        # None = torch's global generators.  Under data parallelism every rank must draw DIFFERENT masks while the
+        # parameters stay identical: seed_rank_streams(seed, rank) after the model is built.
+        self._gen_dev = None
+        self._gen_cpu = None
+        self._gen_seed = None
+        self._warned_wd = False
         from .modules import FactorPack
         self._factors = FactorPack(self)
 
@@ -144,7 +151,7 @@ class CaraEngine:
             nbytes = L.lib().cara_vit_workspace_bytes(C.byref(geom), C.byref(shape))
             if nbytes == 0:
                 raise CaraError(f"unsupported geometry for the HIP path: {geom.depth=} {geom.dim=} {geom.heads=} "
-                                f"{shape.tokens=} (needs head dim 64, tokens <= 224, dim % 256 == 0)")
+                                f"{shape.tokens=} (needs head dim 64, tokens <= 608, dim % 256 == 0)")
             self._ws.clear()  # one live workspace: activations of one step
             ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
             st = {"geom": geom, "shape": shape, "ws": ws, "logits": torch.empty(B, ncls, device=dev)}
@@ -168,8 +175,8 @@ class CaraEngine:
         st["shape"].wd_exact = 1 if use_exact else 0
         st["shape"].wd_p = float(self.weight_dropout_p)
         if use_exact:
-            st["shape"].wd_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if self.weight_dropout_seed is None \
-                else int(self.weight_dropout_seed)
+            st["shape"].wd_seed = int(torch.randint(0, 2 ** 31 - 1, (1,), generator=self._gen_cpu).item()) \
+                if self.weight_dropout_seed is None else int(self.weight_dropout_seed)
         # eval / no_grad: nothing the backward alone reads is kept (cara_vit_shape::inference)
         st["shape"].inference = 0 if need_backward else 1
         cps = self._cp_ptrs([t.detach().contiguous() for t in cp])
@@ -202,6 +209,20 @@ class CaraEngine:
         self._bwd_ready = -1
         return g
 
+    def seed_rank_streams(self, seed: int, rank: int = 0) -> None:
+        """Give this replica its own DropPath / weight-dropout random streams: generator seed = seed * 2^20 + rank.
+        Parameters are not touched (replicas stay identical); only the per-step masks differ between ranks."""
+        self._gen_seed = int(seed) * (1 << 20) + int(rank)
+        self._gen_dev = None
+        self._gen_cpu = torch.Generator().manual_seed(self._gen_seed)
+
+    def _device_generator(self, dev):
+        if self._gen_seed is None:
+            return None
+        if self._gen_dev is None or self._gen_dev.device != dev:
+            self._gen_dev = torch.Generator(device=dev).manual_seed(self._gen_seed)
+        return self._gen_dev
+
     def draw_droppath(self, model, B, dev) -> Optional[torch.Tensor]:
         """Per-sample multipliers mask/keep_prob of timm DropPath for both branches of every block,
         [depth, 2, B]; None in eval mode or when every rate is 0."""
@@ -217,7 +238,7 @@ class CaraEngine:
             self._keep = 1.0 - torch.tensor(rates, device=dev).reshape(-1, 1, 1)
             self._keep_key = key
         keep = self._keep
-        return ((keep + torch.rand(len(rates), 2, B, device=dev)).floor_() / keep).contiguous()
+        return ((keep + torch.rand(len(rates), 2, B, device=dev, generator=self._device_generator(dev))).floor_() / keep).contiguous()
 
     def forward(self, images, droppath: Optional[torch.Tensor] = None):
         model = self._model()
@@ -288,8 +309,8 @@ class CaraEngine:
         model = self._model()
         if not x.is_cuda:
             raise CaraError("cara_amd runs on the GPU only (no CPU fallback)")
-        if x.ndim != 3 or x.shape[2] != model.embed_dim or x.shape[1] > 224:
-            raise CaraError("module-level forward expects x of shape [B, N <= 224, embed_dim]")
+        if x.ndim != 3 or x.shape[2] != model.embed_dim or x.shape[1] > 608:
+            raise CaraError("module-level forward expects x of shape [B, N <= 608, embed_dim]")
         return model, [getattr(model, "CP_" + n) for n in self.cp_fields]
 
     def attn_forward(self, child, x):

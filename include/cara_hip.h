@@ -7,9 +7,12 @@
  *
  * Conventions: plain pointers and sizes only (device pointers unless a comment says host);
  * every entry point enqueues work on `stream` (a hipStream_t passed as void*) and returns an
- * int status: 0 = ok, >0 = CARA_E_* below.  Nothing allocates, frees, synchronises or keeps
- * state, so every call is re-entrant and hipGraph-capturable.  bf16 tensors are raw uint16
- * (round-to-nearest-even of fp32).  All matrices are row-major and dense unless an ld* is given.
+ * int status: 0 = ok, >0 = CARA_E_* below.  Nothing allocates, frees or synchronises, and nothing
+ * keeps state between calls (the one exception is the opt-in diagnostic of cara_profile_sites), so
+ * every call is re-entrant and hipGraph-capturable; all work of a call goes to the caller's stream.
+ * The caller makes the device of its pointers and stream current (hipSetDevice) before calling.
+ * bf16 tensors are raw uint16 (round-to-nearest-even of fp32).  All matrices are row-major and dense
+ * unless an ld* is given.
  */
 #ifndef CARA_HIP_H
 #define CARA_HIP_H
@@ -34,7 +37,8 @@ const char* cara_build_arch(void);       /* "gfx950" */
  * This is the adapter linear of cara.py:25-42,50-58,75-82,87-93 in factored form:
  * A2 = T = X U (cara_skinny_xu), B2 = Vs = s * g (.) V (cara_factor_prep), so that
  * y = X W^T + b + s((X U) (.) g) V^T + s c  costs Rp/K extra MFMA work instead of a second GEMM.
- * Requirements: K % 64 == 0, Rp in {0, 32, 64}; M, N arbitrary (edges are clamped/masked).   */
+ * Requirements: K % 64 == 0, Rp in {0, 32, 64}; M, N arbitrary (edges are clamped/masked); each
+ * operand spans < 4 GiB (32-bit byte offsets), else CARA_E_ARG.                                  */
 enum {
   CARA_EPI_BF16 = 0,   /* C bf16 [M,ldc]          = acc + bias                                  */
   CARA_EPI_F32 = 1,    /* C fp32 [M,ldc]          = acc + bias                                  */
@@ -54,16 +58,15 @@ typedef struct {
   const void* aux;              /* CARA_EPI_RESID: fp32 [M,ldc]; CARA_EPI_DGELU: bf16 [M,ldc] */
   const float* rowscale;        /* CARA_EPI_RESID: fp32 [M / rows_per_sample] or NULL (=1) */
   int rows_per_sample;
-  void* scratch;                /* optional: cara_gemm_scratch_bytes() of caller memory, zeroed once at   */
-  size_t scratch_bytes;         /* allocation, used by ONE stream at a time.  With it, products of at     */
-                                /* least 1024 rows and 256 columns run on the persistent stream-K kernel  */
-                                /* (partial tiles + flags live there); NULL = one tile per workgroup.     */
+  void* scratch;                /* optional: cara_gemm_scratch_bytes() of caller memory, used by ONE call  */
+  size_t scratch_bytes;         /* at a time.  With it, few-row products (M <= 128, K >= 512) cut their K  */
+                                /* loop into slabs that run as one batched launch (fp32 partials there).   */
   int batch;                    /* > 1: `batch` independent products in ONE launch; product z uses A, B,  */
   long long strideA, strideB, strideC;   /* C advanced by z * stride (elements); no A2/B2/aux/C2 then     */
   /* Whole adapter inside the GEMM (Rp == 32, B2 set, A2 NULL): every tile also accumulates its rows of       */
   /* T = A Ut^T (Ut bf16 [32, K], rows >= rank zero: the operand cara_skinny_xu takes), rounds it to bf16 and  */
   /* uses it as the K-extension operand -- the separate skinny pass over A disappears.  The tiles of column   */
-  /* 0 also write T [M,32] and, if non-NULL, Tt [32,ldt] (for cara_tskinny_*).  Default kernel family only.   */
+  /* 0 also write T [M,32] and, if non-NULL, Tt [32,ldt] (for cara_tskinny_*).                                */
   const void* Ut;
   void* T_out;
   void* Tt_out;
@@ -72,10 +75,10 @@ typedef struct {
   /* columns of K step t of ALL rows are contiguous, so the 128 x 32 operand tile of a K step is one 8-KiB run of  */
   /* full cache lines instead of 128 half lines 2*ldb bytes apart (the L2 -> LDS path delivers ~30 % more tile     */
   /* bytes per second that way, tools/micro/kloop_bw.hip).  Frozen weights are packed once at ingest.  The 32-     */
-  /* column-step kernels read it INSTEAD of B when non-NULL; B must still be valid (other kernel families).       */
+  /* GEMM reads it INSTEAD of B when non-NULL (B is then only used by the few-row path).                      */
   const void* Bp;
-  /* Activations in the same K-panel-major layout (bf16 only, default kernel family only: M > 128, no batch, no     */
-  /* scratch-selected kernels).  a_panels = P > 0: A is [K/32][P][32] (P >= M rows per panel), lda is ignored.      */
+  /* Activations in the same K-panel-major layout (bf16 only; M > 128, no batch).                                    */
+  /* a_panels = P > 0: A is [K/32][P][32] (P >= M rows per panel), lda is ignored.      */
   /* c_panels = P > 0 (bf16 epilogues): C is WRITTEN as [N/32][P][32] -- the A operand of the next GEMM, the X of   */
   /* cara_skinny_xu / cara_tskinny_* with ldx = -P -- while C2 / aux keep the row-major ldc.  N % 32 == 0 then.     */
   int a_panels, c_panels;
@@ -84,8 +87,6 @@ int cara_gemm_bf16(const cara_gemm_args* a, void* stream);
 /* B bf16 [N, K] (row stride ldb) -> out bf16 [K/32][N][32] (cara_gemm_args::Bp); K % 32 == 0 */
 int cara_pack_b_panels(const void* B, int ldb, int N, int K, void* out, void* stream);
 size_t cara_gemm_scratch_bytes(void);
-/* number of launches of the persistent 256x256 kernel so far in this process (tests assert the path taken) */
-long cara_debug_gemm_persistent_launches(void);
 
 /* ---- skinny adapter contractions (HBM-bound) --------------------------------------------- */
 /* T[M,Rp] = X[M,K] * Ut[Rp,K]^T, bf16 out, also written transposed Tt[Rp,ldt] when Tt != NULL
@@ -113,7 +114,7 @@ int cara_tskinny_partial2(const void* Xa, int ldxa, const void* Gta, void* slabs
                           int ldg, int M, int Rp, void* stream);
 /* cara_gemm_bf16(a) and cara_tskinny_partial2(...) of the SAME linear as ONE launch: the grid holds the GEMM's tiles
  * and the products' blocks, so the HBM-bound products run under the MFMA-bound GEMM without a second stream (no
- * event between the kernels before and after).  Default GEMM kernel family, M > 128, no batch / Ut; Rp == 32;
+ * event between the kernels before and after).  M > 128, no batch / Ut; Rp == 32;
  * CARA_E_ARG otherwise (callers then launch the two separately).  Results are bitwise those of the two calls.   */
 int cara_gemm_with_tskinny(const cara_gemm_args* a, const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
                            const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b,
@@ -300,10 +301,8 @@ typedef struct {
   int inference;
 } cara_vit_shape;
 size_t cara_vit_workspace_bytes(const cara_geom* g, const cara_vit_shape* s);
-/* Threading: cara_vit_forward / cara_vit_backward keep a little process-global host state (the side stream and its
- * events, the roofline bracket, the scratch of the workspace in use), so calls into them must not overlap in time
- * from different host threads of one process; any number of streams / workspaces may be used one call after the
- * other (data parallelism is one PROCESS per GPU).  Every other entry point of this header is stateless.
+/* Both calls are stateless (everything lives in the caller's workspace and runs in order on the caller's stream):
+ * any number of workspaces / streams / host threads may be in flight at once, one workspace per concurrent call.
  * images fp32 [B,chans,img,img]; droppath fp32 [depth,2,B] per-sample branch multipliers
  * (mask/keep_prob of timm DropPath) or NULL; head_w fp32 [classes,dim], head_b fp32 [classes];
  * logits fp32 [B,classes].  The workspace must be zero-filled once before its first use and
@@ -321,16 +320,26 @@ int cara_head_backward(const float* dlogits, const void* xn_bf16, const float* h
                        float* dhead_b, void* dxn_bf16, int B, int classes, int D, void* stream);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */
-/* Bracket the fc1 forward GEMM (the dominant kernel) of the layers l with l % enable == 0 (enable = 1: every
- * layer; 0: off) with HIP events recorded on the compute stream inside cara_vit_forward; read the average
- * duration of the last (up to 64) bracketed launches after synchronising.  Every bracket idles the chip for
- * ~15 us (three event records), so a timed run brackets a few layers per step, not all.  Process-global
- * diagnostic state; off by default.                                                                        */
-int cara_profile_fc1(int enable);
-int cara_profile_fc1_read(float* avg_ms, int* launches);   /* host pointers */
-/* The same with the markers' own cost made visible: every bracket is followed by an EMPTY bracket (two event
- * records in a row); avg_ms is the mean kernel bracket minus marker_ms, the mean empty bracket.                */
-int cara_profile_fc1_read2(float* avg_ms, float* marker_ms, int* launches);
+/* HIP-event brackets around the kernels of chosen call sites INSIDE cara_vit_forward / cara_vit_backward, recorded
+ * on the compute stream, so that a benchmark can read per-kernel launch durations from within its timed region
+ * (bench.py: `roofline`).  mask = bit set of CARA_SITE_* (0 = off); only the full-size blocks l with l % every == 0
+ * are bracketed.  Every bracket idles the chip for ~15 us (three event records), so a timed run brackets one site
+ * on a few layers per step.  Read after synchronising: avg_ms = mean duration of the last (up to CARA_SITE_RING)
+ * brackets of that site minus marker_ms, the mean of the EMPTY bracket recorded behind each (the markers' own
+ * cost); launches = brackets recorded since cara_profile_sites() (0: the site never ran).  A GEMM site holds exactly the GEMM launch (with the
+ * transposed skinny products that ride in it), a SKINNY site the separate cara_skinny_xu passes.
+ * This is the ONLY process-global state of the library: diagnostic, off by default, not thread-safe.            */
+enum {
+  CARA_SITE_QKV_FWD = 0, CARA_SITE_PROJ_FWD, CARA_SITE_FC1_FWD, CARA_SITE_FC2_FWD,
+  CARA_SITE_QKV_BWD, CARA_SITE_PROJ_BWD, CARA_SITE_FC1_BWD, CARA_SITE_FC2_BWD,
+  CARA_SITE_ATTN_FWD, CARA_SITE_ATTN_BWD,
+  CARA_SITE_LN1_FWD, CARA_SITE_LN2_FWD, CARA_SITE_LN1_BWD, CARA_SITE_LN2_BWD,
+  CARA_SITE_SKINNY_FWD, CARA_SITE_SKINNY_BWD,
+  CARA_SITE_COUNT
+};
+#define CARA_SITE_RING 64
+int cara_profile_sites(unsigned long long mask, int every);
+int cara_profile_site_read(int site, float* avg_ms, float* marker_ms, int* launches);   /* host pointers */
 /* One ds_read_b64_tr_b16 per lane (64 lanes) over an LDS image of 16-bit values sm[i] = i, lane l
  * reading at byte address byte_addr[l] (device int[64], multiples of 8, < 16384); out = device
  * short[256] (4 per lane).  Pins the lane semantics the attention kernels rely on.             */

@@ -148,4 +148,4 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.cara_abi_version() == 1 and lib.cara_build_arch() == b"gfx950"
+    assert lib.cara_abi_version() == 2 and lib.cara_build_arch() == b"gfx950"

@@ -221,12 +221,15 @@ def test_skinny_products_on_k_panel_major_operands(M, K):
     assert torch.equal(D1, D2) and torch.equal(c1, c2)
 
 
+def _sk_scratch():
+    return torch.empty(L().gemm_scratch_bytes(), dtype=torch.uint8, device=DEV)
+
+
 @pytest.mark.parametrize("M,N,K,Rp", [(64, 768, 3072, 32), (64, 3072, 768, 32), (64, 768, 768, 64), (17, 300, 2304, 0), (128, 768, 768, 32)])
 def test_gemm_few_rows_split_k(M, N, K, Rp):
     """Few-row products with caller scratch: K slabs in one batched launch + a finishing kernel (bias, rank-R term,
     epilogue).  Rows strided as the last block's cls rows are (row stride 5 * width)."""
     sc = _sk_scratch()
-    before = L().gemm_persistent_launches()
     stride = 5
     Abig, B = rnd(M * stride, K, seed=1, scale=0.3), rnd(N, K, seed=2, scale=0.3)
     A = Abig.view(M, stride * K)[:, :K]                     # row stride 5K
@@ -258,123 +261,7 @@ def test_gemm_few_rows_split_k(M, N, K, Rp):
     ud = u.double().requires_grad_(True)
     torch.nn.functional.gelu(ud).sum().backward()
     close(dg, (acc - bias.double()) * ud.grad, 2 ** -8, 3e-3 * math.sqrt(K / 64), "few rows dgelu")
-    assert L().gemm_persistent_launches() == before          # not the persistent kernel: the split-K path
 
-
-# ---- LDS-ring kernels (CARA_GEMM_TILE = 256: 256x256, one workgroup per CU; 1282: 128x256, two per CU) --------
-@pytest.mark.parametrize("tile", ["256", "1282", "bm256"])
-@pytest.mark.parametrize("M,N,K,Rp", [(12608, 768, 768, 32), (1500, 3072, 768, 64), (333, 300, 128, 32), (777, 640, 64, 0),
-                                      (130, 2304, 3072, 32)])
-def test_gemm_ring_tiles(M, N, K, Rp, tile, monkeypatch):
-    if tile == "bm256":   # the 256 x 128 form of the default double-buffered kernel (8 waves, two workgroups per CU)
-        monkeypatch.setenv("CARA_GEMM_BM", "2560")
-    else:
-        monkeypatch.setenv("CARA_GEMM_TILE", tile)
-    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
-    bias = rnd(N, seed=3, dtype=torch.float32)
-    A2 = rnd(M, Rp, seed=4) if Rp else None
-    B2 = rnd(N, Rp, seed=5) if Rp else None
-    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
-    L().gemm(A, B, out, epi=L().EPI_F32, bias=bias, A2=A2, B2=B2)
-    ref = A.double() @ B.double().t() + bias.double()
-    if Rp:
-        ref = ref + A2.double() @ B2.double().t()
-    close(out, ref, 1e-4, 1e-3 * math.sqrt(K / 64) + 2e-3, f"ring tile {tile}: {M}x{N}x{K}+{Rp}")
-    h = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    L().gemm(A, B, h, epi=L().EPI_GELU, bias=bias, A2=A2, B2=B2, C2=u)
-    close(u, ref, 2 ** -8, 2e-3 * math.sqrt(K / 64) + 2e-3, "ring gelu u")
-    close(h, torch.nn.functional.gelu(ref), 2 ** -8, 2e-3 * math.sqrt(K / 64) + 2e-3, "ring gelu h")
-
-
-# ---- persistent 256x256 kernel (opt-in: CARA_GEMM_SK=1 + caller scratch; M >= 1024, N >= 256) ----------
-def _sk_scratch():
-    return torch.zeros(L().gemm_scratch_bytes(), dtype=torch.uint8, device=DEV)
-
-
-@pytest.fixture
-def sk_on(monkeypatch):
-    monkeypatch.setenv("CARA_GEMM_SK", "1")
-
-
-@pytest.mark.parametrize("M,N,K,Rp", [
-    (12608, 768, 768, 32),     # proj: 150 tiles x 13 steps: every workgroup holds pieces of two tiles
-    (12608, 3072, 768, 32),    # fc1: 600 tiles
-    (12608, 768, 3072, 32),    # fc2: 49 steps per tile, tiles split three ways
-    (12608, 2304, 768, 64),    # rank 64: full-width extension tile
-    (1100, 300, 128, 0),       # ragged rows and columns, no extension, few iterations per workgroup
-    (2048, 256, 64, 32),       # one K-tile + extension
-    (1024, 520, 192, 32),      # column edge not a multiple of 16
-])
-@pytest.mark.parametrize("tail", ["rounds", "stream-k"])
-def test_gemm_stream_k_f32(M, N, K, Rp, tail, monkeypatch, sk_on):
-    # tail policy: leftover tiles as a partly filled data-parallel round (default at these K), or cut into
-    # equal K ranges with partial-tile hand-offs between workgroups (CARA_GEMM_SK_TAIL = minimum K-steps per tile)
-    monkeypatch.setenv("CARA_GEMM_SK_TAIL", "1" if tail == "stream-k" else "0")
-    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
-    bias = rnd(N, seed=3, dtype=torch.float32)
-    A2 = rnd(M, Rp, seed=4) if Rp else None
-    B2 = rnd(N, Rp, seed=5) if Rp else None
-    scratch = _sk_scratch()
-    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
-    before = L().gemm_persistent_launches()
-    L().gemm(A, B, out, epi=L().EPI_F32, bias=bias, A2=A2, B2=B2, scratch=scratch)
-    assert L().gemm_persistent_launches() == before + 1
-    ref = A.double() @ B.double().t() + bias.double()
-    if Rp:
-        ref = ref + A2.double() @ B2.double().t()
-    close(out, ref, 1e-4, 1e-3 * math.sqrt(K / 64) + 2e-3, f"stream-K gemm {M}x{N}x{K}+{Rp}")
-    # same scratch again (flags carry the previous launch's epoch), bitwise equal: fixed-order partial sums
-    out2 = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
-    L().gemm(A, B, out2, epi=L().EPI_F32, bias=bias, A2=A2, B2=B2, scratch=scratch)
-    assert torch.equal(out, out2), "stream-K must be bitwise reproducible"
-    # and against the one-tile-per-workgroup kernel (different summation order: tolerance)
-    out3 = torch.empty_like(out)
-    monkeypatch.setenv("CARA_GEMM_SK", "0")
-    L().gemm(A, B, out3, epi=L().EPI_F32, bias=bias, A2=A2, B2=B2, scratch=scratch)
-    close(out, out3.double(), 1e-4, 1e-4, "stream-K vs tile kernel")
-
-
-def test_gemm_stream_k_exact_integers(sk_on):
-    M, N, K = 1280, 512, 256
-    A = (torch.arange(M * K).reshape(M, K) % 7 - 3).float()
-    B = (torch.arange(N * K).reshape(N, K) % 5 - 2).float() + (torch.arange(N).reshape(N, 1) % 3).float()
-    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
-    L().gemm(A.bfloat16().to(DEV), B.bfloat16().to(DEV), out, epi=L().EPI_F32, scratch=_sk_scratch())
-    torch.cuda.synchronize()
-    assert torch.equal(out.cpu(), A @ B.t())
-
-
-def test_gemm_stream_k_epilogues(sk_on):
-    M, N, K = 1500, 512, 128
-    A, B = rnd(M, K, seed=1, scale=0.3), rnd(N, K, seed=2, scale=0.3)
-    bias = rnd(N, seed=3, dtype=torch.float32)
-    acc = A.double() @ B.double().t() + bias.double()
-    sc = _sk_scratch()
-    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    L().gemm(A, B, out, epi=L().EPI_BF16, bias=bias, scratch=sc)
-    close(out, acc, 2 ** -8, 1e-3, "sk epi bf16")
-    h = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    L().gemm(A, B, h, epi=L().EPI_GELU, bias=bias, C2=u, scratch=sc)
-    close(u, acc, 2 ** -8, 1e-3, "sk epi gelu u")
-    close(h, torch.nn.functional.gelu(acc), 2 ** -8, 1e-3, "sk epi gelu h")
-    xin = rnd(M, N, seed=5, dtype=torch.float32)
-    rs = torch.tensor([1.0, 0.0, 1.1, 1.1, 0.0, 1.1, 1.0, 1.1, 1.0, 1.1], device=DEV)
-    xo = torch.empty(M, N, dtype=torch.float32, device=DEV)
-    L().gemm(A, B, xo, epi=L().EPI_RESID, bias=bias, aux=xin, rowscale=rs, rows_per_sample=150, scratch=sc)
-    ref = xin.double() + rs.double().repeat_interleave(150)[:, None] * acc
-    close(xo, ref, 1e-5, 1e-4, "sk epi resid")
-    dg = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    L().gemm(A, B, dg, epi=L().EPI_DGELU, aux=u, scratch=sc)
-    ud = u.double().requires_grad_(True)
-    torch.nn.functional.gelu(ud).sum().backward()
-    close(dg, (A.double() @ B.double().t()) * ud.grad, 2 ** -8, 2e-3, "sk epi dgelu")
-    # strided output rows (ldc > N), as the cls-row / residual-stream callers use
-    wide = torch.full((M, N + 64), float("nan"), dtype=torch.float32, device=DEV)
-    L().gemm(A, B, wide, epi=L().EPI_F32, bias=bias, ldc=N + 64, scratch=sc)
-    close(wide[:, :N], acc, 1e-4, 2e-3, "sk strided out")
-    assert torch.isnan(wide[:, N:]).all()
 
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,K,Rp", [(12608, 768, 32), (12608, 3072, 32), (197, 768, 64), (45, 2304, 32)])
@@ -410,7 +297,7 @@ def test_tskinny(M, K1, Rp):
 @pytest.mark.parametrize("M,N,K,epi", [(12608, 768, 3072, "bf16"), (12608, 3072, 768, "dgelu"), (1500, 768, 768, "bf16")])
 def test_gemm_carrying_the_transposed_skinny_products(M, N, K, epi, monkeypatch):
     """cara_gemm_with_tskinny: the dX GEMM of a linear and its two transposed skinny products as ONE launch give
-    bitwise what cara_gemm_bf16 + cara_tskinny_partial2 give, with the products' blocks in front of or behind the tiles."""
+    bitwise what cara_gemm_bf16 + cara_tskinny_partial2 give."""
     lib = L().lib()
     p, st = L().ptr, L().stream
     lib.cara_tskinny_scratch_bytes.restype = C.c_size_t
@@ -441,11 +328,8 @@ def test_gemm_carrying_the_transposed_skinny_products(M, N, K, epi, monkeypatch)
         return out, sa, sb
 
     ref = run(False)
-    for pos in ("0", "1"):
-        monkeypatch.setenv("CARA_TS_POS", pos)
-        got = run(True)
-        assert all(torch.equal(x, y) for x, y in zip(ref, got)), f"CARA_TS_POS={pos}"
-    monkeypatch.delenv("CARA_TS_POS")
+    got = run(True)
+    assert all(torch.equal(x, y) for x, y in zip(ref, got))
     # the same with dY and X K-panel-major (a_panels on the GEMM, negative ld on the products) and packed weights
     dYp, Xp, Wp = _panels(dY), _panels(X), L().pack_b_panels(Wt)
     out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)

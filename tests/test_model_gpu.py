@@ -142,36 +142,6 @@ def test_exact_weight_dropout_mode_against_oracle():
     assert torch.equal(ev, ev_off)
 
 
-def test_whole_model_with_persistent_gemm(monkeypatch):
-    """The opt-in 256x256 persistent GEMM (CARA_GEMM_SK=1) inside the real forward/backward: batch 8 x 197
-    rows >= 1024, so qkv/proj/fc1/fc2 and their dX products all take it.  Same model, same input, both GEMM
-    paths: logits and CP gradients agree to bf16 rounding (the two sum the K steps in different orders)."""
-    from oracle import cara_oracle as O
-    torch.manual_seed(0)
-    w = O.synthetic_backbone()
-    cp = O.synthetic_cp(rank=16)
-    x, y = O.synthetic_batch(batch=8)
-    from cara_amd import _lib as L
-    out = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("CARA_GEMM_SK", mode)
-        m = build(w, cp, 16, 0.1, 12, 224).eval()
-        before = L.gemm_persistent_launches()
-        logits = m(x.to(DEV))
-        torch.nn.functional.cross_entropy(logits, y.to(DEV)).backward()
-        # patch embedding + 12 x (2 forward + 4 dX) products -- forward proj / fc2 carry the adapter inside the
-        # GEMM (cara_gemm_args.Ut), which is its own kernel -- minus the cls-row-only ones of the last block and
-        # the first block's unused qkv dX: 68
-        assert (L.gemm_persistent_launches() - before >= 60) == (mode == "1")
-        out[mode] = (logits.detach().float().cpu(), {n: getattr(m, n).grad.float().cpu() for n in O.CP_NAMES})
-    r = rel(out["1"][0], out["0"][0])
-    worst = max(rel(out["1"][1][n], out["0"][1][n]) for n in O.CP_NAMES)
-    print(f"persistent vs tile GEMM: logits rel-L2 {r:.2e}, worst CP-gradient rel-L2 {worst:.2e}")
-    # (with whole-tile rounds the persistent kernel adds the K steps in the tile kernel's order: often bitwise equal)
-    assert r < 8e-3 and worst < 2e-2, (r, worst)
-    assert torch.equal(out["1"][0].argmax(1), out["0"][0].argmax(1))
-
-
 def test_vit_large_384_against_oracle():
     """BASELINE.json configs[4] dimensioning: ViT-L/16 @384 -- dim 1024, 16 heads, 24 blocks, 577 tokens (the
     two-sweep attention path), CP_A1 [72,R], CP_A3 [16,R], CP_P1 [216,R], CP_A2/P2/P3 [1024,R], biases
