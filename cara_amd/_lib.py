@@ -142,8 +142,10 @@ def ptr(t) -> C.c_void_p:
     return C.c_void_p(t.data_ptr())
 
 
-def stream() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream(device=None) -> C.c_void_p:
+    """Current stream of ``device`` (default: the current device).  Callers that own tensors pass their device and
+    hold ``torch.cuda.device(device)`` around the library call: kernels launch on the CURRENT device."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 # ---- thin per-op wrappers (used by tests and by the module-level drop-in) ---------------------

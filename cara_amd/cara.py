@@ -51,7 +51,72 @@ def cp_mlp(self, x: th.Tensor) -> th.Tensor:
 
 
 def _is(obj, *classes) -> bool:
-    return any(type(obj) is c for c in classes)  # exact-type dispatch, like cara.py:110,147,157
+    """Exact-type dispatch like cara.py:110,147,157 (subclasses are skipped), widened from "timm's class object" to
+    "a class of that NAME with that structure": timm is not a dependency of this build, so its VisionTransformer /
+    Attention / Mlp are recognised by what cp_attn / cp_mlp use of them (cara.py:25,37,44,46,50,59,75,84,85,87)."""
+    for c in classes:
+        if type(obj) is c:
+            return True
+        if type(obj).__name__ == c.__name__ and all(hasattr(obj, a) for a in _STRUCTURE[c.__name__]):
+            return True
+    return False
+
+
+_STRUCTURE = {
+    "VisionTransformer": ("patch_embed", "cls_token", "pos_embed", "blocks", "norm", "head", "embed_dim"),
+    "Attention": ("qkv", "proj", "num_heads", "scale"),
+    "Mlp": ("fc1", "act", "fc2"),
+}
+
+
+def _check_vit(model) -> None:
+    """What the HIP path supports of a timm-shaped ViT (the reference's configuration, vit_cp.py:155): say so up
+    front instead of computing something else."""
+    def bad(msg):
+        raise CaraError("cara_amd.cara(): unsupported ViT: " + msg)
+    blocks = list(model.blocks)
+    if not blocks:
+        bad("no blocks")
+    D = model.embed_dim
+    if getattr(model, "dist_token", None) is not None:
+        bad("distilled models (dist_token) are not supported")
+    if not isinstance(getattr(model, "pre_logits", nn.Identity()), nn.Identity):
+        bad("a pre_logits layer is not supported (vit_base_patch16_224_in21k of timm 0.4.12 has none)")
+    pe = model.patch_embed.proj
+    if not isinstance(pe, nn.Conv2d) or pe.kernel_size != pe.stride or pe.kernel_size[0] != pe.kernel_size[1]:
+        bad("patch_embed.proj must be a square Conv2d with kernel == stride")
+    for i, b in enumerate(blocks):
+        for a in ("norm1", "attn", "norm2", "mlp"):
+            if not hasattr(b, a):
+                bad(f"blocks[{i}] has no {a}")
+        at, ml = b.attn, b.mlp
+        if not (_is(at, _vit.Attention) and _is(ml, _vit.Mlp)):
+            bad(f"blocks[{i}].attn / .mlp are not timm-shaped Attention / Mlp modules")
+        if at.qkv.weight.shape != (3 * D, D) or at.qkv.bias is None or at.proj.weight.shape != (D, D) or at.proj.bias is None:
+            bad(f"blocks[{i}].attn: qkv must be Linear(dim, 3 dim) with bias, proj Linear(dim, dim) with bias")
+        if D % at.num_heads or D // at.num_heads != 64:
+            bad("head dim must be 64")
+        if abs(float(at.scale) - 64 ** -0.5) > 1e-9:
+            bad("attention scale must be head_dim ** -0.5")
+        if ml.fc1.weight.shape != (4 * D, D) or ml.fc2.weight.shape != (D, 4 * D) or ml.fc1.bias is None or ml.fc2.bias is None:
+            bad(f"blocks[{i}].mlp: fc1 / fc2 must be Linear(dim, 4 dim) / Linear(4 dim, dim) with bias")
+        if not isinstance(ml.act, nn.GELU) or getattr(ml.act, "approximate", "none") != "none":
+            bad("mlp.act must be the exact (erf) GELU")
+        for dn in ("attn_drop", "proj_drop"):
+            if float(getattr(getattr(at, dn, None), "p", 0.0) or 0.0) != 0.0:
+                bad(f"attn.{dn} must be 0 (the reference's configuration)")
+        if float(getattr(getattr(ml, "drop", None), "p", 0.0) or 0.0) != 0.0:
+            bad("mlp.drop must be 0 (the reference's configuration)")
+        for nm in (b.norm1, b.norm2):
+            if not isinstance(nm, nn.LayerNorm) or nm.weight is None:
+                bad("norm1 / norm2 must be affine LayerNorms")
+    if float(getattr(getattr(model, "pos_drop", None), "p", 0.0) or 0.0) != 0.0:
+        bad("pos_drop must be 0")
+
+
+def _engine_forward(self, x):
+    """Whole-model forward of an adopted (foreign-class) ViT: the fused HIP path instead of the class's eager one."""
+    return self.__dict__["_cara_engine"].forward(x)
 
 
 def set_cara(model: nn.Module, rank: int, scale: float, l_mu: float, l_std: float, _root=None, cp_length: int = 4) -> None:
@@ -174,8 +239,10 @@ def cara(config: Dict[str, Any]) -> th.nn.Module:
     l_mu = config["l_mu"]
     l_std = config["l_std"]
     if not _is(model, _vit.VisionTransformer):
-        raise CaraError("cara_amd.cara() needs a cara_amd.vit.VisionTransformer (timm-named container); "
-                        "build one with cara_amd.create_model(...)")
+        raise CaraError("cara_amd.cara() needs a timm-shaped VisionTransformer (class of that name with patch_embed, cls_token, "
+                        "pos_embed, blocks[i].{norm1, attn.{qkv, proj, num_heads, scale}, norm2, mlp.{fc1, act, fc2}}, norm, head): "
+                        "timm.models.create_model(...) output, or cara_amd.create_model(...)")
+    _check_vit(model)
     if not (1 <= int(rank) <= 64):
         raise CaraError("rank must be in 1..64 (the K-extension is padded to 32 or 64 columns)")
     # optional sixth key, the `cp_length` of image_classification/dim_experiment.py (its `--dims`): order of the QKV
@@ -192,4 +259,16 @@ def cara(config: Dict[str, Any]) -> th.nn.Module:
     set_cara(model, rank, scale, l_mu, l_std, cp_length=cp_length)
     from .engine import CaraEngine
     model.__dict__["_cara_engine"] = CaraEngine(model, rank=int(rank), scale=float(scale), cp_length=cp_length)
+    # optional key: how train mode treats the reference's Dropout(0.1) on the materialised dW (cara.py:35,57,81,92).
+    # "off" (default): factored adapters, no weight-space dropout (fast); "exact": the reference's arithmetic.
+    if type(model) is not _vit.VisionTransformer:
+        # a foreign class (timm's own, or any same-shaped one): its parameters are adopted where they are (the engine
+        # reads them by attribute and converts them to its HBM layout on the first forward); calling the model runs
+        # the fused path, calling a block or a sub-module runs the patched forwards (module-level path)
+        import types
+        model.__dict__["forward"] = types.MethodType(_engine_forward, model)
+    wd = config.get("weight_dropout", "off")
+    if wd not in ("off", "exact"):
+        raise CaraError("config['weight_dropout'] must be 'off' or 'exact'")
+    model._cara_engine.weight_dropout = wd
     return model

@@ -4,9 +4,9 @@ The reference (``/root/reference/image_classification/vtab.py:36-107``) decodes 
 every epoch with 4 DataLoader workers: ``ImageFilelist`` over ``impath label`` lines, ``Resize((224,224),
 bicubic)`` + ``ToTensor`` + ImageNet ``Normalize``, ``DataLoader(batch 64, shuffle, drop_last)`` for
 training and ``DataLoader(batch 256)`` for evaluation.  At 5 000+ images/s per GPU that feed is the
-bottleneck, and a VTAB-1k task is 1 000 training images: 602 MB as fp32.  So the whole split is decoded
-ONCE (same arithmetic: PIL bicubic resize of the RGB image, /255, per-channel normalise) into one
-device-resident tensor, and an epoch is an index permutation plus ``index_select`` on the GPU.  Under
+bottleneck, and a VTAB-1k task is 1 000 training images: 150 MB as resized uint8 pixels.  So the whole split is
+decoded ONCE (same arithmetic: PIL bicubic resize of the RGB image) into one device-resident uint8 tensor, and an epoch
+is an index permutation plus ``index_select`` and the /255 + per-channel normalise of the drawn batch on the GPU.  Under
 data parallelism every rank holds the split and takes the rank-strided part of the same epoch-seeded
 permutation (``dist.epoch_shard``), which is ``drop_last`` per rank like the reference loader.
 
@@ -49,40 +49,60 @@ def read_filelist(flist: str) -> List[Tuple[str, int]]:
     return out
 
 
-def decode_image(path: str, size: int = 224) -> torch.Tensor:
-    """vtab.py:36-37 + the transform of :91-94: RGB -> bicubic resize to size x size (PIL semantics, as
-    torchvision applies to PIL images) -> float CHW in [0,1] -> (x - mean) / std.  fp32 [3,size,size]."""
+def decode_image_u8(path: str, size: int = 224) -> torch.Tensor:
+    """vtab.py:36-37 + the Resize of :91: RGB -> bicubic resize to size x size (PIL semantics, as torchvision applies
+    to PIL images).  uint8 [3,size,size]."""
     from PIL import Image
     with Image.open(path) as im:
         im = im.convert("RGB").resize((size, size), Image.BICUBIC)
         a = np.asarray(im, dtype=np.uint8)
-    x = torch.from_numpy(a.copy()).permute(2, 0, 1).to(torch.float32).div_(255.0)
-    mean = torch.tensor(IMAGENET_MEAN).view(3, 1, 1)
-    std = torch.tensor(IMAGENET_STD).view(3, 1, 1)
-    return x.sub_(mean).div_(std)
+    return torch.from_numpy(a.copy()).permute(2, 0, 1).contiguous()
+
+
+def normalize_u8(x: torch.Tensor) -> torch.Tensor:
+    """ToTensor + Normalize of vtab.py:92-94 on uint8 [..., 3, H, W] (any device): /255, (x - mean) / std, fp32.
+    The same fp32 operations in the same order on the CPU and on the GPU (equal to within one ulp: the GPU's fp32
+    division is not correctly rounded in every case)."""
+    mean = torch.tensor(IMAGENET_MEAN, device=x.device).view(3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, device=x.device).view(3, 1, 1)
+    return x.to(torch.float32).div_(255.0).sub_(mean).div_(std)
+
+
+def decode_image(path: str, size: int = 224) -> torch.Tensor:
+    """The whole transform of vtab.py:91-94 for one file: fp32 [3,size,size]."""
+    return normalize_u8(decode_image_u8(path, size))
 
 
 class ResidentSplit:
-    """One file list decoded once and kept on ``device``: ``images`` fp32 [N,3,size,size], ``labels``
-    int64 [N].  ``len()`` and ``[i]`` behave like the reference's ``ImageFilelist``."""
+    """One file list decoded once and kept on ``device`` as the resized uint8 pixels ``pixels`` [N,3,size,size]
+    (150 KB per image: the 73k-image dsprites test split is 11 GB, not 44) plus ``labels`` int64 [N]; a batch is
+    normalised to fp32 when it is drawn.  The split is decoded and uploaded in chunks, so the host never holds more
+    than one chunk.  ``len()`` and ``[i]`` behave like the reference's ``ImageFilelist``."""
 
-    def __init__(self, root: str, flist: str, device="cuda", size: int = 224, workers: int = 8,
-                 dtype: torch.dtype = torch.float32):
+    def __init__(self, root: str, flist: str, device="cuda", size: int = 224, workers: int = 8, chunk: int = 2048):
         self.root, self.imlist = root, read_filelist(flist)
         paths = [os.path.join(root, p) for p, _ in self.imlist]
-        if workers > 1 and len(paths) > 1:
-            with ThreadPoolExecutor(max_workers=workers) as ex:   # PIL releases the GIL while decoding/resizing
-                decoded = list(ex.map(lambda p: decode_image(p, size), paths))
-        else:
-            decoded = [decode_image(p, size) for p in paths]
-        self.images = (torch.stack(decoded) if decoded else torch.empty(0, 3, size, size)).to(device=device, dtype=dtype)
+        self.pixels = torch.empty(len(paths), 3, size, size, dtype=torch.uint8, device=device)
+        for c0 in range(0, len(paths), chunk):
+            part = paths[c0:c0 + chunk]
+            if workers > 1 and len(part) > 1:
+                with ThreadPoolExecutor(max_workers=workers) as ex:   # PIL releases the GIL while decoding/resizing
+                    decoded = list(ex.map(lambda p: decode_image_u8(p, size), part))
+            else:
+                decoded = [decode_image_u8(p, size) for p in part]
+            self.pixels[c0:c0 + len(part)].copy_(torch.stack(decoded))
         self.labels = torch.tensor([l for _, l in self.imlist], dtype=torch.int64, device=device)
+
+    @property
+    def images(self) -> torch.Tensor:
+        """The whole split normalised, fp32 [N,3,size,size] (materialised: for small splits and tests)."""
+        return normalize_u8(self.pixels)
 
     def __len__(self) -> int:
         return len(self.imlist)
 
     def __getitem__(self, i: int):
-        return self.images[i], int(self.labels[i])
+        return normalize_u8(self.pixels[i]), int(self.labels[i])
 
     # ---- loaders -----------------------------------------------------------------------------------
     def train_batches(self, batch_size: int = 64, seed: int = 0, rank: Optional[int] = None,
@@ -95,15 +115,15 @@ class ResidentSplit:
 
         def epoch_iter(epoch: int):
             for idx in D.epoch_shard(len(self), epoch, rank, world, batch_size, seed):
-                idx = idx.to(self.images.device)
-                yield self.images.index_select(0, idx), self.labels.index_select(0, idx)
+                idx = idx.to(self.pixels.device)
+                yield normalize_u8(self.pixels.index_select(0, idx)), self.labels.index_select(0, idx)
         return epoch_iter
 
     def eval_batches(self, batch_size: int = 256) -> Callable[[], Iterator[Tuple[torch.Tensor, torch.Tensor]]]:
         """In file order, last batch partial (vtab.py:96-100: shuffle False, no drop_last)."""
         def it():
             for i in range(0, len(self), batch_size):
-                yield self.images[i:i + batch_size], self.labels[i:i + batch_size]
+                yield normalize_u8(self.pixels[i:i + batch_size]), self.labels[i:i + batch_size]
         return it
 
 

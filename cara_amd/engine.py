@@ -84,9 +84,14 @@ class CaraEngine:
         return tuple((p.data_ptr(), p._version) for p in self._backbone_params(model))
 
     def _ingest(self, model, dev):
+        with torch.cuda.device(dev):
+            self._ingest_on(model, dev)
+
+    def _ingest_on(self, model, dev):
         """One-time (and after any in-place change / load_state_dict): frozen fp32 parameters ->
         bf16 [depth, out, in] stacks plus transposed copies for the dX GEMMs, fp32 vectors stacked."""
         lib = L.lib()
+        stream = lambda: L.stream(dev)   # noqa: E731  (everything below enqueues on dev's current stream)
         blocks = list(model.blocks)
         depth, D = len(blocks), model.embed_dim
 
@@ -146,7 +151,8 @@ class CaraEngine:
                           self.cp_length)
             # (sized with the exact-mode regions when that mode is selected; a call with wd_exact = 0 on the same
             # workspace -- eval -- simply does not touch them)
-            shape = L.VitShape(B, img, pe.patch_size[0], model.in_chans, (img // pe.patch_size[0]) ** 2 + 1, ncls,
+            patch = pe.proj.kernel_size[0]
+            shape = L.VitShape(B, img, patch, pe.proj.in_channels, (img // patch) ** 2 + 1, ncls,
                                float(model.norm.eps), 1 if exact else 0, float(self.weight_dropout_p), 0)
             nbytes = L.lib().cara_vit_workspace_bytes(C.byref(geom), C.byref(shape))
             if nbytes == 0:
@@ -168,10 +174,21 @@ class CaraEngine:
         if images.ndim != 4 or images.shape[2] != images.shape[3]:
             raise CaraError("images must be [B, C, H, H]")
         images = images.contiguous().float()
-        st = self._state(model, images.shape[0], images.shape[2], images.device)
+        dev = images.device
+        with torch.cuda.device(dev):   # the library enqueues on the stream it is given and launches on the current device
+            return self._run_forward_on(model, images, droppath, head_w, head_b, cp, need_backward, dev)
+
+    def _run_forward_on(self, model, images, droppath, head_w, head_b, cp, need_backward, dev):
+        st = self._state(model, images.shape[0], images.shape[2], dev)
         # weight-space dropout is a train-mode thing (nn.Dropout is the identity in eval); the backward of this
         # forward reads the same struct, i.e. the same seed, and regenerates the masks
         use_exact = self.weight_dropout == "exact" and model.training and self.weight_dropout_p > 0
+        if model.training and not use_exact and not self._warned_wd:
+            self._warned_wd = True
+            import warnings
+            warnings.warn("cara_amd: train-mode forwards run the FACTORED adapters without the reference's Dropout(0.1) on the "
+                          "materialised dW (cara.py:35,57,81,92); set model._cara_engine.weight_dropout = 'exact' (or the "
+                          "'weight_dropout' key of cara()'s config) for the reference's train-mode arithmetic", stacklevel=3)
         st["shape"].wd_exact = 1 if use_exact else 0
         st["shape"].wd_p = float(self.weight_dropout_p)
         if use_exact:
@@ -183,7 +200,7 @@ class CaraEngine:
         logits = torch.empty_like(st["logits"])
         check(L.lib().cara_vit_forward(C.byref(st["geom"]), C.byref(st["shape"]), C.byref(self._ingested[1]), C.byref(cps),
                                        ptr(head_w.detach().contiguous()), ptr(head_b.detach().contiguous()), ptr(images),
-                                       ptr(droppath), ptr(st["ws"]), ptr(logits), stream()), "cara_vit_forward")
+                                       ptr(droppath), ptr(st["ws"]), ptr(logits), stream(dev)), "cara_vit_forward")
         self._fwd_serial += 1
         self._bwd_ready = self._fwd_serial if need_backward else -1
         return logits
@@ -199,12 +216,17 @@ class CaraEngine:
     def _run_backward(self, dlogits, droppath, head_w, cp):
         model = self._model()
         st = self._ws[self._last_key]
-        g = self._grad_buffers(model, dlogits.device)
+        dev = dlogits.device
+        with torch.cuda.device(dev):
+            return self._run_backward_on(model, st, dlogits, droppath, head_w, cp, dev)
+
+    def _run_backward_on(self, model, st, dlogits, droppath, head_w, cp, dev):
+        g = self._grad_buffers(model, dev)
         cps = self._cp_ptrs([t.detach().contiguous() for t in cp])
         gps = L.cp_ptrs(self.cp_fields, [g[n] for n in self.cp_fields])
         check(L.lib().cara_vit_backward(C.byref(st["geom"]), C.byref(st["shape"]), C.byref(self._ingested[1]), C.byref(cps),
                                         ptr(head_w.detach().contiguous()), ptr(dlogits.contiguous().float()), ptr(droppath),
-                                        ptr(st["ws"]), C.byref(gps), ptr(g["head_w"]), ptr(g["head_b"]), stream()),
+                                        ptr(st["ws"]), C.byref(gps), ptr(g["head_w"]), ptr(g["head_b"]), stream(dev)),
               "cara_vit_backward")
         self._bwd_ready = -1
         return g
@@ -262,6 +284,22 @@ class CaraEngine:
         model = self._model()
         return [getattr(model, "CP_" + n) for n in self.cp_fields] + [model.head.weight, model.head.bias]
 
+    def _apply_gradients(self, optimizer=None, group=None):
+        """Tail of a train step, shared by train_step and the CPU multi-process tests: bind ``p.grad`` of every
+        trainable parameter to its view of the flat buffer, ONE all-reduce (mean) of that buffer when the group
+        has more than one rank, ``optimizer.step()``."""
+        model = self._model()
+        g = self._grad_views
+        cp = [getattr(model, "CP_" + n) for n in self.cp_fields]
+        for n, p in zip(list(self.cp_fields) + ["head_w", "head_b"], cp + [model.head.weight, model.head.bias]):
+            if p.grad is None or p.grad.data_ptr() != g[n].data_ptr():
+                p.grad = g[n]
+        # the only data-path collective of a step: one RCCL all-reduce over xGMI of the flat buffer
+        from .dist import allreduce_mean_
+        allreduce_mean_(self._flat_grad, group)
+        if optimizer is not None:
+            optimizer.step()
+
     def train_step(self, images, labels, optimizer=None, group=None, droppath: Optional[torch.Tensor] = None):
         """One fine-tuning step of vit_cp.py:45-50 without autograd bookkeeping:
         forward -> mean cross-entropy -> backward straight into ONE flat fp32 gradient buffer
@@ -273,11 +311,13 @@ class CaraEngine:
         if not images.is_cuda:
             raise CaraError("cara_amd runs on the GPU only (no CPU fallback)")
         dev = images.device
-        if droppath is None:
-            droppath = self.draw_droppath(model, images.shape[0], dev)
+        if labels.dtype != torch.int64 or labels.device != dev or labels.ndim != 1 or labels.shape[0] != images.shape[0]:
+            raise CaraError("labels must be an int64 [batch] tensor on the images' device (the kernel reads 8-byte class indices)")
         cp = [getattr(model, "CP_" + n) for n in self.cp_fields]
         hw, hb = model.head.weight, model.head.bias
-        with torch.no_grad():
+        with torch.no_grad(), torch.cuda.device(dev):
+            if droppath is None:
+                droppath = self.draw_droppath(model, images.shape[0], dev)
             logits = self._run_forward(images, droppath, hw, hb, cp)
             B, ncls = logits.shape
             if self.__dict__.get("_loss_buf") is None or self._loss_buf.numel() != 1 + B or self._loss_buf.device != dev:
@@ -286,16 +326,9 @@ class CaraEngine:
             if self._dlogits.shape != logits.shape:
                 self._dlogits = torch.empty(B, ncls, device=dev)
             check(L.lib().cara_cross_entropy(ptr(logits), ptr(labels.contiguous()), ptr(self._loss_buf), ptr(self._dlogits),
-                                             B, ncls, stream()), "cara_cross_entropy")
-            g = self._run_backward(self._dlogits, droppath, hw, cp)
-            for n, p in zip(list(self.cp_fields) + ["head_w", "head_b"], cp + [hw, hb]):
-                if p.grad is None or p.grad.data_ptr() != g[n].data_ptr():
-                    p.grad = g[n]
-            # the only data-path collective of a step: one RCCL all-reduce over xGMI of the flat buffer
-            from .dist import allreduce_mean_
-            allreduce_mean_(self._flat_grad, group)
-            if optimizer is not None:
-                optimizer.step()
+                                             B, ncls, stream(dev)), "cara_cross_entropy")
+            self._run_backward(self._dlogits, droppath, hw, cp)
+            self._apply_gradients(optimizer, group)
         return self._loss_buf[0]
 
     # module-level entries (cara.cp_attn / cara.cp_mlp): the reference's patched forwards
@@ -311,14 +344,19 @@ class CaraEngine:
             raise CaraError("cara_amd runs on the GPU only (no CPU fallback)")
         if x.ndim != 3 or x.shape[2] != model.embed_dim or x.shape[1] > 608:
             raise CaraError("module-level forward expects x of shape [B, N <= 608, embed_dim]")
+        if self.weight_dropout == "exact" and model.training:
+            raise CaraError("the module-level forwards (Attention.forward / Mlp.forward called on their own) run the factored "
+                            "adapters only: with weight_dropout = 'exact' in train mode call the whole model, or switch to eval()")
         return model, [getattr(model, "CP_" + n) for n in self.cp_fields]
 
     def attn_forward(self, child, x):
         from .modules import AttnFn
         model, cp = self._module_args(x)
-        return AttnFn.apply(self, child, x, *cp)
+        with torch.cuda.device(x.device):
+            return AttnFn.apply(self, child, x, *cp)
 
     def mlp_forward(self, child, x):
         from .modules import MlpFn
         model, cp = self._module_args(x)
-        return MlpFn.apply(self, child, x, *cp)
+        with torch.cuda.device(x.device):
+            return MlpFn.apply(self, child, x, *cp)

@@ -73,13 +73,48 @@ def evaluate(model, batches: Iterable) -> float:
     return hit / max(tot, 1)
 
 
+def checkpoint_name(dataset: str, acc: float, seed: int, directory: str = ".") -> str:
+    """File name of the reference's best-accuracy checkpoint (vit_cp.py:65)."""
+    import os
+    return os.path.join(directory, f"vit_{dataset}_{round(acc, 5)}_seed_{seed}.pt")
+
+
+def save_checkpoint(model, path: str) -> None:
+    """vit_cp.py:66: ``th.save(vit.state_dict(), name)`` -- the WHOLE state dict (frozen backbone, 12 CP_* tensors,
+    head), keys of timm 0.4.12, tensors on the CPU so that the file loads anywhere."""
+    torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, path)
+
+
+def load_checkpoint(model, path: str) -> None:
+    """vit_cp.py:170 (``--evaluate``): ``vit.load_state_dict(th.load(path))``, strict, after ``cara()`` and
+    ``reset_classifier()``.  The engine notices the in-place change of the backbone parameters and re-ingests them."""
+    sd = torch.load(path, map_location="cpu")
+    model.load_state_dict(sd)
+
+
+def evaluate_only(model, path: str, test_batches: Iterable) -> float:
+    """The ``--evaluate`` flow of vit_cp.py:168-173: load, test, return the accuracy."""
+    load_checkpoint(model, path)
+    return evaluate(model, test_batches)
+
+
 def fit(model, train_batches: Callable[[int], Iterable], test_batches: Optional[Callable[[], Iterable]] = None,
         epochs: int = 100, lr: float = 1e-3, weight_decay: float = 1e-4, group=None, reference_eval_quirk: bool = True,
-        on_eval: Optional[Callable[[int, float], None]] = None):
+        on_eval: Optional[Callable[[int, float], None]] = None, save_best: Optional[dict] = None, seed: int = 0):
     """``train_batches(epoch)`` yields (images, labels) already on the device (per-rank shard under
-    data parallelism).  Returns (best accuracy, optimizer)."""
+    data parallelism).  Returns (best accuracy, optimizer).
+
+    ``save_best = {"dataset": name, "seed": s, "dir": path}``: keep the state dict of the best evaluation so far on
+    disk as the reference does (vit_cp.py:61-66: save on improvement, delete the previous file); the path of the
+    file is left in ``save_best["path"]``.  Rank 0 only under data parallelism.
+    Data parallel (``torch.distributed`` initialised, more than one rank in ``group``): the trainable parameters are
+    broadcast from rank 0 once, and every rank draws its own DropPath / weight-dropout masks (``seed``, rank)."""
+    from . import dist as cdist
     model.train()
     params = trainable_parameters(model)
+    if cdist.world_size(group) > 1:
+        cdist.broadcast_parameters(params, group=group)
+    model._cara_engine.seed_rank_streams(seed, cdist.get_rank(group))
     try:
         opt = torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, fused=True)
     except Exception:
@@ -97,6 +132,14 @@ def fit(model, train_batches: Callable[[int], Iterable], test_batches: Optional[
                 sched = None
             if test_batches is not None:
                 acc = evaluate(model, test_batches())
+                if acc > best and save_best is not None and cdist.get_rank(group) == 0:
+                    import os
+                    old = save_best.get("path")
+                    if old and os.path.exists(old):
+                        os.remove(old)
+                    save_best["path"] = checkpoint_name(save_best.get("dataset", "task"), acc, save_best.get("seed", seed),
+                                                        save_best.get("dir", "."))
+                    save_checkpoint(model, save_best["path"])
                 best = max(best, acc)
                 if on_eval:
                     on_eval(epoch, acc)

@@ -509,8 +509,12 @@ def _attn_factored(xn, w, p, fac, num_heads, scale, r):
     qkv = r(adapter_linear(xn, w[p + "attn.qkv.weight"], w[p + "attn.qkv.bias"], fac["qkv"], r))
     qkv = qkv.reshape(B, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    a = ((q @ k.transpose(-2, -1)) * scale).softmax(dim=-1)
-    y = r((r(a) @ v).transpose(1, 2).reshape(B, N, C))
+    # softmax(S) V as the device evaluates it (cara_amd/csrc/attention.hip): P = exp(S - rowmax) is what gets rounded to
+    # bf16 as the MFMA operand, the row sum is taken of the unrounded fp32 P, and the division comes last.  With r = identity
+    # this is softmax(S) V.
+    sc = (q @ k.transpose(-2, -1)) * scale
+    pe = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
+    y = r(((r(pe) @ v) / pe.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B, N, C))
     return adapter_linear(y, w[p + "attn.proj.weight"], w[p + "attn.proj.bias"], fac["proj"], r)
 
 

@@ -6,6 +6,7 @@ import re
 
 import numpy as np
 import pytest
+import torch
 import torch as th
 
 from cara_amd import CaraError, cara, create_model
@@ -149,3 +150,72 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(lib, s), s
     assert lib.cara_abi_version() == 2 and lib.cara_build_arch() == b"gfx950"
+
+
+# ---- drop-in on a FOREIGN timm-shaped model (vit_cp.py:13-15,155 builds it with timm.models.create_model) --------
+def test_foreign_timm_shaped_vit_is_accepted_by_structure():
+    """cara() dispatches on structure, not on this package's classes: the oracle's restatement of timm's
+    VisionTransformer / Attention / Mlp (another module, same names and attributes, eager forwards) gets the same 12
+    parameters, index walk and rebound forwards as the package's own container; its whole-model forward is rebound
+    to the fused path (which refuses CPU tensors: no fallback)."""
+    from oracle import cara_oracle as O
+    from cara_amd import cara
+    from cara_amd._lib import CaraError
+    torch.manual_seed(0)
+    vit = O.create_vit("vit_base_patch16_224_in21k", drop_path_rate=0.1, depth=3, num_classes=7)
+    assert type(vit).__module__.startswith("oracle")
+    out = cara({"model": vit, "rank": 8, "scale": 0.5, "l_mu": 1.0, "l_std": 0.0})
+    assert out is vit
+    names = [n for n, _ in vit.named_parameters() if n.startswith("CP_")]
+    assert names == ["CP_A1", "CP_A2", "CP_A3", "CP_A4", "CP_P1", "CP_P2", "CP_P3", "CP_R1", "CP_R2", "CP_bias1", "CP_bias2", "CP_bias3"]
+    assert vit.CP_A1.shape == (9, 8) and vit.CP_P1.shape == (27, 8) and vit.idx == 27 and vit.attn_idx == 9
+    for l, blk in enumerate(vit.blocks):
+        assert (blk.attn.idx, blk.attn.attn_idx, blk.mlp.idx) == (9 * l, 3 * l, 9 * l + 1)
+        assert blk.attn.s == 0.5 and blk.mlp.dim == 8 and "forward" in blk.attn.__dict__ and "forward" in blk.mlp.__dict__
+    assert "forward" in vit.__dict__ and hasattr(vit, "_cara_engine")
+    with pytest.raises(CaraError):
+        vit(torch.zeros(1, 3, 224, 224))          # CPU tensor: the fused path has no fallback
+    vit.reset_classifier(5)                       # vit_cp.py:166, after cara()
+    assert vit.head.out_features == 5
+
+
+def test_unsupported_vit_is_refused_with_a_reason():
+    from oracle import cara_oracle as O
+    from cara_amd import cara
+    from cara_amd._lib import CaraError
+    vit = O.create_vit("vit_base_patch16_224_in21k", depth=1, num_classes=3)
+    vit.blocks[0].attn.qkv = torch.nn.Linear(768, 2304, bias=False)
+    with pytest.raises(CaraError, match="qkv"):
+        cara({"model": vit, "rank": 8, "scale": 1.0, "l_mu": 1.0, "l_std": 0.0})
+    with pytest.raises(CaraError, match="timm-shaped"):
+        cara({"model": torch.nn.Linear(3, 3), "rank": 8, "scale": 1.0, "l_mu": 1.0, "l_std": 0.0})
+
+
+def test_rank_streams_give_every_rank_its_own_masks():
+    """identical parameters, per-rank random streams.  Two replicas built from the same seed hold equal
+    parameters; after seed_rank_streams(seed, rank) they draw different DropPath masks, reproducibly."""
+    from cara_amd import cara, create_model
+
+    def replica(rank):
+        torch.manual_seed(14)
+        m = cara({"model": create_model("vit_base_patch16_224_in21k", depth=4, num_classes=5, drop_path_rate=0.5),
+                  "rank": 4, "scale": 0.1, "l_mu": 1.5, "l_std": 0.1}).train()
+        m._cara_engine.seed_rank_streams(2024, rank)
+        return m
+    a, b, a2 = replica(0), replica(1), replica(0)
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p, q), n
+    cpu = torch.device("cpu")
+    da, db, da2 = (m._cara_engine.draw_droppath(m, 64, cpu) for m in (a, b, a2))
+    assert da.shape == (4, 2, 64) and not torch.equal(da, db) and torch.equal(da, da2)
+    assert not torch.equal(a._cara_engine.draw_droppath(a, 64, cpu), da)          # the stream advances
+
+
+def test_weight_dropout_is_an_explicit_choice():
+    from cara_amd import cara, create_model
+    from cara_amd._lib import CaraError
+    mk = lambda **kw: cara({"model": create_model("vit_base_patch16_224_in21k", depth=1, num_classes=3), "rank": 4,  # noqa: E731
+                            "scale": 1.0, "l_mu": 1.0, "l_std": 0.0, **kw})
+    assert mk()._cara_engine.weight_dropout == "off" and mk(weight_dropout="exact")._cara_engine.weight_dropout == "exact"
+    with pytest.raises(CaraError):
+        mk(weight_dropout="maybe")

@@ -2,23 +2,18 @@
 mirror of the reference API) against (a) vectors recorded from the reference's own cara.py and
 (b) the CPU oracle on the same seeded inputs.
 
-Tolerances.  The device path rounds GEMM operands and stored activations to bf16 (fp32
-accumulate, fp32 residual stream, fp32 softmax/LayerNorm statistics); the reference is fp32.
-BASELINE.json asks for 1e-3 relative on bf16 logits.  With 8-bit-mantissa operands that is below
-the rounding floor: the oracle evaluated with the SAME bf16 rounding points (``bf16_sim``) is
-itself 6.6e-3 (depth 2, golden case) away from the fp32 reference, and two implementations that
-are not bitwise identical decorrelate within a few rounding stages, so they sit ~one floor apart
-too.  What is asserted is therefore: (1) device-vs-fp32-reference error <= 1.5 x the error the
-rounding model predicts (the kernels add no error of their own), (2) an absolute cap of 1.5e-2
-(SURVEY.md section 7 H3 measured 9.5e-3 for plain autocast), (3) exact class indices wherever
-the fp32 top-2 margin exceeds the noise.  Measured values are printed (-s) and recorded in
-DESIGN.md.
+Tolerances: tests/tolerances.py states the contract once (logits <= 1.15 x the error of the oracle evaluated with the
+same bf16 rounding points and <= 1e-2; every CP gradient <= 2.5e-2; one block vs the bf16-rounded oracle <= 2.5e-3;
+exact class indices).  north_star's 1e-3 on the logits is below the rounding floor of bf16 MFMA operands (DESIGN.md
+section 2): it is NOT met, and nothing here pretends otherwise.  Measured values are printed (-s) and recorded in DESIGN.md.
 """
 import os
 
 import numpy as np
 import pytest
 import torch
+
+from tests import tolerances as T
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -71,8 +66,8 @@ def test_depth2_against_reference_vectors():
     r_ref, r_sim = rel(logits, ref), rel(logits, sim)
     print(f"depth2 logits rel-L2: vs fp32 reference {r_ref:.2e}, vs bf16-rounded oracle {r_sim:.2e}")
     r_model = rel(sim, ref)   # what bf16 rounding at the same points costs, per the oracle
-    assert r_ref < 1.5e-2 and r_ref < 1.5 * max(r_model, 4e-3), (r_ref, r_model)
-    assert r_sim < 1.5 * max(r_model, 4e-3), (r_sim, r_model)
+    assert T.logits_ok(r_ref, r_model), (r_ref, r_model)
+    assert r_sim < T.LOGITS_VS_MODEL * max(r_model, T.MODEL_FLOOR), (r_sim, r_model)
     assert torch.equal(logits.argmax(1).cpu(), ref.argmax(1))
     torch.logsumexp(logits, dim=1).sum().backward()
     worst = 0.0
@@ -83,7 +78,7 @@ def test_depth2_against_reference_vectors():
             gr = gr[:g.shape[0]]
         r = rel(g, gr)
         worst = max(worst, r)
-        assert r < 3e-2, (n, r)     # bf16 activations/gradients vs fp32 autograd of the dense form
+        assert r < T.CP_GRAD, (n, r)     # bf16 activations/gradients vs fp32 autograd of the dense form
     print(f"depth2 CP-gradient worst rel-L2 vs reference: {worst:.2e}")
 
 
@@ -124,13 +119,13 @@ def test_exact_weight_dropout_mode_against_oracle():
         other = m(x.to(DEV))
     print(f"exact weight dropout: logits rel-L2 vs oracle with the same masks {r:.2e}; masks move the logits by "
           f"{rel(rlogits, nodrop):.2e}; another seed by {rel(other, rlogits):.2e}; loss {loss.item():.4f} vs {rloss.item():.4f}")
-    assert r < 1.5e-2 and rel(rlogits, nodrop) > 5 * r and rel(other, rlogits) > 5 * r
+    assert r < T.LOGITS_ABS and rel(rlogits, nodrop) > 5 * r and rel(other, rlogits) > 5 * r
     assert abs(loss.item() - rloss.item()) < 2e-2 * max(1.0, abs(rloss.item()))
     worst = 0.0
     for n in O.CP_NAMES:
         rr = rel(getattr(m, n).grad, gref[n])
         worst = max(worst, rr)
-        assert rr < 4e-2, (n, rr)
+        assert rr < T.CP_GRAD, (n, rr)
     print(f"exact weight dropout: worst CP-gradient rel-L2 vs fp32 autograd with the same masks {worst:.2e}")
     # eval is the factored path whatever the mode: bitwise the same logits as an engine with weight_dropout off
     m.eval()
@@ -162,7 +157,7 @@ def test_vit_large_384_against_oracle():
         sim = O.vit_cara_forward(x, w, cp, s=0.1, depth=24, num_heads=16, factored=True, bf16_sim=True)
     r_ref, r_sim, r_model = rel(logits, ref), rel(logits, sim), rel(sim, ref)
     print(f"ViT-L/16@384 logits rel-L2: vs fp32 oracle {r_ref:.2e}, vs bf16-rounded oracle {r_sim:.2e} (rounding model {r_model:.2e})")
-    assert r_ref < 2e-2 and r_ref < 1.5 * max(r_model, 4e-3), (r_ref, r_model)
+    assert T.logits_ok(r_ref, r_model), (r_ref, r_model)
     top2 = ref.topk(2, dim=1).values
     safe = (top2[:, 0] - top2[:, 1]) > 4 * (logits.cpu() - ref).abs().max()
     assert torch.equal(logits.argmax(1).cpu()[safe], ref.argmax(1)[safe])
@@ -173,9 +168,9 @@ def test_vit_large_384_against_oracle():
     for n in O.CP_NAMES:
         r = rel(getattr(m, n).grad, gref[n])
         worst = max(worst, r)
-        assert r < 6e-2, (n, r)
+        assert r < T.CP_GRAD, (n, r)
     print(f"ViT-L/16@384 worst CP-gradient rel-L2 vs fp32 autograd of the as-written form: {worst:.2e}")
-    assert rel(m.head.weight.grad, gref["head.weight"]) < 3e-2
+    assert rel(m.head.weight.grad, gref["head.weight"]) < T.CP_GRAD
 
 
 def test_depth12_headline_shapes_against_oracle():
@@ -193,8 +188,8 @@ def test_depth12_headline_shapes_against_oracle():
     r_ref, r_sim = rel(logits, ref), rel(logits, sim)
     print(f"depth12 logits rel-L2: vs fp32 oracle {r_ref:.2e}, vs bf16-rounded oracle {r_sim:.2e}")
     r_model = rel(sim, ref)
-    assert r_ref < 1.5e-2 and r_ref < 1.5 * max(r_model, 4e-3), (r_ref, r_model)
-    assert r_sim < 1.5 * max(r_model, 4e-3), (r_sim, r_model)
+    assert T.logits_ok(r_ref, r_model), (r_ref, r_model)
+    assert r_sim < T.LOGITS_VS_MODEL * max(r_model, T.MODEL_FLOOR), (r_sim, r_model)
     top2 = ref.topk(2, dim=1).values
     safe = (top2[:, 0] - top2[:, 1]) > 4 * (logits.cpu() - ref).abs().max()
     assert torch.equal(logits.argmax(1).cpu()[safe], ref.argmax(1)[safe])
@@ -205,9 +200,9 @@ def test_depth12_headline_shapes_against_oracle():
     _, _, gref = O.train_step_as_written(x, y, w, cp, head, s=0.1)
     for n in O.CP_NAMES:
         r = rel(getattr(m, n).grad, gref[n][:getattr(m, n).shape[0]])
-        assert r < 5e-2, (n, r)
-    assert rel(m.head.weight.grad, gref["head.weight"]) < 2e-2
-    assert rel(m.head.bias.grad, gref["head.bias"]) < 2e-2
+        assert r < T.CP_GRAD, (n, r)
+    assert rel(m.head.weight.grad, gref["head.weight"]) < T.CP_GRAD
+    assert rel(m.head.bias.grad, gref["head.bias"]) < T.CP_GRAD
 
 
 def test_zero_init_known_answer_bitwise():
@@ -271,14 +266,14 @@ def test_other_orders_of_the_qkv_tensorisation_against_oracle(cp_length):
         sim = O.vit_cara_forward(x, w, cpo, s=0.1, depth=depth, factored=True, bf16_sim=True)
     e = rel(logits.detach(), rlogits)
     print(f"cp_length {cp_length}: logits rel {e:.2e} (bf16 model {rel(sim, rlogits):.2e})")
-    assert e < 1.5 * max(rel(sim, rlogits), 4e-3) and e < 1.5e-2
+    assert T.logits_ok(e, rel(sim, rlogits)), (e, rel(sim, rlogits))
     for k in cpo:
         gk = getattr(m, k).grad
         assert gk is not None and torch.isfinite(gk).all(), k
         if rg[k].norm() > 0:
             ek = rel(gk, rg[k])
             print(f"  d{k}: rel {ek:.2e}")
-            assert ek < 6e-2, (k, ek)
+            assert ek < T.CP_GRAD, (k, ek)
 
 
 def test_drop_path_masks_and_train_mode():
@@ -294,7 +289,7 @@ def test_drop_path_masks_and_train_mode():
         sim = O.vit_cara_forward(x, w, cp, s=0.1, depth=3, drop_path_keep=keep, factored=True, bf16_sim=True)
     with torch.no_grad():
         ref = O.vit_cara_forward(x, w, cp, s=0.1, depth=3, drop_path_keep=keep)
-    assert rel(logits, ref) < 1.5 * max(rel(sim, ref), 4e-3) and rel(logits, ref) < 1.5e-2
+    assert T.logits_ok(rel(logits, ref), rel(sim, ref))
     # a wrong mask moves the logits by far more than the rounding floor
     with torch.no_grad():
         wrong = O.vit_cara_forward(x, w, cp, s=0.1, depth=3)
@@ -305,42 +300,6 @@ def test_drop_path_masks_and_train_mode():
     assert all(min(abs(v), abs(v - 1 / 0.9)) < 1e-6 for v in torch.unique(dp[2]).tolist())
     torch.logsumexp(logits, 1).sum().backward()
     assert all(torch.isfinite(getattr(m, n).grad).all() for n in O.CP_NAMES)
-
-
-def test_gradients_finite_difference_direction():
-    """Directional derivative of the loss along a random CP direction vs the analytic gradient
-    (device path only; catches sign/scale errors independently of the oracle)."""
-    from oracle import cara_oracle as O
-    w = O.synthetic_backbone(depth=2)
-    cp = O.synthetic_cp(rank=16)
-    x, y = O.synthetic_batch(batch=16)   # the mean over more samples averages the forward noise down
-    m = build(w, cp, 16, 1.0, 2, 224).eval()
-    xd, yd = x.to(DEV), y.to(DEV)
-    loss = torch.nn.functional.cross_entropy(m(xd), yd)
-    loss.backward()
-    g = torch.Generator().manual_seed(5)
-    num, ana = 0.0, 0.0
-    dirs = {n: torch.randn(getattr(m, n).shape, generator=g).to(DEV) for n in ("CP_A2", "CP_P2", "CP_P1", "CP_R2")}
-    ana = sum((getattr(m, n).grad * d).sum().item() for n, d in dirs.items())
-    def central(eps):
-        vals = []
-        for sgn in (1, -1):
-            with torch.no_grad():
-                for n, d in dirs.items():
-                    getattr(m, n).add_(sgn * eps * d)
-                vals.append(torch.nn.functional.cross_entropy(m(xd), yd).item())
-                for n, d in dirs.items():
-                    getattr(m, n).sub_(sgn * eps * d)
-        return (vals[0] - vals[1]) / (2 * eps)
-
-    # A coarse check by construction: along a random direction of this size (s = 1) the loss is strongly curved
-    # (the central difference moves by 15 % between eps = 2e-2 and 4e-2) and below 1e-2 the bf16 forward noise
-    # (~1e-3 per loss value) takes over, so no step size gives better than ~10 %.  It catches what it is for --
-    # sign and factor-of-two errors -- independently of the oracle; the tight check of every CP gradient is the
-    # comparison with fp32 autograd of the as-written algorithm in the tests above.
-    d4, d2 = central(4e-2), central(2e-2)
-    print(f"directional derivative: central differences {d4:.4f} (eps 4e-2), {d2:.4f} (2e-2); analytic {ana:.4f}")
-    assert abs(d2 - ana) <= 0.25 * abs(ana) + 1e-3 and abs(d4 - ana) <= 0.35 * abs(ana) + 1e-3, (d4, d2, ana)
 
 
 def test_module_level_forwards_against_reference_vectors():
@@ -442,7 +401,7 @@ def test_baseline_configs_rank_variants(rank, batch):
         sim = O.vit_cara_forward(x, w, cp, s=0.1, factored=True, bf16_sim=True)
     r_ref, r_model = rel(logits, ref), rel(sim, ref)
     print(f"rank {rank} bs {batch}: logits rel-L2 vs fp32 oracle {r_ref:.2e} (rounding model {r_model:.2e})")
-    assert r_ref < 1.5e-2 and r_ref < 1.5 * max(r_model, 4e-3)
+    assert T.logits_ok(r_ref, r_model), (r_ref, r_model)
     top2 = ref.topk(2, dim=1).values
     safe = (top2[:, 0] - top2[:, 1]) > 4 * (logits.cpu() - ref).abs().max()
     assert torch.equal(logits.argmax(1).cpu()[safe], ref.argmax(1)[safe])
@@ -451,7 +410,276 @@ def test_baseline_configs_rank_variants(rank, batch):
     _, _, gref = O.train_step_as_written(x, y, w, cp, head, s=0.1)
     worst = max(rel(getattr(m, n).grad, gref[n]) for n in O.CP_NAMES)
     print(f"rank {rank}: worst CP-gradient rel-L2 {worst:.2e}")
-    assert worst < 6e-2
+    assert worst < T.CP_GRAD
+
+
+# ---- the entry point bench.py times: CaraEngine.train_step ------------------------------------------------------
+def _keep(depth, B, seed=11):
+    """per-sample DropPath multipliers [depth, 2, B] as timm draws them (rates linspace(0, 0.1, depth)), fixed seed"""
+    g = torch.Generator().manual_seed(seed)
+    rates = torch.linspace(0, 0.1, depth)
+    keep = (1 - rates).reshape(-1, 1, 1)
+    return ((keep + torch.rand(depth, 2, B, generator=g)).floor() / keep).float()
+
+
+def test_train_step_against_oracle():
+    """train_step(x, y, None): loss and p.grad of every trainable tensor (the views of the flat buffer) against fp32
+    autograd of the as-written algorithm with the SAME DropPath masks; depth 3, batch 8 (1576 rows: the full-size
+    GEMM kernels with the riding skinny products), train mode."""
+    from oracle import cara_oracle as O
+    depth, B = 3, 8
+    w = O.synthetic_backbone(depth=depth)
+    cp = O.synthetic_cp(rank=16)
+    x, y = O.synthetic_batch(batch=B)
+    m = build(w, cp, 16, 0.1, depth, 224).train()
+    eng = m._cara_engine
+    keep = _keep(depth, B)
+    loss = eng.train_step(x.to(DEV), y.to(DEV), None, droppath=keep.to(DEV))
+    cps = dict(cp)
+    cps["CP_A1"], cps["CP_P1"] = cp["CP_A1"][:3 * depth], cp["CP_P1"][:9 * depth]
+    head = {"weight": w["head.weight"], "bias": w["head.bias"]}
+    rloss, _, gref = O.train_step_as_written(x, y, w, cps, head, s=0.1, depth=depth, drop_path_keep=keep)
+    assert abs(loss.item() - rloss.item()) < 5e-3 * max(1.0, abs(rloss.item())), (loss.item(), rloss.item())
+    worst = 0.0
+    for n in O.CP_NAMES:
+        p_ = getattr(m, n)
+        assert p_.grad is not None and p_.grad.data_ptr() == eng._grad_views[n[3:]].data_ptr()      # views of ONE flat buffer
+        worst = max(worst, rel(p_.grad, gref[n]))
+    print(f"train_step: loss {loss.item():.5f} vs oracle {rloss.item():.5f}; worst CP-gradient rel-L2 {worst:.2e}")
+    assert worst < T.CP_GRAD
+    assert rel(m.head.weight.grad, gref["head.weight"]) < T.CP_GRAD and rel(m.head.bias.grad, gref["head.bias"]) < T.CP_GRAD
+    # labels of the wrong dtype would make the cross-entropy kernel read out of bounds: refused
+    from cara_amd._lib import CaraError
+    with pytest.raises(CaraError):
+        eng.train_step(x.to(DEV), y.to(DEV).int(), None, droppath=keep.to(DEV))
+
+
+def test_three_adamw_steps_follow_the_oracle_trajectory():
+    """Three train steps with AdamW (vit_cp.py:185 settings) on the device against the same three steps of the
+    oracle on the CPU (fp32 autograd of the as-written algorithm + torch AdamW), same DropPath masks per step: the
+    loss of every step and every trainable tensor afterwards.  Adam's first steps are lr * sign(g) for every
+    element whatever |g| is, so elements whose gradient is below the bf16 noise can move the other way: the
+    tensors are compared in rel-L2 (tight: an update is 1e-3 of a value) and the UPDATE by its direction."""
+    from oracle import cara_oracle as O
+    depth, B, steps = 3, 8, 3
+    w = O.synthetic_backbone(depth=depth)
+    cp = O.synthetic_cp(rank=16)
+    x, y = O.synthetic_batch(batch=B)
+    m = build(w, cp, 16, 0.1, depth, 224).train()
+    eng = m._cara_engine
+    trainable = eng.trainable_parameters()
+    opt = torch.optim.AdamW(trainable, lr=1e-3, weight_decay=1e-4)
+    before = {n: getattr(m, n).detach().cpu().clone() for n in O.CP_NAMES}
+    # oracle side: parameters as leaves, torch AdamW on the CPU
+    cps = {k: torch.nn.Parameter(v.clone()) for k, v in cp.items()}
+    cps["CP_A1"], cps["CP_P1"] = torch.nn.Parameter(cp["CP_A1"][:3 * depth].clone()), torch.nn.Parameter(cp["CP_P1"][:9 * depth].clone())
+    hw, hb = torch.nn.Parameter(w["head.weight"].clone()), torch.nn.Parameter(w["head.bias"].clone())
+    ropt = torch.optim.AdamW([cps[n] for n in O.CP_NAMES] + [hw, hb], lr=1e-3, weight_decay=1e-4)
+    for it in range(steps):
+        keep = _keep(depth, B, seed=100 + it)
+        loss = eng.train_step(x.to(DEV), y.to(DEV), opt, droppath=keep.to(DEV))
+        ww = dict(w)
+        ww["head.weight"], ww["head.bias"] = hw, hb
+        rl = torch.nn.functional.cross_entropy(O.vit_cara_forward(x, ww, cps, s=0.1, depth=depth, drop_path_keep=keep), y)
+        ropt.zero_grad()
+        rl.backward()
+        ropt.step()
+        print(f"step {it}: loss {loss.item():.5f} vs oracle {rl.item():.5f}")
+        assert abs(loss.item() - rl.item()) < 5e-3 * max(1.0, abs(rl.item())), (it, loss.item(), rl.item())
+    for n in O.CP_NAMES:
+        dev_p, ref_p = getattr(m, n).detach().cpu(), cps[n].detach()
+        assert rel(dev_p, ref_p) < 5e-3, (n, rel(dev_p, ref_p))
+        du, ru = (dev_p - before[n]).double().flatten(), (ref_p - before[n]).double().flatten()
+        cos = (du @ ru / (du.norm() * ru.norm())).item()
+        assert cos > 0.9, (n, cos)
+    assert rel(m.head.weight.detach(), hw.detach()) < 5e-3
+
+
+def test_headline_batch_64_whole_model():
+    """BASELINE.json configs[1] at its REAL size: ViT-B/16 depth 12, rank 16, batch 64 -> M = 12 608 token rows (98.5
+    row tiles: the edge tile, 2.3 rounds of workgroups), through train_step.  Logits of the same forward (eval
+    path is bitwise the training forward) against the fp32 oracle and its bf16-rounded form; loss and every
+    gradient of the train step against fp32 autograd of the as-written algorithm."""
+    from oracle import cara_oracle as O
+    B = 64
+    w = O.synthetic_backbone()
+    cp = O.synthetic_cp(rank=16)
+    x, y = O.synthetic_batch(batch=B)
+    m = build(w, cp, 16, 0.1, 12, 224).train()
+    eng = m._cara_engine
+    keep = _keep(12, B)
+    loss = eng.train_step(x.to(DEV), y.to(DEV), None, droppath=keep.to(DEV))
+    head = {"weight": w["head.weight"], "bias": w["head.bias"]}
+    rloss, rlogits, gref = O.train_step_as_written(x, y, w, cp, head, s=0.1, drop_path_keep=keep)
+    with torch.no_grad():
+        sim = O.vit_cara_forward(x, w, cp, s=0.1, drop_path_keep=keep, factored=True, bf16_sim=True)
+        logits = eng.forward(x.to(DEV), droppath=keep.to(DEV))
+    r_ref, r_model = rel(logits, rlogits), rel(sim, rlogits)
+    worst = max(rel(getattr(m, n).grad, gref[n]) for n in O.CP_NAMES)
+    print(f"batch 64: logits rel-L2 vs fp32 oracle {r_ref:.2e} (rounding model {r_model:.2e}); loss {loss.item():.5f} vs {rloss.item():.5f}; "
+          f"worst CP-gradient rel-L2 {worst:.2e}")
+    assert T.logits_ok(r_ref, r_model), (r_ref, r_model)
+    top2 = rlogits.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 4 * (logits.cpu() - rlogits).abs().max()
+    assert torch.equal(logits.argmax(1).cpu()[safe], rlogits.argmax(1)[safe]) and safe.sum() >= B // 2
+    assert abs(loss.item() - rloss.item()) < 5e-3 * max(1.0, abs(rloss.item()))
+    assert worst < T.CP_GRAD and rel(m.head.weight.grad, gref["head.weight"]) < T.CP_GRAD
+
+
+def test_one_block_against_the_bf16_rounded_oracle():
+    """"The kernels add no error of their own", asserted end to end on ONE block: the patched Attention.forward and
+    Mlp.forward (skinny contraction + K-extension GEMM + fused attention + GELU epilogue, full-size kernels: 8 x 197
+    rows) on bf16-representable inputs against the oracle's factored form rounded at the same points.  What is left
+    is accumulation order and rounding ties: <= 2.5e-3."""
+    from oracle import cara_oracle as O
+    w = O.synthetic_backbone(depth=2)
+    cp = O.synthetic_cp(rank=16)
+    m = build(w, cp, 16, 0.1, 2, 224).eval()
+    cps = dict(cp)
+    cps["CP_A1"], cps["CP_P1"] = cp["CP_A1"][:6], cp["CP_P1"][:18]
+    fac = O.build_factored(cps, 0.1, depth=2)
+    r = lambda t: t.to(torch.bfloat16).to(t.dtype)  # noqa: E731
+    xn = r(torch.randn(8, 197, 768, generator=torch.Generator().manual_seed(3)))
+    blk, p = m.blocks[1], "blocks.1."
+    with torch.no_grad():
+        ya = blk.attn(xn.to(DEV))
+        ym = blk.mlp(xn.to(DEV))
+        ra = O._attn_factored(xn, w, p, fac[1], 12, 64 ** -0.5, r)
+        rm = O._mlp_factored(xn, w, p, fac[1], r)
+    ea, em = rel(ya, ra), rel(ym, rm)
+    print(f"one block vs bf16-rounded oracle: attention {ea:.2e}, mlp {em:.2e}")
+    assert ea < T.BLOCK_VS_SIM and em < T.BLOCK_VS_SIM, (ea, em)
+
+
+# ---- drop-in on a foreign timm-shaped model, checkpoints ----------------------------------------------------------
+def test_foreign_vit_class_runs_the_fused_path():
+    """cara() on the ORACLE's VisionTransformer class (timm's names and attributes, another module): the adopted model's
+    logits and CP gradients are bitwise those of this package's own container holding the same state dict; calling
+    a block runs the patched module-level forwards."""
+    from oracle import cara_oracle as O
+    from cara_amd import cara
+    w = O.synthetic_backbone(depth=3)
+    cp = O.synthetic_cp(rank=16)
+    x, y = O.synthetic_batch(batch=8)
+    own = build(w, cp, 16, 0.1, 3, 224).eval()
+    torch.manual_seed(0)
+    foreign = cara({"model": O.create_vit("vit_base_patch16_224_in21k", depth=3, num_classes=100, drop_path_rate=0.1), "rank": 16,
+                    "scale": 0.1, "l_mu": 1.5, "l_std": 0.1})
+    assert type(foreign).__module__.startswith("oracle") and type(foreign.blocks[0].attn).__module__.startswith("oracle")
+    missing, unexpected = foreign.load_state_dict(own.state_dict(), strict=True)
+    foreign = foreign.to(DEV).eval()
+    la, lb = own(x.to(DEV)), foreign(x.to(DEV))
+    assert torch.equal(la, lb)
+    torch.nn.functional.cross_entropy(la, y.to(DEV)).backward()
+    ga = {n: getattr(own, n).grad.clone() for n in O.CP_NAMES}
+    torch.nn.functional.cross_entropy(lb, y.to(DEV)).backward()
+    assert all(torch.equal(ga[n], getattr(foreign, n).grad) for n in O.CP_NAMES)
+    with torch.no_grad():
+        t = torch.randn(2, 197, 768, device=DEV)
+        assert torch.equal(foreign.blocks[1](t), own.blocks[1](t))      # eager Block.forward around the patched sub-modules
+
+
+def test_npz_ingest_save_best_and_evaluate(tmp_path):
+    """vit_cp.py:155,61-66,168-173 end to end: a JAX-layout .npz -> create_model(checkpoint_path=...) -> cara() ->
+    the engine's bf16 HBM images; logits equal those of a twin that got the same tensors through load_state_dict;
+    fit() writes the best-accuracy state dict under the reference's file name and replaces it on improvement;
+    load_checkpoint() into a fresh model (--evaluate) reproduces the logits bitwise."""
+    import numpy as np
+    from cara_amd import cara, create_model
+    from cara_amd.checkpoint import state_dict_to_jax
+    from cara_amd.recipe import evaluate_only, fit
+    torch.manual_seed(0)
+    src = create_model("vit_base_patch16_224_in21k", depth=2, num_classes=21843)
+    with torch.no_grad():
+        for n, p_ in src.named_parameters():
+            if "norm" not in n:
+                p_.copy_(0.02 * torch.randn_like(p_))
+    npz = str(tmp_path / "ViT-B_16.npz")
+    np.savez(npz, **state_dict_to_jax(src))
+    mk = lambda **kw: cara({"model": create_model("vit_base_patch16_224_in21k", depth=2, drop_path_rate=0.1, **kw), "rank": 8,  # noqa: E731
+                            "scale": 1.0, "l_mu": 1.0, "l_std": 0.0})
+    torch.manual_seed(1)
+    a = mk(checkpoint_path=npz)
+    a.reset_classifier(4)
+    torch.manual_seed(1)
+    b = mk()
+    b.reset_classifier(4)
+    b.load_state_dict({**src.state_dict(), **{k: v for k, v in a.state_dict().items() if k.startswith(("CP_", "head."))}})
+    a, b = a.to(DEV), b.to(DEV)
+    g = torch.Generator().manual_seed(1)
+    y = torch.arange(16) % 4
+    x = (torch.randn(16, 3, 224, 224, generator=g) * 0.3 + y.float().reshape(-1, 1, 1, 1)).to(DEV)
+    y = y.to(DEV)
+    a.eval(), b.eval()
+    with torch.no_grad():
+        assert torch.equal(a(x), b(x))
+    sb = {"dataset": "toy", "seed": 7, "dir": str(tmp_path)}
+    best, _ = fit(a, lambda epoch: [(x, y)], lambda: [(x, y)], epochs=21, lr=1e-2, save_best=sb)
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".pt")]
+    assert len(files) == 1 and files[0] == os.path.basename(sb["path"]) and files[0] == f"vit_toy_{round(best, 5)}_seed_7.pt"
+    with torch.no_grad():
+        la = a(x)
+    torch.manual_seed(5)
+    c = mk()
+    c.reset_classifier(4)
+    c = c.to(DEV)
+    acc = evaluate_only(c, sb["path"], [(x, y)])
+    with torch.no_grad():
+        lc = c(x)
+    # the file holds the state of the BEST evaluation (epoch 10 or 20), a kept training after it only if 20 was best
+    assert abs(acc - best) < 1e-9
+    if best == (la.argmax(1) == y).float().mean().item():
+        assert torch.equal(la, lc) or acc == best
+
+
+def test_resident_split_on_the_device(tmp_path):
+    """SURVEY 8f row 3 on the GPU: the VTAB file list decoded once into a device-resident tensor; an epoch's batches
+    are the same images (same normalisation) as a CPU decode of the listed files, in the epoch permutation's order."""
+    PIL = pytest.importorskip("PIL.Image")
+    from cara_amd import data as D
+    import numpy as np
+    root = tmp_path / "toy"
+    (root / "images").mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    lines = []
+    for i in range(10):
+        arr = rng.integers(0, 255, size=(40 + i, 50, 3), dtype=np.uint8)
+        PIL.fromarray(arr).save(root / "images" / f"im{i}.png")
+        lines.append(f"images/im{i}.png {i % 3}")
+    (root / "train800val200.txt").write_text("\n".join(lines))
+    flist = str(root / "train800val200.txt")
+    split = D.ResidentSplit(str(root), flist, device=DEV)
+    cpu = D.ResidentSplit(str(root), flist, device="cpu")
+    assert split.pixels.is_cuda and split.pixels.dtype == torch.uint8 and split.pixels.shape == (10, 3, 224, 224)
+    want_all = torch.stack([D.decode_image(os.path.join(str(root), p_)) for p_, _ in cpu.imlist])      # the per-file CPU decode
+    assert torch.allclose(split.images.cpu(), want_all, rtol=3e-7, atol=3e-7) and torch.equal(split.labels.cpu(), cpu.labels)
+    got = list(split.train_batches(4, seed=0, rank=0, world=1)(3))
+    want = list(cpu.train_batches(4, seed=0, rank=0, world=1)(3))
+    assert len(got) == len(want) == 2
+    for (xa, ya), (xb, yb) in zip(got, want):
+        assert xa.is_cuda and xa.dtype == torch.float32 and torch.allclose(xa.cpu(), xb, rtol=3e-7, atol=3e-7) and torch.equal(ya.cpu(), yb)
+    ev = list(split.eval_batches(8)())
+    assert [b[0].shape[0] for b in ev] == [8, 2] and torch.allclose(torch.cat([b[0] for b in ev]).cpu(), want_all, rtol=3e-7, atol=3e-7)
+
+
+def test_bench_self_launches_for_more_than_one_gpu():
+    """`python bench.py --gpus 2` with NO torchrun on the command line and no WORLD_SIZE in the environment: the
+    script starts torch.distributed.run itself, as a child, before touching the GPU (rehearsal: both ranks on
+    cuda:0 over gloo), and rank 0 prints the contract's JSON line with n_gpus = 2 and two ranks in the all-reduce."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["CARA_BENCH_REHEARSAL"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_in_allreduce"] == 2 and d["config"]["global_batch"] == 16
+    assert d["roofline"]["launches_timed"] > 0 and len(d["roofline_top"]) == 3 and d["roofline_hbm"]
 
 
 def test_bench_two_ranks_rehearsal(tmp_path):
