@@ -41,3 +41,22 @@ def oracle_case(global_seed, backbone_seed, cp_seed, rank, depth, img_size, l_mu
     cp = O.init_cp_params(rank, l_mu, l_std)
     randomise_cp(cp, cp_seed)
     return O.vit_weights(vit), cp
+
+
+def oracle_case_cp_length(cp_length):
+    """Case 7 of make_golden.py (image_classification/dim_experiment.py's set_CP with cp_length 3 / 5): depth 2, 197
+    tokens, rank 16 -- the same global-RNG order (model ctor under seed 14, CP init under seed 15), the same
+    non-zero fill of the zero-initialised factors.  Returns (weights, cp, images)."""
+    torch.manual_seed(14)
+    vit = O.create_vit("vit_base_patch16_224_in21k", drop_path_rate=0.1, depth=2, num_classes=100)
+    seeded_backbone_into(vit, 401)
+    torch.manual_seed(15)
+    cp = O.init_cp_params(16, 1.5, 0.1, cp_length=cp_length)
+    g = torch.Generator(device="cpu").manual_seed(402)
+    with torch.no_grad():
+        cp["CP_A3" if cp_length == 5 else "CP_A2"].copy_(0.05 * torch.randn(768, 16, generator=g))
+        cp["CP_P2"].copy_(0.05 * torch.randn(768, 16, generator=g))
+        for k in ("CP_bias1", "CP_bias2", "CP_bias3"):
+            cp[k].copy_(0.02 * torch.randn(cp[k].shape, generator=g))
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator(device="cpu").manual_seed(403))
+    return O.vit_weights(vit), cp, img

@@ -40,6 +40,20 @@ def load_reference():
     return mod
 
 
+def load_dim_experiment():
+    """image_classification/dim_experiment.py, in place: its sibling modules (vtab.py, vtab_config.py) are the
+    reference's own files and resolve from its directory."""
+    d = os.path.join(REF, "image_classification")
+    sys.path.insert(0, d)
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_dim_experiment", os.path.join(d, "dim_experiment.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.path.remove(d)
+    return mod
+
+
 def cp_of(model):
     return {n: getattr(model, n).detach().clone() for n in O.CP_NAMES}
 
@@ -175,6 +189,48 @@ def main():
     cp2 = cp_of(m2)
     mine2 = O.vit_cara_forward(img2, O.vit_weights(m2), cp2, s=0.1, depth=2)
     assert torch.allclose(mine2, lg2.detach(), rtol=1e-5, atol=1e-6)
+
+    # ---- 7. the other orders of the QKV tensorisation: image_classification/dim_experiment.py (cp_length 3 and 5) ----
+    # The script's own set_CP / cp_attn / cp_mlp (:186-346), loaded by file path; its module-level imports that are not
+    # on this path (avalanche, wandb, torchvision, timm.scheduler) resolve to import-only stand-ins.  Depth 2, 197
+    # tokens, rank 16, s = 0.1: index walk, init draws, logits and every CP gradient.
+    dim = load_dim_experiment()
+    for n_ in (3, 5):
+        torch.manual_seed(14)
+        vit3 = O.create_vit("vit_base_patch16_224_in21k", drop_path_rate=0.1, depth=2, num_classes=100)
+        seeded_backbone_into(vit3, 401)
+        dim.vit = vit3          # the script keeps the model in a module global (dim_experiment.py:418)
+        torch.manual_seed(15)
+        dim.set_CP(vit3, dim=16, s=0.1, l_mu=1.5, l_std=0.1, cp_length=n_)
+        names = [k for k, _ in vit3.named_parameters() if k.startswith("CP_")]
+        torch.manual_seed(15)
+        mine = O.init_cp_params(16, 1.5, 0.1, cp_length=n_)
+        assert names == list(mine.keys()), (names, list(mine.keys()))
+        for k in names:
+            assert torch.equal(mine[k], getattr(vit3, k).detach()), (n_, k)      # same shapes, initialisers and draw order
+        walk = [(b.attn.idx, b.attn.attn_idx, b.mlp.idx) for b in vit3.blocks]
+        assert walk == [(0, 0, 1), (9, 1 if n_ == 5 else 3, 10)], walk
+        g = torch.Generator(device="cpu").manual_seed(402)
+        with torch.no_grad():       # non-zero adapters: the zero-initialised input factor of the QKV tensor and P2, the biases
+            getattr(vit3, "CP_A3" if n_ == 5 else "CP_A2").copy_(0.05 * torch.randn(768, 16, generator=g))
+            vit3.CP_P2.copy_(0.05 * torch.randn(768, 16, generator=g))
+            for k in ("CP_bias1", "CP_bias2", "CP_bias3"):
+                getattr(vit3, k).copy_(0.02 * torch.randn(getattr(vit3, k).shape, generator=g))
+        vit3.eval()
+        img3 = torch.randn(2, 3, 224, 224, generator=torch.Generator(device="cpu").manual_seed(403))
+        lg3 = vit3(img3)
+        torch.logsumexp(lg3, dim=1).sum().backward()
+        out[f"cpl{n_}_cfg"] = np.array([16, 2, 224, 401, 402, 403, 14, 15], dtype=np.int64)
+        out[f"cpl{n_}_logits"] = lg3.detach().numpy().copy()
+        cp3 = {k: getattr(vit3, k).detach().clone() for k in names}
+        for k in names:
+            out[f"cpl{n_}_grad_{k}"] = getattr(vit3, k).grad.detach().numpy().copy()
+        cpv = {k: v.clone().requires_grad_(True) for k, v in cp3.items()}
+        mine3 = O.vit_cara_forward(img3, O.vit_weights(vit3), cpv, s=0.1, depth=2)
+        assert torch.allclose(mine3, lg3.detach(), rtol=1e-5, atol=5e-6), (n_, (mine3 - lg3).abs().max())   # fp32 summation order of the order-5 cp_to_tensor
+        torch.logsumexp(mine3, dim=1).sum().backward()
+        for k in names:
+            assert torch.allclose(cpv[k].grad, getattr(vit3, k).grad, rtol=1e-4, atol=1e-7), (n_, k)
 
     path = os.path.join(HERE, "cara_reference_vectors.npz")
     np.savez_compressed(path, **out)

@@ -176,3 +176,22 @@ def test_a4_gradient_identities():
         if cs is not None:
             (gc,) = torch.autograd.grad(y, (cs,), dy, retain_graph=True)
             assert torch.allclose(gc, dy.sum(0), atol=1e-10)
+
+
+@pytest.mark.parametrize("cp_length", [3, 5])
+def test_other_orders_match_the_reference_script(cp_length):
+    """Golden case 7: logits and every CP gradient recorded from the reference's OWN image_classification/
+    dim_experiment.py (set_CP / cp_attn / cp_mlp with cp_length 3 and 5) -- the oracle's restatement of those
+    tensorisations, as-written and factored, against them."""
+    from tests.golden.inputs import oracle_case_cp_length
+    w, cp, img = oracle_case_cp_length(cp_length)
+    ref = torch.from_numpy(G[f"cpl{cp_length}_logits"])
+    cpv = {k: v.clone().requires_grad_(True) for k, v in cp.items()}
+    logits = O.vit_cara_forward(img, w, cpv, s=0.1, depth=2)
+    assert torch.allclose(logits, ref, rtol=1e-5, atol=5e-6)
+    torch.logsumexp(logits, dim=1).sum().backward()
+    for k in cp:
+        assert torch.allclose(cpv[k].grad, torch.from_numpy(G[f"cpl{cp_length}_grad_{k}"]), rtol=1e-4, atol=1e-7), k
+    fac = O.vit_cara_forward(img.double(), {k: v.double() for k, v in w.items()}, {k: v.double() for k, v in cp.items()}, s=0.1,
+                             depth=2, factored=True)
+    assert torch.allclose(fac.float(), ref, rtol=1e-4, atol=1e-5)

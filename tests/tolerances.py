@@ -7,14 +7,14 @@ hold is "the kernels add no error of their own":
 * whole-model logits, rel-L2 against the fp32 reference / as-written oracle:  <= LOGITS_VS_MODEL x what the oracle
   evaluated with the SAME bf16 rounding points (``bf16_sim``) is away from fp32, and <= LOGITS_ABS;
 * every CP / head gradient against fp32 autograd of the as-written algorithm:  <= CP_GRAD rel-L2;
-* ONE block on the same (bf16-representable) inputs, device vs ``bf16_sim``:   <= BLOCK_VS_SIM rel-L2;
+* ONE block on the same (bf16-representable) inputs, device vs ``bf16_sim``:   <= BLOCK_VS_SIM rel-L2 (measured 2e-4 attention, 3e-5 MLP);
 * class indices: exact wherever the fp32 top-2 margin exceeds the measured logit noise.
 """
 LOGITS_ABS = 1.0e-2
 LOGITS_VS_MODEL = 1.15
 MODEL_FLOOR = 4.0e-3     # for tiny cases whose rounding-model error is itself near zero
 CP_GRAD = 2.5e-2
-BLOCK_VS_SIM = 2.5e-3
+BLOCK_VS_SIM = 1.0e-3
 
 
 def logits_ok(r_ref: float, r_model: float) -> bool:
