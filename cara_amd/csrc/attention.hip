@@ -317,6 +317,230 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_long_kernel(const bf16* _
 }
 
 // ------------------------------------------------------------------------------------------
+// Forward for 128 < N <= 224 (ViT-B/16 @224: 197 tokens), the headline path: a PERSISTENT kernel, one 7-wave
+// workgroup per CU walking the (batch, head) pairs bh = block, block + grid, ... (64 x 12 = 768 pairs = exactly 3 per
+// CU).  The kernel above is bound by what happens around its arithmetic: K / V are staged through registers and a
+// barrier before any MFMA can issue, two workgroups per CU give 1.5 rounds of 512 slots, and the scores are computed
+// twice to get under 128 VGPRs.  Here
+//   * K and V of head j+1 stream into the OTHER pair of LDS images by LDS-DMA (global_load_lds, full 128-byte rows,
+//     swizzle on the source address) while head j computes: counted vmcnt, raw s_barrier, nothing drains the queue;
+//   * a wave's 32 query rows come the same way into a wave-private 4-KiB image, issued as soon as the wave's Q K^T of
+//     the previous head has consumed its fragments;
+//   * one workgroup per CU leaves a wave 256 VGPRs: the whole score row block stays in registers (7 tiles of 32 x 32),
+//     one sweep, exact two-pass softmax, P feeds P.V from the accumulators as before.
+// LDS: 2 x (K + V) x 28 KiB + 7 x 4 KiB = 140 KiB.
+// ------------------------------------------------------------------------------------------
+constexpr int PF_WAVES = 7;
+
+// LDS-DMA piece written as inline asm (wave-uniform 64-bit base, per-lane 32-bit byte offset, LDS byte address in M0):
+// hipcc does not see it, so it cannot put its own s_waitcnt vmcnt(0) in front of later LDS reads (it does that for the
+// builtin whenever it cannot prove that the DMA's destination and the read do not alias, which would drain the
+// next head's images in the middle of this head's P.V).  Every wait for these pieces is written by hand below.
+__device__ __forceinline__ void glds16_hidden(const char* base, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+}
+
+__global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_persist_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                                            float* __restrict__ lse, int N, int H, int BH, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NPAD = 224, IMG = NPAD * 128;       // one K or V image
+  char* Qs = smem + 4 * IMG;                         // wave-private Q images behind the two (K, V) pairs
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ld = 3 * H * HD;
+  const int ql = lane & 31, h = lane >> 5;
+  const int q0 = wave * 32;
+  const int nkt = (N + 31) >> 5;
+  const float c2 = scale * 1.4426950408889634f;
+  const RowOfs ro = row_ofs(lane);
+  const TrOfs to = tr_ofs(lane);
+  const int last_keys = N - (nkt - 1) * 32;
+  char* myQ = Qs + wave * 4096;
+
+  // per-lane 32-bit byte offsets of the DMA pieces (head-independent; the head's base pointer is wave-uniform, so a
+  // piece is "SGPR base + VGPR offset" with no 64-bit vector arithmetic).  K and V of one head: 2 x 28 pieces of 8 rows,
+  // wave w takes pieces w, w + 7, ... (8 per wave); Q: the wave's own 32 rows = 4 pieces.
+  unsigned kvoff[8], kvdst[8], qoff[4];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int q = wave + t * PF_WAVES;              // 0..55: < 28 -> K, else V
+    const bool isv = q >= 28;
+    const int piece = isv ? q - 28 : q;
+    const int row = piece * 8 + (lane >> 3);
+    const int rr = row < N ? row : N - 1;
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    kvoff[t] = (unsigned)rr * (unsigned)(ld * 2) + (unsigned)(c * 16) + (unsigned)((isv ? 2 : 1) * H * HD * 2);
+    kvdst[t] = (unsigned)((isv ? IMG : 0) + piece * 1024);   // wave-uniform
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = t * 8 + (lane >> 3);
+    int gr = q0 + row;
+    gr = gr < N ? gr : N - 1;
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    qoff[t] = (unsigned)gr * (unsigned)(ld * 2) + (unsigned)(c * 16);
+  }
+  auto lds_of = [](const char* p) { return __builtin_amdgcn_readfirstlane((unsigned)(size_t)p); };   // LDS byte address
+  auto head_base = [&](int bh) {
+    const int b = bh / H, hd = bh - b * H;
+    return reinterpret_cast<const char*>(qkv + (size_t)b * N * ld + hd * HD);   // wave-uniform
+  };
+  auto stage_kv = [&](int bh, int buf) {
+    const char* base = head_base(bh);
+    char* img = smem + buf * 2 * IMG;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) glds16_hidden(base, kvoff[t], lds_of(img) + __builtin_amdgcn_readfirstlane(kvdst[t]));
+  };
+  auto stage_q = [&](int bh) {
+    const char* base = head_base(bh);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) glds16_hidden(base, qoff[t], lds_of(myQ) + t * 1024);
+  };
+
+  int bh = blockIdx.x;
+  if (bh >= BH) return;
+  stage_kv(bh, 0);
+  stage_q(bh);
+  int cur = 0;
+  for (; bh < BH; bh += gridDim.x) {
+    const int nxt = bh + gridDim.x;
+    // every wave is through with the images of the head before this one: refill them with the next head
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (nxt < BH) {
+      stage_kv(nxt, cur ^ 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but the 8 pieces just issued: this head's K, V, Q have landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_barrier" ::: "memory");               // ... for every wave
+    __builtin_amdgcn_sched_barrier(0);
+    const char* Ks = smem + cur * 2 * IMG;
+    const char* Vs = Ks + IMG;
+    const int b = bh / H, head = bh - b * H;
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(myQ + ro.o[ks]);
+    // S^T = K Q^T, the K fragments of tile kt + 1 requested before the MFMAs of tile kt (one wave or two per SIMD: nothing
+    // else hides the LDS latency)
+    f32x16 s[7];
+    bf16x8 ka[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ka[0][ks] = *reinterpret_cast<const bf16x8*>(Ks + ro.o[ks]);
+#pragma unroll
+    for (int kt = 0; kt < 7; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      if (kt < nkt) {
+        if (kt + 1 < nkt) {
+          const char* kb_ = Ks + (kt + 1) * 4096;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) ka[(kt + 1) & 1][ks] = *reinterpret_cast<const bf16x8*>(kb_ + ro.o[ks]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[kt & 1][ks], qf[ks], s[kt], 0, 0, 0);
+      }
+    }
+    // the Q fragments are in registers: the wave's Q image may take the next head's rows
+    if (nxt < BH) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      stage_q(nxt);
+    }
+    // S^T layout: column (lane & 31) = query, row = key kt*32 + crow(r, h); only the last key tile needs a mask
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 7; ++kt) {
+      if (kt < nkt) {
+        if (kt == nkt - 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kt][r] = crow(r, h) < last_keys ? s[kt][r] : -3.0e38f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxc = mx * c2;
+    float sum = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 7; ++kt) {
+      if (kt < nkt) {
+        // the four V fragments of this key tile are requested first: the exponentials below cover their latency
+        const char* vb_ = Vs + kt * 4096;
+        bf16x8 vf[2][2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) vf[st][dt] = tr_frag_at(vb_, to.lo[st][dt], to.hi[st][dt]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] * c2 - mxc);   // <= 0: raw v_exp_f32 (masked keys: exp(-huge) = 0)
+          sum += s[kt][r];
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const bf16x8 pa = pack8(s[kt], st);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[st][dt], pa, o[dt], 0, 0, 0);   // O^T = V^T P^T: d on the rows
+        }
+      }
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    // O^T layout: column (lane & 31) = QUERY, register r of lane half h = d = 32 dt + 8 (r >> 2) + 4 h + (r & 3): a lane
+    // holds its query's row in runs of four d, and 1 / sum of that query is the lane's own.  Lane halves swap runs
+    // (v_permlane32_swap) so that each lane ends up with two runs of EIGHT consecutive d per dt: four 16-byte stores per
+    // lane and head instead of 32 two-byte ones (the store tail was 21 % of the kernel).
+    bf16* ob = out + (size_t)b * N * (H * HD) + head * HD;
+#ifdef CARA_ABLATE_ATTN_STORES
+    if (q0 < N && inv == 123.f) {
+#else
+    if (q0 < N) {
+#endif
+      bf16* orow = ob + (size_t)(q0 + ql < N ? q0 + ql : N - 1) * (H * HD);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        unsigned w[4][2];   // run g = r >> 2 of this lane: d = 32 dt + 8 g + 4 h .. + 3, as two packed dwords
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x2 lo = {(bf16)(o[dt][4 * g] * inv), (bf16)(o[dt][4 * g + 1] * inv)};
+          const bf16x2 hi = {(bf16)(o[dt][4 * g + 2] * inv), (bf16)(o[dt][4 * g + 3] * inv)};
+          w[g][0] = __builtin_bit_cast(unsigned, lo);
+          w[g][1] = __builtin_bit_cast(unsigned, hi);
+        }
+        // after the swaps: half 0 holds d-groups 0 and 1 complete (its own first halves + half 1's second halves),
+        // half 1 holds d-groups 2 and 3
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(w[g][k], w[g + 2][k], false, false);
+            w[g][k] = sw[0];
+            w[g + 2][k] = sw[1];
+          }
+        if (q0 + ql < N) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            // half 0: w[g] = own run (d 8g..8g+3), w[g+2] = half 1's run (d 8g+4..8g+7); half 1: w[g] = half 0's run of
+            // group g+2 (d 8(g+2)..+3), w[g+2] = own (d 8(g+2)+4..+7)
+            const uint4 v = {w[g][0], w[g][1], w[g + 2][0], w[g + 2][1]};
+            *reinterpret_cast<uint4*>(orow + dt * 32 + 8 * (g + 2 * h)) = v;
+          }
+        }
+      }
+      if (h == 0 && q0 + ql < N) lse[(size_t)bh * N + q0 + ql] = mx * scale + __logf(sum);
+    }
+    cur ^= 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward, kernel 1: dK, dV.  One workgroup of 7 waves per (batch, head); wave w owns keys
 // 32w..32w+31 and keeps dK^T, dV^T in accumulators while sweeping the query tiles.  Q and dO are
 // staged in LDS once, row-major: plain ds_read_b128 rows feed S = Q K^T and dP = dO V^T, and the
@@ -579,6 +803,7 @@ static void attn_set_lds_limits() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<4>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<7>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_long_kernel<7>), at, MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_persist_kernel), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<4>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<7>), at, MAX_LDS);
@@ -600,7 +825,13 @@ extern "C" int cara_attention_fwd(const void* qkv, void* out, float* lse, int B,
     const char* e = getenv("CARA_ATTN_LONG");
     use_long = e ? atoi(e) : 1;
   }
-  if (N > NMAX || (use_long && N > 128))
+  static const int use_persist = [] { const char* e = getenv("CARA_ATTN_PERSIST"); return e ? atoi(e) : 1; }();
+  if (use_persist && N > 128 && N <= NMAX) {
+    // one workgroup per CU walks the (batch, head) pairs: K / V of the next pair stream in while this one computes
+    const int BH = B * H, grid = BH < 256 ? BH : 256;
+    hipLaunchKernelGGL(attn_fwd_persist_kernel, dim3(grid), dim3(PF_WAVES * 64), 4 * 224 * 128 + PF_WAVES * 4096, st, (const bf16*)qkv,
+                       (bf16*)out, lse, N, H, BH, scale);
+  } else if (N > NMAX || (use_long && N > 128))
     hipLaunchKernelGGL(attn_fwd_long_kernel<7>, dim3(B * H, (N + 223) / 224), dim3(448), lds, st, (const bf16*)qkv, (bf16*)out, lse, N,
                        H, scale, npad);
   else if (attn_waves(N) == 7)
