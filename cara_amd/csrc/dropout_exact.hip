@@ -11,8 +11,13 @@
 // (cara_dropout_grad_contract), which are exactly the per-layer quantities the factored path hands to
 // cara_factor_grad_reduce.  keep(o,i) is a counter-based hash of (seed, linear id, o*in + i): nothing is stored,
 // the backward regenerates the mask, and tests regenerate it on the CPU (tests/test_exact_dropout.py).
-// Rounding W + dW to ONE bf16 costs what rounding W alone already costs (the error is set by W's ulp).
-// HBM-bound: reads W, writes W_eff (+ its transpose for dX): 2 x 170 MB + 170 MB per step at ViT-B.
+// Rounding W + dW to ONE bf16 loses every adapter element below half an ulp of W (|W| ~ 0.02: 6e-5) -- with the
+// reference's zero-initialised A2 / P2 that is the whole adapter for a long stretch of training.  The whole-model
+// path therefore keeps the two apart: with W == NULL this kernel writes only the masked delta
+//     Dm[o,i] = bf16( keep(o,i)/(1-p) * sum_r Vs[o,r] U[i,r] )                         (full relative precision)
+// and the GEMMs run y = x W^T + x Dm^T as two products accumulated in fp32 (cara_gemm_args::B3).  The merged form
+// stays for the eval-time merge (p = 0) of a trained adapter into the backbone.
+// HBM-bound: writes Dm (+ its transpose for dX): 2 x 170 MB per step at ViT-B.
 #include "common.h"
 
 namespace {
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const bf16* __restrict__ W, 
 #pragma unroll
     for (int r = 0; r < RP; ++r) d += v[r] * Us[ic + j][r];
     const size_t e = (size_t)o * in + i;
-    Weff[e] = (bf16)((float)W[e] + keep_scale((unsigned)e, seed, lin, thresh, inv_keep) * d);
+    Weff[e] = (bf16)((W ? (float)W[e] : 0.f) + keep_scale((unsigned)e, seed, lin, thresh, inv_keep) * d);
   }
 }
 
@@ -178,7 +183,7 @@ extern "C" int cara_materialize_merge(const void* W, const void* U, const void* 
                                       unsigned linear_id, void* Weff, void* stream) {
   unsigned thresh;
   float inv_keep;
-  if (!W || !U || !Vs || !Weff || out <= 0 || in <= 0 || !(Rp == 32 || Rp == 64) || !mask_params(p, &thresh, &inv_keep)) return CARA_E_ARG;
+  if (!U || !Vs || !Weff || out <= 0 || in <= 0 || !(Rp == 32 || Rp == 64) || !mask_params(p, &thresh, &inv_keep)) return CARA_E_ARG;
   if ((unsigned long long)out * in >= (1ull << 32)) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid((in + 63) / 64, (out + 63) / 64);

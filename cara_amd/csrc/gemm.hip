@@ -96,7 +96,8 @@ __device__ __forceinline__ void stage_ext32(const bf16* __restrict__ P, int Rp, 
 // NW = waves per workgroup (NW/2 along M x 2 along N): 4, or 8 with MI = 2 for a 128-row tile made of
 // 32x64 wave tiles (more resident waves per CU)
 // one workgroup's tile; `block` = its index among the nwg tiles of the product, `zb` = product index of a batched launch
-template <int EPI, int MI, int NW>
+// TWOB: the K loop runs twice, over B and then over B3 (cara_gemm_args::B3: same shape and ldb), A re-staged
+template <int EPI, int MI, int NW, bool TWOB = false>
 __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int tiles_n, const int nwg, const int gm,
                                             const int block, const size_t zb_in, char* smem) {
   constexpr int TBM = MI * 16 * (NW / 2);
@@ -145,17 +146,37 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
   stage_tile32_pre<TBM, NW>(A, 0, oA, smem, uwave);
   stage_tile32_pre<BN, NW>(B, 0, oB, smem + A_BYTES, uwave);
   int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    char* sA = smem + cur * SLOT;
-    if (kt + 1 < nk) {
-      char* nA = smem + (cur ^ 1) * SLOT;
-      stage_tile32_pre<TBM, NW>(A, (kt + 1) * kmulA, oA, nA, uwave);
-      stage_tile32_pre<BN, NW>(B, (kt + 1) * kmulB, oB, nA + A_BYTES, uwave);
+  if constexpr (!TWOB) {
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      char* sA = smem + cur * SLOT;
+      if (kt + 1 < nk) {
+        char* nA = smem + (cur ^ 1) * SLOT;
+        stage_tile32_pre<TBM, NW>(A, (kt + 1) * kmulA, oA, nA, uwave);
+        stage_tile32_pre<BN, NW>(B, (kt + 1) * kmulB, oB, nA + A_BYTES, uwave);
+      }
+      mma_tile32<MI>(sA, sA + A_BYTES, acc, wr, wc, lane);
+      cur ^= 1;
     }
-    mma_tile32<MI>(sA, sA + A_BYTES, acc, wr, wc, lane);
-    cur ^= 1;
+  } else {
+    // steps 0 .. nk-1 over B, nk .. 2nk-1 over B3 (same row offsets: same shape and ldb; only the base pointer, a scalar,
+    // changes), A staged again from its first K step
+    const bf16* __restrict__ B3 = static_cast<const bf16*>(p.B3);
+    for (int kt = 0; kt < 2 * nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      char* sA = smem + cur * SLOT;
+      if (kt + 1 < 2 * nk) {
+        char* nA = smem + (cur ^ 1) * SLOT;
+        const int kn = kt + 1, kk = kn < nk ? kn : kn - nk;
+        const bf16* __restrict__ Bn = kn < nk ? B : B3;
+        stage_tile32_pre<TBM, NW>(A, kk * kmulA, oA, nA, uwave);
+        stage_tile32_pre<BN, NW>(Bn, kk * kmulB, oB, nA + A_BYTES, uwave);
+      }
+      mma_tile32<MI>(sA, sA + A_BYTES, acc, wr, wc, lane);
+      cur ^= 1;
+    }
   }
   for (int kk = 0; kk < (p.Rp >> 5); ++kk) {
     __syncthreads();
@@ -183,10 +204,10 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
   }
 }
 
-template <int EPI>
+template <int EPI, bool TWOB = false>
 __global__ __launch_bounds__(256, 4) void gemm32_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm32_body<EPI, 4, 4>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
+  gemm32_body<EPI, 4, 4, TWOB>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
 }
 
 // The dX GEMM of a linear and the two transposed skinny products of the SAME linear (dU = X^T G', dVs = dY^T T) in
@@ -390,7 +411,8 @@ int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr
     return CARA_OK;
   }
   const int nb = a->batch > 1 ? a->batch : 1;
-  hipLaunchKernelGGL((gemm32_kernel<EPI>), dim3(nwg, nb), dim3(256), GEMM_LDS, st, *a, tiles_n, nwg, gm);
+  if (a->B3) hipLaunchKernelGGL((gemm32_kernel<EPI, true>), dim3(nwg, nb), dim3(256), GEMM_LDS, st, *a, tiles_n, nwg, gm);
+  else hipLaunchKernelGGL((gemm32_kernel<EPI>), dim3(nwg, nb), dim3(256), GEMM_LDS, st, *a, tiles_n, nwg, gm);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }
@@ -464,7 +486,7 @@ __global__ __launch_bounds__(256) void small_m_finish_kernel(const cara_gemm_arg
 
 // K slabs of at least 128 columns, at most 16 of them; 0 = not worth it
 static int small_m_slabs(const cara_gemm_args* a) {
-  if (a->M > 128 || a->K < 512 || !a->scratch || a->Ut || a->batch > 1) return 0;
+  if (a->M > 128 || a->K < 512 || !a->scratch || a->Ut || a->batch > 1 || a->B3) return 0;
   int s = a->K / 128;
   if (s > 16) s = 16;
   while (s > 1 && (a->K % (s * 64)) != 0) --s;   // equal slabs, each a multiple of 64 columns
@@ -539,7 +561,8 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
   if (!small_ptrs) return CARA_E_ARG;
   if (a->epi == CARA_EPI_RESID && (!a->aux || (a->rowscale && a->rows_per_sample <= 0))) return CARA_E_ARG;
   if (a->epi == CARA_EPI_DGELU && !a->aux) return CARA_E_ARG;
-  if (ts && (a->Ut || a->batch > 1 || a->M <= 128)) return CARA_E_ARG;
+  if (ts && (a->Ut || a->batch > 1 || a->M <= 128 || a->B3)) return CARA_E_ARG;
+  if (a->B3 && (a->Bp || a->Ut || a->batch > 1 || a->a_panels)) return CARA_E_ARG;
   if (a->Ut) {   // whole adapter inside the GEMM: Rp = 32, T produced here
     if (a->A2 || !a->B2 || a->Rp != 32 || !a->T_out || a->batch > 1 || (a->Tt_out && (a->ldt < a->M || (a->ldt & 7)))) return CARA_E_ARG;
     switch (a->epi) {

@@ -1,7 +1,7 @@
 // Library identification for libcara_hip.so.
 #include "common.h"
 
-extern "C" int cara_abi_version(void) { return 2; }
+extern "C" int cara_abi_version(void) { return 3; }
 extern "C" const char* cara_build_arch(void) { return "gfx950"; }
 
 // Diagnostic: one ds_read_b64_tr_b16 per lane over an LDS image sm[i] = i (16-bit), with the byte

@@ -286,8 +286,8 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
   return cara_tskinny_partial2(X, ldx, Gt, slabU, L.in, dY, lddy, Tt, slabV, L.out, want_dc ? 1 : 0, ldt, Mr, Rp, st);
 }
 
-// ---- exact weight-dropout mode (cara_vit_shape::wd_exact): plain GEMMs on W_eff = W + keep/(1-p) dW ----------
-// forward of one linear: materialise W_eff (and its transpose, for dX) of this layer, then C = X W_eff^T + bias
+// ---- exact weight-dropout mode (cara_vit_shape::wd_exact): y = x W^T + x (keep/(1-p) dW)^T, two accumulated products ----
+// forward of one linear: materialise the masked delta (and its transpose, for dX) of this layer, then C = X (W + Dm)^T + bias
 int lin_fwd_exact(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, char* ws, const Ws& W, const cara_vit_shape* s,
                   cara_gemm_args a, const Ctx& cx) {
   void* st = cx.stream;
@@ -295,9 +295,12 @@ int lin_fwd_exact(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, char* ws
   const size_t wbytes = (size_t)L.out * L.in * 2;
   bf16* weff = reinterpret_cast<bf16*>(ws + W.weff[L.slot] + layer * wbytes);
   bf16* wefft = reinterpret_cast<bf16*>(ws + W.wefft[L.slot] + layer * wbytes);
-  TRY(cara_materialize_merge(L.W, L.U, L.Vs, Rp, L.out, L.in, s->wd_p, s->wd_seed, (unsigned)(4 * layer + L.slot), weff, st));
+  // the masked adapter delta on its own (W == NULL), kept apart from the frozen weight: y = x W^T + x Dm^T as two
+  // products accumulated in fp32 (cara_gemm_args::B3) -- merged into one bf16 weight, a delta below half an ulp of W
+  // would vanish (the reference's zero-initialised A2 / P2: the whole adapter early in training)
+  TRY(cara_materialize_merge(nullptr, L.U, L.Vs, Rp, L.out, L.in, s->wd_p, s->wd_seed, (unsigned)(4 * layer + L.slot), weff, st));
   TRY(cara_transpose_bf16_ld(weff, L.in, wefft, L.out, L.out, L.in, st));
-  a.A = X; a.lda = ldx; a.B = weff; a.ldb = L.in; a.A2 = nullptr; a.B2 = nullptr; a.Rp = 0;
+  a.A = X; a.lda = ldx; a.B = L.W; a.B3 = weff; a.ldb = L.in; a.A2 = nullptr; a.B2 = nullptr; a.Rp = 0;
   a.M = Mr; a.N = L.out; a.K = L.in; a.bias = L.bias;
   if (a.ldc == 0) a.ldc = L.out;
   with_scratch(a, cx);
@@ -337,7 +340,7 @@ int lin_bwd_exact(const Lin& L, const bf16* dY, const bf16* X, int Mr, int Rp, c
                                  reinterpret_cast<float*>(ws + W.dU[L.slot]) + (size_t)layer * L.in * Rp,
                                  reinterpret_cast<float*>(ws + W.dVs[L.slot]) + (size_t)layer * L.out * Rp, ws + W.xscratch, st));
   if (want_dx) {
-    a.A = dY; a.lda = L.out; a.B = wefft; a.ldb = L.out; a.A2 = nullptr; a.B2 = nullptr; a.Rp = 0;
+    a.A = dY; a.lda = L.out; a.B = L.Wt; a.B3 = wefft; a.ldb = L.out; a.A2 = nullptr; a.B2 = nullptr; a.Rp = 0;
     a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
     if (a.ldc == 0) a.ldc = L.in;
     with_scratch(a, cx);

@@ -82,6 +82,11 @@ typedef struct {
   /* c_panels = P > 0 (bf16 epilogues): C is WRITTEN as [N/32][P][32] -- the A operand of the next GEMM, the X of   */
   /* cara_skinny_xu / cara_tskinny_* with ldx = -P -- while C2 / aux keep the row-major ldc.  N % 32 == 0 then.     */
   int a_panels, c_panels;
+  /* Optional SECOND B operand, same shape and ldb as B (row-major, bf16): C = A B^T + A B3^T (+ the K-extension), the two  */
+  /* products accumulated in fp32 in ONE launch (the K loop runs over B, then over B3).  For a small correction to a large   */
+  /* operand -- the exact weight-dropout mode's masked adapter delta against the frozen weight -- that a pre-merged bf16      */
+  /* B + B3 would round away.  Plain product only: no Bp, batch, Ut, a_panels or tskinny with it.                            */
+  const void* B3;
 } cara_gemm_args;
 int cara_gemm_bf16(const cara_gemm_args* a, void* stream);
 /* B bf16 [N, K] (row stride ldb) -> out bf16 [K/32][N][32] (cara_gemm_args::Bp); K % 32 == 0 */
@@ -250,7 +255,9 @@ int cara_factor_grad_reduce(const cara_geom* g, const cara_cp* cp, const cara_la
  * (host-callable mirror of the device hash, so that tests and the oracle can rebuild the masks).             */
 unsigned cara_weight_dropout_hash(unsigned idx, unsigned seed, unsigned linear_id);
 /* Weff bf16 [out,in] = W + keep/(1-p) * (Vs U^T): W bf16 [out,in], U bf16 [in,Rp], Vs bf16 [out,Rp] (= s g (.) V,
- * the operand pack of cara_factor_prep).  p = 0 is the eval-time merge of the reference's dW into W.         */
+ * the operand pack of cara_factor_prep).  p = 0 is the eval-time merge of the reference's dW into W.
+ * W == NULL: only the masked delta keep/(1-p) * (Vs U^T) is written -- the B3 operand of cara_gemm_args, which keeps
+ * an adapter far below W's bf16 ulp (zero-initialised factors early in training) from being rounded away.        */
 int cara_materialize_merge(const void* W, const void* U, const void* Vs, int Rp, int out, int in, float p,
                            unsigned seed, unsigned linear_id, void* Weff, void* stream);
 /* From the dense weight gradient dW (= dY^T X, given as `nslab` split-K partial slabs of fp32 [out,in], slab_stride

@@ -43,6 +43,48 @@ def test_materialize_merge(out, inn, Rp, p):
     assert (err <= 2 ** -8 * ref.abs() + 1e-6).all(), float(err.max())
     if p > 0:   # dropped elements are exactly the frozen weight
         assert torch.equal(Weff[~keep], W[~keep])
+    # W == NULL: the masked delta alone, at ITS OWN precision (the B3 operand of the exact mode's GEMMs)
+    Dm = torch.full((out, inn), float("nan"), dtype=torch.bfloat16, device=DEV)
+    L.check(lib.cara_materialize_merge(None, L.ptr(U), L.ptr(Vs), Rp, out, inn, C.c_float(p), 11, 5, L.ptr(Dm), L.stream()), "delta")
+    dref = keep.double() / (1.0 - p) * (Vs.double() @ U.double().t())
+    assert ((Dm.double() - dref).abs() <= 2 ** -8 * dref.abs() + 1e-6).all()      # (fp32 sum of 32..64 products, then one bf16 rounding)
+    if p > 0:
+        assert torch.count_nonzero(Dm[~keep]) == 0
+
+
+@pytest.mark.gpu
+def test_tiny_adapter_survives_next_to_the_frozen_weight():
+    """The reference zero-initialises A2 / P2, so for a long stretch of training the materialised adapter is 1e-8 .. 1e-6
+    next to weights of ~2e-2: merged into ONE bf16 weight (half an ulp of 0.02 is 6e-5) it would be rounded away
+    completely and the train-mode forward would be the frozen backbone's.  The exact mode therefore runs
+    y = x W^T + x Dm^T as two products accumulated in fp32 (cara_gemm_args::B3): the adapter's contribution comes out
+    at the precision of its OWN bf16 image."""
+    M, N, K = 1500, 768, 768
+    X = _rnd(M, K, seed=1)
+    W = _rnd(N, K, seed=2, scale=0.02)
+    D = _rnd(N, K, seed=3, scale=1e-6)                      # |delta| ~ 1e-6: far below W's ulp
+    merged = (W.float() + D.float()).to(torch.bfloat16)
+    assert (merged == W).float().mean() > 0.95               # what a pre-merged weight keeps of it: (almost) nothing
+    base = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    both = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    L.gemm(X, W, base, epi=L.EPI_F32)
+    L.gemm(X, W, both, epi=L.EPI_F32, B3=D)
+    contrib = (both.double() - base.double())
+    ref = X.double() @ D.double().t()
+    # fp32 accumulation next to an O(1) sum: absolute noise ~1e-7 on a contribution of ~3e-5
+    rel = ((contrib - ref).norm() / ref.norm()).item()
+    assert rel < 2e-2, rel
+    full = X.double() @ (W.double() + D.double()).t()
+    assert ((both.double() - full).norm() / full.norm()).item() < 1e-5
+    # ragged shapes, GELU epilogue, K-extension together with B3
+    M, N, K = 333, 300, 128
+    X, W, D = _rnd(M, K, seed=4), _rnd(N, K, seed=5, scale=0.05), _rnd(N, K, seed=6, scale=0.01)
+    A2, B2, bias = _rnd(M, 32, seed=7), _rnd(N, 32, seed=8, scale=0.05), _rnd(N, seed=9, dtype=torch.float32)
+    h, u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L.gemm(X, W, h, epi=L.EPI_GELU, C2=u, B3=D, A2=A2, B2=B2, bias=bias)
+    ref = X.double() @ (W.double() + D.double()).t() + A2.double() @ B2.double().t() + bias.double()
+    assert ((u.double() - ref).abs() <= 2 ** -7 * ref.abs() + 5e-3).all()
+    assert ((h.double() - torch.nn.functional.gelu(ref)).abs() <= 2 ** -7 * ref.abs() + 5e-3).all()
 
 
 @pytest.mark.gpu

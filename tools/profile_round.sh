@@ -11,6 +11,6 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
   > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_rocprof.err || exit 1
 f=$(find gpurun_out/prof_${tag} -name '*kernel_stats.csv' | head -1)
 cp "$f" gpurun_out/${tag}_kernel_stats_final.csv
-python3 tools/timeline.py gpurun_out/prof_${tag} --steps 10 > gpurun_out/${tag}_timeline.txt 2>&1
+python3 tools/timeline.py gpurun_out/prof_${tag} --steps 10 --skip-last 3 > gpurun_out/${tag}_timeline.txt 2>&1
 rm -rf gpurun_out/prof_${tag}
 tail -c 400 gpurun_out/${tag}_bench_default_run.json; echo; head -5 gpurun_out/${tag}_timeline.txt
