@@ -38,22 +38,40 @@ __device__ __forceinline__ void panel_store(const XuLds<V4>& L, bf16* __restrict
     *reinterpret_cast<bf16x8*>(y + ((size_t)p * yp + row_base + row) * 32 + chunk * 8) =
         *reinterpret_cast<const bf16x8*>(L.y + row * LDY + p * 32 + chunk * 8);
 }
+// a wave's B fragments of the contraction (its K steps wave, wave + 8, ...: C/256 of them, two column tiles each):
+// requested at the top of the kernel so that their L2 latency passes under the row loads and reductions
 template <int V4>
-__device__ __forceinline__ void block_contract(XuLds<V4>& L, const bf16* __restrict__ Ut, bf16* __restrict__ T,
+struct UtFrags {
+  bf16x8 u[V4][2];
+};
+template <int V4>
+__device__ __forceinline__ UtFrags<V4> load_ut_frags(const bf16* __restrict__ Ut) {
+  constexpr int C = V4 * 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  UtFrags<V4> f;
+#pragma unroll
+  for (int k = 0; k < V4; ++k)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      f.u[k][nt] = *reinterpret_cast<const bf16x8*>(Ut + (size_t)(nt * 16 + fr) * C + (wave + k * XU_WAVES) * 32 + fq * 8);
+  return f;
+}
+template <int V4>
+__device__ __forceinline__ void block_contract(XuLds<V4>& L, const UtFrags<V4>& uf, bf16* __restrict__ T,
                                                bf16* __restrict__ Tt, const int ldt, const int row_base, const int M) {
-  constexpr int C = V4 * 256, KS = C / 32, LDY = XuLds<V4>::LDY;
+  constexpr int LDY = XuLds<V4>::LDY;
+  static_assert(XU_WAVES == 8, "K steps per wave = C / 32 / 8 = V4");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   __syncthreads();   // the 16 staged rows are complete
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-  for (int s = wave; s < KS; s += XU_WAVES) {
+  for (int k = 0; k < V4; ++k) {
+    const int s = wave + k * XU_WAVES;
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(L.y + fr * LDY + s * 32 + fq * 8);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const bf16x8 u = *reinterpret_cast<const bf16x8*>(Ut + (size_t)(nt * 16 + fr) * C + s * 32 + fq * 8);
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, u, acc[nt], 0, 0, 0);
-    }
+    for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, uf.u[k][nt], acc[nt], 0, 0, 0);
   }
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<f32x4*>(&L.part[wave][nt][lane * 4]) = acc[nt];
@@ -93,20 +111,36 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_fwd_kernel(const 
   const int lane = threadIdx.x & 63;
   const int row0 = (blockIdx.x * (XU ? XU_WAVES : 4) + (threadIdx.x >> 6)) * RPW;
   __shared__ __attribute__((aligned(16))) XuLds<XU ? V4 : 0> L;
-  for (int row = row0; row < row0 + RPW && row < M; ++row) {
-  const float* xr = x + (size_t)row * ldx;
-  float4 v[V4];
-  float s = 0.f;
+  UtFrags<XU ? V4 : 1> uf;
+  if constexpr (XU) uf = load_ut_frags<V4>(Ut);
+  // all of a wave's rows are requested before anything is reduced: a wave keeps RPW x V4 16-byte loads in flight
+  // instead of V4 (the kernel is latency-bound: one row at a time reached 3.4 TB/s)
+  float4 v[RPW][V4];
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = row0 + rr < M ? row0 + rr : M - 1;
+    const float* xr = x + (size_t)row * ldx;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) v[rr][i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
+  }
+  float4 gm[V4], bt[V4];
 #pragma unroll
   for (int i = 0; i < V4; ++i) {
-    v[i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
-    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    gm[i] = *reinterpret_cast<const float4*>(gamma + i * 256 + lane * 4);
+    bt[i] = *reinterpret_cast<const float4*>(beta + i * 256 + lane * 4);
   }
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+  const int row = row0 + rr;
+  if (row >= M) break;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < V4; ++i) s += (v[rr][i].x + v[rr][i].y) + (v[rr][i].z + v[rr][i].w);
   const float mu = wave_sum(s) * (1.0f / C);
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < V4; ++i) {
-    const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+    const float a = v[rr][i].x - mu, b = v[rr][i].y - mu, c = v[rr][i].z - mu, d = v[rr][i].w - mu;
     q += (a * a + b * b) + (c * c + d * d);
   }
   const float rs = rsqrtf(wave_sum(q) * (1.0f / C) + eps);
@@ -115,10 +149,10 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_fwd_kernel(const 
 #pragma unroll
   for (int i = 0; i < V4; ++i) {
     const int c0 = i * 256 + lane * 4;
-    const float4 g = *reinterpret_cast<const float4*>(gamma + c0);
-    const float4 b = *reinterpret_cast<const float4*>(beta + c0);
-    bf16x4 o = {(bf16)((v[i].x - mu) * rs * g.x + b.x), (bf16)((v[i].y - mu) * rs * g.y + b.y),
-                (bf16)((v[i].z - mu) * rs * g.z + b.z), (bf16)((v[i].w - mu) * rs * g.w + b.w)};
+    const float4 g = gm[i];
+    const float4 b = bt[i];
+    bf16x4 o = {(bf16)((v[rr][i].x - mu) * rs * g.x + b.x), (bf16)((v[rr][i].y - mu) * rs * g.y + b.y),
+                (bf16)((v[rr][i].z - mu) * rs * g.z + b.z), (bf16)((v[rr][i].w - mu) * rs * g.w + b.w)};
     // yp > 0: y as K-panel-major [C/32][yp][32] (the A operand layout of the GEMM that reads it)
     if (!(XU && yp))   // (fused kernels write the panel image from the staged rows, panel_store)
       *reinterpret_cast<bf16x4*>(yp ? y + ((size_t)(c0 >> 5) * yp + row) * 32 + (c0 & 31) : yr + c0) = o;
@@ -139,7 +173,7 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_fwd_kernel(const 
       __syncthreads();
       panel_store<V4>(L, y, yp, blockIdx.x * 16, M);
     }
-    block_contract<V4>(L, Ut, T, Tt, ldt, blockIdx.x * 16, M);   // T = LN(x) U of the next linear
+    block_contract<V4>(L, uf, T, Tt, ldt, blockIdx.x * 16, M);   // T = LN(x) U of the next linear
   }
 }
 
@@ -208,7 +242,9 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_bwd_kernel(const 
       __syncthreads();
       panel_store<V4>(L, dyb, yp, blockIdx.x * 16, M);
     }
-    block_contract<V4>(L, Vst, G, Gt, ldt, blockIdx.x * 16, M);   // G' = dY Vs of the linear below
+    // (the B fragments are requested here, not at the top: holding them through the row loop costs the backward kernel a
+    // workgroup of occupancy -- 138 VGPRs, 36 us instead of 31)
+    block_contract<V4>(L, load_ut_frags<V4>(Vst), G, Gt, ldt, blockIdx.x * 16, M);   // G' = dY Vs of the linear below
   }
 }
 
