@@ -26,25 +26,39 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_wave_base, 16, 0, 0);
 }
 
-// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below the bf16 output resolution):
-// one v_rcp + one v_exp + 6 FMAs instead of the branchy libm erff.  e = exp(-x^2) is returned too:
-// with x = u / sqrt(2) it is also the Gaussian of gelu'(u), so forward and backward share it.
-__device__ __forceinline__ float erf_as(float x, float& e) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-  e = __expf(-ax * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float r = 1.0f - poly * e;
-  return x < 0.f ? -r : r;
+// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below the bf16 output resolution): for y >= 0
+//   erf(y) = 1 - P(t) exp(-y^2),  t = 1 / (1 + 0.3275911 y),  P = t (a1 + t (a2 + t (a3 + t (a4 + t a5))))
+// one v_rcp + one v_exp + a handful of FMAs instead of the branchy libm erff.  The GELU epilogues are VALU-bound (every
+// instruction per element costs ~1 us of an fc1 / fc2-dX product, tools: CARA_ABLATE_GELU), so the two forms below are
+// written for instruction count: the argument scalings are folded into the constants, |u| is a source modifier, and
+// the odd symmetry is used so that no compare / select is needed:
+//   gelu(u)  = u Phi(u) = max(u, 0) - |u| (P/2) e          (u erf(u / sqrt 2) is even)
+//   gelu'(u) = Phi(u) + u phi(u),  Phi(u) = 1/2 + copysign(1/2 - (P/2) e, u),  phi(u) = e / sqrt(2 pi)
+// with e = exp(-u^2 / 2) shared by both terms of the derivative.
+__device__ __forceinline__ float gelu_half_poly(float au, float& e, float usq) {
+  // au = |u|; returns P(t) / 2 for y = au / sqrt(2) and e = exp(-u^2 / 2) = exp2(-u^2 log2(e) / 2)
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.70710678118654752f, au, 1.0f));
+  e = __builtin_amdgcn_exp2f(usq * (-0.5f * 1.4426950408889634f));
+  return t * (0.5f * 0.254829592f + t * (0.5f * -0.284496736f + t * (0.5f * 1.421413741f + t * (0.5f * -1.453152027f + t * (0.5f * 1.061405429f)))));
 }
 __device__ __forceinline__ float gelu_erf(float u) {
+#ifdef CARA_ABLATE_GELU
+  return u * 0.5f;   // timing diagnostic: what the erf arithmetic of the GELU epilogues costs
+#endif
   float e;
-  return 0.5f * u * (1.0f + erf_as(u * 0.70710678118654752f, e));
+  const float au = fabsf(u);
+  const float hp = gelu_half_poly(au, e, u * u);
+  return __builtin_fmaf(-(au * hp), e, fmaxf(u, 0.f));
 }
 __device__ __forceinline__ float gelu_erf_grad(float u) {
+#ifdef CARA_ABLATE_GELU
+  return u * 0.5f;
+#endif
   float e;
-  const float cdf = 0.5f * (1.0f + erf_as(u * 0.70710678118654752f, e));
-  return cdf + u * 0.39894228040143268f * e;
+  const float hp = gelu_half_poly(fabsf(u), e, u * u);
+  const float half_erf = __builtin_fmaf(-hp, e, 0.5f);                    // erf(|u| / sqrt 2) / 2, in [0, 1/2]
+  const float cdf = 0.5f + __builtin_copysignf(half_erf, u);
+  return __builtin_fmaf(u * 0.39894228040143268f, e, cdf);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -185,11 +185,18 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
     __syncthreads();
     mma_tile32<MI>(smem, smem + A_BYTES, acc, wr, wc, lane);
   }
-  // epilogue in NPASS passes of HALF rows: wave-private [HALF][64] fp32 image (8 waves x 4 row tiles: four
-  // 16-row passes, so that the images fit the 48 KiB the K loop uses)
+  // epilogue.  bf16 outputs of interior wave tiles: the fast path of gemm_epilogue.h (values converted in the accumulator
+  // layout, 2-byte LDS transposition); everything else: NPASS passes of HALF rows through a wave-private [HALF][64] fp32 image
   constexpr int NPASS = (NW == 8 && MI == 4) ? 4 : 2;
   constexpr int HALF = MI * 16 / NPASS;
   __syncthreads();
+  if constexpr ((EPI == CARA_EPI_BF16 || EPI == CARA_EPI_GELU) && MI == 4 && NW == 4) {
+    const int mw = m0 + wr * 64, nw = n0 + wc * 64;
+    if (mw + 64 <= p.M && nw + 64 <= p.N && (p.ldc & 7) == 0) {   // wave-uniform
+      epilogue_fast_bf16<EPI>(p, acc, smem + wave * EPI_FAST_WAVE_BYTES, mw, nw, lane, coff);
+      return;
+    }
+  }
   float* stg = reinterpret_cast<float*>(smem) + wave * (HALF * 64);
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll

@@ -112,3 +112,70 @@ __device__ __forceinline__ void epilogue_64x64(const cara_gemm_args& p, const fl
                                                const int nbase, const int lane) {
   epilogue_rows<EPI, 64>(p, stg, mbase, nbase, lane);
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast epilogue for the bf16 outputs of INTERIOR wave tiles (CARA_EPI_BF16, CARA_EPI_GELU): rocprofv3 counted ~700 VALU
+// instructions per wave and tile in the generic path above (12 per output element: fp32 staging moves, per-row bounds
+// tests, 64-bit address arithmetic), and every one of them is exposed -- the GELU arithmetic alone, 12 more per element,
+// is 15 us of a 100 us fc1 product (tools: CARA_ABLATE_GELU).  Here bias, GELU and the bf16 conversion happen in the
+// MFMA accumulator layout (lane = column, 4 consecutive rows per register quad), the bf16 VALUES go through a wave-
+// private LDS image with 2-byte writes (rows padded to 144 B: the four row groups of a write land on disjoint banks),
+// and come back as 16-byte row pieces for the global stores: ~2 VALU per element besides the GELU itself.
+// acc: the wave's 64 x 64 sub-tile as [4][4] accumulators of v_mfma_f32_16x16x32 (row = 16 i + 4 (lane >> 4) + r,
+// column = 16 j + (lane & 15)).  stg: >= 32 * 144 bytes of LDS owned by this wave.  Requires mbase + 64 <= M,
+// nbase + 64 <= N, ldc % 8 == 0 (callers test; edge tiles take the generic path).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int EPI_FAST_ROW_BYTES = 144;
+constexpr int EPI_FAST_WAVE_BYTES = 32 * EPI_FAST_ROW_BYTES;
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_fast_bf16(const cara_gemm_args& p, const f32x4 (&acc)[4][4], char* stg, const int mbase,
+                                                   const int nbase, const int lane, const size_t coff) {
+  static_assert(EPI == CARA_EPI_BF16 || EPI == CARA_EPI_GELU, "bf16 outputs computed from the accumulator alone");
+  const int fr = lane & 15, fq = lane >> 4;
+  float bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[nbase + j * 16 + fr] : 0.f;
+  // this lane's write position inside a 32-row image: row 4 fq + r of row tile i2, column 16 j + fr
+  char* wbase = stg + (4 * fq) * EPI_FAST_ROW_BYTES + fr * 2;
+  // and its read position: row (lane >> 3) of each 8-row pass, 16-byte chunk lane & 7
+  const char* rbase = stg + (lane >> 3) * EPI_FAST_ROW_BYTES + (lane & 7) * 16;
+  const int rrow = lane >> 3, rcol = (lane & 7) * 8;
+  constexpr int NOUT = EPI == CARA_EPI_GELU ? 2 : 1;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      // o == 0: C (h = gelu(u) for CARA_EPI_GELU); o == 1: C2 = u, skipped when the pre-activation is not kept
+      if (o == 1 && !p.C2) continue;
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[half * 2 + i2][j][r] + bv[j];
+            if (EPI == CARA_EPI_GELU && o == 0) v[r] = gelu_erf(v[r]);
+          }
+          char* w = wbase + (i2 * 16) * EPI_FAST_ROW_BYTES + j * 32;
+          const bf16x2 p01 = {(bf16)v[0], (bf16)v[1]}, p23 = {(bf16)v[2], (bf16)v[3]};
+          *reinterpret_cast<bf16*>(w) = p01[0];
+          *reinterpret_cast<bf16*>(w + EPI_FAST_ROW_BYTES) = p01[1];
+          *reinterpret_cast<bf16*>(w + 2 * EPI_FAST_ROW_BYTES) = p23[0];
+          *reinterpret_cast<bf16*>(w + 3 * EPI_FAST_ROW_BYTES) = p23[1];
+        }
+      // (wave-private image: the wave's own LDS operations complete in order, no barrier)
+      bf16* out = static_cast<bf16*>(o == 0 ? p.C : p.C2);
+      const bool panels = o == 0 && p.c_panels;   // C as K-panel-major [N/32][c_panels][32]; C2 / aux keep the row-major ldc
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const bf16x8 val = *reinterpret_cast<const bf16x8*>(rbase + pass * 8 * EPI_FAST_ROW_BYTES);
+        const int m = mbase + half * 32 + pass * 8 + rrow, n = nbase + rcol;
+        bf16* dst = panels ? out + ((size_t)(n >> 5) * p.c_panels + m) * 32 + (n & 31) : out + (size_t)m * p.ldc + n + (o == 0 ? coff : 0);
+        *reinterpret_cast<bf16x8*>(dst) = val;
+      }
+    }
+  }
+}
