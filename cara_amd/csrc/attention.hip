@@ -750,18 +750,328 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16* __r
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const bf16x8 kf = tr_frag_at(kblk, to.lo[st][dt], to.hi[st][dt]);
-        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf, dq[dt], 0, 0, 0);
+        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, a, dq[dt], 0, 0, 0);   // dQ^T = K^T dS^T: d on the rows
       }
     }
   }
-  // dQ layout: column (lane & 31) = d, row = query q0 + crow(r, h)
+  // dQ^T layout: column (lane & 31) = QUERY, register r of lane half h = d = 32 dt + 8 (r >> 2) + 4 h + (r & 3).  As in the
+  // forward: the lane halves swap runs of four d (v_permlane32_swap) and every lane stores two runs of eight consecutive
+  // d per dt -- four 16-byte stores per lane instead of 32 two-byte ones.
+  bf16* qrow_out = dqkv + (size_t)(b * N + qrow) * ld + head * HD;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int q = q0 + crow(r, h);
-    if (q < N) {
+  for (int dt = 0; dt < 2; ++dt) {
+    unsigned w[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const bf16x2 lo = {(bf16)(dq[dt][4 * g] * scale), (bf16)(dq[dt][4 * g + 1] * scale)};
+      const bf16x2 hi = {(bf16)(dq[dt][4 * g + 2] * scale), (bf16)(dq[dt][4 * g + 3] * scale)};
+      w[g][0] = __builtin_bit_cast(unsigned, lo);
+      w[g][1] = __builtin_bit_cast(unsigned, hi);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(w[g][k], w[g + 2][k], false, false);
+        w[g][k] = sw[0];
+        w[g + 2][k] = sw[1];
+      }
+    if (q0 + ql < N) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const uint4 v = {w[g][0], w[g][1], w[g + 2][0], w[g + 2][1]};
+        *reinterpret_cast<uint4*>(qrow_out + dt * 32 + 8 * (g + 2 * h)) = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward for 128 < N <= 224, the headline path: ONE persistent kernel instead of the pair above.  A 7-wave workgroup
+// per CU walks the (batch, head) pairs (768 = 3 per CU); for each pair it runs the dK/dV sweep (wave w owns keys 32w..,
+// phase A) and then the dQ sweep (wave w owns queries 32w.., phase B) on the SAME LDS images, so Q, K, V, dO, O are read
+// from HBM once per head instead of twice (195 -> 116 MB per layer), and the next head's images arrive by hidden LDS-DMA
+// while this head computes:
+//   phase A reads Q, dO (images) + its keys' K, V rows (registers);   meanwhile K, V of THIS head land in their images
+//   phase B reads K, V (images) + its queries' Q, dO rows (registers); meanwhile Q, dO, O of the NEXT head land
+// delta = rowsum(dO . O) is formed from the O and dO images (2 threads per row) before phase A.  Every wait for a DMA
+// piece is a vmcnt(0) placed just before a phase's stores are issued, when everything outstanding is old; four
+// barriers per head.  LDS: five [224][64] images + lse + delta = 145 KiB.  The arithmetic of the two phases is that
+// of attn_bwd_dkv_kernel / attn_bwd_dq_kernel<7> (same operand layouts, same rounding points: bitwise the same results).
+// ------------------------------------------------------------------------------------------
+// 4 bytes per lane (256 B per wave instruction) by hidden LDS-DMA: the forward's LSE row of a head (any 4-byte alignment)
+__device__ __forceinline__ void glds4_hidden(const char* base, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+}
+
+__global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                                const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                                bf16* __restrict__ dqkv, int N, int H, int BH, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NPAD = 224, IMG = NPAD * 128;
+  char* Qs = smem;
+  char* dOs = smem + IMG;
+  char* Os = smem + 2 * IMG;
+  char* Ks = smem + 3 * IMG;
+  char* Vs = smem + 4 * IMG;
+  float* lse_s = reinterpret_cast<float*>(smem + 5 * IMG);
+  float* del_s = lse_s + 256;   // (lse_s takes four 64-float DMA pieces)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ld = 3 * H * HD, ldo = H * HD;
+  const int l31 = lane & 31, h = lane >> 5;
+  const float c2 = scale * 1.4426950408889634f;
+  const RowOfs ro = row_ofs(lane);
+  const TrOfs to = tr_ofs(lane);
+  const int nt = (N + 31) >> 5;                 // query / key tiles (<= 7)
+  const int last = N - (nt - 1) * 32;           // valid rows of the last tile
+  const int t0 = wave * 32;                     // first key (phase A) / query (phase B) of this wave
+  const int trow = t0 + l31 < N ? t0 + l31 : N - 1;
+  const bool tvalid = t0 + l31 < N;
+
+  // per-lane 32-bit byte offsets of this wave's DMA pieces (head-independent; the head's base pointers are wave-uniform).
+  // An image = 28 pieces of 8 rows; wave w takes pieces w, w + 7, w + 14, w + 21 of every image.
+  unsigned off_qkv[4], off_o[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = (wave + t * 7) * 8 + (lane >> 3);
+    const int rr = row < N ? row : N - 1;
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    off_qkv[t] = (unsigned)rr * (unsigned)(ld * 2) + (unsigned)(c * 16);
+    off_o[t] = (unsigned)rr * (unsigned)(ldo * 2) + (unsigned)(c * 16);
+  }
+  auto lds_of = [](const char* p) { return __builtin_amdgcn_readfirstlane((unsigned)(size_t)p); };
+  auto dma_image = [&](const char* base, const unsigned (&off)[4], char* img) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) glds16_hidden(base, off[t], lds_of(img) + (unsigned)((wave + t * 7) * 1024));
+  };
+  auto qkv_base = [&](int bh) { const int b = bh / H, hd = bh - b * H; return reinterpret_cast<const char*>(qkv + (size_t)b * N * ld + hd * HD); };
+  auto o_base = [&](const bf16* p_, int bh) { const int b = bh / H, hd = bh - b * H; return reinterpret_cast<const char*>(p_ + (size_t)b * N * ldo + hd * HD); };
+
+  int bh = blockIdx.x;
+  if (bh >= BH) return;
+  // ---- prologue: what a "phase B" leaves behind for the next head ----
+  bf16x8 kf[4], vf[4];
+  // the head's LSE row: wave 0, four pieces of 64 floats straight into lse_s (raw; scaled to log2 units in the delta step)
+  unsigned off_lse[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = t * 64 + lane;
+    off_lse[t] = (unsigned)((i < N ? i : N - 1) * 4);
+  }
+  auto dma_lse = [&](int bh_) {
+    if (wave == 0) {
+      const char* base = reinterpret_cast<const char*>(lse + (size_t)bh_ * N);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t * 64 < NPAD) glds4_hidden(base, off_lse[t], lds_of(reinterpret_cast<const char*>(lse_s)) + (unsigned)(t * 256));
+    }
+  };
+  {
+    const char* qb = qkv_base(bh);
+    dma_image(qb, off_qkv, Qs);
+    dma_image(o_base(dout, bh), off_o, dOs);
+    dma_image(o_base(out, bh), off_o, Os);
+    const bf16* kb = reinterpret_cast<const bf16*>(qb) + H * HD;
+    const bf16* vb = kb + H * HD;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = *reinterpret_cast<const bf16x8*>(kb + (size_t)trow * ld + ks * 16 + h * 8);
+      vf[ks] = *reinterpret_cast<const bf16x8*>(vb + (size_t)trow * ld + ks * 16 + h * 8);
+    }
+    dma_lse(bh);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  for (; bh < BH; bh += gridDim.x) {
+    const int nxt = bh + gridDim.x;
+    const int b = bh / H, head = bh - b * H;
+    // T0: every wave is through with phase B of the previous head (K, V images free) and has seen its own pieces of this
+    // head's Q, dO, O images land
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // delta[row] = sum_d dO[row][d] O[row][d] from the images, two threads per row (4 chunks of 8 each); lse in log2 units
+    {
+      const int row = tid >> 1, half = tid & 1;
+      float dl = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int off = swz128(row, half * 4 + c);
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Os + off);
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(dOs + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += (float)a[j] * (float)g[j];
+      }
+      dl += __shfl_xor(dl, 1, 64);
+      if (half == 0) del_s[row] = dl;
+      if (tid < NPAD) lse_s[tid] *= 1.4426950408889634f;   // (each element touched by exactly one thread)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // T1
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ================= phase A: dK, dV of keys t0 .. t0 + 31 =================
+    f32x16 dkt[2], dvt[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dkt[dt][r] = 0.f; dvt[dt][r] = 0.f; }
+    for (int qt = 0; qt < nt; ++qt) {
+      const int q0 = qt * 32;
+      const char* qblk = Qs + qt * 4096;
+      const char* dblk = dOs + qt * 4096;
+      f32x16 sacc, pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qblk + ro.o[ks]);
+        const bf16x8 da = *reinterpret_cast<const bf16x8*>(dblk + ro.o[ks]);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], pacc, 0, 0, 0);
+      }
+      if (qt == 0) {
+        // K, V of THIS head into their images (needed by phase B): issued behind the LAST first-use of kf / vf (scheduling
+        // fence), so that none of the waits hipcc puts in front of those uses covers these pieces
+        __builtin_amdgcn_sched_barrier(0);
+        const char* qb = qkv_base(bh);
+        dma_image(qb + H * HD * 2, off_qkv, Ks);
+        dma_image(qb + 2 * H * HD * 2, off_qkv, Vs);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      f32x16 p, ds;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + q0 + 8 * g4 + 4 * h);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + q0 + 8 * g4 + 4 * h);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = 4 * g4 + k;
+          float e = __builtin_amdgcn_exp2f(sacc[r] * c2 - l4[k]);
+          if (qt == nt - 1) e = crow(r, h) < last ? e : 0.f;
+          e = tvalid ? e : 0.f;
+          p[r] = e;
+          ds[r] = e * (pacc[r] - d4[k]);
+        }
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const bf16x8 pb = pack8(p, st), dsb = pack8(ds, st);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 doa = tr_frag_at(dblk, to.lo[st][dt], to.hi[st][dt]);
+          const bf16x8 qta = tr_frag_at(qblk, to.lo[st][dt], to.hi[st][dt]);
+          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa, pb, dvt[dt], 0, 0, 0);
+          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsb, dkt[dt], 0, 0, 0);
+        }
+      }
+    }
+    // T2: this wave's pieces of K, V have landed (they are old by now); then every wave's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (tvalid) {
+      bf16* dk = dqkv + (size_t)(b * N + t0 + l31) * ld + H * HD + head * HD;
+      bf16* dv = dk + H * HD;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
-        dqkv[(size_t)(b * N + q) * ld + head * HD + dt * 32 + ql] = (bf16)(dq[dt][r] * scale);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = dt * 32 + 8 * g + 4 * h;
+          bf16x4 a = {(bf16)(dkt[dt][4 * g] * scale), (bf16)(dkt[dt][4 * g + 1] * scale),
+                      (bf16)(dkt[dt][4 * g + 2] * scale), (bf16)(dkt[dt][4 * g + 3] * scale)};
+          bf16x4 c = {(bf16)dvt[dt][4 * g], (bf16)dvt[dt][4 * g + 1], (bf16)dvt[dt][4 * g + 2], (bf16)dvt[dt][4 * g + 3]};
+          *reinterpret_cast<bf16x4*>(dk + d) = a;
+          *reinterpret_cast<bf16x4*>(dv + d) = c;
+        }
+    }
+
+    // ================= phase B: dQ of queries t0 .. t0 + 31 =================
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(Qs + wave * 4096 + ro.o[ks]);
+      dof[ks] = *reinterpret_cast<const bf16x8*>(dOs + wave * 4096 + ro.o[ks]);
+    }
+    const float lq = lse_s[t0 + l31], dl = del_s[t0 + l31];
+    // T3: every wave holds its Q / dO rows and row constants: the Q, dO, O images may take the next head
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (nxt < BH) {
+      const char* qb = qkv_base(nxt);
+      dma_image(qb, off_qkv, Qs);
+      dma_image(o_base(dout, nxt), off_o, dOs);
+      dma_image(o_base(out, nxt), off_o, Os);
+      const bf16* kb = reinterpret_cast<const bf16*>(qb) + H * HD;
+      const bf16* vb = kb + H * HD;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = *reinterpret_cast<const bf16x8*>(kb + (size_t)trow * ld + ks * 16 + h * 8);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(vb + (size_t)trow * ld + ks * 16 + h * 8);
+      }
+      dma_lse(nxt);
+    }
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+    for (int kt = 0; kt < nt; ++kt) {
+      const char* kblk = Ks + kt * 4096;
+      const char* vblk = Vs + kt * 4096;
+      f32x16 sT, dpT;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sT[r] = 0.f; dpT[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kblk + ro.o[ks]);
+        const bf16x8 va = *reinterpret_cast<const bf16x8*>(vblk + ro.o[ks]);
+        sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], sT, 0, 0, 0);
+        dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dpT, 0, 0, 0);
+      }
+      f32x16 ds;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float e = __builtin_amdgcn_exp2f(sT[r] * c2 - lq);
+        if (kt == nt - 1) e = crow(r, h) < last ? e : 0.f;
+        ds[r] = e * (dpT[r] - dl);
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const bf16x8 a = pack8(ds, st);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 kfr = tr_frag_at(kblk, to.lo[st][dt], to.hi[st][dt]);
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, a, dq[dt], 0, 0, 0);   // dQ^T = K^T dS^T
+        }
+      }
+    }
+    // the next head's images and row fragments have landed (they are old by now): wait for them HERE, before this phase's
+    // stores go out, so that no later wait ever has to cover a store
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bf16* qrow_out = dqkv + (size_t)(b * N + trow) * ld + head * HD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      unsigned w[4][2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const bf16x2 lo = {(bf16)(dq[dt][4 * g] * scale), (bf16)(dq[dt][4 * g + 1] * scale)};
+        const bf16x2 hi = {(bf16)(dq[dt][4 * g + 2] * scale), (bf16)(dq[dt][4 * g + 3] * scale)};
+        w[g][0] = __builtin_bit_cast(unsigned, lo);
+        w[g][1] = __builtin_bit_cast(unsigned, hi);
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(w[g][k], w[g + 2][k], false, false);
+          w[g][k] = sw[0];
+          w[g + 2][k] = sw[1];
+        }
+      if (tvalid) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const uint4 v = {w[g][0], w[g][1], w[g + 2][0], w[g + 2][1]};
+          *reinterpret_cast<uint4*>(qrow_out + dt * 32 + 8 * (g + 2 * h)) = v;
+        }
+      }
     }
   }
 }
@@ -805,6 +1115,7 @@ static void attn_set_lds_limits() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_long_kernel<7>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_persist_kernel), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), at, MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<4>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<7>), at, MAX_LDS);
   done = true;
@@ -850,6 +1161,14 @@ extern "C" int cara_attention_bwd(const void* qkv, const void* out, const void* 
   attn_set_lds_limits();
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int npad = (N + 31) / 32 * 32, lds = 2 * npad * 128;
+  static const int use_fused = [] { const char* e = getenv("CARA_ATTN_PERSIST"); return e ? atoi(e) : 1; }();
+  if (use_fused && N > 128 && N <= NMAX) {
+    const int BH = B * H, grid = BH < 256 ? BH : 256;
+    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(grid), dim3(448), 5 * 224 * 128 + (256 + 224) * 4, st, (const bf16*)qkv, (const bf16*)out,
+                       (const bf16*)dout, lse, (bf16*)dqkv, N, H, BH, scale);
+    CARA_CHECK_LAUNCH();
+    return CARA_OK;
+  }
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H, (N + 223) / 224), dim3(448), dkv_lds_bytes(npad), st, (const bf16*)qkv,
                      (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale, npad);
   CARA_CHECK_LAUNCH();
