@@ -797,7 +797,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16* __r
 // delta = rowsum(dO . O) is formed from the O and dO images (2 threads per row) before phase A.  Every wait for a DMA
 // piece is a vmcnt(0) placed just before a phase's stores are issued, when everything outstanding is old; four
 // barriers per head.  LDS: five [224][64] images + lse + delta = 145 KiB.  The arithmetic of the two phases is that
-// of attn_bwd_dkv_kernel / attn_bwd_dq_kernel<7> (same operand layouts, same rounding points: bitwise the same results).
+// of attn_bwd_dkv_kernel / attn_bwd_dq_kernel<7> (same operand layouts and rounding points; delta is summed in another
+// order, so results agree to fp32 rounding of that one scalar per row, not bitwise).  Deterministic: no atomics.
 // ------------------------------------------------------------------------------------------
 // 4 bytes per lane (256 B per wave instruction) by hidden LDS-DMA: the forward's LSE row of a head (any 4-byte alignment)
 __device__ __forceinline__ void glds4_hidden(const char* base, unsigned voff, unsigned lds_addr) {
