@@ -14,13 +14,13 @@ a = ap.parse_args()
 f = glob.glob(a.path + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")) for r in rows))
-has_bwd = [i for i, e in enumerate(ev) if "attn_bwd_dq" in e[2]]
+has_bwd = [i for i, e in enumerate(ev) if "attn_bwd" in e[2]]
 last_bwd = has_bwd[-1]
 if a.skip_last:   # cut the trace before the prep_kernel of the first skipped step
     allp = [i for i, e in enumerate(ev) if "prep_kernel" in e[2] and i < last_bwd]
     cut = allp[-a.skip_last]
     ev = ev[:cut]
-    has_bwd = [i for i, e in enumerate(ev) if "attn_bwd_dq" in e[2]]
+    has_bwd = [i for i, e in enumerate(ev) if "attn_bwd" in e[2]]
     last_bwd = has_bwd[-1]
 preps = [i for i, e in enumerate(ev) if "prep_kernel" in e[2] and i < last_bwd]
 # the last `steps` forward+backward steps: from the (steps)th-last prep before the last backward kernel
