@@ -25,6 +25,30 @@
 #include "gemm_epilogue.h"
 #include "tskinny_body.h"
 
+#ifdef CARA_GEMM_STAMPS
+// Diagnostic build (tools/gemm_stamps.py): wave 0 of every workgroup records s_memrealtime (100 MHz) at its start, at the
+// end of its K loop and after its epilogue's stores have retired, plus where it ran, into a buffer of their own.
+__device__ unsigned long long* g_stamp_buf = nullptr;
+extern "C" int cara_debug_gemm_stamps(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#define STAMP(slot)                                                                         \
+  do {                                                                                      \
+    if (g_stamp_buf && threadIdx.x == 0) g_stamp_buf[(size_t)blockIdx.x * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#define STAMP_END()                                                                         \
+  do {                                                                                      \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
+    if (g_stamp_buf && threadIdx.x == 0) {                                                  \
+      g_stamp_buf[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();           \
+      g_stamp_buf[(size_t)blockIdx.x * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); \
+    }                                                                                       \
+  } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#define STAMP_END() do {} while (0)
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;   // (K granule the C ABI promises: K % 64 == 0)
@@ -105,6 +129,7 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
   constexpr int SLOT = A_BYTES + B32_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
+  STAMP(0);
   // Tile order: each XCD gets a contiguous run of logical tile indices (xcd_remap); inside the run
   // the tiles are walked in groups of `gm` tile rows, row index fastest (a "supertile"), so that the
   // ~128 tiles an XCD keeps in flight touch about sqrt(128)+sqrt(128) operand panels instead of
@@ -187,13 +212,17 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
   }
   // epilogue.  bf16 outputs of interior wave tiles: the fast path of gemm_epilogue.h (values converted in the accumulator
   // layout, 2-byte LDS transposition); everything else: NPASS passes of HALF rows through a wave-private [HALF][64] fp32 image
-  constexpr int NPASS = (NW == 8 && MI == 4) ? 4 : 2;
+  constexpr int NPASS = ((NW == 8 && MI == 4) || MI == 8) ? 4 : 2;
   constexpr int HALF = MI * 16 / NPASS;
   __syncthreads();
-  if constexpr ((EPI == CARA_EPI_BF16 || EPI == CARA_EPI_GELU) && MI == 4 && NW == 4) {
-    const int mw = m0 + wr * 64, nw = n0 + wc * 64;
-    if (mw + 64 <= p.M && nw + 64 <= p.N && (p.ldc & 7) == 0) {   // wave-uniform
-      epilogue_fast_bf16<EPI>(p, acc, smem + wave * EPI_FAST_WAVE_BYTES, mw, nw, lane, coff);
+  STAMP(1);
+  if constexpr ((EPI == CARA_EPI_BF16 || EPI == CARA_EPI_GELU) && (MI == 4 || MI == 8) && NW == 4) {
+    const int mw = m0 + wr * (MI * 16), nw = n0 + wc * 64;
+    if (mw + MI * 16 <= p.M && nw + 64 <= p.N && (p.ldc & 7) == 0) {   // wave-uniform
+#pragma unroll
+      for (int q = 0; q < MI / 4; ++q)
+        epilogue_fast_bf16<EPI>(p, *reinterpret_cast<const f32x4(*)[4][4]>(&acc[q * 4]), smem + wave * EPI_FAST_WAVE_BYTES, mw + q * 64, nw, lane, coff);
+      STAMP_END();
       return;
     }
   }
@@ -209,6 +238,7 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
         for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[half * (MI / NPASS) + i][j][r];
     epilogue_rows<EPI, HALF>(p, stg, m0 + wr * (MI * 16) + half * HALF, n0 + wc * 64, lane, coff);
   }
+  STAMP_END();
 }
 
 template <int EPI, bool TWOB = false>
@@ -217,14 +247,24 @@ __global__ __launch_bounds__(256, 4) void gemm32_kernel(const cara_gemm_args p, 
   gemm32_body<EPI, 4, 4, TWOB>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
 }
 
+// 256 x 128 tiles from the same body: each of the four waves owns 128 x 64 (8 x 4 accumulators, 128 registers), so a K step
+// stages 24 KiB for twice the MFMAs of the 128 x 128 tile (3/4 of the bytes per flop through the CU's load-return path,
+// which the counters show ~70 % busy in the default kernel) and reads 3/4 of the LDS bytes per flop; 48 KiB of LDS and
+// < 256 registers: two workgroups per CU.  CARA_GEMM_BM=256 selects it for the wide products (N >= 2304).
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void gemm32_tall_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm32_body<EPI, 8, 4>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
+}
+
 // The dX GEMM of a linear and the two transposed skinny products of the SAME linear (dU = X^T G', dVs = dY^T T) in
 // one grid: blocks [0, nts) are tskinny blocks (HBM-bound, one LDS stage per wave), the rest GEMM tiles (MFMA-bound).
 // The products used to run on a side stream under the GEMM, which costs a fork (an event record = 3..7 us of idle
 // chip, 44 of them per backward pass) and overlaps only as well as two queues happen to interleave; as one launch
 // there is no event at all and the dispatcher mixes the two kinds of workgroup on every CU.  Needs Rp = 32 products
 // (84 VGPRs; the Rp = 64 form needs 136) and 36 KiB of LDS per workgroup (still four per CU).
-template <int EPI, bool COLSUM>
-__global__ __launch_bounds__(256, 4) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
+template <int EPI, bool COLSUM, int MI = 4>
+__global__ __launch_bounds__(256, MI == 8 ? 3 : 4) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
                                                            const TsProblem t0, const TsProblem t1, const int ldg, const int Mts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // the products' blocks sit BEHIND the GEMM tiles: they fill the slots the GEMM's last, partly filled round leaves
@@ -233,7 +273,7 @@ __global__ __launch_bounds__(256, 4) void gemm32_ts_kernel(const cara_gemm_args 
   if (b >= nwg) {
     tskinny_body<2, COLSUM, 1>(t0, t1, ldg, Mts, b - nwg, smem);
   } else {
-    gemm32_body<EPI, 4, 4>(p, tiles_n, nwg, gm, b, 0, smem);
+    gemm32_body<EPI, MI, 4>(p, tiles_n, nwg, gm, b, 0, smem);
   }
 }
 
@@ -369,6 +409,8 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
   }
 }
 
+#include "gemm_big.h"
+
 static int group_m(int tiles_n);
 
 template <int EPI>
@@ -407,6 +449,20 @@ int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr
   const int gm = group_m(tiles_n);
   const int nwg = ((a->M + 127) / 128) * tiles_n;
   constexpr int GEMM_LDS = 2 * (128 * BK32 * 2 + B32_BYTES);
+  static const int tall = [] { const char* e = getenv("CARA_GEMM_BM"); return e ? atoi(e) : 0; }();
+  const bool use_tall = (tall == 256 || tall == 2562) && a->N >= 2304 && a->M > 1024 && a->batch <= 1 && !a->B3;
+  constexpr int TALL_LDS = 2 * (256 * BK32 * 2 + B32_BYTES);
+  if (ts && use_tall) {
+    const int nts = ts->a.nblk + ts->b.nblk;
+    const int nwg_t = ((a->M + 255) / 256) * tiles_n;
+    constexpr int LDS = TsRing<2, 1>::BLOCK_BYTES > TALL_LDS ? TsRing<2, 1>::BLOCK_BYTES : TALL_LDS;
+    if (ts->any_cs)
+      hipLaunchKernelGGL((gemm32_ts_kernel<EPI, true, 8>), dim3(nwg_t + nts), dim3(256), LDS, st, *a, tiles_n, nwg_t, gm, ts->a, ts->b, ts->ldg, ts->M);
+    else
+      hipLaunchKernelGGL((gemm32_ts_kernel<EPI, false, 8>), dim3(nwg_t + nts), dim3(256), LDS, st, *a, tiles_n, nwg_t, gm, ts->a, ts->b, ts->ldg, ts->M);
+    CARA_CHECK_LAUNCH();
+    return CARA_OK;
+  }
   if (ts) {
     const int nts = ts->a.nblk + ts->b.nblk;
     constexpr int LDS = TsRing<2, 1>::BLOCK_BYTES > GEMM_LDS ? TsRing<2, 1>::BLOCK_BYTES : GEMM_LDS;
@@ -418,6 +474,19 @@ int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr
     return CARA_OK;
   }
   const int nb = a->batch > 1 ? a->batch : 1;
+  if (use_tall) {
+    const int nwg_t = ((a->M + 255) / 256) * tiles_n;
+    // 48 KiB: three workgroups per CU (168 registers); asking for 72 KiB holds it at two (A/B)
+    const int lds = tall == 256 ? TALL_LDS : 72 * 1024;
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm32_tall_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess) return CARA_E_LAUNCH;
+      attr = true;
+    }
+    hipLaunchKernelGGL((gemm32_tall_kernel<EPI>), dim3(nwg_t), dim3(256), lds, st, *a, tiles_n, nwg_t, gm);
+    CARA_CHECK_LAUNCH();
+    return CARA_OK;
+  }
   if (a->B3) hipLaunchKernelGGL((gemm32_kernel<EPI, true>), dim3(nwg, nb), dim3(256), GEMM_LDS, st, *a, tiles_n, nwg, gm);
   else hipLaunchKernelGGL((gemm32_kernel<EPI>), dim3(nwg, nb), dim3(256), GEMM_LDS, st, *a, tiles_n, nwg, gm);
   CARA_CHECK_LAUNCH();
@@ -592,6 +661,19 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
       case CARA_EPI_GELU: return launch_small_m<CARA_EPI_GELU>(a, nslab, st);
       case CARA_EPI_RESID: return launch_small_m<CARA_EPI_RESID>(a, nslab, st);
       case CARA_EPI_DGELU: return launch_small_m<CARA_EPI_DGELU>(a, nslab, st);
+      default: return CARA_E_ARG;
+    }
+  }
+  // CARA_GEMM_BIG: 1 = the 208 x 256 one-workgroup-per-CU tile for the products whose tiles fit one round (N = 768 at M = 12608),
+  // 2 = for every product it can take
+  static const int big = [] { const char* e = getenv("CARA_GEMM_BIG"); return e ? atoi(e) : 0; }();
+  if (big && !ts && big_tile_ok(a) && (big >= 2 || ((a->M + GB_TM - 1) / GB_TM) * (a->N / GB_TN) <= 256)) {
+    switch (a->epi) {
+      case CARA_EPI_BF16: return launch_big<CARA_EPI_BF16>(a, st);
+      case CARA_EPI_F32: return launch_big<CARA_EPI_F32>(a, st);
+      case CARA_EPI_GELU: return launch_big<CARA_EPI_GELU>(a, st);
+      case CARA_EPI_RESID: return launch_big<CARA_EPI_RESID>(a, st);
+      case CARA_EPI_DGELU: return launch_big<CARA_EPI_DGELU>(a, st);
       default: return CARA_E_ARG;
     }
   }

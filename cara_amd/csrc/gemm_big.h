@@ -1,0 +1,240 @@
+// The 208 x 256 tile of the bf16 GEMM (gfx950): ONE 512-thread workgroup per CU.  Included by gemm.hip inside its
+// anonymous namespace (uses swz32, glds16, epilogue_rows, the STAMP macros).
+//
+// Why a second tile.  In-kernel time stamps (tools/gemm_stamps.py) show what bounds the K loop of the 128 x 128 kernel:
+// a CU takes in ~33-38 bytes per clock through its vector-memory path (L2 -> L1 -> LDS; the L1's outstanding requests
+// x line size / L2 latency), whatever the number of resident workgroups or the prefetch depth: 4 workgroups x 16 KiB per
+// 0.92 us, 3 x 24 KiB per 1.18 us, 2.3 x 18 KiB per 0.58 us -- always ~70 GB/s per CU.  A product's K-loop time is
+// therefore (bytes staged by its busiest CU) / 70 GB/s.  The N = 768 products (594 tiles of 128 x 128: three on the
+// busiest CUs, 96 K steps each) stage 4.7 MB there = 65 us of a 83 us launch.  This tile stages (208 + 256) x 64 B per K
+// step for 3.25x the flops of a 128 x 128 step (0.55x the bytes per flop), and its 61 x 3 = 183 tiles (M = 12608) are one
+// per CU: 2.85 MB on every CU that has one.
+//
+//  * 8 waves as 2 (M: row tiles 0..6 | 7..12) x 4 (N: 64 columns each); a wave of row 0 owns 7 x 4 accumulators of
+//    v_mfma_f32_16x16x32_bf16, a wave of row 1 owns 6 x 4; waves w and w + 4 share a SIMD, so every SIMD issues 52 MFMAs
+//    per K step.
+//  * The two wave rows run half a K step apart (two barriers per step): while one row issues its MFMAs the other
+//    issues its share of the LDS-DMA for step k + 2, reads its fragments of step k and waits -- the matrix pipe of
+//    every SIMD always has one wave feeding it (MI355X_MICROARCH.md, two waves per SIMD).
+//  * K steps of 32 in a ring of four 29-KiB slots (A 208 x 64 B | B 256 x 64 B, 16-byte-chunk XOR swizzle applied on
+//    the global source address as in the 128 x 128 kernel), three steps in flight behind a counted vmcnt; the K-extension
+//    ([T | Vs], Rp = 32) is one more step of the same loop with other base pointers.
+//  * Row tiles start every `stride` <= 208 rows (stride = ceil(M / ceil(M / 208))): a tile computes 208 rows and
+//    stores the first `stride` of them, so that M = 12608 is 61 equal tiles instead of 60 and a sliver.
+#pragma once
+
+constexpr int GB_RT = 13;
+constexpr int GB_TM = GB_RT * 16;                  // 208
+constexpr int GB_TN = 256;
+constexpr int GB_A_BYTES = GB_TM * 64;             // 13312
+constexpr int GB_B_BYTES = GB_TN * 64;             // 16384
+constexpr int GB_SLOT = GB_A_BYTES + GB_B_BYTES;   // 29696
+constexpr int GB_SLOTS = 4;
+constexpr int GB_LDS = GB_SLOTS * GB_SLOT;         // 89088
+constexpr int GB_PIECES = GB_RT + GB_TN / 16;      // 29 one-KiB LDS-DMA pieces per K step
+constexpr int GB_R0 = 7;                           // row tiles of wave row 0
+
+struct GbStage {
+  // per wave: up to four pieces (index wave + 8 t); per lane: byte offsets of its 16 bytes in a main step (m) / the extension step (e)
+  // (scalars, not arrays: every member stays in a register)
+  unsigned m0, m1, m2, m3, e0, e1, e2, e3;
+  int d0, d1, d2, d3;  // LDS byte offset of the piece inside a slot (wave-uniform)
+  bool isA1;           // piece 1 is an A piece (waves 0..4) or a B piece (waves 5..7)
+  bool four;           // this wave issues four pieces per step (waves 0..4) or three
+};
+
+__device__ __forceinline__ void gb_piece(const cara_gemm_args& p, const bool packed, const int m0, const int n0, const int idx, const int lane,
+                                         unsigned& om, unsigned& oe, int& dst) {
+  const int cg = (lane & 3) ^ (((lane >> 5) & 1) * 3);   // rows of a piece start at a multiple of 16: (row >> 3) & 1 = lane >> 5
+  const bool isA = idx < GB_RT;
+  const int row = (isA ? idx : idx - GB_RT) * 16 + (lane >> 2);
+  dst = isA ? idx * 1024 : GB_A_BYTES + (idx - GB_RT) * 1024;
+  int g = (isA ? m0 : n0) + row;
+  const int gmax = (isA ? p.M : p.N) - 1;
+  g = g < gmax ? g : gmax;
+  const unsigned ld2 = isA ? (p.a_panels ? 64u : (unsigned)p.lda * 2u) : (packed ? 64u : (unsigned)p.ldb * 2u);
+  om = (unsigned)g * ld2 + (unsigned)(cg * 16);
+  oe = (unsigned)g * 64u + (unsigned)(cg * 16);
+}
+
+__device__ __forceinline__ GbStage gb_stage_init(const cara_gemm_args& p, const bool packed, const int m0, const int n0, const int wave,
+                                                 const int lane) {
+  GbStage s;
+  s.isA1 = wave < GB_RT - 8;
+  s.four = wave + 24 < GB_PIECES;
+  gb_piece(p, packed, m0, n0, wave, lane, s.m0, s.e0, s.d0);
+  gb_piece(p, packed, m0, n0, wave + 8, lane, s.m1, s.e1, s.d1);
+  gb_piece(p, packed, m0, n0, wave + 16, lane, s.m2, s.e2, s.d2);
+  gb_piece(p, packed, m0, n0, s.four ? wave + 24 : wave + 16, lane, s.m3, s.e3, s.d3);
+  return s;
+}
+
+// the LDS-DMA of one K step into the ring slot at `slot`: this wave's pieces, at the given per-lane offsets
+__device__ __forceinline__ void gb_issue(const char* pa, const char* pb, const unsigned o0, const unsigned o1, const unsigned o2, const unsigned o3,
+                                         const int d0, const int d1, const int d2, const int d3, const bool isA1, const bool four, char* slot) {
+  glds16(pa + o0, slot + d0);
+  glds16((isA1 ? pa : pb) + o1, slot + d1);
+  glds16(pb + o2, slot + d2);
+  if (four) glds16(pb + o3, slot + d3);
+}
+
+template <int MI>
+__device__ __forceinline__ void gb_read(bf16x8 (&a)[GB_R0], bf16x8 (&b)[4], const char* slot, const int row0, const int wc, const int fr, const int fq) {
+#pragma unroll
+  for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(slot + swz32(row0 + i * 16 + fr, fq));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(slot + GB_A_BYTES + swz32(wc * 64 + j * 16 + fr, fq));
+}
+template <int MI>
+__device__ __forceinline__ void gb_mma(f32x4 (&acc)[GB_R0][4], const bf16x8 (&a)[GB_R0], const bf16x8 (&b)[4]) {
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+}
+
+// all of this wave's LDS-DMA but its `younger` youngest batches (the steps after the one about to be read) has landed
+__device__ __forceinline__ void gb_wait_batch(const int younger, const bool four) {
+  static_assert(GB_SLOTS == 4, "vmcnt literals: two batches may stay in flight");
+  if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (younger == 1) {
+    if (four) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  } else {
+    if (four) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  }
+}
+__device__ __forceinline__ void gb_barrier() {
+  // pinned: hipcc moves register-only instructions (the MFMAs) across a bare inline-asm barrier
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void gb_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// one workgroup's tile; `block` = its index among the nwg tiles
+template <int EPI>
+__device__ __forceinline__ void gemm_big_body(const cara_gemm_args& p, const int tiles_n, const int nwg, const int stride, const int block,
+                                              char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  STAMP(0);
+  const int tile = xcd_remap(block, nwg);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * stride, n0 = tn * GB_TN;
+  const bool packed = p.Bp != nullptr;
+  const GbStage sg = gb_stage_init(p, packed, m0, n0, wave, lane);
+  const char* A = static_cast<const char*>(p.A);
+  const char* B = static_cast<const char*>(packed ? p.Bp : p.B);
+  const long ksA = p.a_panels ? (long)p.a_panels * 64 : 64;   // bytes per K step
+  const long ksB = packed ? (long)p.N * 64 : 64;
+  const int nk = p.K >> 5;
+  const int ntot = nk + (p.Rp ? 1 : 0);
+  const char* A2 = static_cast<const char*>(p.A2);
+  const char* B2 = static_cast<const char*>(p.B2);
+  // (values, not references into sg: a select between two members of a struct held by reference makes hipcc keep the
+  // struct in scratch memory and reload it inside the K loop)
+  const unsigned m0o = sg.m0, m1o = sg.m1, m2o = sg.m2, m3o = sg.m3, e0o = sg.e0, e1o = sg.e1, e2o = sg.e2, e3o = sg.e3;
+  const int d0 = sg.d0, d1 = sg.d1, d2 = sg.d2, d3 = sg.d3;
+  const bool isA1 = sg.isA1, four = sg.four;
+  auto issue = [&](int s, int slot) {
+    char* dst = smem + slot * GB_SLOT;
+    if (s < nk) gb_issue(A + s * ksA, B + s * ksB, m0o, m1o, m2o, m3o, d0, d1, d2, d3, isA1, four, dst);
+    else gb_issue(A2, B2, e0o, e1o, e2o, e3o, d0, d1, d2, d3, isA1, four, dst);
+  };
+  f32x4 acc[GB_R0][4];
+#pragma unroll
+  for (int i = 0; i < GB_R0; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 a[GB_R0], b[4];
+  // steps 0 .. GB_SLOTS - 2 are in flight before the loop; iteration k issues step k + GB_SLOTS - 1 into the slot step k - 1 left
+  constexpr int D = GB_SLOTS - 1;
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < ntot) issue(s, s);
+  int cur = 0, nxt = D;   // ring slots of step k and of step k + D
+  if (wr == 0) {
+    for (int k = 0; k < ntot; ++k) {
+      gb_wait_batch(ntot - 1 - k, four);
+      gb_barrier();                                   // A(k): step k is in LDS; the slot of step k - 1 is free
+      gb_read<GB_R0>(a, b, smem + cur * GB_SLOT, 0, wc, fr, fq);
+      __builtin_amdgcn_sched_barrier(0);              // fragment reads first: they return while the DMA issue queues up
+      if (k + D < ntot) issue(k + D, nxt);
+      gb_lgkm0();
+      gb_barrier();                                   // B(k)
+      gb_mma<GB_R0>(acc, a, b);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = cur == GB_SLOTS - 1 ? 0 : cur + 1;
+      nxt = nxt == GB_SLOTS - 1 ? 0 : nxt + 1;
+    }
+  } else {
+    for (int k = 0; k < ntot; ++k) {
+      gb_wait_batch(ntot - 1 - k, four);
+      gb_lgkm0();                                     // this wave's reads of slot k - 1 are done before row 0 refills it
+      gb_barrier();                                   // A(k)
+      if (k > 0) gb_mma<GB_RT - GB_R0>(acc, a, b);    // step k - 1
+      __builtin_amdgcn_sched_barrier(0);
+      gb_barrier();                                   // B(k)
+      gb_read<GB_RT - GB_R0>(a, b, smem + cur * GB_SLOT, GB_R0 * 16, wc, fr, fq);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k + D < ntot) issue(k + D, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = cur == GB_SLOTS - 1 ? 0 : cur + 1;
+      nxt = nxt == GB_SLOTS - 1 ? 0 : nxt + 1;
+    }
+    gb_lgkm0();
+    gb_mma<GB_RT - GB_R0>(acc, a, b);
+  }
+  __syncthreads();   // every wave is done with the ring
+  STAMP(1);
+  // epilogue: 16 rows at a time through a wave-private [16][64] fp32 image; rows beyond this tile's share are not stored
+  cara_gemm_args pm = p;
+  pm.M = m0 + stride < p.M ? m0 + stride : p.M;
+  float* stg = reinterpret_cast<float*>(smem) + wave * (16 * 64);
+  const int nrt = wr == 0 ? GB_R0 : GB_RT - GB_R0;
+  const int mrow0 = m0 + (wr == 0 ? 0 : GB_R0 * 16);
+#pragma unroll
+  for (int i = 0; i < GB_R0; ++i) {
+    if (i < nrt && mrow0 + i * 16 < pm.M) {   // wave-uniform
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg[(fq * 4 + r) * 64 + j * 16 + fr] = acc[i][j][r];
+      epilogue_rows<EPI, 16>(pm, stg, mrow0 + i * 16, n0 + wc * 64, lane, 0);
+    }
+  }
+  STAMP_END();
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_big_body<EPI>(p, tiles_n, nwg, stride, blockIdx.x, smem);
+}
+
+// what the tile takes: full 256-column strips, the plain K-extension, one product per launch
+static bool big_tile_ok(const cara_gemm_args* a) {
+  return (a->N % GB_TN) == 0 && a->M >= 1024 && (a->K % 32) == 0 && (a->Rp == 0 || (a->Rp == 32 && a->A2)) && a->batch <= 1 && !a->B3 &&
+         !a->Ut;
+}
+
+template <int EPI>
+int launch_big(const cara_gemm_args* a, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS) != hipSuccess)
+      return CARA_E_LAUNCH;
+    attr = true;
+  }
+  const int tiles_n = a->N / GB_TN;
+  const int tiles_m = (a->M + GB_TM - 1) / GB_TM;
+  const int stride = (a->M + tiles_m - 1) / tiles_m;
+  const int nwg = tiles_m * tiles_n;
+  hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(nwg), dim3(512), GB_LDS, st, *a, tiles_n, nwg, stride);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
