@@ -11,7 +11,7 @@ pids=()
 for s in $SRCS; do
   o=build/${s%.hip}.o
   OBJS="$OBJS $o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ gemm_epilogue.h -nt "$o" ] || [ tskinny_body.h -nt "$o" ] || [ gemm_big.h -nt "$o" ] || [ ../../include/cara_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ gemm_epilogue.h -nt "$o" ] || [ tskinny_body.h -nt "$o" ] || [ ../../include/cara_hip.h -nt "$o" ]; then
     hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -c "$s" -o "$o" &
     pids+=($!)
   fi

@@ -8,7 +8,7 @@ pids=()
 for s in lib gemm skinny norm_misc attention factors dropout_exact vit; do
   o=build_stamps/$s.o
   OBJS="$OBJS $o"
-  if [ ! -f "$o" ] || [ "$s.hip" -nt "$o" ] || [ gemm_epilogue.h -nt "$o" ] || [ common.h -nt "$o" ] || [ gemm_big.h -nt "$o" ] || [ tskinny_body.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s.hip" -nt "$o" ] || [ gemm_epilogue.h -nt "$o" ] || [ common.h -nt "$o" ] || [ tskinny_body.h -nt "$o" ]; then
     hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -DCARA_GEMM_STAMPS -c $s.hip -o $o &
     pids+=($!)
   fi

@@ -34,13 +34,16 @@ constexpr int GB_LDS = GB_SLOTS * GB_SLOT;         // 89088
 constexpr int GB_PIECES = GB_RT + GB_TN / 16;      // 29 one-KiB LDS-DMA pieces per K step
 constexpr int GB_R0 = 7;                           // row tiles of wave row 0
 
+constexpr int GB_LOADERS = 4;                      // DMA-only waves (waves 8..11)
+constexpr int GB_THREADS = (8 + GB_LOADERS) * 64;  // 768
+
+// Loader wave l issues the pieces l, l + 4, ..., (l + 28): eight of them for l = 0, seven for the others.  Pieces 0..12 are
+// A's 16-row groups, 13..28 B's.  Per lane: the byte offset of its 16 bytes in a main K step (m) and in the extension step (e).
 struct GbStage {
-  // per wave: up to four pieces (index wave + 8 t); per lane: byte offsets of its 16 bytes in a main step (m) / the extension step (e)
-  // (scalars, not arrays: every member stays in a register)
-  unsigned m0, m1, m2, m3, e0, e1, e2, e3;
-  int d0, d1, d2, d3;  // LDS byte offset of the piece inside a slot (wave-uniform)
-  bool isA1;           // piece 1 is an A piece (waves 0..4) or a B piece (waves 5..7)
-  bool four;           // this wave issues four pieces per step (waves 0..4) or three
+  unsigned m[8], e[8];
+  int dst[8];          // LDS byte offset of the piece inside a slot (wave-uniform)
+  int na;              // this wave's first `na` pieces are A pieces (4 for l = 0, else 3)
+  bool eight;
 };
 
 __device__ __forceinline__ void gb_piece(const cara_gemm_args& p, const bool packed, const int m0, const int n0, const int idx, const int lane,
@@ -55,27 +58,6 @@ __device__ __forceinline__ void gb_piece(const cara_gemm_args& p, const bool pac
   const unsigned ld2 = isA ? (p.a_panels ? 64u : (unsigned)p.lda * 2u) : (packed ? 64u : (unsigned)p.ldb * 2u);
   om = (unsigned)g * ld2 + (unsigned)(cg * 16);
   oe = (unsigned)g * 64u + (unsigned)(cg * 16);
-}
-
-__device__ __forceinline__ GbStage gb_stage_init(const cara_gemm_args& p, const bool packed, const int m0, const int n0, const int wave,
-                                                 const int lane) {
-  GbStage s;
-  s.isA1 = wave < GB_RT - 8;
-  s.four = wave + 24 < GB_PIECES;
-  gb_piece(p, packed, m0, n0, wave, lane, s.m0, s.e0, s.d0);
-  gb_piece(p, packed, m0, n0, wave + 8, lane, s.m1, s.e1, s.d1);
-  gb_piece(p, packed, m0, n0, wave + 16, lane, s.m2, s.e2, s.d2);
-  gb_piece(p, packed, m0, n0, s.four ? wave + 24 : wave + 16, lane, s.m3, s.e3, s.d3);
-  return s;
-}
-
-// the LDS-DMA of one K step into the ring slot at `slot`: this wave's pieces, at the given per-lane offsets
-__device__ __forceinline__ void gb_issue(const char* pa, const char* pb, const unsigned o0, const unsigned o1, const unsigned o2, const unsigned o3,
-                                         const int d0, const int d1, const int d2, const int d3, const bool isA1, const bool four, char* slot) {
-  glds16(pa + o0, slot + d0);
-  glds16((isA1 ? pa : pb) + o1, slot + d1);
-  glds16(pb + o2, slot + d2);
-  if (four) glds16(pb + o3, slot + d3);
 }
 
 template <int MI>
@@ -93,16 +75,16 @@ __device__ __forceinline__ void gb_mma(f32x4 (&acc)[GB_R0][4], const bf16x8 (&a)
     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
 }
 
-// all of this wave's LDS-DMA but its `younger` youngest batches (the steps after the one about to be read) has landed
-__device__ __forceinline__ void gb_wait_batch(const int younger, const bool four) {
+// (loader waves) all of this wave's LDS-DMA but its `younger` youngest batches (the steps after the one about to be read) has landed
+__device__ __forceinline__ void gb_wait_batch(const int younger, const bool eight) {
   static_assert(GB_SLOTS == 4, "vmcnt literals: two batches may stay in flight");
   if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if (younger == 1) {
-    if (four) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (eight) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   } else {
-    if (four) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (eight) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
   }
 }
 __device__ __forceinline__ void gb_barrier() {
@@ -119,72 +101,88 @@ __device__ __forceinline__ void gemm_big_body(const cara_gemm_args& p, const int
                                               char* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
   const int fr = lane & 15, fq = lane >> 4;
   STAMP(0);
   const int tile = xcd_remap(block, nwg);
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * stride, n0 = tn * GB_TN;
-  const bool packed = p.Bp != nullptr;
-  const GbStage sg = gb_stage_init(p, packed, m0, n0, wave, lane);
-  const char* A = static_cast<const char*>(p.A);
-  const char* B = static_cast<const char*>(packed ? p.Bp : p.B);
-  const long ksA = p.a_panels ? (long)p.a_panels * 64 : 64;   // bytes per K step
-  const long ksB = packed ? (long)p.N * 64 : 64;
   const int nk = p.K >> 5;
   const int ntot = nk + (p.Rp ? 1 : 0);
-  const char* A2 = static_cast<const char*>(p.A2);
-  const char* B2 = static_cast<const char*>(p.B2);
-  // (values, not references into sg: a select between two members of a struct held by reference makes hipcc keep the
-  // struct in scratch memory and reload it inside the K loop)
-  const unsigned m0o = sg.m0, m1o = sg.m1, m2o = sg.m2, m3o = sg.m3, e0o = sg.e0, e1o = sg.e1, e2o = sg.e2, e3o = sg.e3;
-  const int d0 = sg.d0, d1 = sg.d1, d2 = sg.d2, d3 = sg.d3;
-  const bool isA1 = sg.isA1, four = sg.four;
-  auto issue = [&](int s, int slot) {
-    char* dst = smem + slot * GB_SLOT;
-    if (s < nk) gb_issue(A + s * ksA, B + s * ksB, m0o, m1o, m2o, m3o, d0, d1, d2, d3, isA1, four, dst);
-    else gb_issue(A2, B2, e0o, e1o, e2o, e3o, d0, d1, d2, d3, isA1, four, dst);
-  };
+  constexpr int D = GB_SLOTS - 1;   // steps 0 .. D - 1 are in flight before the loop; iteration k issues step k + D into the slot of step k - 1
+  if (wave >= 8) {
+    // ---- loader wave: nothing but LDS-DMA.  The MFMA waves never stall on a DMA issue, and the CU has 3..4 pieces per loader and
+    // step queued at its vector-memory path at all times (its throughput grows with the number of waves that feed it) ----
+    const int l = wave - 8;
+    const bool packed = p.Bp != nullptr;
+    unsigned om[8], oe[8];
+    int dst[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) gb_piece(p, packed, m0, n0, t * GB_LOADERS + l < GB_PIECES ? t * GB_LOADERS + l : l, lane, om[t], oe[t], dst[t]);
+    const bool eight = l + 7 * GB_LOADERS < GB_PIECES;
+    const int na = l + 3 * GB_LOADERS < GB_RT ? 4 : 3;
+    const char* A = static_cast<const char*>(p.A);
+    const char* B = static_cast<const char*>(packed ? p.Bp : p.B);
+    const long ksA = p.a_panels ? (long)p.a_panels * 64 : 64;   // bytes per K step
+    const long ksB = packed ? (long)p.N * 64 : 64;
+    const char* A2 = static_cast<const char*>(p.A2);
+    const char* B2 = static_cast<const char*>(p.B2);
+    // (constant indices and no select between the two offset arrays: both stay in registers)
+    auto issue = [&](int s, int slot) {
+      char* d = smem + slot * GB_SLOT;
+      if (s < nk) {
+        const char* pa = A + s * ksA;
+        const char* pb = B + s * ksB;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (t < 7 || eight) glds16((t < 3 || (t == 3 && na == 4) ? pa : pb) + om[t], d + dst[t]);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (t < 7 || eight) glds16((t < 3 || (t == 3 && na == 4) ? A2 : B2) + oe[t], d + dst[t]);
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+      if (s < ntot) issue(s, s);
+    int nxt = D;
+    for (int k = 0; k < ntot; ++k) {
+      gb_wait_batch(ntot - 1 - k, eight);
+      gb_barrier();                                   // A(k): step k is in LDS; the slot of step k - 1 is free
+      if constexpr (!GB_ABLATE(2)) { if (k + D < ntot) issue(k + D, nxt); }
+      nxt = nxt == GB_SLOTS - 1 ? 0 : nxt + 1;
+      gb_barrier();                                   // B(k)
+    }
+    __syncthreads();
+    return;
+  }
+  const int wr = wave >> 2, wc = wave & 3;
   f32x4 acc[GB_R0][4];
 #pragma unroll
   for (int i = 0; i < GB_R0; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 a[GB_R0], b[4];
-  // steps 0 .. GB_SLOTS - 2 are in flight before the loop; iteration k issues step k + GB_SLOTS - 1 into the slot step k - 1 left
-  constexpr int D = GB_SLOTS - 1;
-#pragma unroll
-  for (int s = 0; s < D; ++s)
-    if (s < ntot) issue(s, s);
-  int cur = 0, nxt = D;   // ring slots of step k and of step k + D
+  int cur = 0;
   if (wr == 0) {
     for (int k = 0; k < ntot; ++k) {
-      gb_wait_batch(ntot - 1 - k, four);
-      gb_barrier();                                   // A(k): step k is in LDS; the slot of step k - 1 is free
-      gb_read<GB_R0>(a, b, smem + cur * GB_SLOT, 0, wc, fr, fq);
-      __builtin_amdgcn_sched_barrier(0);              // fragment reads first: they return while the DMA issue queues up
-      if (k + D < ntot) issue(k + D, nxt);
+      gb_barrier();                                   // A(k)
+      if constexpr (!GB_ABLATE(4)) gb_read<GB_R0>(a, b, smem + cur * GB_SLOT, 0, wc, fr, fq);
       gb_lgkm0();
       gb_barrier();                                   // B(k)
-      gb_mma<GB_R0>(acc, a, b);
+      if constexpr (!GB_ABLATE(1)) gb_mma<GB_R0>(acc, a, b);
       __builtin_amdgcn_sched_barrier(0);
       cur = cur == GB_SLOTS - 1 ? 0 : cur + 1;
-      nxt = nxt == GB_SLOTS - 1 ? 0 : nxt + 1;
     }
   } else {
     for (int k = 0; k < ntot; ++k) {
-      gb_wait_batch(ntot - 1 - k, four);
-      gb_lgkm0();                                     // this wave's reads of slot k - 1 are done before row 0 refills it
+      gb_lgkm0();                                     // this wave's reads of slot k - 1 are done before a loader refills it
       gb_barrier();                                   // A(k)
-      if (k > 0) gb_mma<GB_RT - GB_R0>(acc, a, b);    // step k - 1
+      if constexpr (!GB_ABLATE(1)) { if (k > 0) gb_mma<GB_RT - GB_R0>(acc, a, b); }   // step k - 1
       __builtin_amdgcn_sched_barrier(0);
       gb_barrier();                                   // B(k)
-      gb_read<GB_RT - GB_R0>(a, b, smem + cur * GB_SLOT, GB_R0 * 16, wc, fr, fq);
-      __builtin_amdgcn_sched_barrier(0);
-      if (k + D < ntot) issue(k + D, nxt);
+      if constexpr (!GB_ABLATE(4)) gb_read<GB_RT - GB_R0>(a, b, smem + cur * GB_SLOT, GB_R0 * 16, wc, fr, fq);
       __builtin_amdgcn_sched_barrier(0);
       cur = cur == GB_SLOTS - 1 ? 0 : cur + 1;
-      nxt = nxt == GB_SLOTS - 1 ? 0 : nxt + 1;
     }
     gb_lgkm0();
     gb_mma<GB_RT - GB_R0>(acc, a, b);
@@ -211,9 +209,29 @@ __device__ __forceinline__ void gemm_big_body(const cara_gemm_args& p, const int
 }
 
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int stride) {
+__global__ __launch_bounds__(GB_THREADS) void gemm_big_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   gemm_big_body<EPI>(p, tiles_n, nwg, stride, blockIdx.x, smem);
+}
+
+// The same tile carrying the two transposed skinny products of its linear (cara_gemm_with_tskinny): the blocks behind the GEMM's
+// tiles are three 256-thread tskinny blocks each.  They land on the CUs the tiles leave free (M = 12608, N = 768: 183 tiles
+// on 256 CUs) and run under the GEMM.
+template <int EPI, bool COLSUM>
+__global__ __launch_bounds__(GB_THREADS) void gemm_big_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int stride,
+                                                                 const TsProblem t0, const TsProblem t1, const int ldg, const int Mts) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x;
+  if (b >= nwg) {
+    constexpr int TSB = TsRing<2, 1>::BLOCK_BYTES;
+    static_assert(3 * TSB <= GB_LDS, "three tskinny blocks share the tile's LDS");
+    const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+    const int nts = t0.nblk + t1.nblk;
+    const int blk = 3 * (b - nwg) + sub;
+    tskinny_body<2, COLSUM, 1>(t0, t1, ldg, Mts, blk < nts ? blk : nts - 1, smem + sub * TSB, threadIdx.x & 255, blk < nts);
+  } else {
+    gemm_big_body<EPI>(p, tiles_n, nwg, stride, b, smem);
+  }
 }
 
 // what the tile takes: full 256-column strips, the plain K-extension, one product per launch
@@ -222,19 +240,6 @@ static bool big_tile_ok(const cara_gemm_args* a) {
          !a->Ut;
 }
 
+struct TsPair;
 template <int EPI>
-int launch_big(const cara_gemm_args* a, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS) != hipSuccess)
-      return CARA_E_LAUNCH;
-    attr = true;
-  }
-  const int tiles_n = a->N / GB_TN;
-  const int tiles_m = (a->M + GB_TM - 1) / GB_TM;
-  const int stride = (a->M + tiles_m - 1) / tiles_m;
-  const int nwg = tiles_m * tiles_n;
-  hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(nwg), dim3(512), GB_LDS, st, *a, tiles_n, nwg, stride);
-  CARA_CHECK_LAUNCH();
-  return CARA_OK;
-}
+int launch_big(const cara_gemm_args* a, hipStream_t st, const TsPair* ts);

@@ -32,6 +32,12 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 extern "C" int cara_debug_gemm_stamps(void* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
 }
+// timing ablations of the 208 x 256 tile (results wrong), compile time: -DCARA_GB_ABLATE=mask, 1 = no MFMAs, 2 = no LDS-DMA in the
+// loop, 4 = no fragment reads
+#ifndef CARA_GB_ABLATE
+#define CARA_GB_ABLATE 0
+#endif
+#define GB_ABLATE(bit) ((CARA_GB_ABLATE & (bit)) != 0)
 #define STAMP(slot)                                                                         \
   do {                                                                                      \
     if (g_stamp_buf && threadIdx.x == 0) g_stamp_buf[(size_t)blockIdx.x * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
@@ -45,6 +51,7 @@ extern "C" int cara_debug_gemm_stamps(void* buf) {
     }                                                                                       \
   } while (0)
 #else
+#define GB_ABLATE(bit) false
 #define STAMP(slot) do {} while (0)
 #define STAMP_END() do {} while (0)
 #endif
@@ -247,14 +254,24 @@ __global__ __launch_bounds__(256, 4) void gemm32_kernel(const cara_gemm_args p, 
   gemm32_body<EPI, 4, 4, TWOB>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
 }
 
+// 256 x 128 tiles from the same body: each of the four waves owns 128 x 64 (8 x 4 accumulators, 128 registers), so a K step
+// stages 24 KiB for twice the MFMAs of the 128 x 128 tile (3/4 of the bytes per flop through the CU's load-return path,
+// which the counters show ~70 % busy in the default kernel) and reads 3/4 of the LDS bytes per flop; 48 KiB of LDS and
+// < 256 registers: two workgroups per CU.  CARA_GEMM_BM=256 selects it for the wide products (N >= 2304).
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void gemm32_tall_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm32_body<EPI, 8, 4>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
+}
+
 // The dX GEMM of a linear and the two transposed skinny products of the SAME linear (dU = X^T G', dVs = dY^T T) in
 // one grid: blocks [0, nts) are tskinny blocks (HBM-bound, one LDS stage per wave), the rest GEMM tiles (MFMA-bound).
 // The products used to run on a side stream under the GEMM, which costs a fork (an event record = 3..7 us of idle
 // chip, 44 of them per backward pass) and overlaps only as well as two queues happen to interleave; as one launch
 // there is no event at all and the dispatcher mixes the two kinds of workgroup on every CU.  Needs Rp = 32 products
 // (84 VGPRs; the Rp = 64 form needs 136) and 36 KiB of LDS per workgroup (still four per CU).
-template <int EPI, bool COLSUM>
-__global__ __launch_bounds__(256, 4) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
+template <int EPI, bool COLSUM, int MI = 4>
+__global__ __launch_bounds__(256, MI == 8 ? 3 : 4) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
                                                            const TsProblem t0, const TsProblem t1, const int ldg, const int Mts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // the products' blocks sit BEHIND the GEMM tiles: they fill the slots the GEMM's last, partly filled round leaves
@@ -263,7 +280,7 @@ __global__ __launch_bounds__(256, 4) void gemm32_ts_kernel(const cara_gemm_args 
   if (b >= nwg) {
     tskinny_body<2, COLSUM, 1>(t0, t1, ldg, Mts, b - nwg, smem);
   } else {
-    gemm32_body<EPI, 4, 4>(p, tiles_n, nwg, gm, b, 0, smem);
+    gemm32_body<EPI, MI, 4>(p, tiles_n, nwg, gm, b, 0, smem);
   }
 }
 
@@ -399,6 +416,8 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
   }
 }
 
+#include "gemm_big.h"
+
 static int group_m(int tiles_n);
 
 template <int EPI>
@@ -432,11 +451,52 @@ struct TsPair {
 };
 
 template <int EPI>
+int launch_big(const cara_gemm_args* a, hipStream_t st, const TsPair* ts) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_ts_kernel<EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_ts_kernel<EPI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, GB_LDS) != hipSuccess)
+      return CARA_E_LAUNCH;
+    attr = true;
+  }
+  const int tiles_n = a->N / GB_TN;
+  const int tiles_m = (a->M + GB_TM - 1) / GB_TM;
+  const int stride = (a->M + tiles_m - 1) / tiles_m;
+  const int nwg = tiles_m * tiles_n;
+  if (ts) {
+    const int nts = (ts->a.nblk + ts->b.nblk + 2) / 3;
+    if (ts->any_cs)
+      hipLaunchKernelGGL((gemm_big_ts_kernel<EPI, true>), dim3(nwg + nts), dim3(GB_THREADS), GB_LDS, st, *a, tiles_n, nwg, stride, ts->a, ts->b, ts->ldg, ts->M);
+    else
+      hipLaunchKernelGGL((gemm_big_ts_kernel<EPI, false>), dim3(nwg + nts), dim3(GB_THREADS), GB_LDS, st, *a, tiles_n, nwg, stride, ts->a, ts->b, ts->ldg, ts->M);
+  } else {
+    hipLaunchKernelGGL((gemm_big_kernel<EPI>), dim3(nwg), dim3(GB_THREADS), GB_LDS, st, *a, tiles_n, nwg, stride);
+  }
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
+template <int EPI>
 int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr) {
   const int tiles_n = (a->N + BN - 1) / BN;
   const int gm = group_m(tiles_n);
   const int nwg = ((a->M + 127) / 128) * tiles_n;
   constexpr int GEMM_LDS = 2 * (128 * BK32 * 2 + B32_BYTES);
+  static const int tall = [] { const char* e = getenv("CARA_GEMM_BM"); return e ? atoi(e) : 0; }();
+  const bool use_tall = (tall == 256 || tall == 2562) && a->N >= 2304 && a->M > 1024 && a->batch <= 1 && !a->B3;
+  constexpr int TALL_LDS = 2 * (256 * BK32 * 2 + B32_BYTES);
+  if (ts && use_tall) {
+    const int nts = ts->a.nblk + ts->b.nblk;
+    const int nwg_t = ((a->M + 255) / 256) * tiles_n;
+    constexpr int LDS = TsRing<2, 1>::BLOCK_BYTES > TALL_LDS ? TsRing<2, 1>::BLOCK_BYTES : TALL_LDS;
+    if (ts->any_cs)
+      hipLaunchKernelGGL((gemm32_ts_kernel<EPI, true, 8>), dim3(nwg_t + nts), dim3(256), LDS, st, *a, tiles_n, nwg_t, gm, ts->a, ts->b, ts->ldg, ts->M);
+    else
+      hipLaunchKernelGGL((gemm32_ts_kernel<EPI, false, 8>), dim3(nwg_t + nts), dim3(256), LDS, st, *a, tiles_n, nwg_t, gm, ts->a, ts->b, ts->ldg, ts->M);
+    CARA_CHECK_LAUNCH();
+    return CARA_OK;
+  }
   if (ts) {
     const int nts = ts->a.nblk + ts->b.nblk;
     constexpr int LDS = TsRing<2, 1>::BLOCK_BYTES > GEMM_LDS ? TsRing<2, 1>::BLOCK_BYTES : GEMM_LDS;
@@ -448,6 +508,19 @@ int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr
     return CARA_OK;
   }
   const int nb = a->batch > 1 ? a->batch : 1;
+  if (use_tall) {
+    const int nwg_t = ((a->M + 255) / 256) * tiles_n;
+    // 48 KiB: three workgroups per CU (168 registers); asking for 72 KiB holds it at two (A/B)
+    const int lds = tall == 256 ? TALL_LDS : 72 * 1024;
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm32_tall_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess) return CARA_E_LAUNCH;
+      attr = true;
+    }
+    hipLaunchKernelGGL((gemm32_tall_kernel<EPI>), dim3(nwg_t), dim3(256), lds, st, *a, tiles_n, nwg_t, gm);
+    CARA_CHECK_LAUNCH();
+    return CARA_OK;
+  }
   if (a->B3) hipLaunchKernelGGL((gemm32_kernel<EPI, true>), dim3(nwg, nb), dim3(256), GEMM_LDS, st, *a, tiles_n, nwg, gm);
   else hipLaunchKernelGGL((gemm32_kernel<EPI>), dim3(nwg, nb), dim3(256), GEMM_LDS, st, *a, tiles_n, nwg, gm);
   CARA_CHECK_LAUNCH();
@@ -622,6 +695,19 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
       case CARA_EPI_GELU: return launch_small_m<CARA_EPI_GELU>(a, nslab, st);
       case CARA_EPI_RESID: return launch_small_m<CARA_EPI_RESID>(a, nslab, st);
       case CARA_EPI_DGELU: return launch_small_m<CARA_EPI_DGELU>(a, nslab, st);
+      default: return CARA_E_ARG;
+    }
+  }
+  // CARA_GEMM_BIG: 1 = the 208 x 256 one-workgroup-per-CU tile for the products whose tiles fit one round (N = 768 at M = 12608),
+  // 2 = for every product it can take
+  static const int big = [] { const char* e = getenv("CARA_GEMM_BIG"); return e ? atoi(e) : 0; }();
+  if (big && big_tile_ok(a) && (big >= 2 || ((a->M + GB_TM - 1) / GB_TM) * (a->N / GB_TN) <= 256)) {
+    switch (a->epi) {
+      case CARA_EPI_BF16: return launch_big<CARA_EPI_BF16>(a, st, ts);
+      case CARA_EPI_F32: return launch_big<CARA_EPI_F32>(a, st, ts);
+      case CARA_EPI_GELU: return launch_big<CARA_EPI_GELU>(a, st, ts);
+      case CARA_EPI_RESID: return launch_big<CARA_EPI_RESID>(a, st, ts);
+      case CARA_EPI_DGELU: return launch_big<CARA_EPI_DGELU>(a, st, ts);
       default: return CARA_E_ARG;
     }
   }
