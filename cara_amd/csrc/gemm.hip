@@ -66,15 +66,21 @@ __device__ __forceinline__ int swz32(int row, int chunk) { return row * 64 + ((c
 // two thirds of them this address arithmetic.  Needs the operand to span < 4 GiB (checked at dispatch).
 template <int ROWS, int NW = 4>
 struct TileOfs {
-  unsigned off[ROWS / (16 * NW)];
+  static constexpr int NP = ROWS / 16;                  // one-KiB pieces of the tile
+  static constexpr int PPW = (NP + NW - 1) / NW;         // pieces per wave (the last one only on the first NP % NW waves)
+  static constexpr bool EVEN = NP % NW == 0;
+  unsigned off[PPW];
+  // piece t of a wave: blocked (wave * PPW + t) when the pieces divide evenly, interleaved (wave + NW * t) otherwise
+  static __device__ __forceinline__ int piece(int wave, int t) { return EVEN ? wave * PPW + t : wave + NW * t; }
 };
 template <int ROWS, int NW = 4>
 __device__ __forceinline__ TileOfs<ROWS, NW> tile_ofs(int ld, int r0, int rmax, int wave, int lane) {
-  constexpr int PPW = ROWS / (16 * NW);
-  TileOfs<ROWS, NW> o;
+  using T = TileOfs<ROWS, NW>;
+  T o;
 #pragma unroll
-  for (int t = 0; t < PPW; ++t) {
-    const int r = (wave * PPW + t) * 16 + (lane >> 2);
+  for (int t = 0; t < T::PPW; ++t) {
+    const int pc = T::piece(wave, t) < T::NP ? T::piece(wave, t) : T::NP - 1;
+    const int r = pc * 16 + (lane >> 2);
     const int cg = (lane & 3) ^ (((r >> 3) & 1) * 3);
     int gr = r0 + r;
     gr = gr < rmax ? gr : rmax;
@@ -84,10 +90,11 @@ __device__ __forceinline__ TileOfs<ROWS, NW> tile_ofs(int ld, int r0, int rmax, 
 }
 template <int ROWS, int NW = 4>
 __device__ __forceinline__ void stage_tile32_pre(const bf16* __restrict__ P, int k0, const TileOfs<ROWS, NW>& o, char* lds_tile, int wave) {
-  constexpr int PPW = ROWS / (16 * NW);
+  using T = TileOfs<ROWS, NW>;
   const char* base = reinterpret_cast<const char*>(P + k0);   // wave-uniform
 #pragma unroll
-  for (int t = 0; t < PPW; ++t) glds16(base + o.off[t], lds_tile + (wave * PPW + t) * 1024);
+  for (int t = 0; t < T::PPW; ++t)
+    if (T::EVEN || T::piece(wave, t) < T::NP) glds16(base + o.off[t], lds_tile + T::piece(wave, t) * 1024);
 }
 
 template <int MI>
@@ -212,8 +219,10 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
   }
   // epilogue.  bf16 outputs of interior wave tiles: the fast path of gemm_epilogue.h (values converted in the accumulator
   // layout, 2-byte LDS transposition); everything else: NPASS passes of HALF rows through a wave-private [HALF][64] fp32 image
-  constexpr int NPASS = ((NW == 8 && MI == 4) || MI == 8) ? 4 : 2;
+  constexpr int NPASS = (MI % 2) ? MI : (((NW == 8 && MI == 4) || MI == 8) ? 4 : 2);
   constexpr int HALF = MI * 16 / NPASS;
+  // one LDS region per wave for BOTH epilogue paths (in an edge tile some waves take the fast path and others the generic one)
+  constexpr int WAVE_STG = HALF * 64 * 4 > EPI_FAST_WAVE_BYTES ? HALF * 64 * 4 : EPI_FAST_WAVE_BYTES;
   __syncthreads();
   STAMP(1);
   if constexpr ((EPI == CARA_EPI_BF16 || EPI == CARA_EPI_GELU) && (MI == 4 || MI == 8) && NW == 4) {
@@ -221,12 +230,19 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
     if (mw + MI * 16 <= p.M && nw + 64 <= p.N && (p.ldc & 7) == 0) {   // wave-uniform
 #pragma unroll
       for (int q = 0; q < MI / 4; ++q)
-        epilogue_fast_bf16<EPI>(p, *reinterpret_cast<const f32x4(*)[4][4]>(&acc[q * 4]), smem + wave * EPI_FAST_WAVE_BYTES, mw + q * 64, nw, lane, coff);
+        epilogue_fast_bf16<EPI>(p, *reinterpret_cast<const f32x4(*)[4][4]>(&acc[q * 4]), smem + wave * WAVE_STG, mw + q * 64, nw, lane, coff);
+      STAMP_END();
+      return;
+    }
+  } else if constexpr (EPI == CARA_EPI_BF16 || EPI == CARA_EPI_GELU) {
+    const int mw = m0 + wr * (MI * 16), nw = n0 + wc * 64;
+    if (mw + MI * 16 <= p.M && nw + 64 <= p.N && (p.ldc & 7) == 0) {   // wave-uniform
+      epilogue_fast_bf16_rt<EPI, MI>(p, acc, smem + wave * WAVE_STG, mw, nw, lane, coff);
       STAMP_END();
       return;
     }
   }
-  float* stg = reinterpret_cast<float*>(smem) + wave * (HALF * 64);
+  float* stg = reinterpret_cast<float*>(smem + wave * WAVE_STG);
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
   for (int half = 0; half < NPASS; ++half) {
@@ -241,10 +257,13 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
   STAMP_END();
 }
 
-template <int EPI, bool TWOB = false>
+// MI = 5: 160 x 128 tiles (80 x 64 per wave) for the products with N >= 3072 -- their 99 x 24 = 2376 tiles of 128 rows are 2.32
+// rounds of the 1024 workgroup slots (the last third of the launch runs at a fraction of the occupancy, tools/gemm_stamps.py),
+// 79 x 24 = 1896 tiles of 160 rows are 1.85, and a tile stages 10 % fewer bytes per flop; 36 KiB of LDS, still four per CU
+template <int EPI, bool TWOB = false, int MI = 4>
 __global__ __launch_bounds__(256, 4) void gemm32_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm32_body<EPI, 4, 4, TWOB>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
+  gemm32_body<EPI, MI, 4, TWOB>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
 }
 
 // The dX GEMM of a linear and the two transposed skinny products of the SAME linear (dU = X^T G', dVs = dY^T T) in
@@ -253,7 +272,7 @@ __global__ __launch_bounds__(256, 4) void gemm32_kernel(const cara_gemm_args p, 
 // chip, 44 of them per backward pass) and overlaps only as well as two queues happen to interleave; as one launch
 // there is no event at all and the dispatcher mixes the two kinds of workgroup on every CU.  Needs Rp = 32 products
 // (84 VGPRs; the Rp = 64 form needs 136) and 36 KiB of LDS per workgroup (still four per CU).
-template <int EPI, bool COLSUM>
+template <int EPI, bool COLSUM, int MI = 4>
 __global__ __launch_bounds__(256, 4) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
                                                            const TsProblem t0, const TsProblem t1, const int ldg, const int Mts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -263,7 +282,7 @@ __global__ __launch_bounds__(256, 4) void gemm32_ts_kernel(const cara_gemm_args 
   if (b >= nwg) {
     tskinny_body<2, COLSUM, 1>(t0, t1, ldg, Mts, b - nwg, smem);
   } else {
-    gemm32_body<EPI, 4, 4>(p, tiles_n, nwg, gm, b, 0, smem);
+    gemm32_body<EPI, MI, 4>(p, tiles_n, nwg, gm, b, 0, smem);
   }
 }
 
@@ -437,6 +456,27 @@ int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr
   const int gm = group_m(tiles_n);
   const int nwg = ((a->M + 127) / 128) * tiles_n;
   constexpr int GEMM_LDS = 2 * (128 * BK32 * 2 + B32_BYTES);
+  // CARA_GEMM_BM=160: the 160-row tile for the widest products (A/B)
+  // The 160-row tile for the widest products (N >= 3072: fc1 forward, fc2 dX).  CARA_GEMM_BM=128 keeps the 128-row tile (A/B runs:
+  // 9.22 -> 9.08 and 9.37 -> 9.28 ms per step on two boxes; for the N = 768 products, whose 594 / 474 tiles are a single
+  // round either way, it made no difference in the step and stays off)
+  static const int bm = [] { const char* e = getenv("CARA_GEMM_BM"); return e ? atoi(e) : 160; }();
+  if (bm == 160 && a->N >= 3072 && a->M > 1024 && a->batch <= 1 && !a->B3) {
+    constexpr int LDS160 = 2 * (160 * BK32 * 2 + B32_BYTES);
+    const int nwg5 = ((a->M + 159) / 160) * tiles_n;
+    if (ts) {
+      const int nts = ts->a.nblk + ts->b.nblk;
+      constexpr int LDS = TsRing<2, 1>::BLOCK_BYTES > LDS160 ? TsRing<2, 1>::BLOCK_BYTES : LDS160;
+      if (ts->any_cs)
+        hipLaunchKernelGGL((gemm32_ts_kernel<EPI, true, 5>), dim3(nwg5 + nts), dim3(256), LDS, st, *a, tiles_n, nwg5, gm, ts->a, ts->b, ts->ldg, ts->M);
+      else
+        hipLaunchKernelGGL((gemm32_ts_kernel<EPI, false, 5>), dim3(nwg5 + nts), dim3(256), LDS, st, *a, tiles_n, nwg5, gm, ts->a, ts->b, ts->ldg, ts->M);
+    } else {
+      hipLaunchKernelGGL((gemm32_kernel<EPI, false, 5>), dim3(nwg5), dim3(256), LDS160, st, *a, tiles_n, nwg5, gm);
+    }
+    CARA_CHECK_LAUNCH();
+    return CARA_OK;
+  }
   if (ts) {
     const int nts = ts->a.nblk + ts->b.nblk;
     constexpr int LDS = TsRing<2, 1>::BLOCK_BYTES > GEMM_LDS ? TsRing<2, 1>::BLOCK_BYTES : GEMM_LDS;

@@ -179,3 +179,55 @@ __device__ __forceinline__ void epilogue_fast_bf16(const cara_gemm_args& p, cons
     }
   }
 }
+
+// The same for NT row tiles of 16 rows, one row tile at a time through a 16-row image per output (the 160-row tile: 5 row tiles)
+template <int EPI, int NT>
+__device__ __forceinline__ void epilogue_fast_bf16_rt(const cara_gemm_args& p, const f32x4 (&acc)[NT][4], char* stg, const int mbase,
+                                                      const int nbase, const int lane, const size_t coff) {
+  static_assert(EPI == CARA_EPI_BF16 || EPI == CARA_EPI_GELU, "bf16 outputs computed from the accumulator alone");
+  const int fr = lane & 15, fq = lane >> 4;
+  float bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bv[j] = p.bias ? p.bias[nbase + j * 16 + fr] : 0.f;
+  char* wbase = stg + (4 * fq) * EPI_FAST_ROW_BYTES + fr * 2;
+  const char* rbase = stg + (lane >> 3) * EPI_FAST_ROW_BYTES + (lane & 7) * 16;
+  const int rrow = lane >> 3, rcol = (lane & 7) * 8;
+  constexpr int NOUT = EPI == CARA_EPI_GELU ? 2 : 1;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      if (o == 1 && !p.C2) continue;
+      char* w0 = wbase + (o * 16) * EPI_FAST_ROW_BYTES;   // the two outputs use the two 16-row halves of the image
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[i][j][r] + bv[j];
+          if (EPI == CARA_EPI_GELU && o == 0) v[r] = gelu_erf(v[r]);
+        }
+        char* w = w0 + j * 32;
+        const bf16x2 p01 = {(bf16)v[0], (bf16)v[1]}, p23 = {(bf16)v[2], (bf16)v[3]};
+        *reinterpret_cast<bf16*>(w) = p01[0];
+        *reinterpret_cast<bf16*>(w + EPI_FAST_ROW_BYTES) = p01[1];
+        *reinterpret_cast<bf16*>(w + 2 * EPI_FAST_ROW_BYTES) = p23[0];
+        *reinterpret_cast<bf16*>(w + 3 * EPI_FAST_ROW_BYTES) = p23[1];
+      }
+      // (compiler fences: the 2-byte stores and the 16-byte loads of the image are different types to the alias analysis)
+      asm volatile("" ::: "memory");
+      bf16* out = static_cast<bf16*>(o == 0 ? p.C : p.C2);
+      const bool panels = o == 0 && p.c_panels;
+      bf16x8 v8[2];
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) v8[pass] = *reinterpret_cast<const bf16x8*>(rbase + (o * 16 + pass * 8) * EPI_FAST_ROW_BYTES);
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int m = mbase + i * 16 + pass * 8 + rrow, n = nbase + rcol;
+        bf16* dst = panels ? out + ((size_t)(n >> 5) * p.c_panels + m) * 32 + (n & 31) : out + (size_t)m * p.ldc + n + (o == 0 ? coff : 0);
+        *reinterpret_cast<bf16x8*>(dst) = v8[pass];
+      }
+    }
+  }
+}
