@@ -55,13 +55,13 @@ SITES = ["qkv_fwd", "proj_fwd", "fc1_fwd", "fc2_fwd", "qkv_bwd", "proj_bwd", "fc
 SITE_KERNEL = {
     "qkv_fwd": "gemm32_kernel<BF16> (qkv forward, [xn1 | T][W | Vs]^T)",
     "proj_fwd": "gemm32ft_kernel<RESID> (proj forward, T = X U inside)",
-    "fc1_fwd": "gemm32_kernel<GELU> (fc1 forward, two bf16 outputs u and gelu(u))",
+    "fc1_fwd": "gemm32_kernel<GELU, MI=5> (fc1 forward, 160 x 128 tiles, two bf16 outputs u and gelu(u))",
     "fc2_fwd": "gemm32ft_kernel<RESID> (fc2 forward, T = X U inside)",
     "qkv_bwd": "gemm32_ts_kernel<BF16,false> (qkv dX + its dU / dVs products in one launch)",
     "proj_bwd": "gemm32_ts_kernel<BF16,true> (proj dX + dU / dVs / dc)",
     "fc1_bwd": "gemm32_ts_kernel<BF16,true> (fc1 dX + dU / dVs / dc)",
-    "fc2_bwd": "gemm32_ts_kernel<DGELU,true> (fc2 dX with gelu' epilogue + dU / dVs / dc)",
-    "attn_fwd": "attn_fwd_long_kernel<7>", "attn_bwd": "attn_bwd_dkv_kernel + attn_bwd_dq_kernel",
+    "fc2_bwd": "gemm32_ts_kernel<DGELU,true, MI=5> (fc2 dX, 160 x 128 tiles, gelu' epilogue + dU / dVs / dc)",
+    "attn_fwd": "attn_fwd_persist_kernel (3 heads per CU)", "attn_bwd": "attn_bwd_fused_kernel (dK/dV sweep then dQ sweep per head)",
     "ln1_fwd": "ln_fwd_kernel<XU> (LayerNorm 1 + T = LN(x) U of qkv)", "ln2_fwd": "ln_fwd_kernel<XU> (LayerNorm 2 + T of fc1)",
     "ln1_bwd": "ln_bwd_kernel<XU> (LayerNorm 1 backward + G' of the fc2 below)", "ln2_bwd": "ln_bwd_kernel<XU> (LayerNorm 2 backward + G' of proj)",
     "skinny_fwd": "skinny_xu_sliced_kernel (T = X U)", "skinny_bwd": "skinny_xu_sliced_kernel (G' = dY Vs of fc1 / qkv)",

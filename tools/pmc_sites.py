@@ -23,13 +23,12 @@ SITES = {
     "qkv_fwd": ("gemm32_kernel<0,", lambda r, w: w > 50 * MB),
     "fc2_fwd": ("gemm32ft_kernel<3>", lambda r, w: r > 100 * MB),               # reads h (77 MB) + the fp32 residual
     "proj_fwd": ("gemm32ft_kernel<3>", lambda r, w: 30 * MB < r <= 100 * MB),
-    "fc2_bwd": ("gemm32_ts_kernel<4, true>", lambda r, w: w > 50 * MB),
-    "fc1_bwd": ("gemm32_ts_kernel<0, true>", lambda r, w: r > 150 * MB),        # dH as GEMM operand and as the products' operand
-    "proj_bwd": ("gemm32_ts_kernel<0, true>", lambda r, w: 20 * MB < r <= 150 * MB),
-    "qkv_bwd": ("gemm32_ts_kernel<0, false>", lambda r, w: w > 10 * MB),
+    "fc2_bwd": ("gemm32_ts_kernel<4, true", lambda r, w: w > 50 * MB),
+    "fc1_bwd": ("gemm32_ts_kernel<0, true", lambda r, w: r > 150 * MB),        # dH as GEMM operand and as the products' operand
+    "proj_bwd": ("gemm32_ts_kernel<0, true", lambda r, w: 20 * MB < r <= 150 * MB),
+    "qkv_bwd": ("gemm32_ts_kernel<0, false", lambda r, w: w > 10 * MB),
     "attn_fwd": ("attn_fwd_persist_kernel", lambda r, w: True),
-    "attn_bwd_dkv": ("attn_bwd_dkv_kernel", lambda r, w: True),
-    "attn_bwd_dq": ("attn_bwd_dq_kernel", lambda r, w: True),
+    "attn_bwd": ("attn_bwd_fused_kernel", lambda r, w: True),
     "ln_fwd": ("ln_fwd_kernelILi3ELb1", lambda r, w: w > 15 * MB),
     "ln_bwd": ("ln_bwd_kernelILi3ELb1", lambda r, w: w > 40 * MB),
     "skinny_bwd": ("skinny_xu_sliced_kernel", lambda r, w: r > 40 * MB),
