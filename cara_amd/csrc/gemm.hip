@@ -243,6 +243,17 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
     }
   }
   float* stg = reinterpret_cast<float*>(smem + wave * WAVE_STG);
+  if constexpr (EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU) {
+    // interior wave tiles: the epilogue's input operand requested a pass group ahead (gemm_epilogue.h)
+    const int mw = m0 + wr * (MI * 16), nw = n0 + wc * 64;
+    const bool ok = mw + MI * 16 <= p.M && nw + 64 <= p.N && (p.ldc & 7) == 0 && coff == 0 &&
+                    (EPI == CARA_EPI_DGELU || !p.rowscale || p.rows_per_sample >= MI * 16) && (!p.bias || (nw & 3) == 0);
+    if (ok) {   // wave-uniform
+      epilogue_interior_aux<EPI, MI, 1>(p, acc, stg, mw, nw, lane);
+      STAMP_END();
+      return;
+    }
+  }
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
   for (int half = 0; half < NPASS; ++half) {
@@ -252,7 +263,9 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[half * (MI / NPASS) + i][j][r];
+    asm volatile("" ::: "memory");   // (scalar stores, 16-byte loads of the same image: keep the compiler from reordering them)
     epilogue_rows<EPI, HALF>(p, stg, m0 + wr * (MI * 16) + half * HALF, n0 + wc * 64, lane, coff);
+    asm volatile("" ::: "memory");
   }
   STAMP_END();
 }
@@ -260,8 +273,10 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
 // MI = 5: 160 x 128 tiles (80 x 64 per wave) for the products with N >= 3072 -- their 99 x 24 = 2376 tiles of 128 rows are 2.32
 // rounds of the 1024 workgroup slots (the last third of the launch runs at a fraction of the occupancy, tools/gemm_stamps.py),
 // 79 x 24 = 1896 tiles of 160 rows are 1.85, and a tile stages 10 % fewer bytes per flop; 36 KiB of LDS, still four per CU
+// (the 160-row tile with an epilogue that reads a second operand and no riding products -- not a product of the model -- would spill
+// a few registers at four workgroups per CU: it gets three)
 template <int EPI, bool TWOB = false, int MI = 4>
-__global__ __launch_bounds__(256, 4) void gemm32_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
+__global__ __launch_bounds__(256, (MI == 5 && (EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU)) ? 3 : 4) void gemm32_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   gemm32_body<EPI, MI, 4, TWOB>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
 }
@@ -406,6 +421,15 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
   constexpr int HALF = 32;
   __syncthreads();
   float* stg = reinterpret_cast<float*>(smem) + wave * (HALF * 64);
+  if constexpr (EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU) {
+    const int mw = m0 + wr * 64, nw = n0 + wc * 64;
+    const bool ok = mw + 64 <= p.M && nw + 64 <= p.N && (p.ldc & 7) == 0 &&
+                    (EPI == CARA_EPI_DGELU || !p.rowscale || p.rows_per_sample >= 64) && (!p.bias || (nw & 3) == 0);
+    if (ok) {   // wave-uniform
+      epilogue_interior_aux<EPI, 4, 2>(p, acc, stg, mw, nw, lane);
+      return;
+    }
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -414,7 +438,9 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[half * 2 + i][j][r];
+    asm volatile("" ::: "memory");
     epilogue_rows<EPI, HALF>(p, stg, m0 + wr * 64 + half * HALF, n0 + wc * 64, lane);
+    asm volatile("" ::: "memory");
   }
 }
 

@@ -166,7 +166,9 @@ __device__ __forceinline__ void epilogue_fast_bf16(const cara_gemm_args& p, cons
           *reinterpret_cast<bf16*>(w + 2 * EPI_FAST_ROW_BYTES) = p23[0];
           *reinterpret_cast<bf16*>(w + 3 * EPI_FAST_ROW_BYTES) = p23[1];
         }
-      // (wave-private image: the wave's own LDS operations complete in order, no barrier)
+      // (wave-private image: the wave's own LDS operations complete in order, no barrier; the fences keep the COMPILER from
+      // reordering the 2-byte stores and the 16-byte loads, different types to its alias analysis)
+      asm volatile("" ::: "memory");
       bf16* out = static_cast<bf16*>(o == 0 ? p.C : p.C2);
       const bool panels = o == 0 && p.c_panels;   // C as K-panel-major [N/32][c_panels][32]; C2 / aux keep the row-major ldc
 #pragma unroll
@@ -176,6 +178,7 @@ __device__ __forceinline__ void epilogue_fast_bf16(const cara_gemm_args& p, cons
         bf16* dst = panels ? out + ((size_t)(n >> 5) * p.c_panels + m) * 32 + (n & 31) : out + (size_t)m * p.ldc + n + (o == 0 ? coff : 0);
         *reinterpret_cast<bf16x8*>(dst) = val;
       }
+      asm volatile("" ::: "memory");
     }
   }
 }
@@ -228,6 +231,116 @@ __device__ __forceinline__ void epilogue_fast_bf16_rt(const cara_gemm_args& p, c
         bf16* dst = panels ? out + ((size_t)(n >> 5) * p.c_panels + m) * 32 + (n & 31) : out + (size_t)m * p.ldc + n + (o == 0 ? coff : 0);
         *reinterpret_cast<bf16x8*>(dst) = v8[pass];
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Epilogues that READ a second operand (CARA_EPI_RESID: the fp32 residual stream, CARA_EPI_DGELU: the bf16 pre-activation)
+// for INTERIOR wave tiles.  In the generic path above every group of passes waits for its own loads: in-kernel time
+// stamps put a workgroup's residual epilogue at 12.8 us (25 us from cold caches), four exposed memory latencies in a row.
+// Here the operand rows of a whole HALF-row pass group are requested at once, and the NEXT group's while the current one
+// is converted and stored: one exposed latency per tile.  No bounds tests (interior), the per-sample DropPath scale
+// without an integer division per row (a wave tile of at most 128 rows spans at most two samples when rows_per_sample
+// >= its height; callers test that), row addresses by increments.
+// acc: [NT][4] accumulators of v_mfma_f32_16x16x32 (row = 16 i + 4 (lane >> 4) + r, column = 16 j + (lane & 15));
+// stg: a wave-private [GROUP * 16][64] fp32 image; GROUP = row tiles per pass group (NT % GROUP == 0).
+// ---------------------------------------------------------------------------------------------------------------
+template <int EPI, int NT, int GROUP>
+__device__ __forceinline__ void epilogue_interior_aux(const cara_gemm_args& p, const f32x4 (&acc)[NT][4], float* stg, const int mbase,
+                                                      const int nbase, const int lane) {
+  static_assert(EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU, "epilogues with an input operand");
+  static_assert(NT % GROUP == 0, "whole pass groups");
+  constexpr int ROWS = GROUP * 16, NG = NT / GROUP;
+  const int fr = lane & 15, fq = lane >> 4;
+  if constexpr (EPI == CARA_EPI_RESID) {
+    constexpr int NP = ROWS / 4;   // passes of 4 rows x 256 B, 16 B per lane
+    const int c4 = (lane & 15) * 4, rl = lane >> 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + nbase + c4);
+    // DropPath scale of this lane's rows: sample s0 for rows below `edge`, s0 + 1 from there on
+    float r0 = 1.f, r1 = 1.f;
+    int edge = 0x7fffffff;
+    if (p.rowscale) {
+      const int s0 = mbase / p.rows_per_sample;   // wave-uniform: one scalar division per tile
+      edge = (s0 + 1) * p.rows_per_sample;
+      r0 = p.rowscale[s0];
+      r1 = edge < mbase + NT * 16 ? p.rowscale[s0 + 1] : r0;
+    }
+    const float* xin = static_cast<const float*>(p.aux) + (size_t)(mbase + rl) * p.ldc + nbase + c4;
+    float* dst = static_cast<float*>(p.C) + (size_t)(mbase + rl) * p.ldc + nbase + c4;
+    const size_t step = (size_t)4 * p.ldc;
+    f32x4 x[2][NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) x[0][q] = *reinterpret_cast<const f32x4*>(xin + q * step);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+      for (int i = 0; i < GROUP; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[g * GROUP + i][j][r];
+      // (compiler fence: the scalar stores and the 16-byte loads of the image are different types to the alias analysis, which
+      // once moved the first load above the last store)
+      asm volatile("" ::: "memory");
+      if (g + 1 < NG) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) x[(g + 1) & 1][q] = *reinterpret_cast<const f32x4*>(xin + ((g + 1) * NP + q) * step);
+      }
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(stg + (q * 4 + rl) * 64 + c4);
+        const float rs = mbase + g * ROWS + q * 4 + rl < edge ? r0 : r1;
+        const f32x4 xv = x[g & 1][q];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = xv[k] + rs * (a[k] + bv[k]);
+        *reinterpret_cast<f32x4*>(dst + (g * NP + q) * step) = o;
+      }
+      asm volatile("" ::: "memory");
+    }
+  } else {
+    constexpr int NP = ROWS / 8;   // passes of 8 rows x 128 B, 16 B per lane
+    const int c8 = (lane & 7) * 8, rl = lane >> 3;
+    const bf16* up = static_cast<const bf16*>(p.aux) + (size_t)(mbase + rl) * p.ldc + nbase + c8;
+    const size_t step = (size_t)8 * p.ldc;
+    bf16x8 u[2][NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) u[0][q] = *reinterpret_cast<const bf16x8*>(up + q * step);
+    const int n = nbase + c8;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+      for (int i = 0; i < GROUP; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[g * GROUP + i][j][r];
+      // (compiler fence: the scalar stores and the 16-byte loads of the image are different types to the alias analysis, which
+      // once moved the first load above the last store)
+      asm volatile("" ::: "memory");
+      if (g + 1 < NG) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) u[(g + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(up + ((g + 1) * NP + q) * step);
+      }
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + (q * 8 + rl) * 64 + c8);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(stg + (q * 8 + rl) * 64 + c8 + 4);
+        const bf16x8 uv = u[g & 1][q];
+        bf16x8 out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          out[k] = (bf16)(a0[k] * gelu_erf_grad((float)uv[k]));
+          out[4 + k] = (bf16)(a1[k] * gelu_erf_grad((float)uv[4 + k]));
+        }
+        const int m = mbase + g * ROWS + q * 8 + rl;
+        bf16* dst = p.c_panels ? static_cast<bf16*>(p.C) + ((size_t)(n >> 5) * p.c_panels + m) * 32 + (n & 31)
+                               : static_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
+        *reinterpret_cast<bf16x8*>(dst) = out;
+      }
+      asm volatile("" ::: "memory");
     }
   }
 }

@@ -96,6 +96,30 @@ def test_gemm_epilogues():
     close(dg, (A.double() @ B.double().t()) * ud.grad, 2 ** -8, 2e-3, "epi dgelu")
 
 
+@pytest.mark.parametrize("M,N,K,inside", [(1300, 768, 256, False), (1300, 768, 256, True), (1700, 3072, 128, False)])
+def test_gemm_residual_epilogue_of_interior_tiles(M, N, K, inside):
+    """The residual epilogue of interior wave tiles (input rows requested a pass group ahead, the per-sample scale without a
+    division per row): samples of 197 rows, so that wave tiles straddle sample boundaries; with and without T = X U inside."""
+    rps, Rp, rank = 197, 32, 16
+    A, B = rnd(M, K, seed=1, scale=0.3), rnd(N, K, seed=2, scale=0.3)
+    bias = rnd(N, seed=3, dtype=torch.float32)
+    xin = rnd(M, N, seed=5, dtype=torch.float32)
+    rs = torch.rand((M + rps - 1) // rps, generator=torch.Generator().manual_seed(7)).to(DEV) + 0.25
+    Vs = rnd(N, Rp, seed=9, scale=0.3)
+    Ut = torch.zeros(Rp, K, dtype=torch.bfloat16, device=DEV)
+    Ut[:rank] = rnd(rank, K, seed=8, scale=0.3)
+    T = (A.double() @ Ut.double().t()).bfloat16()
+    acc = A.double() @ B.double().t() + bias.double() + T.double() @ Vs.double().t()
+    ref = xin.double() + rs.double().repeat_interleave(rps)[:M, None] * acc
+    xo = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    if inside:
+        Tb = torch.empty(M, Rp, dtype=torch.bfloat16, device=DEV)
+        L().gemm(A, B, xo, epi=L().EPI_RESID, bias=bias, aux=xin, rowscale=rs, rows_per_sample=rps, B2=Vs, Ut=Ut, T_out=Tb)
+    else:
+        L().gemm(A, B, xo, epi=L().EPI_RESID, bias=bias, aux=xin, rowscale=rs, rows_per_sample=rps, A2=T, B2=Vs)
+    close(xo, ref, 1e-5, 2e-3, "resid interior")
+
+
 @pytest.mark.parametrize("M,N", [(300, 200), (192, 328), (1200, 3080)])
 def test_gemm_edge_tiles_mixing_epilogue_paths(M, N):
     """Edge tiles in which some waves own a complete 64-column (or row) sub-tile and take the fast bf16 epilogue while others
