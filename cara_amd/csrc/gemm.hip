@@ -179,14 +179,24 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
   stage_tile32_pre<BN, NW>(B, 0, oB, smem + A_BYTES, uwave);
   int cur = 0;
   if constexpr (!TWOB) {
-    for (int kt = 0; kt < nk; ++kt) {
+    // The K-extension ([T | Vs], Rp / 32 steps) is the tail of the SAME pipelined loop: its 64-byte rows are staged by LDS-DMA a
+    // step ahead like every other step (it used to be a separate phase of plain loads behind the loop: an exposed memory
+    // latency and two more barriers per tile).  Its row offsets are computed when it is staged, not kept through the loop.
+    const int ntot = nk + (p.Rp >> 5);
+    for (int kt = 0; kt < ntot; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       char* sA = smem + cur * SLOT;
+      char* nA = smem + (cur ^ 1) * SLOT;
       if (kt + 1 < nk) {
-        char* nA = smem + (cur ^ 1) * SLOT;
         stage_tile32_pre<TBM, NW>(A, (kt + 1) * kmulA, oA, nA, uwave);
         stage_tile32_pre<BN, NW>(B, (kt + 1) * kmulB, oB, nA + A_BYTES, uwave);
+      } else if (kt + 1 < ntot) {
+        const int e = kt + 1 - nk;
+        const TileOfs<TBM, NW> eA = tile_ofs<TBM, NW>(p.Rp, m0, p.M - 1, wave, lane);
+        const TileOfs<BN, NW> eB = tile_ofs<BN, NW>(p.Rp, n0, p.N - 1, wave, lane);
+        stage_tile32_pre<TBM, NW>(static_cast<const bf16*>(p.A2), e * 32, eA, nA, uwave);
+        stage_tile32_pre<BN, NW>(static_cast<const bf16*>(p.B2), e * 32, eB, nA + A_BYTES, uwave);
       }
       mma_tile32<MI>(sA, sA + A_BYTES, acc, wr, wc, lane);
       cur ^= 1;
@@ -210,12 +220,14 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
       cur ^= 1;
     }
   }
-  for (int kk = 0; kk < (p.Rp >> 5); ++kk) {
-    __syncthreads();
-    stage_ext32<TBM, NW>(static_cast<const bf16*>(p.A2), p.Rp, m0, p.M - 1, kk, smem, tid);
-    stage_ext32<BN, NW>(static_cast<const bf16*>(p.B2), p.Rp, n0, p.N - 1, kk, smem + A_BYTES, tid);
-    __syncthreads();
-    mma_tile32<MI>(smem, smem + A_BYTES, acc, wr, wc, lane);
+  if constexpr (TWOB) {   // (the two-operand loop keeps the separate extension phase)
+    for (int kk = 0; kk < (p.Rp >> 5); ++kk) {
+      __syncthreads();
+      stage_ext32<TBM, NW>(static_cast<const bf16*>(p.A2), p.Rp, m0, p.M - 1, kk, smem, tid);
+      stage_ext32<BN, NW>(static_cast<const bf16*>(p.B2), p.Rp, n0, p.N - 1, kk, smem + A_BYTES, tid);
+      __syncthreads();
+      mma_tile32<MI>(smem, smem + A_BYTES, acc, wr, wc, lane);
+    }
   }
   // epilogue.  bf16 outputs of interior wave tiles: the fast path of gemm_epilogue.h (values converted in the accumulator
   // layout, 2-byte LDS transposition); everything else: NPASS passes of HALF rows through a wave-private [HALF][64] fp32 image
@@ -363,11 +375,16 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     char* sA = smem + cur * SLOT;
+    char* nA = smem + (cur ^ 1) * SLOT;
     if (kt + 1 < nk) {
-      char* nA = smem + (cur ^ 1) * SLOT;
       stage_tile32_pre<TBM, 4>(A, (kt + 1) * kmulA, oA, nA, uwave);
       stage_tile32_pre<BN, 4>(B, (kt + 1) * kmulB, oB, nA + A_BYTES, uwave);
       stage_u((kt + 1) * BK32, nA + A_BYTES + B32_BYTES);
+    } else {
+      // last K step: the extension's B operand (Vs rows of this column tile, 64-byte rows) goes to the free slot by LDS-DMA
+      // under this step's MFMAs (it used to be plain loads behind the loop: an exposed memory latency per tile)
+      const TileOfs<BN, 4> eB = tile_ofs<BN, 4>(32, n0, p.N - 1, wave, lane);
+      stage_tile32_pre<BN, 4>(static_cast<const bf16*>(p.B2), 0, eB, nA + A_BYTES, uwave);
     }
     const char* sB = sA + A_BYTES;
     const char* sU = sB + B32_BYTES;
@@ -385,9 +402,11 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
     }
     cur ^= 1;
   }
-  // T tile (rows wr*64 .., columns wc*16 ..) -> bf16 -> the A image of the extension step; column-0 tiles also
-  // write it (and its transpose) to global for the backward's transposed skinny products
+  // T tile (rows wr*64 .., columns wc*16 ..) -> bf16 -> the A image of the extension step (in the slot the loop left free,
+  // next to the Vs rows already on their way there); column-0 tiles also write it (and its transpose) to global for the
+  // backward's transposed skinny products
   __syncthreads();
+  char* sE = smem + cur * SLOT;
   {
     bf16* T = static_cast<bf16*>(p.T_out);
     bf16* Tt = static_cast<bf16*>(p.Tt_out);
@@ -397,7 +416,7 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
       const int row0 = wr * 64 + i * 16 + fq * 4;
       bf16x4 tv = {(bf16)accg[i][0], (bf16)accg[i][1], (bf16)accg[i][2], (bf16)accg[i][3]};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) *reinterpret_cast<bf16*>(smem + swz32(row0 + r, col >> 3) + (col & 7) * 2) = tv[r];
+      for (int r = 0; r < 4; ++r) *reinterpret_cast<bf16*>(sE + swz32(row0 + r, col >> 3) + (col & 7) * 2) = tv[r];
       if (tn == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -414,9 +433,9 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
       }
     }
   }
-  stage_ext32<BN, 4>(static_cast<const bf16*>(p.B2), 32, n0, p.N - 1, 0, smem + A_BYTES, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Vs rows have landed
   __syncthreads();
-  mma_tile32<4>(smem, smem + A_BYTES, acc, wr, wc, lane);
+  mma_tile32<4>(sE, sE + A_BYTES, acc, wr, wc, lane);
   // epilogue: two 32-row halves through a wave-private [32][64] fp32 image
   constexpr int HALF = 32;
   __syncthreads();

@@ -194,26 +194,55 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_bwd_kernel(const 
   const int lane = threadIdx.x & 63;
   const int row0 = (blockIdx.x * (XU ? XU_WAVES : 4) + (threadIdx.x >> 6)) * RPW;
   __shared__ __attribute__((aligned(16))) XuLds<XU ? V4 : 0> L;
-  for (int row = row0; row < row0 + RPW && row < M; ++row) {
-  const float mu = mean[row], rs = rstd[row];
-  const float* xr = x + (size_t)row * ldx;
-  const bf16* dr = dy + (size_t)row * C;
+  // Every load of the wave's rows -- x, dy AND the running gradient dx_in, which the second half of a row's work reads -- is
+  // requested before anything is reduced: one memory latency per wave instead of two per row (the kernel is one round of
+  // waves, all in the same phase: nothing else hides a dependent load)
+  float4 xv[RPW][V4], pv[RPW][V4];
+  bf16x4 dv[RPW][V4];
+  float mu_[RPW], rs_[RPW];
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = row0 + rr < M ? row0 + rr : M - 1;
+    const float* xr = x + (size_t)row * ldx;
+    const bf16* dr = dy + (size_t)row * C;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+      xv[rr][i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
+      dv[rr][i] = *reinterpret_cast<const bf16x4*>(dr + i * 256 + lane * 4);
+    }
+    mu_[rr] = mean[row];
+    rs_[rr] = rstd[row];
+  }
+  if (dx_in) {
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int row = row0 + rr < M ? row0 + rr : M - 1;
+#pragma unroll
+      for (int i = 0; i < V4; ++i) pv[rr][i] = *reinterpret_cast<const float4*>(dx_in + (size_t)row * ldx + i * 256 + lane * 4);
+    }
+  }
+  float4 gmv[V4];
+#pragma unroll
+  for (int i = 0; i < V4; ++i) gmv[i] = *reinterpret_cast<const float4*>(gamma + i * 256 + lane * 4);
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+  const int row = row0 + rr;
+  if (row >= M) break;
+  const float mu = mu_[rr], rs = rs_[rr];
   float4 g[V4], xh[V4];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < V4; ++i) {
-    const int c0 = i * 256 + lane * 4;
-    const float4 xv = *reinterpret_cast<const float4*>(xr + c0);
-    const float4 gm = *reinterpret_cast<const float4*>(gamma + c0);
-    const bf16x4 d = *reinterpret_cast<const bf16x4*>(dr + c0);
-    xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+    const float4 xq = xv[rr][i];
+    const float4 gm = gmv[i];
+    const bf16x4 d = dv[rr][i];
+    xh[i] = make_float4((xq.x - mu) * rs, (xq.y - mu) * rs, (xq.z - mu) * rs, (xq.w - mu) * rs);
     g[i] = make_float4((float)d[0] * gm.x, (float)d[1] * gm.y, (float)d[2] * gm.z, (float)d[3] * gm.w);
     s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
     s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
   }
   const float c1 = wave_sum(s1) * (1.0f / C), c2 = wave_sum(s2) * (1.0f / C);
   const float sc = rowscale ? rowscale[row / rows_per_sample] : 1.f;
-  const float* di = dx_in ? dx_in + (size_t)row * ldx : nullptr;
   float* dor = dx_out + (size_t)row * ldx;
   bf16* db = dyb ? dyb + (size_t)row * ldx : nullptr;
   bf16x4 yb[V4];
@@ -222,9 +251,9 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_bwd_kernel(const 
     const int c0 = i * 256 + lane * 4;
     float4 o = make_float4(rs * (g[i].x - c1 - xh[i].x * c2), rs * (g[i].y - c1 - xh[i].y * c2),
                            rs * (g[i].z - c1 - xh[i].z * c2), rs * (g[i].w - c1 - xh[i].w * c2));
-    if (di) {
-      const float4 p = *reinterpret_cast<const float4*>(di + c0);
-      o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+    if (dx_in) {
+      const float4 pq = pv[rr][i];
+      o.x += pq.x; o.y += pq.y; o.z += pq.z; o.w += pq.w;
     }
     *reinterpret_cast<float4*>(dor + c0) = o;
     bf16x4 b = {(bf16)(o.x * sc), (bf16)(o.y * sc), (bf16)(o.z * sc), (bf16)(o.w * sc)};
