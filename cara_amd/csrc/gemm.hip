@@ -307,7 +307,10 @@ __global__ __launch_bounds__(256, 4) void gemm32_ts_kernel(const cara_gemm_args 
   // free (in front of the tiles: +0.05 ms per step; spread among them: +0.7 ms)
   const int b = blockIdx.x;
   if (b >= nwg) {
+    STAMP(0);
     tskinny_body<2, COLSUM, 1>(t0, t1, ldg, Mts, b - nwg, smem);
+    STAMP(1);
+    STAMP_END();
   } else {
     gemm32_body<EPI, MI, 4>(p, tiles_n, nwg, gm, b, 0, smem);
   }

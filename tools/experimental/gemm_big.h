@@ -22,6 +22,7 @@
 //  * Row tiles start every `stride` <= 208 rows (stride = ceil(M / ceil(M / 208))): a tile computes 208 rows and
 //    stores the first `stride` of them, so that M = 12608 is 61 equal tiles instead of 60 and a sliver.
 #pragma once
+#include <type_traits>
 
 constexpr int GB_RT = 13;
 constexpr int GB_TM = GB_RT * 16;                  // 208
@@ -148,7 +149,7 @@ __device__ __forceinline__ void gemm_big_body(const cara_gemm_args& p, const int
     for (int k = 0; k < ntot; ++k) {
       gb_wait_batch(ntot - 1 - k, eight);
       gb_barrier();                                   // A(k): step k is in LDS; the slot of step k - 1 is free
-      if constexpr (!GB_ABLATE(2)) { if (k + D < ntot) issue(k + D, nxt); }
+      if (k + D < ntot) issue(k + D, nxt);
       nxt = nxt == GB_SLOTS - 1 ? 0 : nxt + 1;
       gb_barrier();                                   // B(k)
     }
@@ -166,10 +167,10 @@ __device__ __forceinline__ void gemm_big_body(const cara_gemm_args& p, const int
   if (wr == 0) {
     for (int k = 0; k < ntot; ++k) {
       gb_barrier();                                   // A(k)
-      if constexpr (!GB_ABLATE(4)) gb_read<GB_R0>(a, b, smem + cur * GB_SLOT, 0, wc, fr, fq);
+      gb_read<GB_R0>(a, b, smem + cur * GB_SLOT, 0, wc, fr, fq);
       gb_lgkm0();
       gb_barrier();                                   // B(k)
-      if constexpr (!GB_ABLATE(1)) gb_mma<GB_R0>(acc, a, b);
+      gb_mma<GB_R0>(acc, a, b);
       __builtin_amdgcn_sched_barrier(0);
       cur = cur == GB_SLOTS - 1 ? 0 : cur + 1;
     }
@@ -177,10 +178,10 @@ __device__ __forceinline__ void gemm_big_body(const cara_gemm_args& p, const int
     for (int k = 0; k < ntot; ++k) {
       gb_lgkm0();                                     // this wave's reads of slot k - 1 are done before a loader refills it
       gb_barrier();                                   // A(k)
-      if constexpr (!GB_ABLATE(1)) { if (k > 0) gb_mma<GB_RT - GB_R0>(acc, a, b); }   // step k - 1
+      if (k > 0) gb_mma<GB_RT - GB_R0>(acc, a, b);    // step k - 1
       __builtin_amdgcn_sched_barrier(0);
       gb_barrier();                                   // B(k)
-      if constexpr (!GB_ABLATE(4)) gb_read<GB_RT - GB_R0>(a, b, smem + cur * GB_SLOT, GB_R0 * 16, wc, fr, fq);
+      gb_read<GB_RT - GB_R0>(a, b, smem + cur * GB_SLOT, GB_R0 * 16, wc, fr, fq);
       __builtin_amdgcn_sched_barrier(0);
       cur = cur == GB_SLOTS - 1 ? 0 : cur + 1;
     }
@@ -189,20 +190,50 @@ __device__ __forceinline__ void gemm_big_body(const cara_gemm_args& p, const int
   }
   __syncthreads();   // every wave is done with the ring
   STAMP(1);
-  // epilogue: 16 rows at a time through a wave-private [16][64] fp32 image; rows beyond this tile's share are not stored
+  // epilogue.  Rows beyond this tile's share (m0 + stride) are not stored.  The row tiles of a wave that lie wholly inside the
+  // share take the interior paths of gemm_epilogue.h (bf16 outputs converted in the accumulator layout; the input operand of
+  // the residual / gelu' epilogues requested a pass group ahead); the rest -- the 15-row sliver at the end of a 207-row share,
+  // edge tiles -- go 16 rows at a time through a wave-private [16][64] fp32 image.
   cara_gemm_args pm = p;
   pm.M = m0 + stride < p.M ? m0 + stride : p.M;
-  float* stg = reinterpret_cast<float*>(smem) + wave * (16 * 64);
+  constexpr int WAVE_STG = EPI_FAST_WAVE_BYTES > 16 * 64 * 4 ? EPI_FAST_WAVE_BYTES : 16 * 64 * 4;
+  char* wstg = smem + wave * WAVE_STG;
+  float* stg = reinterpret_cast<float*>(wstg);
   const int nrt = wr == 0 ? GB_R0 : GB_RT - GB_R0;
   const int mrow0 = m0 + (wr == 0 ? 0 : GB_R0 * 16);
+  const int nw = n0 + wc * 64;
+  int done = 0;   // row tiles already stored by an interior path
+  const bool aligned = (p.ldc & 7) == 0 && (!p.bias || (nw & 3) == 0);
+  auto interior = [&](auto nt_tag) {
+    constexpr int NTI = decltype(nt_tag)::value;
+    if constexpr (EPI == CARA_EPI_BF16 || EPI == CARA_EPI_GELU) {
+      epilogue_fast_bf16_rt<EPI, NTI>(pm, *reinterpret_cast<const f32x4(*)[NTI][4]>(&acc[0]), wstg, mrow0, nw, lane, 0);
+      done = NTI;
+    } else if constexpr (EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU) {
+      if (EPI == CARA_EPI_DGELU || !p.rowscale || p.rows_per_sample >= NTI * 16) {
+        epilogue_interior_aux<EPI, NTI, 1>(pm, *reinterpret_cast<const f32x4(*)[NTI][4]>(&acc[0]), stg, mrow0, nw, lane);
+        done = NTI;
+      }
+    }
+  };
+  if (aligned) {   // (wave-uniform)
+    if (wr == 0) {
+      if (mrow0 + GB_R0 * 16 <= pm.M) interior(std::integral_constant<int, GB_R0>{});
+    } else {
+      if (mrow0 + (GB_RT - GB_R0) * 16 <= pm.M) interior(std::integral_constant<int, GB_RT - GB_R0>{});
+      else if (mrow0 + (GB_RT - GB_R0 - 1) * 16 <= pm.M) interior(std::integral_constant<int, GB_RT - GB_R0 - 1>{});
+    }
+  }
 #pragma unroll
   for (int i = 0; i < GB_R0; ++i) {
-    if (i < nrt && mrow0 + i * 16 < pm.M) {   // wave-uniform
+    if (i >= done && i < nrt && mrow0 + i * 16 < pm.M) {   // wave-uniform
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) stg[(fq * 4 + r) * 64 + j * 16 + fr] = acc[i][j][r];
-      epilogue_rows<EPI, 16>(pm, stg, mrow0 + i * 16, n0 + wc * 64, lane, 0);
+      asm volatile("" ::: "memory");
+      epilogue_rows<EPI, 16>(pm, stg, mrow0 + i * 16, nw, lane, 0);
+      asm volatile("" ::: "memory");
     }
   }
   STAMP_END();
@@ -237,7 +268,7 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_big_ts_kernel(const cara_gemm
 // what the tile takes: full 256-column strips, the plain K-extension, one product per launch
 static bool big_tile_ok(const cara_gemm_args* a) {
   return (a->N % GB_TN) == 0 && a->M >= 1024 && (a->K % 32) == 0 && (a->Rp == 0 || (a->Rp == 32 && a->A2)) && a->batch <= 1 && !a->B3 &&
-         !a->Ut;
+         !a->Ut && !a->c_panels;
 }
 
 struct TsPair;

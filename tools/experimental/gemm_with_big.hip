@@ -32,12 +32,6 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 extern "C" int cara_debug_gemm_stamps(void* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
 }
-// timing ablations of the 208 x 256 tile (results wrong), compile time: -DCARA_GB_ABLATE=mask, 1 = no MFMAs, 2 = no LDS-DMA in the
-// loop, 4 = no fragment reads
-#ifndef CARA_GB_ABLATE
-#define CARA_GB_ABLATE 0
-#endif
-#define GB_ABLATE(bit) ((CARA_GB_ABLATE & (bit)) != 0)
 #define STAMP(slot)                                                                         \
   do {                                                                                      \
     if (g_stamp_buf && threadIdx.x == 0) g_stamp_buf[(size_t)blockIdx.x * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
@@ -51,7 +45,6 @@ extern "C" int cara_debug_gemm_stamps(void* buf) {
     }                                                                                       \
   } while (0)
 #else
-#define GB_ABLATE(bit) false
 #define STAMP(slot) do {} while (0)
 #define STAMP_END() do {} while (0)
 #endif
@@ -73,15 +66,21 @@ __device__ __forceinline__ int swz32(int row, int chunk) { return row * 64 + ((c
 // two thirds of them this address arithmetic.  Needs the operand to span < 4 GiB (checked at dispatch).
 template <int ROWS, int NW = 4>
 struct TileOfs {
-  unsigned off[ROWS / (16 * NW)];
+  static constexpr int NP = ROWS / 16;                  // one-KiB pieces of the tile
+  static constexpr int PPW = (NP + NW - 1) / NW;         // pieces per wave (the last one only on the first NP % NW waves)
+  static constexpr bool EVEN = NP % NW == 0;
+  unsigned off[PPW];
+  // piece t of a wave: blocked (wave * PPW + t) when the pieces divide evenly, interleaved (wave + NW * t) otherwise
+  static __device__ __forceinline__ int piece(int wave, int t) { return EVEN ? wave * PPW + t : wave + NW * t; }
 };
 template <int ROWS, int NW = 4>
 __device__ __forceinline__ TileOfs<ROWS, NW> tile_ofs(int ld, int r0, int rmax, int wave, int lane) {
-  constexpr int PPW = ROWS / (16 * NW);
-  TileOfs<ROWS, NW> o;
+  using T = TileOfs<ROWS, NW>;
+  T o;
 #pragma unroll
-  for (int t = 0; t < PPW; ++t) {
-    const int r = (wave * PPW + t) * 16 + (lane >> 2);
+  for (int t = 0; t < T::PPW; ++t) {
+    const int pc = T::piece(wave, t) < T::NP ? T::piece(wave, t) : T::NP - 1;
+    const int r = pc * 16 + (lane >> 2);
     const int cg = (lane & 3) ^ (((r >> 3) & 1) * 3);
     int gr = r0 + r;
     gr = gr < rmax ? gr : rmax;
@@ -91,10 +90,11 @@ __device__ __forceinline__ TileOfs<ROWS, NW> tile_ofs(int ld, int r0, int rmax, 
 }
 template <int ROWS, int NW = 4>
 __device__ __forceinline__ void stage_tile32_pre(const bf16* __restrict__ P, int k0, const TileOfs<ROWS, NW>& o, char* lds_tile, int wave) {
-  constexpr int PPW = ROWS / (16 * NW);
+  using T = TileOfs<ROWS, NW>;
   const char* base = reinterpret_cast<const char*>(P + k0);   // wave-uniform
 #pragma unroll
-  for (int t = 0; t < PPW; ++t) glds16(base + o.off[t], lds_tile + (wave * PPW + t) * 1024);
+  for (int t = 0; t < T::PPW; ++t)
+    if (T::EVEN || T::piece(wave, t) < T::NP) glds16(base + o.off[t], lds_tile + T::piece(wave, t) * 1024);
 }
 
 template <int MI>
@@ -179,14 +179,24 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
   stage_tile32_pre<BN, NW>(B, 0, oB, smem + A_BYTES, uwave);
   int cur = 0;
   if constexpr (!TWOB) {
-    for (int kt = 0; kt < nk; ++kt) {
+    // The K-extension ([T | Vs], Rp / 32 steps) is the tail of the SAME pipelined loop: its 64-byte rows are staged by LDS-DMA a
+    // step ahead like every other step (it used to be a separate phase of plain loads behind the loop: an exposed memory
+    // latency and two more barriers per tile).  Its row offsets are computed when it is staged, not kept through the loop.
+    const int ntot = nk + (p.Rp >> 5);
+    for (int kt = 0; kt < ntot; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       char* sA = smem + cur * SLOT;
+      char* nA = smem + (cur ^ 1) * SLOT;
       if (kt + 1 < nk) {
-        char* nA = smem + (cur ^ 1) * SLOT;
         stage_tile32_pre<TBM, NW>(A, (kt + 1) * kmulA, oA, nA, uwave);
         stage_tile32_pre<BN, NW>(B, (kt + 1) * kmulB, oB, nA + A_BYTES, uwave);
+      } else if (kt + 1 < ntot) {
+        const int e = kt + 1 - nk;
+        const TileOfs<TBM, NW> eA = tile_ofs<TBM, NW>(p.Rp, m0, p.M - 1, wave, lane);
+        const TileOfs<BN, NW> eB = tile_ofs<BN, NW>(p.Rp, n0, p.N - 1, wave, lane);
+        stage_tile32_pre<TBM, NW>(static_cast<const bf16*>(p.A2), e * 32, eA, nA, uwave);
+        stage_tile32_pre<BN, NW>(static_cast<const bf16*>(p.B2), e * 32, eB, nA + A_BYTES, uwave);
       }
       mma_tile32<MI>(sA, sA + A_BYTES, acc, wr, wc, lane);
       cur ^= 1;
@@ -210,17 +220,21 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
       cur ^= 1;
     }
   }
-  for (int kk = 0; kk < (p.Rp >> 5); ++kk) {
-    __syncthreads();
-    stage_ext32<TBM, NW>(static_cast<const bf16*>(p.A2), p.Rp, m0, p.M - 1, kk, smem, tid);
-    stage_ext32<BN, NW>(static_cast<const bf16*>(p.B2), p.Rp, n0, p.N - 1, kk, smem + A_BYTES, tid);
-    __syncthreads();
-    mma_tile32<MI>(smem, smem + A_BYTES, acc, wr, wc, lane);
+  if constexpr (TWOB) {   // (the two-operand loop keeps the separate extension phase)
+    for (int kk = 0; kk < (p.Rp >> 5); ++kk) {
+      __syncthreads();
+      stage_ext32<TBM, NW>(static_cast<const bf16*>(p.A2), p.Rp, m0, p.M - 1, kk, smem, tid);
+      stage_ext32<BN, NW>(static_cast<const bf16*>(p.B2), p.Rp, n0, p.N - 1, kk, smem + A_BYTES, tid);
+      __syncthreads();
+      mma_tile32<MI>(smem, smem + A_BYTES, acc, wr, wc, lane);
+    }
   }
   // epilogue.  bf16 outputs of interior wave tiles: the fast path of gemm_epilogue.h (values converted in the accumulator
   // layout, 2-byte LDS transposition); everything else: NPASS passes of HALF rows through a wave-private [HALF][64] fp32 image
-  constexpr int NPASS = ((NW == 8 && MI == 4) || MI == 8) ? 4 : 2;
+  constexpr int NPASS = (MI % 2) ? MI : (((NW == 8 && MI == 4) || MI == 8) ? 4 : 2);
   constexpr int HALF = MI * 16 / NPASS;
+  // one LDS region per wave for BOTH epilogue paths (in an edge tile some waves take the fast path and others the generic one)
+  constexpr int WAVE_STG = HALF * 64 * 4 > EPI_FAST_WAVE_BYTES ? HALF * 64 * 4 : EPI_FAST_WAVE_BYTES;
   __syncthreads();
   STAMP(1);
   if constexpr ((EPI == CARA_EPI_BF16 || EPI == CARA_EPI_GELU) && (MI == 4 || MI == 8) && NW == 4) {
@@ -228,12 +242,30 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
     if (mw + MI * 16 <= p.M && nw + 64 <= p.N && (p.ldc & 7) == 0) {   // wave-uniform
 #pragma unroll
       for (int q = 0; q < MI / 4; ++q)
-        epilogue_fast_bf16<EPI>(p, *reinterpret_cast<const f32x4(*)[4][4]>(&acc[q * 4]), smem + wave * EPI_FAST_WAVE_BYTES, mw + q * 64, nw, lane, coff);
+        epilogue_fast_bf16<EPI>(p, *reinterpret_cast<const f32x4(*)[4][4]>(&acc[q * 4]), smem + wave * WAVE_STG, mw + q * 64, nw, lane, coff);
+      STAMP_END();
+      return;
+    }
+  } else if constexpr (EPI == CARA_EPI_BF16 || EPI == CARA_EPI_GELU) {
+    const int mw = m0 + wr * (MI * 16), nw = n0 + wc * 64;
+    if (mw + MI * 16 <= p.M && nw + 64 <= p.N && (p.ldc & 7) == 0) {   // wave-uniform
+      epilogue_fast_bf16_rt<EPI, MI>(p, acc, smem + wave * WAVE_STG, mw, nw, lane, coff);
       STAMP_END();
       return;
     }
   }
-  float* stg = reinterpret_cast<float*>(smem) + wave * (HALF * 64);
+  float* stg = reinterpret_cast<float*>(smem + wave * WAVE_STG);
+  if constexpr (EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU) {
+    // interior wave tiles: the epilogue's input operand requested a pass group ahead (gemm_epilogue.h)
+    const int mw = m0 + wr * (MI * 16), nw = n0 + wc * 64;
+    const bool ok = mw + MI * 16 <= p.M && nw + 64 <= p.N && (p.ldc & 7) == 0 && coff == 0 &&
+                    (EPI == CARA_EPI_DGELU || !p.rowscale || p.rows_per_sample >= MI * 16) && (!p.bias || (nw & 3) == 0);
+    if (ok) {   // wave-uniform
+      epilogue_interior_aux<EPI, MI, 1>(p, acc, stg, mw, nw, lane);
+      STAMP_END();
+      return;
+    }
+  }
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
   for (int half = 0; half < NPASS; ++half) {
@@ -243,25 +275,22 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[half * (MI / NPASS) + i][j][r];
+    asm volatile("" ::: "memory");   // (scalar stores, 16-byte loads of the same image: keep the compiler from reordering them)
     epilogue_rows<EPI, HALF>(p, stg, m0 + wr * (MI * 16) + half * HALF, n0 + wc * 64, lane, coff);
+    asm volatile("" ::: "memory");
   }
   STAMP_END();
 }
 
-template <int EPI, bool TWOB = false>
-__global__ __launch_bounds__(256, 4) void gemm32_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
+// MI = 5: 160 x 128 tiles (80 x 64 per wave) for the products with N >= 3072 -- their 99 x 24 = 2376 tiles of 128 rows are 2.32
+// rounds of the 1024 workgroup slots (the last third of the launch runs at a fraction of the occupancy, tools/gemm_stamps.py),
+// 79 x 24 = 1896 tiles of 160 rows are 1.85, and a tile stages 10 % fewer bytes per flop; 36 KiB of LDS, still four per CU
+// (the 160-row tile with an epilogue that reads a second operand and no riding products -- not a product of the model -- would spill
+// a few registers at four workgroups per CU: it gets three)
+template <int EPI, bool TWOB = false, int MI = 4>
+__global__ __launch_bounds__(256, (MI == 5 && (EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU)) ? 3 : 4) void gemm32_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm32_body<EPI, 4, 4, TWOB>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
-}
-
-// 256 x 128 tiles from the same body: each of the four waves owns 128 x 64 (8 x 4 accumulators, 128 registers), so a K step
-// stages 24 KiB for twice the MFMAs of the 128 x 128 tile (3/4 of the bytes per flop through the CU's load-return path,
-// which the counters show ~70 % busy in the default kernel) and reads 3/4 of the LDS bytes per flop; 48 KiB of LDS and
-// < 256 registers: two workgroups per CU.  CARA_GEMM_BM=256 selects it for the wide products (N >= 2304).
-template <int EPI>
-__global__ __launch_bounds__(256, 3) void gemm32_tall_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm32_body<EPI, 8, 4>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
+  gemm32_body<EPI, MI, 4, TWOB>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
 }
 
 // The dX GEMM of a linear and the two transposed skinny products of the SAME linear (dU = X^T G', dVs = dY^T T) in
@@ -271,14 +300,17 @@ __global__ __launch_bounds__(256, 3) void gemm32_tall_kernel(const cara_gemm_arg
 // there is no event at all and the dispatcher mixes the two kinds of workgroup on every CU.  Needs Rp = 32 products
 // (84 VGPRs; the Rp = 64 form needs 136) and 36 KiB of LDS per workgroup (still four per CU).
 template <int EPI, bool COLSUM, int MI = 4>
-__global__ __launch_bounds__(256, MI == 8 ? 3 : 4) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
+__global__ __launch_bounds__(256, 4) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
                                                            const TsProblem t0, const TsProblem t1, const int ldg, const int Mts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // the products' blocks sit BEHIND the GEMM tiles: they fill the slots the GEMM's last, partly filled round leaves
   // free (in front of the tiles: +0.05 ms per step; spread among them: +0.7 ms)
   const int b = blockIdx.x;
   if (b >= nwg) {
+    STAMP(0);
     tskinny_body<2, COLSUM, 1>(t0, t1, ldg, Mts, b - nwg, smem);
+    STAMP(1);
+    STAMP_END();
   } else {
     gemm32_body<EPI, MI, 4>(p, tiles_n, nwg, gm, b, 0, smem);
   }
@@ -346,11 +378,16 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     char* sA = smem + cur * SLOT;
+    char* nA = smem + (cur ^ 1) * SLOT;
     if (kt + 1 < nk) {
-      char* nA = smem + (cur ^ 1) * SLOT;
       stage_tile32_pre<TBM, 4>(A, (kt + 1) * kmulA, oA, nA, uwave);
       stage_tile32_pre<BN, 4>(B, (kt + 1) * kmulB, oB, nA + A_BYTES, uwave);
       stage_u((kt + 1) * BK32, nA + A_BYTES + B32_BYTES);
+    } else {
+      // last K step: the extension's B operand (Vs rows of this column tile, 64-byte rows) goes to the free slot by LDS-DMA
+      // under this step's MFMAs (it used to be plain loads behind the loop: an exposed memory latency per tile)
+      const TileOfs<BN, 4> eB = tile_ofs<BN, 4>(32, n0, p.N - 1, wave, lane);
+      stage_tile32_pre<BN, 4>(static_cast<const bf16*>(p.B2), 0, eB, nA + A_BYTES, uwave);
     }
     const char* sB = sA + A_BYTES;
     const char* sU = sB + B32_BYTES;
@@ -368,9 +405,11 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
     }
     cur ^= 1;
   }
-  // T tile (rows wr*64 .., columns wc*16 ..) -> bf16 -> the A image of the extension step; column-0 tiles also
-  // write it (and its transpose) to global for the backward's transposed skinny products
+  // T tile (rows wr*64 .., columns wc*16 ..) -> bf16 -> the A image of the extension step (in the slot the loop left free,
+  // next to the Vs rows already on their way there); column-0 tiles also write it (and its transpose) to global for the
+  // backward's transposed skinny products
   __syncthreads();
+  char* sE = smem + cur * SLOT;
   {
     bf16* T = static_cast<bf16*>(p.T_out);
     bf16* Tt = static_cast<bf16*>(p.Tt_out);
@@ -380,7 +419,7 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
       const int row0 = wr * 64 + i * 16 + fq * 4;
       bf16x4 tv = {(bf16)accg[i][0], (bf16)accg[i][1], (bf16)accg[i][2], (bf16)accg[i][3]};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) *reinterpret_cast<bf16*>(smem + swz32(row0 + r, col >> 3) + (col & 7) * 2) = tv[r];
+      for (int r = 0; r < 4; ++r) *reinterpret_cast<bf16*>(sE + swz32(row0 + r, col >> 3) + (col & 7) * 2) = tv[r];
       if (tn == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -397,13 +436,22 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
       }
     }
   }
-  stage_ext32<BN, 4>(static_cast<const bf16*>(p.B2), 32, n0, p.N - 1, 0, smem + A_BYTES, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Vs rows have landed
   __syncthreads();
-  mma_tile32<4>(smem, smem + A_BYTES, acc, wr, wc, lane);
+  mma_tile32<4>(sE, sE + A_BYTES, acc, wr, wc, lane);
   // epilogue: two 32-row halves through a wave-private [32][64] fp32 image
   constexpr int HALF = 32;
   __syncthreads();
   float* stg = reinterpret_cast<float*>(smem) + wave * (HALF * 64);
+  if constexpr (EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU) {
+    const int mw = m0 + wr * 64, nw = n0 + wc * 64;
+    const bool ok = mw + 64 <= p.M && nw + 64 <= p.N && (p.ldc & 7) == 0 &&
+                    (EPI == CARA_EPI_DGELU || !p.rowscale || p.rows_per_sample >= 64) && (!p.bias || (nw & 3) == 0);
+    if (ok) {   // wave-uniform
+      epilogue_interior_aux<EPI, 4, 2>(p, acc, stg, mw, nw, lane);
+      return;
+    }
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -412,7 +460,9 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[half * 2 + i][j][r];
+    asm volatile("" ::: "memory");
     epilogue_rows<EPI, HALF>(p, stg, m0 + wr * 64 + half * HALF, n0 + wc * 64, lane);
+    asm volatile("" ::: "memory");
   }
 }
 
@@ -483,17 +533,24 @@ int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr
   const int gm = group_m(tiles_n);
   const int nwg = ((a->M + 127) / 128) * tiles_n;
   constexpr int GEMM_LDS = 2 * (128 * BK32 * 2 + B32_BYTES);
-  static const int tall = [] { const char* e = getenv("CARA_GEMM_BM"); return e ? atoi(e) : 0; }();
-  const bool use_tall = (tall == 256 || tall == 2562) && a->N >= 2304 && a->M > 1024 && a->batch <= 1 && !a->B3;
-  constexpr int TALL_LDS = 2 * (256 * BK32 * 2 + B32_BYTES);
-  if (ts && use_tall) {
-    const int nts = ts->a.nblk + ts->b.nblk;
-    const int nwg_t = ((a->M + 255) / 256) * tiles_n;
-    constexpr int LDS = TsRing<2, 1>::BLOCK_BYTES > TALL_LDS ? TsRing<2, 1>::BLOCK_BYTES : TALL_LDS;
-    if (ts->any_cs)
-      hipLaunchKernelGGL((gemm32_ts_kernel<EPI, true, 8>), dim3(nwg_t + nts), dim3(256), LDS, st, *a, tiles_n, nwg_t, gm, ts->a, ts->b, ts->ldg, ts->M);
-    else
-      hipLaunchKernelGGL((gemm32_ts_kernel<EPI, false, 8>), dim3(nwg_t + nts), dim3(256), LDS, st, *a, tiles_n, nwg_t, gm, ts->a, ts->b, ts->ldg, ts->M);
+  // CARA_GEMM_BM=160: the 160-row tile for the widest products (A/B)
+  // The 160-row tile for the widest products (N >= 3072: fc1 forward, fc2 dX).  CARA_GEMM_BM=128 keeps the 128-row tile (A/B runs:
+  // 9.22 -> 9.08 and 9.37 -> 9.28 ms per step on two boxes; for the N = 768 products, whose 594 / 474 tiles are a single
+  // round either way, it made no difference in the step and stays off)
+  static const int bm = [] { const char* e = getenv("CARA_GEMM_BM"); return e ? atoi(e) : 160; }();
+  if (bm == 160 && a->N >= 3072 && a->M > 1024 && a->batch <= 1 && !a->B3) {
+    constexpr int LDS160 = 2 * (160 * BK32 * 2 + B32_BYTES);
+    const int nwg5 = ((a->M + 159) / 160) * tiles_n;
+    if (ts) {
+      const int nts = ts->a.nblk + ts->b.nblk;
+      constexpr int LDS = TsRing<2, 1>::BLOCK_BYTES > LDS160 ? TsRing<2, 1>::BLOCK_BYTES : LDS160;
+      if (ts->any_cs)
+        hipLaunchKernelGGL((gemm32_ts_kernel<EPI, true, 5>), dim3(nwg5 + nts), dim3(256), LDS, st, *a, tiles_n, nwg5, gm, ts->a, ts->b, ts->ldg, ts->M);
+      else
+        hipLaunchKernelGGL((gemm32_ts_kernel<EPI, false, 5>), dim3(nwg5 + nts), dim3(256), LDS, st, *a, tiles_n, nwg5, gm, ts->a, ts->b, ts->ldg, ts->M);
+    } else {
+      hipLaunchKernelGGL((gemm32_kernel<EPI, false, 5>), dim3(nwg5), dim3(256), LDS160, st, *a, tiles_n, nwg5, gm);
+    }
     CARA_CHECK_LAUNCH();
     return CARA_OK;
   }
@@ -508,19 +565,6 @@ int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr
     return CARA_OK;
   }
   const int nb = a->batch > 1 ? a->batch : 1;
-  if (use_tall) {
-    const int nwg_t = ((a->M + 255) / 256) * tiles_n;
-    // 48 KiB: three workgroups per CU (168 registers); asking for 72 KiB holds it at two (A/B)
-    const int lds = tall == 256 ? TALL_LDS : 72 * 1024;
-    static bool attr = false;
-    if (!attr) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm32_tall_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) != hipSuccess) return CARA_E_LAUNCH;
-      attr = true;
-    }
-    hipLaunchKernelGGL((gemm32_tall_kernel<EPI>), dim3(nwg_t), dim3(256), lds, st, *a, tiles_n, nwg_t, gm);
-    CARA_CHECK_LAUNCH();
-    return CARA_OK;
-  }
   if (a->B3) hipLaunchKernelGGL((gemm32_kernel<EPI, true>), dim3(nwg, nb), dim3(256), GEMM_LDS, st, *a, tiles_n, nwg, gm);
   else hipLaunchKernelGGL((gemm32_kernel<EPI>), dim3(nwg, nb), dim3(256), GEMM_LDS, st, *a, tiles_n, nwg, gm);
   CARA_CHECK_LAUNCH();
@@ -698,10 +742,10 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
       default: return CARA_E_ARG;
     }
   }
-  // CARA_GEMM_BIG: 1 = the 208 x 256 one-workgroup-per-CU tile for the products whose tiles fit one round (N = 768 at M = 12608),
-  // 2 = for every product it can take
-  static const int big = [] { const char* e = getenv("CARA_GEMM_BIG"); return e ? atoi(e) : 0; }();
-  if (big && big_tile_ok(a) && (big >= 2 || ((a->M + GB_TM - 1) / GB_TM) * (a->N / GB_TN) <= 256)) {
+  // The 208 x 256 one-workgroup-per-CU tile (gemm_big.h) for the long-K products whose tiles are a single round (M = 12608:
+  // N = 768 with K >= 2304).  CARA_GEMM_BIG=0 keeps the 128-row tile (A/B runs)
+  static const int big = [] { const char* e = getenv("CARA_GEMM_BIG"); return e ? atoi(e) : 1; }();
+  if (big && big_tile_ok(a) && a->K >= 2304 && ((a->M + GB_TM - 1) / GB_TM) * (a->N / GB_TN) <= 256) {
     switch (a->epi) {
       case CARA_EPI_BF16: return launch_big<CARA_EPI_BF16>(a, st, ts);
       case CARA_EPI_F32: return launch_big<CARA_EPI_F32>(a, st, ts);

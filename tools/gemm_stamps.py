@@ -25,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="fc1_fwd")
     ap.add_argument("--bin", type=float, default=2.0, help="histogram bin, us")
+    ap.add_argument("--ts", action="store_true", help="the launch also carries the linear's two transposed skinny products (cara_gemm_with_tskinny)")
     ap.add_argument("--cold", action="store_true", help="write 512 MB to another buffer before the measured launch")
     a = ap.parse_args()
     N, K, epi = SHAPES[a.shape]
@@ -50,15 +51,31 @@ def main():
     buf = torch.zeros(nmax * 4, dtype=torch.int64, device=dev)
     lib.cara_debug_gemm_stamps.argtypes = [C.c_void_p]
     junk = torch.empty(512 * 1000 * 1000 // 4, device=dev)
+    launch = lambda: L.gemm(A, B, out, **kw)
+    if a.ts:   # dX = dY Wt^T with dU = X^T G' and dVs = dY^T T riding: A = dY [M, K], X = the linear's input [M, N]
+        lib.cara_tskinny_scratch_bytes.restype = C.c_size_t
+        X = torch.randn(M, N, generator=g).bfloat16().to(dev)
+        ldg = (M + 31) // 32 * 32
+        Gt = torch.zeros(32, ldg, dtype=torch.bfloat16, device=dev); Tt = torch.zeros_like(Gt)
+        Gt[:, :M] = torch.randn(32, M, generator=g).bfloat16().to(dev); Tt[:, :M] = torch.randn(32, M, generator=g).bfloat16().to(dev)
+        sa = torch.zeros(int(lib.cara_tskinny_scratch_bytes(M, N, 32)), dtype=torch.uint8, device=dev)
+        sb = torch.zeros(int(lib.cara_tskinny_scratch_bytes(M, K, 32)), dtype=torch.uint8, device=dev)
+        ga = L.GemmArgs()
+        ga.A, ga.lda, ga.B, ga.ldb, ga.Bp, ga.A2, ga.B2, ga.Rp = L.ptr(A), K, L.ptr(B), K, L.ptr(kw["Bp"]), L.ptr(kw["A2"]), L.ptr(kw["B2"]), 32
+        ga.M, ga.N, ga.K, ga.C, ga.ldc, ga.epi = M, N, K, L.ptr(out), N, kw["epi"]
+        ga.aux = L.ptr(kw.get("aux"))
+        keep = (X, Gt, Tt, sa, sb)
+        launch = lambda: L.check(lib.cara_gemm_with_tskinny(C.byref(ga), L.ptr(X), N, L.ptr(Gt), L.ptr(sa), N, L.ptr(A), K, L.ptr(Tt), L.ptr(sb), K,
+                                                           1, ldg, M, 32, L.stream()), "cara_gemm_with_tskinny")
     for _ in range(3):
-        L.gemm(A, B, out, **kw)
+        launch()
     torch.cuda.synchronize()
     assert lib.cara_debug_gemm_stamps(C.c_void_p(buf.data_ptr())) == 0
     if a.cold:
         junk.fill_(1.0)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    L.gemm(A, B, out, **kw)
+    launch()
     e1.record()
     torch.cuda.synchronize()
     lib.cara_debug_gemm_stamps(C.c_void_p(0))
@@ -71,6 +88,14 @@ def main():
     cu = ((hw >> 32) & 0xf) * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 50 + ((hw >> 8) & 0xf)
     print(f"{a.shape}: N={N} K={K} {epi}; {len(used)} workgroups on {len(set(cu.tolist()))} CUs; event time {e0.elapsed_time(e1) * 1e3:.1f} us; "
           f"span of stamps {float(en.max()):.1f} us")
+    if a.ts:   # the products' blocks sit behind the GEMM's tiles
+        th = 160 if N >= 3072 else 128
+        ntile = ((M + th - 1) // th) * (N // 128)
+        idx = used
+        r = idx >= ntile
+        print(f"GEMM tiles {int((~r).sum())}: last K-loop end {float(kl[~r].max()):.1f} us, last end {float(en[~r].max()):.1f} us;  "
+              f"product blocks {int(r.sum())}: start {float(st[r].min()):.1f} .. {float(st[r].max()):.1f} us, end {float(en[r].min()):.1f} .. {float(en[r].max()):.1f} us, "
+              f"duration median {float((en[r] - st[r]).median()):.1f} us")
     kd, ed = kl - st, en - kl
     q = lambda x: [round(float(v), 1) for v in torch.quantile(x, torch.tensor([0.05, 0.5, 0.95], dtype=torch.double))]
     print(f"K loop us (5/50/95 %): {q(kd)}   epilogue us: {q(ed)}   start us: {q(st)}")
