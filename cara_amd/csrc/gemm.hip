@@ -9,16 +9,19 @@
 // second dense GEMM on a materialised dW.
 //
 // Structure: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 =
-// 4x4 v_mfma_f32_16x16x32_bf16 accumulators), BK = 32, two LDS slots of A 128x32 + B 128x32 bf16
-// (32 KiB -> FOUR workgroups per CU: one's prologue / epilogue runs under the K loops of the others),
+// 4x4 v_mfma_f32_16x16x32_bf16 accumulators) -- 160x128 (80x64 per wave) for the N >= 3072 products, whose tiles are
+// then 1.85 rounds of the workgroup slots instead of 2.32 --, BK = 32, two LDS slots of A rows x 32 + B 128x32 bf16
+// (32 / 36 KiB -> FOUR workgroups per CU: one's prologue / epilogue runs under the K loops of the others),
 // tiles staged by 16-byte global_load_lds (LDS-DMA, no VGPR round trip) issued one K-step ahead
-// of the MFMAs that consume them; one barrier per K-step.  LDS image is [row][32 bf16] with the
-// 16-byte chunk index XOR-swizzled, applied on the global SOURCE address (the DMA destination is
+// of the MFMAs that consume them, the K-extension step ([T | Vs]) included; one barrier per K-step.  LDS image is
+// [row][32 bf16] with the 16-byte chunk index XOR-swizzled, applied on the global SOURCE address (the DMA destination is
 // lane-linear) and again on the ds_read_b128 address: conflict-free fragment reads.
 // 1-D grid remapped so that each XCD's L2 sees a contiguous run of tiles.
+// What bounds it: a CU takes in ~70 GB/s through its vector-memory path whatever the number of
+// resident workgroups or the prefetch depth; epilogues: gemm_epilogue.h.
 // (Other structures that were built and measured slower on this model's shapes -- a 64-deep double buffer,
-// 256x256 / 128x256 LDS-ring kernels, a persistent stream-K kernel -- live in tools/experimental/, outside the
-// library.)
+// 256x256 / 128x256 LDS-ring kernels, a persistent stream-K kernel, 256x128 tiles, a 208x256 one-workgroup-per-CU
+// tile with DMA-only loader waves -- live in tools/experimental/, outside the library.)
 #include <stdlib.h>
 
 #include "common.h"
