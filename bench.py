@@ -203,6 +203,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--all-sites", action="store_true", help="diagnostic: roofline_top lists every bracketed MFMA site, not the top three")
     ap.add_argument("--weight-dropout", default="off", choices=["off", "exact"],
                     help="exact = the reference's train-mode Dropout(0.1) on the materialised adapters (merged weights + "
                          "dense dW gradients); informational, the reported metric uses the factored default")
@@ -348,7 +349,7 @@ def main():
             return d
         per_step = {n: v["brackets"] // 3 for n, v in post.items()}
         ranked = sorted((n for n in post if work[n][0] == "mfma"), key=lambda n: -post[n]["avg_ms"] * per_step[n])
-        top = [entry(n, post[n], per_step[n]) for n in ranked[:3]]
+        top = [entry(n, post[n], per_step[n]) for n in (ranked if args.all_sites else ranked[:3])]
         hbm = [entry(n, post[n], per_step[n]) for n in post if work[n][0] == "hbm"]
         if dom:
             fl = work[dominant][1]
