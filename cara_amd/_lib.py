@@ -22,7 +22,7 @@ SYMBOLS = (
     "cara_attention_fwd", "cara_attention_bwd", "cara_im2col_patches", "cara_assemble_tokens",
     "cara_cross_entropy", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_transpose_bf16_ld", "cara_pack_offsets",
     "cara_weight_dropout_hash", "cara_materialize_merge", "cara_dropout_grad_scratch_bytes", "cara_dropout_grad_contract", "cara_colsum_scratch_bytes", "cara_colsum_bf16", "cara_factor_prep", "cara_factor_grad_scratch_bytes", "cara_factor_grad_reduce", "cara_vit_workspace_bytes", "cara_vit_forward",
-    "cara_vit_backward", "cara_head_backward", "cara_profile_sites", "cara_profile_site_read", "cara_debug_tr_probe", "cara_debug_tr_frag",
+    "cara_vit_backward", "cara_head_backward", "cara_sizeof_struct", "cara_sizeof_gemm_args", "cara_profile_sites", "cara_profile_site_read", "cara_debug_tr_probe", "cara_debug_tr_frag",
 )
 
 EPI_BF16, EPI_F32, EPI_GELU, EPI_RESID, EPI_DGELU = range(5)
@@ -98,6 +98,15 @@ class VitShape(C.Structure):
                 ("wd_exact", C.c_int), ("wd_p", C.c_float), ("wd_seed", C.c_uint), ("inference", C.c_int)]
 
 
+class TsReduce(C.Structure):
+    _fields_ = [("slabs", C.c_void_p), ("slab_stride", C.c_size_t), ("D", C.c_void_p), ("colsum", C.c_void_p),
+                ("batch", C.c_int), ("M", C.c_int), ("K1", C.c_int), ("Rp", C.c_int)]
+
+
+# CARA_STRUCT_* of include/cara_hip.h -> the mirror above (lib() asserts that every size agrees with the library's)
+STRUCT_MIRRORS = (GemmArgs, Geom, CpPtrs, PackLayout, LayerGrads, VitWeights, VitShape, TsReduce)
+
+
 class CaraError(RuntimeError):
     pass
 
@@ -123,6 +132,13 @@ def lib() -> C.CDLL:
             _lib.cara_weight_dropout_hash.restype = C.c_uint
             _lib.cara_dropout_grad_scratch_bytes.restype = C.c_size_t
             _lib.cara_colsum_scratch_bytes.restype = C.c_size_t
+        _lib.cara_sizeof_struct.restype = C.c_size_t
+        _lib.cara_sizeof_gemm_args.restype = C.c_size_t
+        for which, mirror in enumerate(STRUCT_MIRRORS):   # a mirror that is short would make the library read past it
+            want = int(_lib.cara_sizeof_struct(which))
+            if want != C.sizeof(mirror):
+                raise CaraError(f"{LIB_PATH}: sizeof({mirror.__name__}) is {C.sizeof(mirror)} here, {want} in the library: "
+                                "cara_amd/_lib.py and include/cara_hip.h disagree (rebuild, or update the mirror)")
     return _lib
 
 

@@ -112,6 +112,47 @@ def _check_vit(model) -> None:
                 bad("norm1 / norm2 must be affine LayerNorms")
     if float(getattr(getattr(model, "pos_drop", None), "p", 0.0) or 0.0) != 0.0:
         bad("pos_drop must be 0")
+    # Features of newer timm releases the fused path does not compute (timm 0.4.12, the reference's pin, has none of
+    # them): a model that carries one would silently run a different function
+    def live(m):   # a sub-module that does something
+        return m is not None and not isinstance(m, nn.Identity)
+
+    def drop_p(m):
+        return float(getattr(m, "p", getattr(m, "prob", 0.0)) or 0.0)
+    for name in ("fc_norm", "norm_pre", "patch_drop", "attn_pool"):
+        m = getattr(model, name, None)
+        if live(m) and not (name == "patch_drop" and drop_p(m) == 0.0):
+            bad(f"{name} is not supported (timm 0.4.12's VisionTransformer has none)")
+    if getattr(model, "global_pool", "token") not in ("token", "", None):
+        bad(f"global_pool = {model.global_pool!r}: only the cls-token readout is supported")
+    if int(getattr(model, "num_prefix_tokens", 1)) != 1 or getattr(model, "no_embed_class", False) or \
+            getattr(model, "reg_token", None) is not None:
+        bad("exactly one prefix token (cls, with its own position embedding) is supported")
+    if getattr(model, "dynamic_img_size", False):
+        bad("dynamic_img_size is not supported")
+    k = pe.kernel_size[0]
+    img = getattr(model.patch_embed, "img_size", None)
+    if img is not None:
+        side = int(img[0] if isinstance(img, (tuple, list)) else img)
+        if model.pos_embed.shape[1] != (side // k) ** 2 + 1:
+            bad(f"pos_embed has {model.pos_embed.shape[1]} positions, the patch grid of a {side}-pixel image + cls needs "
+                f"{(side // k) ** 2 + 1}")
+    if model.pos_embed.shape[-1] != D or model.cls_token.shape[-1] != D:
+        bad("pos_embed / cls_token width must equal embed_dim")
+    for i, b in enumerate(blocks):
+        for name in ("ls1", "ls2"):
+            if live(getattr(b, name, None)):
+                bad(f"blocks[{i}].{name} (LayerScale) is not supported")
+        for name in ("q_norm", "k_norm"):
+            if live(getattr(b.attn, name, None)):
+                bad(f"blocks[{i}].attn.{name} (qk_norm) is not supported")
+        if live(getattr(b.mlp, "norm", None)):
+            bad(f"blocks[{i}].mlp.norm is not supported")
+        for name in ("drop1", "drop2"):
+            if drop_p(getattr(b.mlp, name, None)) != 0.0:
+                bad(f"blocks[{i}].mlp.{name} must be 0 (the reference's configuration)")
+        if getattr(b.attn, "fused_attn", False) and drop_p(getattr(b.attn, "attn_drop", None)) != 0.0:
+            bad("attn_drop must be 0")
 
 
 def _engine_forward(self, x):
@@ -127,85 +168,36 @@ def set_cara(model: nn.Module, rank: int, scale: float, l_mu: float, l_std: floa
     ``[L, 3, dim, heads, dim/heads]`` (A1 ``[L, R]``, A2 ``[3, R]``, A3 ``[dim, R]``, A4 ``[heads, R]``, A5
     ``[dim/heads, R]``; ``attn_idx`` then advances by 1 per block, ``:334``).  Same initialisers in the same order."""
     root = _root
-    if _is(model, _vit.VisionTransformer) and cp_length in (3, 5):
+    if _is(model, _vit.VisionTransformer):
         root = model
         dim, heads, depth = model.embed_dim, model.blocks[0].attn.num_heads, len(model.blocks)
-        if cp_length == 5:   # dim_experiment.py:266-276
-            model.CP_A1 = nn.Parameter(th.empty([depth, rank]), requires_grad=True)
-            model.CP_A2 = nn.Parameter(th.empty([3, rank]), requires_grad=True)
-            model.CP_A3 = nn.Parameter(th.empty([dim, rank]), requires_grad=True)
-            model.CP_A4 = nn.Parameter(th.empty([heads, rank]), requires_grad=True)
-            model.CP_A5 = nn.Parameter(th.empty([dim // heads, rank]), requires_grad=True)
-            nn.init.xavier_normal_(model.CP_A1)
-            nn.init.orthogonal_(model.CP_A2)
-            nn.init.zeros_(model.CP_A3)
-            nn.init.orthogonal_(model.CP_A4)
-            nn.init.orthogonal_(model.CP_A5)
-        else:                # dim_experiment.py:286-292
-            model.CP_A1 = nn.Parameter(th.empty([3 * depth, rank]), requires_grad=True)
-            model.CP_A2 = nn.Parameter(th.empty([dim, rank]), requires_grad=True)
-            model.CP_A3 = nn.Parameter(th.empty([dim, rank]), requires_grad=True)
-            nn.init.xavier_normal_(model.CP_A1)
-            nn.init.zeros_(model.CP_A2)
-            nn.init.orthogonal_(model.CP_A3)
-        model.CP_P1 = nn.Parameter(th.empty([9 * depth, rank]), requires_grad=True)
-        model.CP_P2 = nn.Parameter(th.empty([dim, rank]), requires_grad=True)
-        model.CP_P3 = nn.Parameter(th.empty([dim, rank]), requires_grad=True)
-        model.CP_R1 = nn.Parameter(th.empty([rank]), requires_grad=True)
-        model.CP_R2 = nn.Parameter(th.empty([rank]), requires_grad=True)
-        model.CP_bias1 = nn.Parameter(th.empty([dim]), requires_grad=True)
-        model.CP_bias2 = nn.Parameter(th.empty([dim * 4]), requires_grad=True)
-        model.CP_bias3 = nn.Parameter(th.empty([dim]), requires_grad=True)
-        nn.init.xavier_normal_(model.CP_P1)
-        nn.init.zeros_(model.CP_P2)
-        nn.init.orthogonal_(model.CP_P3)
-        if l_std != 0.0:
-            nn.init.normal_(model.CP_R1, mean=l_mu, std=l_std)
-            nn.init.normal_(model.CP_R2, mean=l_mu, std=l_std)
-        elif l_mu == 1.0 and l_std == 0.0:
-            nn.init.ones_(model.CP_R1)
-            nn.init.ones_(model.CP_R2)
-        nn.init.zeros_(model.CP_bias1)
-        nn.init.zeros_(model.CP_bias2)
-        nn.init.zeros_(model.CP_bias3)
+        # (name, rows, initialiser) in declaration order; the initialisers run in this order too, so the draws from the
+        # global RNG are the reference's (cp_length 4: A1, A3, A4, P1, P3, then R1, R2 -- cara.py:127-139)
+        xav, zero, orth = nn.init.xavier_normal_, nn.init.zeros_, nn.init.orthogonal_
+        qkv_factors = {
+            4: (("A1", 3 * depth, xav), ("A2", dim, zero), ("A3", heads, orth), ("A4", dim // heads, orth)),   # cara.py:112-117
+            3: (("A1", 3 * depth, xav), ("A2", dim, zero), ("A3", dim, orth)),                                 # dim_experiment.py:286-292
+            5: (("A1", depth, xav), ("A2", 3, orth), ("A3", dim, zero), ("A4", heads, orth),
+                ("A5", dim // heads, orth)),                                                                   # dim_experiment.py:266-276
+        }[cp_length]
+        for name, rows, init in qkv_factors + (("P1", 9 * depth, xav), ("P2", dim, zero), ("P3", dim, orth)):   # cara.py:118-120
+            p = nn.Parameter(th.empty([rows, rank]), requires_grad=True)
+            init(p)
+            setattr(model, "CP_" + name, p)
+        for name in ("R1", "R2"):
+            p = nn.Parameter(th.empty([rank]), requires_grad=True)
+            if l_std != 0.0:
+                nn.init.normal_(p, mean=l_mu, std=l_std)
+            elif l_mu == 1.0 and l_std == 0.0:
+                nn.init.ones_(p)
+            # (else: left as allocated, like the reference, cara.py:134-139)
+            setattr(model, "CP_" + name, p)
+        for name, n in (("bias1", dim), ("bias2", dim * 4), ("bias3", dim)):
+            setattr(model, "CP_" + name, nn.Parameter(th.zeros([n]), requires_grad=True))
         model.idx = 0
         model.attn_idx = 0
-        model.cp_l = cp_length
-    elif _is(model, _vit.VisionTransformer):
-        root = model
-        dim, heads, depth = model.embed_dim, model.blocks[0].attn.num_heads, len(model.blocks)
-        model.CP_A1 = nn.Parameter(th.empty([3 * depth, rank]), requires_grad=True)
-        model.CP_A2 = nn.Parameter(th.empty([dim, rank]), requires_grad=True)
-        model.CP_A3 = nn.Parameter(th.empty([heads, rank]), requires_grad=True)
-        model.CP_A4 = nn.Parameter(th.empty([dim // heads, rank]), requires_grad=True)
-        model.CP_P1 = nn.Parameter(th.empty([9 * depth, rank]), requires_grad=True)
-        model.CP_P2 = nn.Parameter(th.empty([dim, rank]), requires_grad=True)
-        model.CP_P3 = nn.Parameter(th.empty([dim, rank]), requires_grad=True)
-        model.CP_R1 = nn.Parameter(th.empty([rank]), requires_grad=True)
-        model.CP_R2 = nn.Parameter(th.empty([rank]), requires_grad=True)
-        model.CP_bias1 = nn.Parameter(th.empty([dim]), requires_grad=True)
-        model.CP_bias2 = nn.Parameter(th.empty([dim * 4]), requires_grad=True)
-        model.CP_bias3 = nn.Parameter(th.empty([dim]), requires_grad=True)
-        # same initialisers in the same order => same draws from the global RNG (A1, A3, A4, P1, P3, R1, R2)
-        nn.init.xavier_normal_(model.CP_A1)
-        nn.init.zeros_(model.CP_A2)
-        nn.init.orthogonal_(model.CP_A3)
-        nn.init.orthogonal_(model.CP_A4)
-        nn.init.xavier_normal_(model.CP_P1)
-        nn.init.zeros_(model.CP_P2)
-        nn.init.orthogonal_(model.CP_P3)
-        if l_std != 0.0:
-            nn.init.normal_(model.CP_R1, mean=l_mu, std=l_std)
-            nn.init.normal_(model.CP_R2, mean=l_mu, std=l_std)
-        elif l_mu == 1.0 and l_std == 0.0:
-            nn.init.ones_(model.CP_R1)
-            nn.init.ones_(model.CP_R2)
-        # (else: left as allocated, like the reference)
-        nn.init.zeros_(model.CP_bias1)
-        nn.init.zeros_(model.CP_bias2)
-        nn.init.zeros_(model.CP_bias3)
-        model.idx = 0
-        model.attn_idx = 0
+        if cp_length != 4:
+            model.cp_l = cp_length
     if root is None:
         return
     for child in model.children():

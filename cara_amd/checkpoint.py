@@ -5,8 +5,11 @@ The reference loads its backbone with ``create_model(args.model, checkpoint_path
 key mapping.  timm is not a dependency here, so the mapping is restated from its published source
 (query/key/value kernels [D,H,hd] -> one qkv matrix [3D,D]; out kernel [H,hd,D] -> [D,D]; Dense
 kernels transposed; conv kernel HWIO -> OIHW; position embedding resized bilinearly when the token
-grid differs).  No ``.npz`` is available offline, so this is checked by a round trip through the
-inverse mapping (``tests/test_checkpoint.py``), not against a real file.
+grid differs).  No ``.npz`` is available offline, so the mapping is checked (i) against a hand-built dict in the
+Flax layer layout with the forward evaluated from the Flax definitions (``tests/test_checkpoint.py::
+test_jax_key_mapping_against_the_flax_layer_definitions`` on the CPU, ``tests/test_model_gpu.py::
+test_flax_layout_npz_through_the_device_path`` through ``create_model(checkpoint_path=...)`` -> ``cara()`` -> the
+HIP forward) and (ii) by a round trip through the inverse mapping -- not against a real file.
 
 Host-side, one-time plumbing: the engine converts the loaded fp32 parameters to its bf16 HBM
 layout on the next forward (``CaraEngine._ingest``).

@@ -337,7 +337,7 @@ constexpr int PF_WAVES = 7;
 // builtin whenever it cannot prove that the DMA's destination and the read do not alias, which would drain the
 // next head's images in the middle of this head's P.V).  Every wait for these pieces is written by hand below.
 __device__ __forceinline__ void glds16_hidden(const char* base, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory", "m0");
 }
 
 __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_persist_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16* __r
 // ------------------------------------------------------------------------------------------
 // 4 bytes per lane (256 B per wave instruction) by hidden LDS-DMA: the forward's LSE row of a head (any 4-byte alignment)
 __device__ __forceinline__ void glds4_hidden(const char* base, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory", "m0");
 }
 
 __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,

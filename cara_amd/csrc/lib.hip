@@ -1,8 +1,23 @@
 // Library identification for libcara_hip.so.
 #include "common.h"
 
-extern "C" int cara_abi_version(void) { return 3; }
+extern "C" int cara_abi_version(void) { return 4; }
 extern "C" const char* cara_build_arch(void) { return "gfx950"; }
+
+extern "C" size_t cara_sizeof_struct(int which) {
+  switch (which) {
+    case CARA_STRUCT_GEMM_ARGS: return sizeof(cara_gemm_args);
+    case CARA_STRUCT_GEOM: return sizeof(cara_geom);
+    case CARA_STRUCT_CP: return sizeof(cara_cp);
+    case CARA_STRUCT_PACK_LAYOUT: return sizeof(cara_pack_layout);
+    case CARA_STRUCT_LAYER_GRADS: return sizeof(cara_layer_grads);
+    case CARA_STRUCT_VIT_WEIGHTS: return sizeof(cara_vit_weights);
+    case CARA_STRUCT_VIT_SHAPE: return sizeof(cara_vit_shape);
+    case CARA_STRUCT_TS_REDUCE: return sizeof(cara_ts_reduce);
+    default: return 0;
+  }
+}
+extern "C" size_t cara_sizeof_gemm_args(void) { return sizeof(cara_gemm_args); }
 
 // Diagnostic: one ds_read_b64_tr_b16 per lane over an LDS image sm[i] = i (16-bit), with the byte
 // address of every lane given by the caller.  Used by tests to pin the lane semantics of the

@@ -238,9 +238,19 @@ class CaraEngine:
         self._gen_dev = None
         self._gen_cpu = torch.Generator().manual_seed(self._gen_seed)
 
+    @staticmethod
+    def _norm_device(dev):
+        """torch.device with an explicit index ('cuda' / torch.device('cuda') -> the current device): what generators
+        and tensors report, so that comparisons against it hold."""
+        dev = torch.device(dev)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        return dev
+
     def _device_generator(self, dev):
         if self._gen_seed is None:
             return None
+        dev = self._norm_device(dev)
         if self._gen_dev is None or self._gen_dev.device != dev:
             self._gen_dev = torch.Generator(device=dev).manual_seed(self._gen_seed)
         return self._gen_dev
@@ -250,9 +260,16 @@ class CaraEngine:
         [depth, 2, B]; None in eval mode or when every rate is 0."""
         if not model.training:
             return None
-        rates = [float(getattr(b.drop_path, "drop_prob", 0.0) or 0.0) for b in model.blocks]
+        # timm 0.4.12: one `drop_path` per block; newer timm: `drop_path1` / `drop_path2` (same rate for both branches)
+        def rate(b):
+            r = [float(getattr(getattr(b, n, None), "drop_prob", 0.0) or 0.0) for n in ("drop_path", "drop_path1", "drop_path2")]
+            if r[1] != r[2]:
+                raise CaraError("drop_path1 and drop_path2 of a block must have the same rate")
+            return r[0] if hasattr(b, "drop_path") else r[1]
+        rates = [rate(b) for b in model.blocks]
         if not any(r > 0 for r in rates):
             return None
+        dev = self._norm_device(dev)
         # the keep probabilities stay on the device: a host -> device copy here would make the host wait for the
         # previous step's kernels at the top of every step (and leave the GPU idle until the queue refills)
         key = (tuple(rates), str(dev))
@@ -314,7 +331,11 @@ class CaraEngine:
         if labels.dtype != torch.int64 or labels.device != dev or labels.ndim != 1 or labels.shape[0] != images.shape[0]:
             raise CaraError("labels must be an int64 [batch] tensor on the images' device (the kernel reads 8-byte class indices)")
         cp = [getattr(model, "CP_" + n) for n in self.cp_fields]
+        if not hasattr(model.head, "weight"):
+            raise CaraError("the classifier head must be a Linear (num_classes > 0)")
         hw, hb = model.head.weight, model.head.bias
+        if hw.device != dev or any(t.device != dev for t in cp):
+            raise CaraError("model parameters and images must be on the same device")
         with torch.no_grad(), torch.cuda.device(dev):
             if droppath is None:
                 droppath = self.draw_droppath(model, images.shape[0], dev)

@@ -100,7 +100,7 @@ def evaluate_only(model, path: str, test_batches: Iterable) -> float:
 
 def fit(model, train_batches: Callable[[int], Iterable], test_batches: Optional[Callable[[], Iterable]] = None,
         epochs: int = 100, lr: float = 1e-3, weight_decay: float = 1e-4, group=None, reference_eval_quirk: bool = True,
-        on_eval: Optional[Callable[[int, float], None]] = None, save_best: Optional[dict] = None, seed: int = 0):
+        on_eval: Optional[Callable[[int, float], None]] = None, save_best: Optional[dict] = None, seed: Optional[int] = None):
     """``train_batches(epoch)`` yields (images, labels) already on the device (per-rank shard under
     data parallelism).  Returns (best accuracy, optimizer).
 
@@ -108,13 +108,21 @@ def fit(model, train_batches: Callable[[int], Iterable], test_batches: Optional[
     disk as the reference does (vit_cp.py:61-66: save on improvement, delete the previous file); the path of the
     file is left in ``save_best["path"]``.  Rank 0 only under data parallelism.
     Data parallel (``torch.distributed`` initialised, more than one rank in ``group``): the trainable parameters are
-    broadcast from rank 0 once, and every rank draws its own DropPath / weight-dropout masks (``seed``, rank)."""
+    broadcast from rank 0 once, and every rank draws its own DropPath / weight-dropout masks from private streams
+    seeded with (``seed``, rank); ``seed = None`` derives it from ``torch.initial_seed()`` (what the reference's
+    ``torch.manual_seed(args.seed)`` set, vit_cp.py:139-144), so runs with different global seeds stay uncorrelated.
+    Single process: the masks come from torch's global generators, exactly as in the reference, unless a ``seed`` is
+    passed explicitly."""
     from . import dist as cdist
     model.train()
     params = trainable_parameters(model)
     if cdist.world_size(group) > 1:
         cdist.broadcast_parameters(params, group=group)
-    model._cara_engine.seed_rank_streams(seed, cdist.get_rank(group))
+    if cdist.world_size(group) > 1 or seed is not None:
+        run_seed = int(seed) if seed is not None else int(torch.initial_seed() % (1 << 40))
+        model._cara_engine.seed_rank_streams(run_seed, cdist.get_rank(group))
+    if seed is None:
+        seed = int(torch.initial_seed() % (1 << 31))   # (only names the checkpoint file below, like args.seed in vit_cp.py:65)
     try:
         opt = torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, fused=True)
     except Exception:

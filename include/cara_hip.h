@@ -326,6 +326,19 @@ int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, const cara_vi
 int cara_head_backward(const float* dlogits, const void* xn_bf16, const float* head_w, float* dhead_w,
                        float* dhead_b, void* dxn_bf16, int B, int classes, int D, void* stream);
 
+/* ---- ABI self-description ------------------------------------------------------------------- */
+/* sizeof() of the structs above as THIS library was compiled, so that a binding can assert that its own mirror of a
+ * struct (ctypes.Structure, cgo, JNA ...) has the same size before it hands one over: a field missing at the end of
+ * the mirror would otherwise make the library read past it.  cara_sizeof_struct(CARA_STRUCT_*) returns 0 for an
+ * unknown id.                                                                                                   */
+enum {
+  CARA_STRUCT_GEMM_ARGS = 0, CARA_STRUCT_GEOM, CARA_STRUCT_CP, CARA_STRUCT_PACK_LAYOUT, CARA_STRUCT_LAYER_GRADS,
+  CARA_STRUCT_VIT_WEIGHTS, CARA_STRUCT_VIT_SHAPE, CARA_STRUCT_TS_REDUCE,
+  CARA_STRUCT_COUNT
+};
+size_t cara_sizeof_struct(int which);
+size_t cara_sizeof_gemm_args(void);      /* == cara_sizeof_struct(CARA_STRUCT_GEMM_ARGS) */
+
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 /* HIP-event brackets around the kernels of chosen call sites INSIDE cara_vit_forward / cara_vit_backward, recorded
  * on the compute stream, so that a benchmark can read per-kernel launch durations from within its timed region

@@ -149,7 +149,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.cara_abi_version() == 3 and lib.cara_build_arch() == b"gfx950"
+    assert lib.cara_abi_version() == 4 and lib.cara_build_arch() == b"gfx950"
 
 
 # ---- drop-in on a FOREIGN timm-shaped model (vit_cp.py:13-15,155 builds it with timm.models.create_model) --------
@@ -219,3 +219,98 @@ def test_weight_dropout_is_an_explicit_choice():
     assert mk()._cara_engine.weight_dropout == "off" and mk(weight_dropout="exact")._cara_engine.weight_dropout == "exact"
     with pytest.raises(CaraError):
         mk(weight_dropout="maybe")
+
+
+def _newer_timm_style(depth=2, **feature):
+    """A stand-in shaped like a newer timm VisionTransformer (1.x): blocks carry ls1 / ls2 and drop_path1 / drop_path2
+    instead of drop_path, Attention carries q_norm / k_norm, Mlp drop1 / drop2 / norm, the model fc_norm / norm_pre /
+    patch_drop / global_pool / num_prefix_tokens.  With every extra an Identity (or 0) it computes timm 0.4.12's
+    function and must be accepted; `feature` switches one of them on."""
+    from oracle import cara_oracle as O
+    nn = torch.nn
+    vit = O.create_vit("vit_base_patch16_224_in21k", drop_path_rate=0.1, depth=depth, num_classes=3)
+    vit.fc_norm, vit.norm_pre, vit.patch_drop = nn.Identity(), nn.Identity(), nn.Identity()
+    vit.global_pool, vit.num_prefix_tokens, vit.no_embed_class, vit.reg_token = "token", 1, False, None
+    for b in vit.blocks:
+        b.ls1, b.ls2 = nn.Identity(), nn.Identity()
+        b.drop_path1, b.drop_path2 = b.drop_path, b.drop_path
+        del b.drop_path
+        b.attn.q_norm, b.attn.k_norm = nn.Identity(), nn.Identity()
+        b.mlp.drop1, b.mlp.drop2, b.mlp.norm = nn.Dropout(0.0), nn.Dropout(0.0), nn.Identity()
+    blk = vit.blocks[0]
+    for k, v in feature.items():
+        if k in ("ls1", "ls2"):
+            setattr(blk, k, nn.Linear(768, 768))
+        elif k in ("q_norm", "k_norm"):
+            setattr(blk.attn, k, nn.LayerNorm(64))
+        elif k == "mlp_norm":
+            blk.mlp.norm = nn.LayerNorm(3072)
+        elif k in ("drop1", "drop2"):
+            setattr(blk.mlp, k, nn.Dropout(0.1))
+        elif k in ("fc_norm", "norm_pre"):
+            setattr(vit, k, nn.LayerNorm(768))
+        elif k == "patch_drop":
+            vit.patch_drop = nn.Dropout(0.25)
+        else:
+            setattr(vit, k, v)
+    return vit
+
+
+def test_newer_timm_shaped_vit_without_extras_is_accepted_and_draws_droppath():
+    from cara_amd import cara
+    vit = cara({"model": _newer_timm_style(), "rank": 8, "scale": 1.0, "l_mu": 1.0, "l_std": 0.0}).train()
+    dp = vit._cara_engine.draw_droppath(vit, 4, torch.device("cpu"))     # rates read from drop_path1 / drop_path2
+    assert dp.shape == (2, 2, 4)
+    assert torch.all(dp[0] == 1.0) and all(v == 0.0 or abs(v - 1.0 / 0.9) < 1e-6 for v in dp[1].flatten().tolist())
+
+
+@pytest.mark.parametrize("feature,word", [
+    ({"ls1": 1}, "LayerScale"), ({"q_norm": 1}, "qk_norm"), ({"mlp_norm": 1}, "mlp.norm"), ({"drop2": 1}, "drop2"),
+    ({"fc_norm": 1}, "fc_norm"), ({"norm_pre": 1}, "norm_pre"), ({"patch_drop": 1}, "patch_drop"),
+    ({"global_pool": "avg"}, "global_pool"), ({"num_prefix_tokens": 5}, "prefix"), ({"no_embed_class": True}, "prefix"),
+])
+def test_newer_timm_features_the_fused_path_does_not_compute_are_refused(feature, word):
+    """a newer timm ViT with qk_norm, LayerScale, fc_norm, avg pooling, register tokens ... passed the
+    structure check and would have silently computed timm 0.4.12's function instead."""
+    from cara_amd import cara
+    from cara_amd._lib import CaraError
+    with pytest.raises(CaraError, match=word):
+        cara({"model": _newer_timm_style(depth=1, **feature), "rank": 8, "scale": 1.0, "l_mu": 1.0, "l_std": 0.0})
+
+
+def test_pos_embed_must_match_the_patch_grid():
+    from oracle import cara_oracle as O
+    from cara_amd import cara
+    from cara_amd._lib import CaraError
+    vit = O.create_vit("vit_base_patch16_224_in21k", depth=1, num_classes=3)
+    vit.pos_embed = torch.nn.Parameter(torch.zeros(1, 50, 768))
+    vit.patch_embed.img_size = (224, 224)
+    with pytest.raises(CaraError, match="pos_embed"):
+        cara({"model": vit, "rank": 8, "scale": 1.0, "l_mu": 1.0, "l_std": 0.0})
+
+
+def test_device_generator_is_kept_across_equivalent_device_spellings():
+    """an unindexed torch.device('cuda') never compared equal to the generator's 'cuda:0', so the private
+    stream was rebuilt from its seed on every call and every step drew the SAME DropPath masks."""
+    from cara_amd.engine import CaraEngine
+    assert CaraEngine._norm_device("cpu") == torch.device("cpu")
+    assert CaraEngine._norm_device(torch.device("cuda", 0)) == torch.device("cuda", 0)
+    from cara_amd import cara, create_model
+    m = cara({"model": create_model("vit_base_patch16_224_in21k", depth=2, num_classes=3, drop_path_rate=0.5), "rank": 4,
+              "scale": 1.0, "l_mu": 1.0, "l_std": 0.0}).train()
+    m._cara_engine.seed_rank_streams(7, 0)
+    a = m._cara_engine.draw_droppath(m, 32, "cpu")           # a string, then a torch.device: one generator, advancing
+    b = m._cara_engine.draw_droppath(m, 32, torch.device("cpu"))
+    assert m._cara_engine._gen_dev is not None and not torch.equal(a, b)
+
+
+def test_fit_does_not_replace_the_global_rng_in_a_single_process(monkeypatch):
+    """fit() seeded private mask streams with a default seed of 0 in every run; single-process runs now keep
+    torch's global generators (what the reference's torch.manual_seed(args.seed) controls) unless a seed is passed."""
+    from cara_amd import cara, create_model, recipe
+    m = cara({"model": create_model("vit_base_patch16_224_in21k", depth=1, num_classes=3), "rank": 4, "scale": 1.0, "l_mu": 1.0,
+              "l_std": 0.0})
+    recipe.fit(m, lambda epoch: [], epochs=1)
+    assert m._cara_engine._gen_seed is None
+    recipe.fit(m, lambda epoch: [], epochs=1, seed=5)
+    assert m._cara_engine._gen_seed == 5 * (1 << 20)
