@@ -733,3 +733,151 @@ def test_bench_two_ranks_rehearsal(tmp_path):
         assert k in d, k
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
     assert d["value"] > 0 and "cpu_baseline" not in d          # the CPU baseline is a rank-0, N = 1 leg
+
+
+# ---- SURVEY 8f row 1 on the device: a Flax-layout .npz, evaluated from the Flax layer definitions -------------------------
+def _flax_dict(depth, grid, D=768, H=12, hd=64, P=16, classes=7, seed=0):
+    """A hand-built dict in the published ViT-B_16.npz layout (conv kernel HWIO, per-head query/key/value kernels
+    [D,H,hd] with biases [H,hd], out kernel [H,hd,D], Dense kernels [in,out]); magnitudes of a trained ViT."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda std, *s: (torch.randn(*s, generator=g, dtype=torch.float64) * std).numpy()  # noqa: E731
+    w = {"embedding/kernel": rn(0.02, P, P, 3, D), "embedding/bias": rn(0.02, D), "cls": rn(0.02, 1, 1, D),
+         "Transformer/posembed_input/pos_embedding": rn(0.02, 1, grid * grid + 1, D),
+         "Transformer/encoder_norm/scale": 1.0 + rn(0.1, D), "Transformer/encoder_norm/bias": rn(0.02, D),
+         "head/kernel": rn(0.02, D, classes), "head/bias": rn(0.02, classes)}
+    for l in range(depth):
+        pre = f"Transformer/encoderblock_{l}/"
+        mha = pre + "MultiHeadDotProductAttention_1/"
+        for ln in ("LayerNorm_0", "LayerNorm_2"):
+            w[pre + ln + "/scale"], w[pre + ln + "/bias"] = 1.0 + rn(0.1, D), rn(0.02, D)
+        w[pre + "MlpBlock_3/Dense_0/kernel"], w[pre + "MlpBlock_3/Dense_0/bias"] = rn(0.02, D, 4 * D), rn(0.02, 4 * D)
+        w[pre + "MlpBlock_3/Dense_1/kernel"], w[pre + "MlpBlock_3/Dense_1/bias"] = rn(0.02, 4 * D, D), rn(0.02, D)
+        w[mha + "out/kernel"], w[mha + "out/bias"] = rn(0.02, H, hd, D), rn(0.02, D)
+        for n in ("query", "key", "value"):
+            w[mha + n + "/kernel"], w[mha + n + "/bias"] = rn(0.02, D, H, hd), rn(0.02, H, hd)
+    return w
+
+
+def _flax_cara_forward(img, w, cp, s, depth, pos, H=12, hd=64, P=16):
+    """ViT + CaRA evaluated in fp64 straight from the Flax layer definitions (einsums over the .npz arrays as they are
+    stored) with the adapters of cara.py:26-42,50-58,72-82,87-93 added as written: independent of cara_amd.checkpoint,
+    of the oracle's timm restatement and of the factored form."""
+    T = lambda k: torch.from_numpy(np.asarray(w[k])).double()  # noqa: E731
+    cpd = {k: v.double() for k, v in cp.items()}
+    B, g = img.shape[0], img.shape[2] // P
+    D = H * hd
+
+    def ln(x, scale, bias):
+        mu, var = x.mean(-1, keepdim=True), x.var(-1, unbiased=False, keepdim=True)
+        return (x - mu) / torch.sqrt(var + 1e-6) * scale + bias
+    nhwc = img.double().permute(0, 2, 3, 1).reshape(B, g, P, g, P, 3)
+    x = (torch.einsum("bidjec,deco->bijo", nhwc, T("embedding/kernel")) + T("embedding/bias")).reshape(B, g * g, D)
+    x = torch.cat([T("cls").expand(B, 1, D), x], 1) + pos.double()
+    N = x.shape[1]
+    for l in range(depth):
+        pre = f"Transformer/encoderblock_{l}/"
+        mha = pre + "MultiHeadDotProductAttention_1/"
+        y = ln(x, T(pre + "LayerNorm_0/scale"), T(pre + "LayerNorm_0/bias"))
+        dW = torch.einsum("r,kr,er,hr,dr->kehd", cpd["CP_R1"], cpd["CP_A1"][3 * l:3 * l + 3], cpd["CP_A2"], cpd["CP_A3"], cpd["CP_A4"])
+        delta = torch.einsum("bne,kehd->kbhnd", y, dW)
+        q, k, v = (torch.einsum("bne,ehd->bhnd", y, T(mha + n + "/kernel")) + T(mha + n + "/bias")[None, :, None, :] + s * delta[i]
+                   for i, n in enumerate(("query", "key", "value")))
+        a = torch.softmax(q @ k.transpose(-1, -2) / hd ** 0.5, dim=-1) @ v
+        ao = a.permute(0, 2, 1, 3).reshape(B, N, D)
+        Tp = torch.einsum("r,jr,cr->jc", cpd["CP_R2"] * cpd["CP_P1"][9 * l], cpd["CP_P2"], cpd["CP_P3"])
+        x = x + torch.einsum("bhnd,hdo->bno", a, T(mha + "out/kernel")) + T(mha + "out/bias") + s * (ao @ Tp.T + cpd["CP_bias1"])
+        y = ln(x, T(pre + "LayerNorm_2/scale"), T(pre + "LayerNorm_2/bias"))
+        Tu = torch.einsum("r,ar,jr,cr->ajc", cpd["CP_R2"], cpd["CP_P1"][9 * l + 1:9 * l + 5], cpd["CP_P2"], cpd["CP_P3"]).reshape(4 * D, D)
+        up = y @ T(pre + "MlpBlock_3/Dense_0/kernel") + T(pre + "MlpBlock_3/Dense_0/bias") + s * (y @ Tu.T + cpd["CP_bias2"])
+        h = torch.nn.functional.gelu(up)
+        Td = torch.einsum("r,ar,jr,cr->ajc", cpd["CP_R2"], cpd["CP_P1"][9 * l + 5:9 * l + 9], cpd["CP_P2"], cpd["CP_P3"]).reshape(4 * D, D)
+        x = x + h @ T(pre + "MlpBlock_3/Dense_1/kernel") + T(pre + "MlpBlock_3/Dense_1/bias") + s * (h @ Td + cpd["CP_bias3"])
+    x = ln(x, T("Transformer/encoder_norm/scale"), T("Transformer/encoder_norm/bias"))
+    return x[:, 0] @ T("head/kernel") + T("head/bias")
+
+
+def _random_cp(depth, R, seed=5, D=768, H=12, hd=64):
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda std, *s: torch.randn(*s, generator=g) * std  # noqa: E731
+    return {"CP_A1": rn(0.3, 3 * depth, R), "CP_A2": rn(0.05, D, R), "CP_A3": rn(0.3, H, R), "CP_A4": rn(0.15, hd, R),
+            "CP_P1": rn(0.3, 9 * depth, R), "CP_P2": rn(0.05, D, R), "CP_P3": rn(0.05, D, R),
+            "CP_R1": 1.5 + rn(0.1, R), "CP_R2": 1.5 + rn(0.1, R),
+            "CP_bias1": rn(0.02, D), "CP_bias2": rn(0.02, 4 * D), "CP_bias3": rn(0.02, D)}
+
+
+def _bilinear_grid_resize(grid, new):
+    """Independent restatement of a bilinear resize with half-pixel centres (align_corners = False, no antialiasing):
+    numpy loops over the output grid.  grid [old, old, D] -> [new, new, D]."""
+    old = grid.shape[0]
+    out = np.zeros((new, new, grid.shape[2]), dtype=np.float64)
+    sc = old / new
+
+    def taps(i):
+        src = max((i + 0.5) * sc - 0.5, 0.0)
+        i0 = min(int(np.floor(src)), old - 1)
+        i1 = min(i0 + 1, old - 1)
+        return i0, i1, src - i0
+    for i in range(new):
+        a0, a1, fa = taps(i)
+        for j in range(new):
+            b0, b1, fb = taps(j)
+            out[i, j] = (1 - fa) * ((1 - fb) * grid[a0, b0] + fb * grid[a0, b1]) + fa * ((1 - fb) * grid[a1, b0] + fb * grid[a1, b1])
+    return out
+
+
+def test_flax_layout_npz_through_the_device_path(tmp_path):
+    """vit_cp.py:155 on the device, closed without the builder's own inverse mapping: a hand-built Flax-layout dict ->
+    .npz -> create_model(checkpoint_path=...) -> cara() -> the HIP forward; logits against the Flax layer definitions
+    evaluated directly (fp64 einsums over the arrays as stored) with the as-written adapters on top."""
+    from cara_amd import cara, create_model
+    depth, R, s = 2, 16, 0.1
+    w = _flax_dict(depth, grid=14)
+    npz = str(tmp_path / "ViT-B_16.npz")
+    np.savez(npz, **w)
+    torch.manual_seed(3)
+    m = create_model("vit_base_patch16_224_in21k", checkpoint_path=npz, depth=depth, num_classes=7)
+    m = cara({"model": m, "rank": R, "scale": s, "l_mu": 1.5, "l_std": 0.1})
+    cp = _random_cp(depth, R)
+    missing, unexpected = m.load_state_dict(cp, strict=False)
+    assert not unexpected and not any(k.startswith("CP_") for k in missing)
+    m = m.to(DEV).eval()
+    img = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        got = m(img.to(DEV))
+    want = _flax_cara_forward(img, w, cp, s, depth, torch.from_numpy(w["Transformer/posembed_input/pos_embedding"]))
+    base = _flax_cara_forward(img, w, {k: torch.zeros_like(v) for k, v in cp.items()}, s, depth,
+                              torch.from_numpy(w["Transformer/posembed_input/pos_embedding"]))
+    r = rel(got, want)
+    moved = rel(base, want)
+    print(f"\nflax-layout npz -> device: logits rel-L2 {r:.2e} vs the Flax definitions (the adapters move them by {moved:.2e})")
+    assert moved > 5 * r                  # the adapters are live and far above the noise
+    assert r <= T.LOGITS_ABS
+    assert torch.equal(got.argmax(1).cpu(), want.argmax(1))
+
+
+def test_flax_layout_npz_with_resized_position_embedding_at_384(tmp_path):
+    """The 384-pixel path of timm's loader: the .npz holds a 14 x 14 (+ cls) position embedding, the model a 24 x 24 grid;
+    checkpoint.resize_pos_embed against an INDEPENDENT bilinear restatement (numpy loops), then the whole thing through
+    the device (577 tokens: the long-sequence attention kernels) against the Flax definitions with that embedding."""
+    from cara_amd import cara, create_model
+    depth, R, s = 1, 8, 0.1
+    w = _flax_dict(depth, grid=14, seed=1)
+    npz = str(tmp_path / "ViT-B_16.npz")
+    np.savez(npz, **w)
+    m = create_model("vit_base_patch16_224_in21k", checkpoint_path=npz, depth=depth, num_classes=7, img_size=384)
+    pe = w["Transformer/posembed_input/pos_embedding"]
+    grid = _bilinear_grid_resize(pe[0, 1:].reshape(14, 14, 768), 24).reshape(1, 576, 768)
+    pos = torch.from_numpy(np.concatenate([pe[:, :1], grid], axis=1))
+    assert m.pos_embed.shape == (1, 577, 768)
+    assert torch.allclose(m.pos_embed.detach().double(), pos, atol=1e-6), (m.pos_embed.detach().double() - pos).abs().max()
+    m = cara({"model": m, "rank": R, "scale": s, "l_mu": 1.5, "l_std": 0.1})
+    cp = _random_cp(depth, R, seed=6)
+    m.load_state_dict(cp, strict=False)
+    m = m.to(DEV).eval()
+    img = torch.randn(2, 3, 384, 384, generator=torch.Generator().manual_seed(10))
+    with torch.no_grad():
+        got = m(img.to(DEV))
+    want = _flax_cara_forward(img, w, cp, s, depth, pos)
+    r = rel(got, want)
+    print(f"\nflax-layout npz @384 (resized position embedding) -> device: logits rel-L2 {r:.2e}")
+    assert r <= T.LOGITS_ABS and torch.equal(got.argmax(1).cpu(), want.argmax(1))

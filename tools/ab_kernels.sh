@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 i=0
 for envs in "$1" "$2"; do
   i=$((i+1))
-  ( export $envs; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abk_$i -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/abk_$i.log 2>&1 ) || exit 1
+  ( export $envs; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abk_$i -- python3 bench.py --no-cpu-baseline --no-info-legs --steps 10 --warmup 3 > gpurun_out/abk_$i.log 2>&1 ) || exit 1
   cp "$(find gpurun_out/abk_$i -name '*kernel_stats.csv' | head -1)" gpurun_out/abk_$i.csv
   rm -rf gpurun_out/abk_$i
 done

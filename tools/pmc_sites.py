@@ -48,6 +48,14 @@ for site, (key, pick) in SITES.items():
                      "hbm_bytes_per_launch_corrected": int(r + w)}
 meta = {"_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes over bench.py --steps 2 (tools/pmc_traffic.sh); "
                    "read = 2 x FETCH_SIZE (gfx950 reports half the bytes of wide coalesced reads)"}
+# which kernels this was measured on (bench.py compares it with the sources of the run that quotes the number)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    from bench import kernel_source_sha16
+    meta["_meta"] = {"kernel_source_sha16": kernel_source_sha16(), "profile": os.environ.get("CARA_PMC_TAG", "unnamed")}
+except Exception as e:   # noqa: BLE001
+    meta["_meta"] = {"kernel_source_sha16": None, "profile": f"hash unavailable: {e}"}
 meta.update(out)
 json.dump(meta, open(sys.argv[3], "w"), indent=1)
 for k, v in out.items():

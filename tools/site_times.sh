@@ -2,7 +2,7 @@
 var=$1; shift
 for v in "$@"; do
   echo "== $var=$v"
-  env $var=$v timeout -k 10 200 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --all-sites 2>/dev/null | python -c "
+  env $var=$v timeout -k 10 200 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-info-legs --all-sites 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.readline())
 print('ms/step',d['ms_per_step'])
