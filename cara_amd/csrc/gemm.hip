@@ -302,8 +302,11 @@ __global__ __launch_bounds__(256, (MI == 5 && (EPI == CARA_EPI_RESID || EPI == C
 // chip, 44 of them per backward pass) and overlaps only as well as two queues happen to interleave; as one launch
 // there is no event at all and the dispatcher mixes the two kinds of workgroup on every CU.  Needs Rp = 32 products
 // (84 VGPRs; the Rp = 64 form needs 136) and 36 KiB of LDS per workgroup (still four per CU).
-template <int EPI, bool COLSUM, int MI = 4>
-__global__ __launch_bounds__(256, 4) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
+// NT = Rp / 16 of the riding products: 2 (rank <= 32: four workgroups per CU) or 4 (rank <= 64: the products' 16 more
+// accumulator tiles take the kernel to 136 VGPRs, three workgroups per CU -- still far better than the products as a
+// launch of their own behind the GEMM, 55 us per pair at rank 64)
+template <int EPI, bool COLSUM, int MI = 4, int NT = 2>
+__global__ __launch_bounds__(256, NT == 2 ? 4 : 3) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
                                                            const TsProblem t0, const TsProblem t1, const int ldg, const int Mts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // the products' blocks sit BEHIND the GEMM tiles: they fill the slots the GEMM's last, partly filled round leaves
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256, 4) void gemm32_ts_kernel(const cara_gemm_args 
   const int b = blockIdx.x;
   if (b >= nwg) {
     STAMP(0);
-    tskinny_body<2, COLSUM, 1>(t0, t1, ldg, Mts, b - nwg, smem);
+    tskinny_body<NT, COLSUM, 1>(t0, t1, ldg, Mts, b - nwg, smem);
     STAMP(1);
     STAMP_END();
   } else {
@@ -326,11 +329,13 @@ __global__ __launch_bounds__(256, 4) void gemm32_ts_kernel(const cara_gemm_args 
 // the LDS image the K-extension step reads, and the tiles of column 0 write T / Tt out for the backward.  The
 // separate cara_skinny_xu pass (a full re-read of A, a launch, a dependency) is gone.
 // ---------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
+// NU = Rp / 32: 1 (rank <= 32) or 2 (rank <= 64: a 4-KiB slab of Ut per K step, eight T tiles per wave, two extension steps; 140
+// VGPRs, three workgroups per CU -- the kernel serves the N = 768 products, whose 594 tiles never put more than three on a CU)
+template <int EPI, int NU = 1>
+__global__ __launch_bounds__(256, NU == 1 ? 4 : 3) void gemm32ft_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
   constexpr int TBM = 128;
-  constexpr int A_BYTES = TBM * BK32 * 2, U_BYTES = 32 * BK32 * 2;
-  constexpr int SLOT = A_BYTES + B32_BYTES + U_BYTES;   // 18 KiB; two slots = 36 KiB, still 4 workgroups per CU
+  constexpr int A_BYTES = TBM * BK32 * 2, U_BYTES = NU * 32 * BK32 * 2;
+  constexpr int SLOT = A_BYTES + B32_BYTES + U_BYTES;   // 18 KiB; two slots = 36 KiB, still 4 workgroups per CU (NU = 2: 20 / 40 KiB)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -355,19 +360,20 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
   const bf16* __restrict__ B = static_cast<const bf16*>(packed ? p.Bp : p.B);
   const int kmulB = packed ? p.N * BK32 : BK32;
   const bf16* __restrict__ Ut = static_cast<const bf16*>(p.Ut);
-  f32x4 acc[4][4], accg[4];
+  f32x4 acc[4][4], accg[4][NU];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    accg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NU; ++c) accg[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  // the 32 x 32 slab of Ut of one K step = two 1-KiB pieces (16 rows x 64 B), issued by waves 0 and 1
+  // the Rp x 32 slab of Ut of one K step = 2 NU one-KiB pieces (16 rows x 64 B), issued by waves 0 .. 2 NU - 1
   const int uwave = __builtin_amdgcn_readfirstlane(wave);
-  const unsigned offU = (unsigned)((wave & 1) * 16 + (lane >> 2)) * (unsigned)(p.K * 2) +
+  const unsigned offU = (unsigned)((wave & (2 * NU - 1)) * 16 + (lane >> 2)) * (unsigned)(p.K * 2) +
                         (unsigned)((((lane & 3) ^ ((((lane >> 2) >> 3) & 1) * 3))) * 16);
   auto stage_u = [&](int k0, char* dst) {
-    if (uwave < 2) glds16(reinterpret_cast<const char*>(Ut + k0) + offU, dst + uwave * 1024);
+    if (uwave < 2 * NU) glds16(reinterpret_cast<const char*>(Ut + k0) + offU, dst + uwave * 1024);
   };
   const int nk = p.K / BK32;
   const TileOfs<TBM, 4> oA = tile_ofs<TBM, 4>(p.a_panels ? BK32 : p.lda, m0, p.M - 1, wave, lane);
@@ -389,51 +395,65 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
     } else {
       // last K step: the extension's B operand (Vs rows of this column tile, 64-byte rows) goes to the free slot by LDS-DMA
       // under this step's MFMAs (it used to be plain loads behind the loop: an exposed memory latency per tile)
-      const TileOfs<BN, 4> eB = tile_ofs<BN, 4>(32, n0, p.N - 1, wave, lane);
+      const TileOfs<BN, 4> eB = tile_ofs<BN, 4>(32 * NU, n0, p.N - 1, wave, lane);
       stage_tile32_pre<BN, 4>(static_cast<const bf16*>(p.B2), 0, eB, nA + A_BYTES, uwave);
     }
     const char* sB = sA + A_BYTES;
     const char* sU = sB + B32_BYTES;
-    bf16x8 a[4], b[4];
+    bf16x8 a[4], b[4], bu[NU];
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sA + swz32(wr * 64 + i * 16 + fr, fq));
 #pragma unroll
     for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sB + swz32(wc * 64 + j * 16 + fr, fq));
-    const bf16x8 bu = *reinterpret_cast<const bf16x8*>(sU + swz32(wc * 16 + fr, fq));   // this wave's 16 columns of T
+#pragma unroll
+    for (int c = 0; c < NU; ++c) bu[c] = *reinterpret_cast<const bf16x8*>(sU + swz32((wc * NU + c) * 16 + fr, fq));   // this wave's 16 NU columns of T
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-      accg[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bu, accg[i], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < NU; ++c) accg[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bu[c], accg[i][c], 0, 0, 0);
     }
     cur ^= 1;
   }
-  // T tile (rows wr*64 .., columns wc*16 ..) -> bf16 -> the A image of the extension step (in the slot the loop left free,
-  // next to the Vs rows already on their way there); column-0 tiles also write it (and its transpose) to global for the
+  // T tile (rows wr*64 .., columns wc*16 NU ..) -> bf16 -> the A image(s) of the extension step(s): image 0 in the slot the
+  // loop left free, next to the Vs rows already on their way there; NU = 2: image 1 (T columns 32..63, all of them wave
+  // column 1's) in the other slot, whose last K step every wave has read past the barrier below, next to the second
+  // 32 columns of the Vs rows, requested here.  Column-0 tiles also write T (and its transpose) to global for the
   // backward's transposed skinny products
   __syncthreads();
   char* sE = smem + cur * SLOT;
+  char* sO = smem + (cur ^ 1) * SLOT;
+  if constexpr (NU == 2) {
+    const TileOfs<BN, 4> eB = tile_ofs<BN, 4>(32 * NU, n0, p.N - 1, wave, lane);
+    stage_tile32_pre<BN, 4>(static_cast<const bf16*>(p.B2), 32, eB, sO + A_BYTES, uwave);
+  }
   {
     bf16* T = static_cast<bf16*>(p.T_out);
     bf16* Tt = static_cast<bf16*>(p.Tt_out);
-    const int col = wc * 16 + fr;
+    char* img = (NU == 2 && wc == 1) ? sO : sE;   // the image that holds this wave's T columns
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row0 = wr * 64 + i * 16 + fq * 4;
-      bf16x4 tv = {(bf16)accg[i][0], (bf16)accg[i][1], (bf16)accg[i][2], (bf16)accg[i][3]};
+    for (int c = 0; c < NU; ++c) {
+      const int icol = (NU == 2 ? c : wc) * 16 + fr;      // column inside its 32-column image
+      const int col = NU == 2 ? wc * 32 + icol : icol;     // column of T
 #pragma unroll
-      for (int r = 0; r < 4; ++r) *reinterpret_cast<bf16*>(sE + swz32(row0 + r, col >> 3) + (col & 7) * 2) = tv[r];
-      if (tn == 0) {
+      for (int i = 0; i < 4; ++i) {
+        const int row0 = wr * 64 + i * 16 + fq * 4;
+        bf16x4 tv = {(bf16)accg[i][c][0], (bf16)accg[i][c][1], (bf16)accg[i][c][2], (bf16)accg[i][c][3]};
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (m0 + row0 + r < p.M) T[(size_t)(m0 + row0 + r) * 32 + col] = tv[r];
-        if (Tt) {
-          if (m0 + row0 + 4 <= p.M) {
-            *reinterpret_cast<bf16x4*>(Tt + (size_t)col * p.ldt + m0 + row0) = tv;
-          } else {
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<bf16*>(img + swz32(row0 + r, icol >> 3) + (icol & 7) * 2) = tv[r];
+        if (tn == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (m0 + row0 + r < p.M) Tt[(size_t)col * p.ldt + m0 + row0 + r] = tv[r];
+          for (int r = 0; r < 4; ++r)
+            if (m0 + row0 + r < p.M) T[(size_t)(m0 + row0 + r) * (32 * NU) + col] = tv[r];
+          if (Tt) {
+            if (m0 + row0 + 4 <= p.M) {
+              *reinterpret_cast<bf16x4*>(Tt + (size_t)col * p.ldt + m0 + row0) = tv;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (m0 + row0 + r < p.M) Tt[(size_t)col * p.ldt + m0 + row0 + r] = tv[r];
+            }
           }
         }
       }
@@ -442,6 +462,7 @@ __global__ __launch_bounds__(256, 4) void gemm32ft_kernel(const cara_gemm_args p
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Vs rows have landed
   __syncthreads();
   mma_tile32<4>(sE, sE + A_BYTES, acc, wr, wc, lane);
+  if constexpr (NU == 2) mma_tile32<4>(sO, sO + A_BYTES, acc, wr, wc, lane);
   // epilogue: two 32-row halves through a wave-private [32][64] fp32 image
   constexpr int HALF = 32;
   __syncthreads();
@@ -479,9 +500,13 @@ int launch32ft(const cara_gemm_args* a, hipStream_t st) {
   // consumers read Tt in whole 32-row steps: keep columns [M, roundup32(M)) zero, as cara_skinny_xu does
   const int m32 = (a->M + 31) / 32 * 32;
   if (a->Tt_out && m32 > a->M && m32 <= a->ldt &&
-      hipMemset2DAsync(static_cast<bf16*>(a->Tt_out) + a->M, (size_t)a->ldt * 2, 0, (size_t)(m32 - a->M) * 2, 32, st) != hipSuccess)
+      hipMemset2DAsync(static_cast<bf16*>(a->Tt_out) + a->M, (size_t)a->ldt * 2, 0, (size_t)(m32 - a->M) * 2, a->Rp, st) != hipSuccess)
     return CARA_E_LAUNCH;
-  hipLaunchKernelGGL((gemm32ft_kernel<EPI>), dim3(nwg), dim3(256), 2 * (128 * BK32 * 2 + B32_BYTES + 32 * BK32 * 2), st, *a, tiles_n, nwg, gm);
+  if (a->Rp == 64) {
+    hipLaunchKernelGGL((gemm32ft_kernel<EPI, 2>), dim3(nwg), dim3(256), 2 * (128 * BK32 * 2 + B32_BYTES + 64 * BK32 * 2), st, *a, tiles_n, nwg, gm);
+  } else {
+    hipLaunchKernelGGL((gemm32ft_kernel<EPI>), dim3(nwg), dim3(256), 2 * (128 * BK32 * 2 + B32_BYTES + 32 * BK32 * 2), st, *a, tiles_n, nwg, gm);
+  }
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }
@@ -499,7 +524,27 @@ struct TsPair {
   TsProblem a, b;
   int ldg, M;
   bool any_cs;
+  int nt;   // Rp / 16 of the products: 2 or 4
 };
+
+// one launch of the GEMM-with-riders kernel: COLSUM and NT (the products' Rp / 16) picked at run time
+template <int EPI, int MI>
+void launch_ts(const cara_gemm_args* a, hipStream_t st, const TsPair* ts, int tiles_n, int nwg, int gm, int gemm_lds) {
+  const int nts = ts->a.nblk + ts->b.nblk;
+  const dim3 grid(nwg + nts), block(256);
+#define TS_GO(CS, NT)                                                                                                       \
+  do {                                                                                                                      \
+    constexpr int RB = TsRing<NT, 1>::BLOCK_BYTES;                                                                          \
+    const int lds = RB > gemm_lds ? RB : gemm_lds;                                                                          \
+    hipLaunchKernelGGL((gemm32_ts_kernel<EPI, CS, MI, NT>), grid, block, lds, st, *a, tiles_n, nwg, gm, ts->a, ts->b, ts->ldg, ts->M); \
+  } while (0)
+  if (ts->nt == 4) {
+    if (ts->any_cs) TS_GO(true, 4); else TS_GO(false, 4);
+  } else {
+    if (ts->any_cs) TS_GO(true, 2); else TS_GO(false, 2);
+  }
+#undef TS_GO
+}
 
 template <int EPI>
 int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr) {
@@ -516,12 +561,7 @@ int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr
     constexpr int LDS160 = 2 * (160 * BK32 * 2 + B32_BYTES);
     const int nwg5 = ((a->M + 159) / 160) * tiles_n;
     if (ts) {
-      const int nts = ts->a.nblk + ts->b.nblk;
-      constexpr int LDS = TsRing<2, 1>::BLOCK_BYTES > LDS160 ? TsRing<2, 1>::BLOCK_BYTES : LDS160;
-      if (ts->any_cs)
-        hipLaunchKernelGGL((gemm32_ts_kernel<EPI, true, 5>), dim3(nwg5 + nts), dim3(256), LDS, st, *a, tiles_n, nwg5, gm, ts->a, ts->b, ts->ldg, ts->M);
-      else
-        hipLaunchKernelGGL((gemm32_ts_kernel<EPI, false, 5>), dim3(nwg5 + nts), dim3(256), LDS, st, *a, tiles_n, nwg5, gm, ts->a, ts->b, ts->ldg, ts->M);
+      launch_ts<EPI, 5>(a, st, ts, tiles_n, nwg5, gm, LDS160);
     } else {
       hipLaunchKernelGGL((gemm32_kernel<EPI, false, 5>), dim3(nwg5), dim3(256), LDS160, st, *a, tiles_n, nwg5, gm);
     }
@@ -529,12 +569,7 @@ int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr
     return CARA_OK;
   }
   if (ts) {
-    const int nts = ts->a.nblk + ts->b.nblk;
-    constexpr int LDS = TsRing<2, 1>::BLOCK_BYTES > GEMM_LDS ? TsRing<2, 1>::BLOCK_BYTES : GEMM_LDS;
-    if (ts->any_cs)
-      hipLaunchKernelGGL((gemm32_ts_kernel<EPI, true>), dim3(nwg + nts), dim3(256), LDS, st, *a, tiles_n, nwg, gm, ts->a, ts->b, ts->ldg, ts->M);
-    else
-      hipLaunchKernelGGL((gemm32_ts_kernel<EPI, false>), dim3(nwg + nts), dim3(256), LDS, st, *a, tiles_n, nwg, gm, ts->a, ts->b, ts->ldg, ts->M);
+    launch_ts<EPI, 4>(a, st, ts, tiles_n, nwg, gm, GEMM_LDS);
     CARA_CHECK_LAUNCH();
     return CARA_OK;
   }
@@ -661,11 +696,11 @@ extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) { return ge
 extern "C" int cara_gemm_with_tskinny(const cara_gemm_args* a, const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
                                       const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b, int ldg,
                                       int M, int Rp, void* stream) {
-  if (Rp != 32 || !ts_args_ok(Xa, ldxa, Gta, ldg, slabs_a, M, K1a, Rp) || !ts_args_ok(Xb, ldxb, Gtb, ldg, slabs_b, M, K1b, Rp)) return CARA_E_ARG;
+  if (!(Rp == 32 || Rp == 64) || !ts_args_ok(Xa, ldxa, Gta, ldg, slabs_a, M, K1a, Rp) || !ts_args_ok(Xb, ldxb, Gtb, ldg, slabs_b, M, K1b, Rp)) return CARA_E_ARG;
   TsPair ts;
   ts.a = ts_problem(Xa, ldxa, Gta, slabs_a, 0, M, K1a, Rp);
   ts.b = ts_problem(Xb, ldxb, Gtb, slabs_b, want_colsum_b, M, K1b, Rp);
-  ts.ldg = ldg; ts.M = M; ts.any_cs = want_colsum_b != 0;
+  ts.ldg = ldg; ts.M = M; ts.any_cs = want_colsum_b != 0; ts.nt = Rp / 16;
   return gemm_bf16_impl(a, stream, &ts);
 }
 
@@ -692,7 +727,7 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
   if (ts && (a->Ut || a->batch > 1 || a->M <= 128 || a->B3)) return CARA_E_ARG;
   if (a->B3 && (a->Bp || a->Ut || a->batch > 1 || a->a_panels)) return CARA_E_ARG;
   if (a->Ut) {   // whole adapter inside the GEMM: Rp = 32, T produced here
-    if (a->A2 || !a->B2 || a->Rp != 32 || !a->T_out || a->batch > 1 || (a->Tt_out && (a->ldt < a->M || (a->ldt & 7)))) return CARA_E_ARG;
+    if (a->A2 || !a->B2 || !(a->Rp == 32 || a->Rp == 64) || !a->T_out || a->batch > 1 || (a->Tt_out && (a->ldt < a->M || (a->ldt & 7)))) return CARA_E_ARG;
     switch (a->epi) {
       case CARA_EPI_BF16: return launch32ft<CARA_EPI_BF16>(a, st);
       case CARA_EPI_F32: return launch32ft<CARA_EPI_F32>(a, st);

@@ -18,18 +18,19 @@ namespace {
 // replaces) or held in LDS (as slow as LayerNorm + cara_skinny_xu: ~250 VALU instructions per row).
 constexpr int XU_WAVES = 8;         // waves per block of the fused kernels
 constexpr int XU_ROWS = 16 / XU_WAVES;   // rows per wave: 16 per block (one MFMA row tile)
-template <int V4>
+// NT = Rp / 16 column tiles of the contraction: 2 (rank <= 32) or 4 (rank <= 64)
+template <int V4, int NT = 2>
 struct XuLds {
   static constexpr int LDY = V4 * 256 + 8;   // bf16 elements per staged row
   bf16 y[16 * LDY];
-  float part[XU_WAVES][2][64 * 4];
+  float part[XU_WAVES][NT][64 * 4];
 };
 // the block's 16 staged bf16 rows -> K-panel-major global image [C/32][yp][32]: a wave writes one panel's 16 rows
 // (16 x 64 B = one contiguous KiB of full cache lines) per instruction, instead of each row's 8-byte pieces
 // scattered over C/32 panels.  Call after the rows are complete (a __syncthreads() away from the staging).
-template <int V4>
-__device__ __forceinline__ void panel_store(const XuLds<V4>& L, bf16* __restrict__ y, const int yp, const int row_base, const int M) {
-  constexpr int C = V4 * 256, LDY = XuLds<V4>::LDY;
+template <int V4, int NT>
+__device__ __forceinline__ void panel_store(const XuLds<V4, NT>& L, bf16* __restrict__ y, const int yp, const int row_base, const int M) {
+  constexpr int C = V4 * 256, LDY = XuLds<V4, NT>::LDY;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane >> 2, chunk = lane & 3;
   if (row_base + row >= M) return;
@@ -40,43 +41,45 @@ __device__ __forceinline__ void panel_store(const XuLds<V4>& L, bf16* __restrict
 }
 // a wave's B fragments of the contraction (its K steps wave, wave + 8, ...: C/256 of them, two column tiles each):
 // requested at the top of the kernel so that their L2 latency passes under the row loads and reductions
-template <int V4>
+template <int V4, int NT = 2>
 struct UtFrags {
-  bf16x8 u[V4][2];
+  bf16x8 u[V4][NT];
 };
-template <int V4>
-__device__ __forceinline__ UtFrags<V4> load_ut_frags(const bf16* __restrict__ Ut) {
+template <int V4, int NT>
+__device__ __forceinline__ UtFrags<V4, NT> load_ut_frags(const bf16* __restrict__ Ut) {
   constexpr int C = V4 * 256;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  UtFrags<V4> f;
+  UtFrags<V4, NT> f;
 #pragma unroll
   for (int k = 0; k < V4; ++k)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
       f.u[k][nt] = *reinterpret_cast<const bf16x8*>(Ut + (size_t)(nt * 16 + fr) * C + (wave + k * XU_WAVES) * 32 + fq * 8);
   return f;
 }
-template <int V4>
-__device__ __forceinline__ void block_contract(XuLds<V4>& L, const UtFrags<V4>& uf, bf16* __restrict__ T,
+template <int V4, int NT>
+__device__ __forceinline__ void block_contract(XuLds<V4, NT>& L, const UtFrags<V4, NT>& uf, bf16* __restrict__ T,
                                                bf16* __restrict__ Tt, const int ldt, const int row_base, const int M) {
-  constexpr int LDY = XuLds<V4>::LDY;
+  constexpr int LDY = XuLds<V4, NT>::LDY;
   static_assert(XU_WAVES == 8, "K steps per wave = C / 32 / 8 = V4");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   __syncthreads();   // the 16 staged rows are complete
-  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < V4; ++k) {
     const int s = wave + k * XU_WAVES;
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(L.y + fr * LDY + s * 32 + fq * 8);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, uf.u[k][nt], acc[nt], 0, 0, 0);
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, uf.u[k][nt], acc[nt], 0, 0, 0);
   }
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<f32x4*>(&L.part[wave][nt][lane * 4]) = acc[nt];
+  for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(&L.part[wave][nt][lane * 4]) = acc[nt];
   __syncthreads();
-  if (wave < 2) {   // wave nt sums column tile nt: lane (fr, fq) holds rows fq*4 .. +3 of column nt*16 + fr
+  if (wave < NT) {   // wave nt sums column tile nt: lane (fr, fq) holds rows fq*4 .. +3 of column nt*16 + fr
     const int nt = wave;
     f32x4 t = *reinterpret_cast<const f32x4*>(&L.part[0][nt][lane * 4]);
 #pragma unroll
@@ -85,7 +88,7 @@ __device__ __forceinline__ void block_contract(XuLds<V4>& L, const UtFrags<V4>& 
     const bf16x4 o = {(bf16)t[0], (bf16)t[1], (bf16)t[2], (bf16)t[3]};
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (m0 + r < M) T[(size_t)(m0 + r) * 32 + col] = o[r];
+      if (m0 + r < M) T[(size_t)(m0 + r) * (NT * 16) + col] = o[r];
     if (Tt) {
       if (m0 + 4 <= M) {
         *reinterpret_cast<bf16x4*>(Tt + (size_t)col * ldt + m0) = o;
@@ -98,7 +101,7 @@ __device__ __forceinline__ void block_contract(XuLds<V4>& L, const UtFrags<V4>& 
   }
 }
 
-template <int V4, bool XU>  // V4 = C / 256 : float4 per lane; XU: fused contraction, XU_ROWS rows per wave
+template <int V4, bool XU, int NT = 2>  // V4 = C / 256 : float4 per lane; XU: fused contraction, XU_ROWS rows per wave
 __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_fwd_kernel(const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta,
@@ -110,9 +113,11 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_fwd_kernel(const 
   constexpr int RPW = XU ? XU_ROWS : 1;
   const int lane = threadIdx.x & 63;
   const int row0 = (blockIdx.x * (XU ? XU_WAVES : 4) + (threadIdx.x >> 6)) * RPW;
-  __shared__ __attribute__((aligned(16))) XuLds<XU ? V4 : 0> L;
-  UtFrags<XU ? V4 : 1> uf;
-  if constexpr (XU) uf = load_ut_frags<V4>(Ut);
+  __shared__ __attribute__((aligned(16))) XuLds<XU ? V4 : 0, XU ? NT : 1> L;
+  // (NT = 4: twice the fragments; they are requested behind the row loop, as in the backward kernel, so that the kernel
+  // keeps its occupancy)
+  UtFrags<XU ? V4 : 1, XU ? NT : 1> uf;
+  if constexpr (XU && NT == 2) uf = load_ut_frags<V4, NT>(Ut);
   // all of a wave's rows are requested before anything is reduced: a wave keeps RPW x V4 16-byte loads in flight
   // instead of V4 (the kernel is latency-bound: one row at a time reached 3.4 TB/s)
   float4 v[RPW][V4];
@@ -165,20 +170,21 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_fwd_kernel(const 
   if constexpr (XU) {
 #pragma unroll
     for (int i = 0; i < V4; ++i)
-      *reinterpret_cast<bf16x4*>(L.y + (row - blockIdx.x * 16) * XuLds<V4>::LDY + i * 256 + lane * 4) = yb[i];
+      *reinterpret_cast<bf16x4*>(L.y + (row - blockIdx.x * 16) * XuLds<V4, NT>::LDY + i * 256 + lane * 4) = yb[i];
   }
   }
   if constexpr (XU) {
     if (yp) {
       __syncthreads();
-      panel_store<V4>(L, y, yp, blockIdx.x * 16, M);
+      panel_store<V4, NT>(L, y, yp, blockIdx.x * 16, M);
     }
-    block_contract<V4>(L, uf, T, Tt, ldt, blockIdx.x * 16, M);   // T = LN(x) U of the next linear
+    if constexpr (NT != 2) uf = load_ut_frags<V4, NT>(Ut);
+    block_contract<V4, NT>(L, uf, T, Tt, ldt, blockIdx.x * 16, M);   // T = LN(x) U of the next linear
   }
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mu) * rstd
-template <int V4, bool XU>
+template <int V4, bool XU, int NT = 2>
 __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x,
                                                      long ldx, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean,
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_bwd_kernel(const 
   constexpr int RPW = XU ? XU_ROWS : 1;
   const int lane = threadIdx.x & 63;
   const int row0 = (blockIdx.x * (XU ? XU_WAVES : 4) + (threadIdx.x >> 6)) * RPW;
-  __shared__ __attribute__((aligned(16))) XuLds<XU ? V4 : 0> L;
+  __shared__ __attribute__((aligned(16))) XuLds<XU ? V4 : 0, XU ? NT : 1> L;
   // Every load of the wave's rows -- x, dy AND the running gradient dx_in, which the second half of a row's work reads -- is
   // requested before anything is reduced: one memory latency per wave instead of two per row (the kernel is one round of
   // waves, all in the same phase: nothing else hides a dependent load)
@@ -263,17 +269,17 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_bwd_kernel(const 
   if constexpr (XU) {
 #pragma unroll
     for (int i = 0; i < V4; ++i)
-      *reinterpret_cast<bf16x4*>(L.y + (row - blockIdx.x * 16) * XuLds<V4>::LDY + i * 256 + lane * 4) = yb[i];
+      *reinterpret_cast<bf16x4*>(L.y + (row - blockIdx.x * 16) * XuLds<V4, NT>::LDY + i * 256 + lane * 4) = yb[i];
   }
   }
   if constexpr (XU) {
     if (yp) {
       __syncthreads();
-      panel_store<V4>(L, dyb, yp, blockIdx.x * 16, M);
+      panel_store<V4, NT>(L, dyb, yp, blockIdx.x * 16, M);
     }
     // (the B fragments are requested here, not at the top: holding them through the row loop costs the backward kernel a
     // workgroup of occupancy -- 138 VGPRs, 36 us instead of 31)
-    block_contract<V4>(L, load_ut_frags<V4>(Vst), G, Gt, ldt, blockIdx.x * 16, M);   // G' = dY Vs of the linear below
+    block_contract<V4, NT>(L, load_ut_frags<V4, NT>(Vst), G, Gt, ldt, blockIdx.x * 16, M);   // G' = dY Vs of the linear below
   }
 }
 
@@ -415,8 +421,8 @@ struct XuArgs {   // optional fused skinny product (all NULL / 0 = plain LayerNo
 };
 bool xu_ok(const XuArgs& a, int M, int C) {
   if (!a.Ut) return true;
-  // two 16-column MFMA tiles = Rp 32 (rows of Ut beyond the rank are zero, so the pad columns come out zero)
-  return a.T && a.Rp == 32 && a.rank > 0 && a.rank <= 32 && (!a.Tt || (a.ldt >= M && !(a.ldt & 7))) &&
+  // Rp / 16 column tiles of 16 (rows of Ut beyond the rank are zero, so the pad columns come out zero)
+  return a.T && (a.Rp == 32 || a.Rp == 64) && a.rank > 0 && a.rank <= a.Rp && (!a.Tt || (a.ldt >= M && !(a.ldt & 7))) &&
          (C == 768 || C == 256 || C == 1024);
 }
 // consumers (cara_tskinny_*) read Tt in whole 32-row steps: keep columns [M, roundup32(M)) zero (as cara_skinny_xu does)
@@ -438,7 +444,13 @@ int ln_fwd_launch(const float* x, long ldx, const float* gamma, const float* bet
   const dim3 grid((M + rows_per_block - 1) / rows_per_block), block(a.Ut ? XU_WAVES * 64 : 256);
 #define LNF(V, X) hipLaunchKernelGGL((ln_fwd_kernel<V, X>), grid, block, 0, st, x, ldx, gamma, beta, (bf16*)y, mean, rstd, M, eps, \
                                      a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp)
-  if (a.Ut) {
+#define LNF4(V) hipLaunchKernelGGL((ln_fwd_kernel<V, true, 4>), grid, block, 0, st, x, ldx, gamma, beta, (bf16*)y, mean, rstd, M, eps, \
+                                   a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp)
+  if (a.Ut && a.Rp == 64) {
+    if (C == 768) LNF4(3);
+    else if (C == 1024) LNF4(4);
+    else LNF4(1);
+  } else if (a.Ut) {
     if (C == 768) LNF(3, true);
     else if (C == 1024) LNF(4, true);
     else LNF(1, true);
@@ -447,6 +459,7 @@ int ln_fwd_launch(const float* x, long ldx, const float* gamma, const float* bet
   else if (C == 256) LNF(1, false);
   else return CARA_E_ARG;
 #undef LNF
+#undef LNF4
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }
@@ -463,7 +476,13 @@ int ln_bwd_launch(const void* dy, const float* x, long ldx, const float* gamma, 
   const dim3 grid((M + rows_per_block - 1) / rows_per_block), block(a.Ut ? XU_WAVES * 64 : 256);
 #define LNB(V, X) hipLaunchKernelGGL((ln_bwd_kernel<V, X>), grid, block, 0, st, (const bf16*)dy, x, ldx, gamma, mean, rstd, \
                                      dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M, a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp)
-  if (a.Ut) {
+#define LNB4(V) hipLaunchKernelGGL((ln_bwd_kernel<V, true, 4>), grid, block, 0, st, (const bf16*)dy, x, ldx, gamma, mean, rstd, \
+                                   dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M, a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp)
+  if (a.Ut && a.Rp == 64) {
+    if (C == 768) LNB4(3);
+    else if (C == 1024) LNB4(4);
+    else LNB4(1);
+  } else if (a.Ut) {
     if (C == 768) LNB(3, true);
     else if (C == 1024) LNB(4, true);
     else LNB(1, true);
@@ -472,6 +491,7 @@ int ln_bwd_launch(const void* dy, const float* x, long ldx, const float* gamma, 
   else if (C == 256) LNB(1, false);
   else return CARA_E_ARG;
 #undef LNB
+#undef LNB4
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }

@@ -30,8 +30,10 @@ struct TsRing {
   static constexpr int STAGE = X_BYTES + G_BYTES;
   static constexpr int PIECES = 4 + NT;
   static constexpr int WAVE_BYTES = NSTAGE * STAGE;
-  // the end-of-block combine needs [4 waves][NT * 4][64] f32x4 + [4 waves][4][64] floats
-  static constexpr int COMBINE_BYTES = 4 * NT * 4 * 64 * 16 + 4 * 4 * 64 * 4;
+  // the end-of-block combine runs in passes of 8 accumulator tiles (two r-tiles x four i-tiles): [4 waves][8][64] f32x4
+  // + [4 waves][4][64] floats, whatever NT (Rp = 64 as one pass would be 68 KiB: two workgroups per CU for the GEMM
+  // the products ride in)
+  static constexpr int COMBINE_BYTES = 4 * 8 * 64 * 16 + 4 * 4 * 64 * 4;
   static constexpr int BLOCK_BYTES = 4 * WAVE_BYTES > COMBINE_BYTES ? 4 * WAVE_BYTES : COMBINE_BYTES;
 };
 
@@ -161,30 +163,36 @@ __device__ __forceinline__ void tskinny_body(const TsProblem& p0, const TsProble
         acc[rt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt], b, acc[rt][it], 0, 0, 0);
     }
   }
-  // ---- combine the 4 waves through LDS (ring memory is dead now) ----
+  // ---- combine the 4 waves through LDS (ring memory is dead now), two r-tiles (8 accumulator tiles) per pass ----
   __syncthreads();
-  f32x4* red = reinterpret_cast<f32x4*>(smem);  // [wave][NT*4][64]
-#pragma unroll
-  for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-    for (int it = 0; it < 4; ++it) red[(wave * NT * 4 + rt * 4 + it) * 64 + lane] = acc[rt][it];
-  float* cred = reinterpret_cast<float*>(smem + 4 * NT * 4 * 64 * 16);  // [wave][4 it][64 lanes]
-  if constexpr (COLSUM) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) cred[(wave * 4 + it) * 64 + lane] = csum[it];
-  }
-  __syncthreads();
+  f32x4* red = reinterpret_cast<f32x4*>(smem);  // [wave][8][64]
+  float* cred = reinterpret_cast<float*>(smem + 4 * 8 * 64 * 16);  // [wave][4 it][64 lanes]
   float* slab = slabs + (size_t)bid * TS_COLS * (NT * 16);
-  for (int t = wave; t < NT * 4; t += 4) {
-    f32x4 s = red[t * 64 + lane];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      const f32x4 v = red[(w * NT * 4 + t) * 64 + lane];
-      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+  for (int h = 0; h < NT / 2; ++h) {
+    if (h) __syncthreads();   // the previous pass's sums have been read
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) red[(wave * 8 + r2 * 4 + it) * 64 + lane] = acc[h * 2 + r2][it];
+    if constexpr (COLSUM) {
+      if (h == 0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) cred[(wave * 4 + it) * 64 + lane] = csum[it];
+      }
     }
-    const int rt = t >> 2, it = t & 3;
-    // C layout: row (= r) = rt*16 + fq*4 + reg, col (= i) = it*16 + fr  ->  slab[i][r..r+3]
-    *reinterpret_cast<f32x4*>(slab + (size_t)(it * 16 + fr) * (NT * 16) + rt * 16 + fq * 4) = s;
+    __syncthreads();
+    for (int t = wave; t < 8; t += 4) {
+      f32x4 s = red[t * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const f32x4 v = red[(w * 8 + t) * 64 + lane];
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+      }
+      const int rt = h * 2 + (t >> 2), it = t & 3;
+      // C layout: row (= r) = rt*16 + fq*4 + reg, col (= i) = it*16 + fr  ->  slab[i][r..r+3]
+      *reinterpret_cast<f32x4*>(slab + (size_t)(it * 16 + fr) * (NT * 16) + rt * 16 + fq * 4) = s;
+    }
   }
   if constexpr (COLSUM) {
     if (want_cs && tid < TS_COLS) {

@@ -191,7 +191,7 @@ int env_once(const char* name, int dflt) {
 // separate cara_skinny_xu passes instead of fusing them into the LayerNorm kernels
 bool fuse_xu(const cara_geom* g) {
   static const int v = env_once("CARA_FUSE_XU", 1);
-  return v != 0 && g->Rp == 32 && (g->dim == 768 || g->dim == 1024 || g->dim == 256);   // what cara_layernorm_*_xu take
+  return v != 0 && (g->Rp == 32 || g->Rp == 64) && (g->dim == 768 || g->dim == 1024 || g->dim == 256);   // what cara_layernorm_*_xu take
 }
 
 // CARA_FUSE_GEMM_T: bit 0 (default on) computes T = X U of forward proj / fc2 inside the GEMM that consumes it
@@ -199,7 +199,7 @@ bool fuse_xu(const cara_geom* g) {
 // for G' = dY Vs of the backward's qkv / fc1.
 bool fuse_gemm_t(int Mr, int Rp, bool backward) {
   static const int v = env_once("CARA_FUSE_GEMM_T", 1);
-  return (v & (backward ? 2 : 1)) != 0 && Rp == 32 && Mr >= 1024;
+  return (v & (backward ? 2 : 1)) != 0 && (Rp == 32 || Rp == 64) && Mr >= 1024;
 }
 
 // CARA_PANEL_ACTS = mask of the activation groups written K-panel-major ([K/32][M][32], cara_gemm_args::c_panels /
@@ -216,7 +216,7 @@ bool panel_acts(int Mr, const cara_vit_shape* s, int what = 1) {
 // riding in that GEMM's launch (cara_gemm_with_tskinny).  Rp = 32, full-size products only.
 bool fuse_ts(int Mr, int Rp) {
   static const int v = env_once("CARA_FUSE_TS", 1);
-  return v != 0 && Rp == 32 && Mr >= 1024;
+  return v != 0 && (Rp == 32 || Rp == 64) && Mr >= 1024;
 }
 
 void with_scratch(cara_gemm_args& a, const Ctx& cx) {

@@ -63,10 +63,10 @@ typedef struct {
                                 /* loop into slabs that run as one batched launch (fp32 partials there).   */
   int batch;                    /* > 1: `batch` independent products in ONE launch; product z uses A, B,  */
   long long strideA, strideB, strideC;   /* C advanced by z * stride (elements); no A2/B2/aux/C2 then     */
-  /* Whole adapter inside the GEMM (Rp == 32, B2 set, A2 NULL): every tile also accumulates its rows of       */
-  /* T = A Ut^T (Ut bf16 [32, K], rows >= rank zero: the operand cara_skinny_xu takes), rounds it to bf16 and  */
+  /* Whole adapter inside the GEMM (Rp in {32, 64}, B2 set, A2 NULL): every tile also accumulates its rows of */
+  /* T = A Ut^T (Ut bf16 [Rp, K], rows >= rank zero: the operand cara_skinny_xu takes), rounds it to bf16 and  */
   /* uses it as the K-extension operand -- the separate skinny pass over A disappears.  The tiles of column   */
-  /* 0 also write T [M,32] and, if non-NULL, Tt [32,ldt] (for cara_tskinny_*).                                */
+  /* 0 also write T [M,Rp] and, if non-NULL, Tt [Rp,ldt] (for cara_tskinny_*).                                */
   const void* Ut;
   void* T_out;
   void* Tt_out;
@@ -119,7 +119,7 @@ int cara_tskinny_partial2(const void* Xa, int ldxa, const void* Gta, void* slabs
                           int ldg, int M, int Rp, void* stream);
 /* cara_gemm_bf16(a) and cara_tskinny_partial2(...) of the SAME linear as ONE launch: the grid holds the GEMM's tiles
  * and the products' blocks, so the HBM-bound products run under the MFMA-bound GEMM without a second stream (no
- * event between the kernels before and after).  M > 128, no batch / Ut; Rp == 32;
+ * event between the kernels before and after).  M > 128, no batch / Ut; Rp in {32, 64} (64: three workgroups per CU);
  * CARA_E_ARG otherwise (callers then launch the two separately).  Results are bitwise those of the two calls.   */
 int cara_gemm_with_tskinny(const cara_gemm_args* a, const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
                            const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b,
@@ -151,7 +151,7 @@ int cara_layernorm_bwd(const void* dy, const float* x, long ldx, const float* ga
  *   _fwd_xu: T[M,Rp] = y Ut^T (Ut bf16 [Rp,C], rows >= rank zero), Tt[Rp,ldt] its transpose (or NULL);
  *   _bwd_xu: G[M,Rp] = dyb Vst^T with dyb the row-scaled bf16 gradient this kernel emits (dyb may be NULL
  *            when only G is wanted), Gt its transpose.  Same rounding points as cara_skinny_xu.
- * Rp == 32 only (rank <= 32), C in {256, 768, 1024}; else CARA_E_ARG (callers then keep the separate
+ * Rp in {32, 64} (rank <= Rp), C in {256, 768, 1024}; else CARA_E_ARG (callers then keep the separate
  * cara_skinny_xu pass).                                                                                  */
 int cara_layernorm_fwd_xu(const float* x, long ldx, const float* gamma, const float* beta, void* y,
                           float* mean, float* rstd, int M, int C, float eps, const void* Ut, int rank,

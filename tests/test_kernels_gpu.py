@@ -139,11 +139,13 @@ def test_gemm_edge_tiles_mixing_epilogue_paths(M, N):
         close(h[:, :N], torch.nn.functional.gelu(acc), 2 ** -8, 1e-3, "edge gelu h")
 
 
-@pytest.mark.parametrize("M,N,K,rank", [(12608, 768, 3072, 16), (12608, 768, 768, 8), (1500, 3072, 768, 32), (333, 300, 128, 16)])
+@pytest.mark.parametrize("M,N,K,rank", [(12608, 768, 3072, 16), (12608, 768, 768, 8), (1500, 3072, 768, 32), (333, 300, 128, 16),
+                                        (12608, 768, 3072, 64), (12608, 768, 768, 48), (333, 300, 128, 33)])
 def test_gemm_with_adapter_inside(M, N, K, rank):
     """cara_gemm_args.Ut: T = A Ut^T computed per tile inside the GEMM and used as the K-extension operand; must
-    agree with cara_skinny_xu + the ordinary K-extension, and leave T / Tt behind for the backward."""
-    Rp = 32
+    agree with cara_skinny_xu + the ordinary K-extension, and leave T / Tt behind for the backward.  Rank > 32: Rp = 64
+    (two extension steps, eight T tiles per wave)."""
+    Rp = 32 if rank <= 32 else 64
     A, B = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
     Ut = rnd(Rp, K, seed=3, scale=0.1)
     Ut[rank:] = 0
@@ -337,32 +339,34 @@ def test_tskinny(M, K1, Rp):
     assert torch.equal(D, D2), "tskinny must be bitwise reproducible (fixed-order slab sum)"
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(12608, 768, 3072, "bf16"), (12608, 3072, 768, "dgelu"), (1500, 768, 768, "bf16")])
-def test_gemm_carrying_the_transposed_skinny_products(M, N, K, epi, monkeypatch):
+@pytest.mark.parametrize("M,N,K,epi,Rp", [(12608, 768, 3072, "bf16", 32), (12608, 3072, 768, "dgelu", 32), (1500, 768, 768, "bf16", 32),
+                                          (12608, 768, 3072, "bf16", 64), (12608, 3072, 768, "dgelu", 64), (1500, 2304, 768, "bf16", 64)])
+def test_gemm_carrying_the_transposed_skinny_products(M, N, K, epi, Rp, monkeypatch):
     """cara_gemm_with_tskinny: the dX GEMM of a linear and its two transposed skinny products as ONE launch give
-    bitwise what cara_gemm_bf16 + cara_tskinny_partial2 give."""
+    bitwise what cara_gemm_bf16 + cara_tskinny_partial2 give (Rp = 64: the products' 16 accumulator tiles, combined
+    in two passes)."""
     lib = L().lib()
     p, st = L().ptr, L().stream
     lib.cara_tskinny_scratch_bytes.restype = C.c_size_t
     dY, Wt = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)          # dX = dY Wt^T: K = out features, N = in features
     X = rnd(M, N, seed=3)
-    G, U = rnd(M, 32, seed=4, scale=0.5), rnd(N, 32, seed=5, scale=0.3)
+    G, U = rnd(M, Rp, seed=4, scale=0.5), rnd(N, Rp, seed=5, scale=0.3)
     ldg = (M + 31) // 32 * 32
-    Gt, Tt = (torch.zeros(32, ldg, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    Gt, Tt = (torch.zeros(Rp, ldg, dtype=torch.bfloat16, device=DEV) for _ in range(2))
     Gt[:, :M] = G.t()
-    Tt[:, :M] = rnd(M, 32, seed=6, scale=0.5).t()
+    Tt[:, :M] = rnd(M, Rp, seed=6, scale=0.5).t()
     aux = rnd(M, N, seed=7)
 
     def run(fused):
         out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
-        sa = torch.zeros(int(lib.cara_tskinny_scratch_bytes(M, N, 32)), dtype=torch.uint8, device=DEV)
-        sb = torch.zeros(int(lib.cara_tskinny_scratch_bytes(M, K, 32)), dtype=torch.uint8, device=DEV)
+        sa = torch.zeros(int(lib.cara_tskinny_scratch_bytes(M, N, Rp)), dtype=torch.uint8, device=DEV)
+        sb = torch.zeros(int(lib.cara_tskinny_scratch_bytes(M, K, Rp)), dtype=torch.uint8, device=DEV)
         a = L().GemmArgs()
-        a.A, a.lda, a.B, a.ldb, a.A2, a.B2, a.Rp = p(dY), K, p(Wt), K, p(G), p(U), 32
+        a.A, a.lda, a.B, a.ldb, a.A2, a.B2, a.Rp = p(dY), K, p(Wt), K, p(G), p(U), Rp
         a.M, a.N, a.K, a.C, a.ldc = M, N, K, p(out), N
         a.epi = L().EPI_DGELU if epi == "dgelu" else L().EPI_BF16
         a.aux = p(aux) if epi == "dgelu" else None
-        ts = (p(X), N, p(Gt), p(sa), N, p(dY), K, p(Tt), p(sb), K, 1, ldg, M, 32, st())
+        ts = (p(X), N, p(Gt), p(sa), N, p(dY), K, p(Tt), p(sb), K, 1, ldg, M, Rp, st())
         if fused:
             L().check(lib.cara_gemm_with_tskinny(C.byref(a), *ts), "cara_gemm_with_tskinny")
         else:
@@ -373,17 +377,25 @@ def test_gemm_carrying_the_transposed_skinny_products(M, N, K, epi, monkeypatch)
     ref = run(False)
     got = run(True)
     assert all(torch.equal(x, y) for x, y in zip(ref, got))
+    # ... and right: the products' slabs, summed, against fp64 (dU = X^T G, dVs = dY^T T, dc = colsum dY)
+    D = torch.empty(N, Rp, device=DEV)
+    L().check(lib.cara_tskinny_reduce(p(got[1]), C.c_size_t(0), p(D), None, 1, M, N, Rp, st()), "reduce dU")
+    close(D, X.double().t() @ G.double(), 1e-3, 2e-2 * math.sqrt(M / 1000), "riding dU")
+    D2, cs = torch.empty(K, Rp, device=DEV), torch.empty(K, device=DEV)
+    L().check(lib.cara_tskinny_reduce(p(got[2]), C.c_size_t(0), p(D2), p(cs), 1, M, K, Rp, st()), "reduce dVs")
+    close(D2, dY.double().t() @ Tt[:, :M].double().t(), 1e-3, 2e-2 * math.sqrt(M / 1000), "riding dVs")
+    close(cs, dY.double().sum(0), 1e-3, 2e-2 * math.sqrt(M / 1000), "riding dc")
     # the same with dY and X K-panel-major (a_panels on the GEMM, negative ld on the products) and packed weights
     dYp, Xp, Wp = _panels(dY), _panels(X), L().pack_b_panels(Wt)
     out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
-    sa = torch.zeros(int(lib.cara_tskinny_scratch_bytes(M, N, 32)), dtype=torch.uint8, device=DEV)
-    sb = torch.zeros(int(lib.cara_tskinny_scratch_bytes(M, K, 32)), dtype=torch.uint8, device=DEV)
+    sa = torch.zeros(int(lib.cara_tskinny_scratch_bytes(M, N, Rp)), dtype=torch.uint8, device=DEV)
+    sb = torch.zeros(int(lib.cara_tskinny_scratch_bytes(M, K, Rp)), dtype=torch.uint8, device=DEV)
     a = L().GemmArgs()
-    a.A, a.lda, a.a_panels, a.B, a.ldb, a.Bp, a.A2, a.B2, a.Rp = p(dYp), 0, M, p(Wt), K, p(Wp), p(G), p(U), 32
+    a.A, a.lda, a.a_panels, a.B, a.ldb, a.Bp, a.A2, a.B2, a.Rp = p(dYp), 0, M, p(Wt), K, p(Wp), p(G), p(U), Rp
     a.M, a.N, a.K, a.C, a.ldc = M, N, K, p(out), N
     a.epi = L().EPI_DGELU if epi == "dgelu" else L().EPI_BF16
     a.aux = p(aux) if epi == "dgelu" else None
-    L().check(lib.cara_gemm_with_tskinny(C.byref(a), p(Xp), -M, p(Gt), p(sa), N, p(dYp), -M, p(Tt), p(sb), K, 1, ldg, M, 32, st()),
+    L().check(lib.cara_gemm_with_tskinny(C.byref(a), p(Xp), -M, p(Gt), p(sa), N, p(dYp), -M, p(Tt), p(sb), K, 1, ldg, M, Rp, st()),
               "cara_gemm_with_tskinny, panels")
     assert all(torch.equal(x, y) for x, y in zip(ref, (out, sa, sb))), "panel-major operands"
     # not fusable: few rows
@@ -391,9 +403,9 @@ def test_gemm_carrying_the_transposed_skinny_products(M, N, K, epi, monkeypatch)
     a.A, a.lda, a.B, a.ldb, a.M, a.N, a.K, a.ldc = p(dY), K, p(Wt), K, 64, N, K, N
     out = torch.empty(64, N, dtype=torch.bfloat16, device=DEV)
     a.C, a.epi = p(out), L().EPI_BF16
-    sa = torch.zeros(int(lib.cara_tskinny_scratch_bytes(64, N, 32)), dtype=torch.uint8, device=DEV)
-    sb = torch.zeros(int(lib.cara_tskinny_scratch_bytes(64, K, 32)), dtype=torch.uint8, device=DEV)
-    assert lib.cara_gemm_with_tskinny(C.byref(a), p(X), N, p(Gt), p(sa), N, p(dY), K, p(Tt), p(sb), K, 0, ldg, 64, 32, st()) != 0
+    sa = torch.zeros(int(lib.cara_tskinny_scratch_bytes(64, N, Rp)), dtype=torch.uint8, device=DEV)
+    sb = torch.zeros(int(lib.cara_tskinny_scratch_bytes(64, K, Rp)), dtype=torch.uint8, device=DEV)
+    assert lib.cara_gemm_with_tskinny(C.byref(a), p(X), N, p(Gt), p(sa), N, p(dY), K, p(Tt), p(sb), K, 0, ldg, 64, Rp, st()) != 0
 
 
 def test_tskinny_reductions_in_one_launch():
@@ -461,7 +473,8 @@ def test_layernorm_fwd_bwd(M, C_):
     close(dyb, refdx * rs.double().repeat_interleave(rps)[:M, None], 2 ** -8, 1e-3, "ln bwd dyb")
 
 
-@pytest.mark.parametrize("M,C_,rank,Rp", [(12608, 768, 16, 32), (333, 768, 8, 32), (197, 1024, 16, 32), (70, 768, 32, 32), (5, 256, 3, 32)])
+@pytest.mark.parametrize("M,C_,rank,Rp", [(12608, 768, 16, 32), (333, 768, 8, 32), (197, 1024, 16, 32), (70, 768, 32, 32), (5, 256, 3, 32),
+                                          (12608, 768, 64, 64), (333, 1024, 40, 64), (21, 256, 64, 64)])
 def test_layernorm_fused_adapter_contraction(M, C_, rank, Rp):
     """cara_layernorm_fwd_xu / _bwd_xu: LayerNorm + the skinny product of the next linear (T = y U, G' = dyb Vs)
     from the row held in registers; must agree with the separate cara_skinny_xu pass on the same bf16 rows."""

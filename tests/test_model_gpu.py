@@ -524,17 +524,19 @@ def test_three_adamw_steps_follow_the_oracle_trajectory():
     assert rel(m.head.weight.detach(), hw.detach()) < 5e-3
 
 
-def test_headline_batch_64_whole_model():
-    """BASELINE.json configs[1] at its REAL size: ViT-B/16 depth 12, rank 16, batch 64 -> M = 12 608 token rows (98.5
-    row tiles: the edge tile, 2.3 rounds of workgroups), through train_step.  Logits of the same forward (eval
-    path is bitwise the training forward) against the fp32 oracle and its bf16-rounded form; loss and every
-    gradient of the train step against fp32 autograd of the as-written algorithm."""
+@pytest.mark.parametrize("rank", [16, 64])
+def test_headline_batch_64_whole_model(rank):
+    """BASELINE.json configs[1] (rank 16) and configs[3] (rank 64: Rp = 64 kernels -- adapter inside the N = 768 GEMMs,
+    LayerNorm-fused contractions, riding products with 16 accumulator tiles) at their REAL size: ViT-B/16 depth 12,
+    batch 64 -> M = 12 608 token rows (98.5 row tiles: the edge tile, 2.3 rounds of workgroups), through train_step.
+    Logits of the same forward (eval path is bitwise the training forward) against the fp32 oracle and its bf16-rounded
+    form; loss and every gradient of the train step against fp32 autograd of the as-written algorithm."""
     from oracle import cara_oracle as O
     B = 64
     w = O.synthetic_backbone()
-    cp = O.synthetic_cp(rank=16)
+    cp = O.synthetic_cp(rank=rank)
     x, y = O.synthetic_batch(batch=B)
-    m = build(w, cp, 16, 0.1, 12, 224).train()
+    m = build(w, cp, rank, 0.1, 12, 224).train()
     eng = m._cara_engine
     keep = _keep(12, B)
     loss = eng.train_step(x.to(DEV), y.to(DEV), None, droppath=keep.to(DEV))
@@ -545,7 +547,7 @@ def test_headline_batch_64_whole_model():
         logits = eng.forward(x.to(DEV), droppath=keep.to(DEV))
     r_ref, r_model = rel(logits, rlogits), rel(sim, rlogits)
     worst = max(rel(getattr(m, n).grad, gref[n]) for n in O.CP_NAMES)
-    print(f"batch 64: logits rel-L2 vs fp32 oracle {r_ref:.2e} (rounding model {r_model:.2e}); loss {loss.item():.5f} vs {rloss.item():.5f}; "
+    print(f"batch 64, rank {rank}: logits rel-L2 vs fp32 oracle {r_ref:.2e} (rounding model {r_model:.2e}); loss {loss.item():.5f} vs {rloss.item():.5f}; "
           f"worst CP-gradient rel-L2 {worst:.2e}")
     assert T.logits_ok(r_ref, r_model), (r_ref, r_model)
     top2 = rlogits.topk(2, dim=1).values
