@@ -332,15 +332,14 @@ __global__ __launch_bounds__(256, NT == 2 ? 4 : 3) void gemm32_ts_kernel(const c
 // NU = Rp / 32: 1 (rank <= 32) or 2 (rank <= 64: a 4-KiB slab of Ut per K step, eight T tiles per wave, two extension steps; 140
 // VGPRs, three workgroups per CU -- the kernel serves the N = 768 products, whose 594 tiles never put more than three on a CU)
 template <int EPI, int NU = 1>
-__global__ __launch_bounds__(256, NU == 1 ? 4 : 3) void gemm32ft_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
+__device__ __forceinline__ void gemm32ft_body(const cara_gemm_args& p, const int tiles_n, const int nwg, const int gm, const int block, char* smem) {
   constexpr int TBM = 128;
   constexpr int A_BYTES = TBM * BK32 * 2, U_BYTES = NU * 32 * BK32 * 2;
   constexpr int SLOT = A_BYTES + B32_BYTES + U_BYTES;   // 18 KiB; two slots = 36 KiB, still 4 workgroups per CU (NU = 2: 20 / 40 KiB)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int fr = lane & 15, fq = lane >> 4;
-  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int tile = xcd_remap(block, nwg);
   int tm, tn;
   if (gm <= 1) {
     tm = tile / tiles_n;
@@ -490,26 +489,27 @@ __global__ __launch_bounds__(256, NU == 1 ? 4 : 3) void gemm32ft_kernel(const ca
   }
 }
 
-static int group_m(int tiles_n);
-
-template <int EPI>
-int launch32ft(const cara_gemm_args* a, hipStream_t st) {
-  const int tiles_n = (a->N + BN - 1) / BN;
-  const int gm = group_m(tiles_n);
-  const int nwg = ((a->M + 127) / 128) * tiles_n;
-  // consumers read Tt in whole 32-row steps: keep columns [M, roundup32(M)) zero, as cara_skinny_xu does
-  const int m32 = (a->M + 31) / 32 * 32;
-  if (a->Tt_out && m32 > a->M && m32 <= a->ldt &&
-      hipMemset2DAsync(static_cast<bf16*>(a->Tt_out) + a->M, (size_t)a->ldt * 2, 0, (size_t)(m32 - a->M) * 2, a->Rp, st) != hipSuccess)
-    return CARA_E_LAUNCH;
-  if (a->Rp == 64) {
-    hipLaunchKernelGGL((gemm32ft_kernel<EPI, 2>), dim3(nwg), dim3(256), 2 * (128 * BK32 * 2 + B32_BYTES + 64 * BK32 * 2), st, *a, tiles_n, nwg, gm);
-  } else {
-    hipLaunchKernelGGL((gemm32ft_kernel<EPI>), dim3(nwg), dim3(256), 2 * (128 * BK32 * 2 + B32_BYTES + 32 * BK32 * 2), st, *a, tiles_n, nwg, gm);
-  }
-  CARA_CHECK_LAUNCH();
-  return CARA_OK;
+template <int EPI, int NU = 1>
+__global__ __launch_bounds__(256, NU == 1 ? 4 : 3) void gemm32ft_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm32ft_body<EPI, NU>(p, tiles_n, nwg, gm, blockIdx.x, smem);
 }
+
+// the adapter-inside GEMM carrying a pair of transposed skinny products (of ANOTHER linear: this launch only now produces
+// the G' its own products would read) behind its tiles, as gemm32_ts_kernel does
+template <int EPI, int NU, bool COLSUM>
+__global__ __launch_bounds__(256, NU == 1 ? 4 : 3) void gemm32ft_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
+                                                                           const TsProblem t0, const TsProblem t1, const int ldg, const int Mts) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x;
+  if (b >= nwg) tskinny_body<2 * NU, COLSUM, 1>(t0, t1, ldg, Mts, b - nwg, smem);
+  else gemm32ft_body<EPI, NU>(p, tiles_n, nwg, gm, b, smem);
+}
+
+static int group_m(int tiles_n);
+struct TsPair;
+template <int EPI>
+int launch32ft(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr);
 
 // rows per supertile (1 = plain row-major order)
 static int group_m(int tiles_n) {
@@ -544,6 +544,42 @@ void launch_ts(const cara_gemm_args* a, hipStream_t st, const TsPair* ts, int ti
     if (ts->any_cs) TS_GO(true, 2); else TS_GO(false, 2);
   }
 #undef TS_GO
+}
+
+template <int EPI>
+int launch32ft(const cara_gemm_args* a, hipStream_t st, const TsPair* ts) {
+  const int tiles_n = (a->N + BN - 1) / BN;
+  const int gm = group_m(tiles_n);
+  const int nwg = ((a->M + 127) / 128) * tiles_n;
+  // consumers read Tt in whole 32-row steps: keep columns [M, roundup32(M)) zero, as cara_skinny_xu does
+  const int m32 = (a->M + 31) / 32 * 32;
+  if (a->Tt_out && m32 > a->M && m32 <= a->ldt &&
+      hipMemset2DAsync(static_cast<bf16*>(a->Tt_out) + a->M, (size_t)a->ldt * 2, 0, (size_t)(m32 - a->M) * 2, a->Rp, st) != hipSuccess)
+    return CARA_E_LAUNCH;
+  const int lds1 = 2 * (128 * BK32 * 2 + B32_BYTES + 32 * BK32 * 2), lds2 = 2 * (128 * BK32 * 2 + B32_BYTES + 64 * BK32 * 2);
+  if (ts) {   // (plain bf16 output only: the backward's fc1 / qkv dX)
+    if constexpr (EPI == CARA_EPI_BF16) {
+      if (ts->nt != a->Rp / 16) return CARA_E_ARG;
+      const dim3 grid(nwg + ts->a.nblk + ts->b.nblk), block(256);
+      constexpr int RB = TsRing<2, 1>::BLOCK_BYTES;   // the same for every NT (two-pass combine)
+#define FT_GO(NU, CS, L)                                                                                                    \
+      hipLaunchKernelGGL((gemm32ft_ts_kernel<EPI, NU, CS>), grid, block, (RB > L ? RB : L), st, *a, tiles_n, nwg, gm, ts->a, ts->b, ts->ldg, ts->M)
+      if (a->Rp == 64) {
+        if (ts->any_cs) FT_GO(2, true, lds2); else FT_GO(2, false, lds2);
+      } else {
+        if (ts->any_cs) FT_GO(1, true, lds1); else FT_GO(1, false, lds1);
+      }
+#undef FT_GO
+      CARA_CHECK_LAUNCH();
+      return CARA_OK;
+    } else {
+      return CARA_E_ARG;
+    }
+  }
+  if (a->Rp == 64) hipLaunchKernelGGL((gemm32ft_kernel<EPI, 2>), dim3(nwg), dim3(256), lds2, st, *a, tiles_n, nwg, gm);
+  else hipLaunchKernelGGL((gemm32ft_kernel<EPI>), dim3(nwg), dim3(256), lds1, st, *a, tiles_n, nwg, gm);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
 }
 
 template <int EPI>
@@ -724,12 +760,12 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
   if (!small_ptrs) return CARA_E_ARG;
   if (a->epi == CARA_EPI_RESID && (!a->aux || (a->rowscale && a->rows_per_sample <= 0))) return CARA_E_ARG;
   if (a->epi == CARA_EPI_DGELU && !a->aux) return CARA_E_ARG;
-  if (ts && (a->Ut || a->batch > 1 || a->M <= 128 || a->B3)) return CARA_E_ARG;
+  if (ts && (a->batch > 1 || a->M <= 128 || a->B3 || (a->Ut && a->epi != CARA_EPI_BF16))) return CARA_E_ARG;
   if (a->B3 && (a->Bp || a->Ut || a->batch > 1 || a->a_panels)) return CARA_E_ARG;
   if (a->Ut) {   // whole adapter inside the GEMM: Rp = 32, T produced here
     if (a->A2 || !a->B2 || !(a->Rp == 32 || a->Rp == 64) || !a->T_out || a->batch > 1 || (a->Tt_out && (a->ldt < a->M || (a->ldt & 7)))) return CARA_E_ARG;
     switch (a->epi) {
-      case CARA_EPI_BF16: return launch32ft<CARA_EPI_BF16>(a, st);
+      case CARA_EPI_BF16: return launch32ft<CARA_EPI_BF16>(a, st, ts);
       case CARA_EPI_F32: return launch32ft<CARA_EPI_F32>(a, st);
       case CARA_EPI_GELU: return launch32ft<CARA_EPI_GELU>(a, st);
       case CARA_EPI_RESID: return launch32ft<CARA_EPI_RESID>(a, st);

@@ -23,16 +23,24 @@ namespace {
 // ------------------------------------------------------------------------------------------
 constexpr int XU_KSLICE = 192, XU_GROUPS = 4;
 
+// Rp = 64 (rank > 32): the Ut fragments of 64 columns would be 96 VGPRs per wave, over the budget of a 1024-thread
+// workgroup, so the columns are cut into halves of 32 handled by TWO workgroups of the same rows (blockIdx.y = half:
+// rows [32 y, 32 y + 32) of Ut, columns [32 y, ...) of T whose row stride is ldT = Rp); they run side by side, so the
+// second read of a row block is served by the caches rather than by HBM.
 template <int NT>
 __global__ __launch_bounds__(1024) void skinny_xu_sliced_kernel(const bf16* __restrict__ X, int ldx,
                                                                 const bf16* __restrict__ Ut,
                                                                 bf16* __restrict__ T, bf16* __restrict__ Tt,
-                                                                int ldt, int M, int K) {
+                                                                int ldt, int M, int K, const int ldT) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* red = reinterpret_cast<f32x4*>(smem);   // [nwaves][NT][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  constexpr int Rp = NT * 16, KS = XU_KSLICE / 32;
+  constexpr int KS = XU_KSLICE / 32;
+  const int Rp = ldT;
+  Ut += (size_t)blockIdx.y * (NT * 16) * K;
+  T += blockIdx.y * (NT * 16);
+  if (Tt) Tt += (size_t)blockIdx.y * (NT * 16) * ldt;
   const int k0 = wave * XU_KSLICE + fq * 8;
   bf16x8 u[KS][NT];
 #pragma unroll
@@ -282,13 +290,12 @@ extern "C" int cara_skinny_xu(const void* X, int ldx, const void* Ut, void* T, v
     return CARA_E_LAUNCH;
   const bf16* x = (const bf16*)X;
   const bf16* u = (const bf16*)Ut;
-  // (Rp = 64 would need 96 VGPRs of Ut fragments per wave: over the 128-VGPR budget of a
-  // 1024-thread workgroup, so rank > 32 stays on v1)
-  if (Rp == 32 && K % XU_KSLICE == 0 && K / XU_KSLICE <= 16 && M >= 64) {
+  // (Rp = 64: two workgroups per row block, 32 columns each -- see the kernel)
+  if ((Rp == 32 || Rp == 64) && K % XU_KSLICE == 0 && K / XU_KSLICE <= 16 && M >= 64) {
     const int nw = K / XU_KSLICE;
-    const dim3 g2((M + 16 * XU_GROUPS - 1) / (16 * XU_GROUPS)), b2(nw * 64);
+    const dim3 g2((M + 16 * XU_GROUPS - 1) / (16 * XU_GROUPS), Rp / 32), b2(nw * 64);
     const size_t lds = (size_t)nw * 2 * 64 * sizeof(f32x4);
-    hipLaunchKernelGGL(skinny_xu_sliced_kernel<2>, g2, b2, lds, st, x, ldx, u, (bf16*)T, (bf16*)Tt, ldt, M, K);
+    hipLaunchKernelGGL(skinny_xu_sliced_kernel<2>, g2, b2, lds, st, x, ldx, u, (bf16*)T, (bf16*)Tt, ldt, M, K, Rp);
     CARA_CHECK_LAUNCH();
     return CARA_OK;
   }

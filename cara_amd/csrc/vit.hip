@@ -150,13 +150,32 @@ struct Prof {
 };
 Prof g_prof;
 
+// A linear's two transposed skinny products (dU = X^T G', dVs = dY^T T, dc) as arguments of cara_tskinny_partial2 /
+// cara_gemm_with_tskinny: the pair waits here until a GEMM launch carries it (its own dX GEMM, or -- CARA_DEFER_TS -- the
+// NEXT dX GEMM of the pass, which lets a GEMM compute the G' its own products read) or it is flushed as a launch of its own.
+struct TsPending {
+  bool valid = false;
+  const void *Xa, *Gta, *Xb, *Gtb;
+  void *slabs_a, *slabs_b;
+  int ldxa, K1a, ldxb, K1b, want_cs, ldg, M, Rp;
+};
+
 // per-call context: what lin_fwd / lin_bwd need besides their operands (nothing here outlives the call)
 struct Ctx {
   void* stream;
   char* scratch;   // split-K scratch of the workspace in use (few-row products)
   int layer;
   bool full;       // this block runs on all token rows (not the cls-row-only last block)
+  TsPending* pend = nullptr;   // backward: the pair of products waiting for a carrier
 };
+
+int flush_pending(const Ctx& cx) {
+  TsPending* q = cx.pend;
+  if (!q || !q->valid) return CARA_OK;
+  q->valid = false;
+  return cara_tskinny_partial2(q->Xa, q->ldxa, q->Gta, q->slabs_a, q->K1a, q->Xb, q->ldxb, q->Gtb, q->slabs_b, q->K1b, q->want_cs,
+                               q->ldg, q->M, q->Rp, cx.stream);
+}
 
 struct SiteBracket {   // RAII: event 0 .. kernel(s) .. event 1, event 2 (an empty bracket: the markers' own cost)
   hipEvent_t* ev = nullptr;
@@ -219,6 +238,19 @@ bool fuse_ts(int Mr, int Rp) {
   return v != 0 && (Rp == 32 || Rp == 64) && Mr >= 1024;
 }
 
+// CARA_DEFER_TS=1 (default off): a linear's transposed skinny products ride in the NEXT dX GEMM launch of the backward pass
+// instead of its own (everything they read -- dY, G'^T, the saved input, T^T -- stays untouched until well after that launch:
+// the dY / G' buffers of a linear are next written one block later).  That frees a dX GEMM to compute the G' = dY Vs its own
+// products read (CARA_FUSE_GEMM_T bit 1: no separate pass over dY), and lets any launch be the carrier of any pair.
+// Measured (same box, r03): it LOSES -- 8.95 -> 9.20 ms per step alone, 9.11 with G' inside the dX GEMMs (rank 16); rank 64
+// 10.53 -> 10.85 / 10.27.  A pair that rides in its OWN linear's launch reads the dY the GEMM is streaming as its A operand
+// at that moment (cache hits); a deferred pair reads 96 MB nothing else touches, and the heaviest pair lands on the
+// shortest GEMM (fc1's on proj dX).
+bool defer_ts() {
+  static const int v = env_once("CARA_DEFER_TS", 0);
+  return v != 0;
+}
+
 void with_scratch(cara_gemm_args& a, const Ctx& cx) {
   a.scratch = cx.scratch;
   a.scratch_bytes = cx.scratch ? cara_gemm_scratch_bytes() : 0;
@@ -265,12 +297,21 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
   void* slabV = ws + W.slabV[L.slot] + (size_t)cx.layer * W.strideV[L.slot];
   const void* Tt = ws + lw.Tt[L.slot];
   // (have_G: the LayerNorm backward that produced dY already left G' and its transpose, cara_layernorm_bwd_xu)
-  // inside: the dX GEMM computes G' = dY Vs itself (cara_gemm_args::Ut) and leaves G / Gt behind
-  const bool inside = !have_G && want_dx && fuse_gemm_t(Mr, Rp, true);
+  // inside: the dX GEMM computes G' = dY Vs itself (cara_gemm_args::Ut) and leaves G / Gt behind -- its own products then
+  // cannot ride in it (they read that G'): only with deferred products (a later launch carries them)
+  TsPending* pend = cx.pend;
+  const bool can_carry = fuse_ts(Mr, Rp);
+  const bool defer = pend && defer_ts() && can_carry;
+  const bool inside = !have_G && want_dx && fuse_gemm_t(Mr, Rp, true) && defer && a.epi == CARA_EPI_BF16;
   if (!have_G && !inside) {
     SiteBracket b(CARA_SITE_SKINNY_BWD, cx);
     TRY(cara_skinny_xu(dY, lddy, L.Vst, G, Gt, ldt, Mr, L.out, Rp, st));
   }
+  TsPending mine;
+  mine.valid = true;
+  mine.Xa = X; mine.ldxa = ldx; mine.Gta = Gt; mine.slabs_a = slabU; mine.K1a = L.in;
+  mine.Xb = dY; mine.ldxb = lddy; mine.Gtb = Tt; mine.slabs_b = slabV; mine.K1b = L.out; mine.want_cs = want_dc ? 1 : 0;
+  mine.ldg = ldt; mine.M = Mr; mine.Rp = Rp;
   if (want_dx) {
     a.A = dY; a.lda = lddy; a.B = L.Wt; a.Bp = L.Wtp; a.ldb = L.out; a.A2 = inside ? nullptr : G; a.B2 = L.U; a.Rp = Rp;
     if (lddy < 0) { a.a_panels = -lddy; a.lda = 0; }
@@ -279,10 +320,27 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
     if (a.ldc == 0) a.ldc = L.in;
     with_scratch(a, cx);
     SiteBracket b(SITE_BWD[L.slot], cx);
-    if (!inside && fuse_ts(Mr, Rp))
-      return cara_gemm_with_tskinny(&a, X, ldx, Gt, slabU, L.in, dY, lddy, Tt, slabV, L.out, want_dc ? 1 : 0, ldt, Mr, Rp, st);
-    TRY(cara_gemm_bf16(&a, st));
+    // which pair this launch carries: the one that waits (deferred), else its own
+    const TsPending* carry = nullptr;
+    if (can_carry) {
+      if (defer) carry = (pend->valid && pend->Rp == Rp) ? pend : nullptr;
+      else if (!inside) carry = &mine;
+    }
+    if (carry) {
+      TRY(cara_gemm_with_tskinny(&a, carry->Xa, carry->ldxa, carry->Gta, carry->slabs_a, carry->K1a, carry->Xb, carry->ldxb, carry->Gtb,
+                                 carry->slabs_b, carry->K1b, carry->want_cs, carry->ldg, carry->M, carry->Rp, st));
+      if (carry == pend) pend->valid = false;
+      if (carry == &mine) return CARA_OK;
+    } else {
+      TRY(cara_gemm_bf16(&a, st));
+    }
   }
+  if (defer) {
+    TRY(flush_pending(cx));   // (a pair that found no carrier -- none waits in the steady state)
+    *pend = mine;
+    return CARA_OK;
+  }
+  if (pend) TRY(flush_pending(cx));
   return cara_tskinny_partial2(X, ldx, Gt, slabU, L.in, dY, lddy, Tt, slabV, L.out, want_dc ? 1 : 0, ldt, Mr, Rp, st);
 }
 
@@ -568,7 +626,8 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
   Ws W;
   if (!layout(g, s, &W) || !w || !cp || !head_w || !dlogits || !workspace || !grads || !dhead_w || !dhead_b) return CARA_E_ARG;
   char* ws = static_cast<char*>(workspace);
-  Ctx cx{stream, ws + W.gemm_scratch, 0, false};
+  TsPending pending;
+  Ctx cx{stream, ws + W.gemm_scratch, 0, false, &pending};
   hipStream_t hs = static_cast<hipStream_t>(stream);
   const int D = g->dim, M = W.M, Rp = g->Rp, B = s->B, N = s->tokens;
   const float att_scale = 1.0f / sqrtf((float)(D / g->heads));
@@ -661,6 +720,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
       have_G_fc2 = fx;
     }
   }
+  TRY(flush_pending(cx));   // block 0's qkv products have no dX GEMM behind them
   if (!ex) {   // (the exact mode wrote dU / dVs / dc of every layer directly)
     const int ins[4] = {D, D, D, 4 * D}, outs[4] = {3 * D, D, 4 * D, D};
     const int L = g->depth;

@@ -119,8 +119,10 @@ int cara_tskinny_partial2(const void* Xa, int ldxa, const void* Gta, void* slabs
                           int ldg, int M, int Rp, void* stream);
 /* cara_gemm_bf16(a) and cara_tskinny_partial2(...) of the SAME linear as ONE launch: the grid holds the GEMM's tiles
  * and the products' blocks, so the HBM-bound products run under the MFMA-bound GEMM without a second stream (no
- * event between the kernels before and after).  M > 128, no batch / Ut; Rp in {32, 64} (64: three workgroups per CU);
- * CARA_E_ARG otherwise (callers then launch the two separately).  Results are bitwise those of the two calls.   */
+ * event between the kernels before and after).  M > 128, no batch; Rp in {32, 64} (64: three workgroups per CU); the
+ * products need not be those of the GEMM's own linear (their M may differ from a->M); with a->Ut (the adapter inside
+ * the GEMM) only CARA_EPI_BF16 and products of the same Rp.  CARA_E_ARG otherwise (callers then launch the two
+ * separately).  Results are bitwise those of the two calls.                                                      */
 int cara_gemm_with_tskinny(const cara_gemm_args* a, const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
                            const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b,
                            int ldg, int M, int Rp, void* stream);

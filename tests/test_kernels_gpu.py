@@ -309,12 +309,13 @@ def test_gemm_few_rows_split_k(M, N, K, Rp):
 
 
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,K,Rp", [(12608, 768, 32), (12608, 3072, 32), (197, 768, 64), (45, 2304, 32)])
+@pytest.mark.parametrize("M,K,Rp", [(12608, 768, 32), (12608, 3072, 32), (197, 768, 64), (45, 2304, 32),
+                                    (12608, 3072, 64), (12608, 2304, 64), (1001, 768, 64)])
 def test_skinny_xu(M, K, Rp):
     X, Ut = rnd(M, K, seed=1), rnd(Rp, K, seed=2, scale=0.1)
     ldt = (M + 31) // 32 * 32
-    T = torch.empty(M, Rp, dtype=torch.bfloat16, device=DEV)
-    Tt = torch.zeros(Rp, ldt, dtype=torch.bfloat16, device=DEV)
+    T = torch.full((M, Rp), float("nan"), dtype=torch.bfloat16, device=DEV)
+    Tt = torch.full((Rp, ldt), float("nan"), dtype=torch.bfloat16, device=DEV)
     L().skinny_xu(X, Ut, T, Tt)
     ref = X.double() @ Ut.double().t()
     close(T, ref, 2 ** -8, 1e-3, "skinny T")
@@ -406,6 +407,59 @@ def test_gemm_carrying_the_transposed_skinny_products(M, N, K, epi, Rp, monkeypa
     sa = torch.zeros(int(lib.cara_tskinny_scratch_bytes(64, N, Rp)), dtype=torch.uint8, device=DEV)
     sb = torch.zeros(int(lib.cara_tskinny_scratch_bytes(64, K, Rp)), dtype=torch.uint8, device=DEV)
     assert lib.cara_gemm_with_tskinny(C.byref(a), p(X), N, p(Gt), p(sa), N, p(dY), K, p(Tt), p(sb), K, 0, ldg, 64, Rp, st()) != 0
+
+
+@pytest.mark.parametrize("M,N,K,Rp,Mts", [(12608, 768, 3072, 32, 12608), (12608, 768, 2304, 64, 12608), (1500, 768, 768, 32, 700)])
+def test_adapter_inside_gemm_carrying_another_linears_products(M, N, K, Rp, Mts):
+    """cara_gemm_with_tskinny with cara_gemm_args.Ut: the dX GEMM that computes its own G' = dY Vs inside carries the
+    transposed skinny products of ANOTHER linear (deferred products: their row count may differ); bitwise what the two
+    separate launches give."""
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+    lib.cara_tskinny_scratch_bytes.restype = C.c_size_t
+    dY, Wt = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    Vst, U = rnd(Rp, K, seed=3, scale=0.1), rnd(N, Rp, seed=5, scale=0.3)
+    K1a, K1b = 768, 2304                                   # the carried pair: another linear's X [Mts, K1a] and dY [Mts, K1b]
+    Xo, dYo = rnd(Mts, K1a, seed=6), rnd(Mts, K1b, seed=7)
+    ldg = (Mts + 31) // 32 * 32
+    Gt, Tt = (torch.zeros(Rp, ldg, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    Gt[:, :Mts] = rnd(Mts, Rp, seed=8, scale=0.5).t()
+    Tt[:, :Mts] = rnd(Mts, Rp, seed=9, scale=0.5).t()
+    ldt = (M + 31) // 32 * 32
+
+    def run(fused):
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        G = torch.full((M, Rp), float("nan"), dtype=torch.bfloat16, device=DEV)
+        Gto = torch.full((Rp, ldt), float("nan"), dtype=torch.bfloat16, device=DEV)
+        sa = torch.zeros(int(lib.cara_tskinny_scratch_bytes(Mts, K1a, Rp)), dtype=torch.uint8, device=DEV)
+        sb = torch.zeros(int(lib.cara_tskinny_scratch_bytes(Mts, K1b, Rp)), dtype=torch.uint8, device=DEV)
+        a = L().GemmArgs()
+        a.A, a.lda, a.B, a.ldb, a.B2, a.Rp = p(dY), K, p(Wt), K, p(U), Rp
+        a.Ut, a.T_out, a.Tt_out, a.ldt = p(Vst), p(G), p(Gto), ldt
+        a.M, a.N, a.K, a.C, a.ldc, a.epi = M, N, K, p(out), N, L().EPI_BF16
+        ts = (p(Xo), K1a, p(Gt), p(sa), K1a, p(dYo), K1b, p(Tt), p(sb), K1b, 1, ldg, Mts, Rp, st())
+        if fused:
+            L().check(lib.cara_gemm_with_tskinny(C.byref(a), *ts), "cara_gemm_with_tskinny (adapter inside)")
+        else:
+            L().check(lib.cara_gemm_bf16(C.byref(a), st()), "gemm")
+            L().check(lib.cara_tskinny_partial2(*ts), "partial2")
+        return out, G, Gto, sa, sb
+
+    ref, got = run(False), run(True)
+    assert all(torch.equal(x, y) for x, y in zip(ref, got))
+    close(got[1], dY.double() @ Vst.double().t(), 2 ** -8, 1e-3 * math.sqrt(K / 64), "G' inside")
+    D = torch.empty(K1b, Rp, device=DEV)
+    L().check(lib.cara_tskinny_reduce(p(got[4]), C.c_size_t(0), p(D), None, 1, Mts, K1b, Rp, st()), "reduce")
+    close(D, dYo.double().t() @ Tt[:, :Mts].double().t(), 1e-3, 2e-2 * math.sqrt(Mts / 1000), "carried dVs")
+    # a non-bf16 epilogue with the adapter inside cannot carry products
+    a = L().GemmArgs()
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    G = torch.empty(M, Rp, dtype=torch.bfloat16, device=DEV)
+    a.A, a.lda, a.B, a.ldb, a.B2, a.Rp, a.Ut, a.T_out = p(dY), K, p(Wt), K, p(U), Rp, p(Vst), p(G)
+    a.M, a.N, a.K, a.C, a.ldc, a.epi = M, N, K, p(out), N, L().EPI_F32
+    sa = torch.zeros(int(lib.cara_tskinny_scratch_bytes(Mts, K1a, Rp)), dtype=torch.uint8, device=DEV)
+    sb = torch.zeros(int(lib.cara_tskinny_scratch_bytes(Mts, K1b, Rp)), dtype=torch.uint8, device=DEV)
+    assert lib.cara_gemm_with_tskinny(C.byref(a), p(Xo), K1a, p(Gt), p(sa), K1a, p(dYo), K1b, p(Tt), p(sb), K1b, 1, ldg, Mts, Rp, st()) != 0
 
 
 def test_tskinny_reductions_in_one_launch():
