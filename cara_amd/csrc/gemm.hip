@@ -296,6 +296,17 @@ __global__ __launch_bounds__(256, (MI == 5 && (EPI == CARA_EPI_RESID || EPI == C
   gemm32_body<EPI, MI, 4, TWOB>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
 }
 
+// 8-wave workgroups (4 along M x 2 along N, 64-column wave tiles): MI = 3 -> 192 x 128 tiles, MI = 4 -> 256 x 128.  For the
+// N = 768 products: their 594 tiles of 128 rows put THREE workgroups on 82 of the 256 CUs and two on the rest, and a CU's
+// K loops run at what its load path delivers, so the launch lasts as long as three tiles on one CU;
+// 66 x 6 = 396 tiles of 192 rows are at most two per CU, 0.83 of the staged bytes per flop, and two 8-wave workgroups keep
+// 16 waves feeding the path.
+template <int EPI, int MI>
+__global__ __launch_bounds__(512, 4) void gemm32w8_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm32_body<EPI, MI, 8>(p, tiles_n, nwg, gm, blockIdx.x, 0, smem);
+}
+
 // The dX GEMM of a linear and the two transposed skinny products of the SAME linear (dU = X^T G', dVs = dY^T T) in
 // one grid: blocks [0, nts) are tskinny blocks (HBM-bound, one LDS stage per wave), the rest GEMM tiles (MFMA-bound).
 // The products used to run on a side stream under the GEMM, which costs a fork (an event record = 3..7 us of idle
@@ -606,6 +617,19 @@ int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr
   }
   if (ts) {
     launch_ts<EPI, 4>(a, st, ts, tiles_n, nwg, gm, GEMM_LDS);
+    CARA_CHECK_LAUNCH();
+    return CARA_OK;
+  }
+  // CARA_GEMM_W8 = 3 / 4: 192 x 128 / 256 x 128 tiles of 8 waves for the narrow products (N <= 1024)
+  static const int w8 = [] { const char* e = getenv("CARA_GEMM_W8"); return e ? atoi(e) : 0; }();
+  if ((w8 == 3 || w8 == 4) && a->N <= 1024 && a->M > 1024 && a->batch <= 1 && !a->B3) {
+    if (w8 == 3) {
+      const int nw = ((a->M + 191) / 192) * tiles_n;
+      hipLaunchKernelGGL((gemm32w8_kernel<EPI, 3>), dim3(nw), dim3(512), 2 * (192 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nw, gm);
+    } else {
+      const int nw = ((a->M + 255) / 256) * tiles_n;
+      hipLaunchKernelGGL((gemm32w8_kernel<EPI, 4>), dim3(nw), dim3(512), 2 * (256 * BK32 * 2 + B32_BYTES), st, *a, tiles_n, nw, gm);
+    }
     CARA_CHECK_LAUNCH();
     return CARA_OK;
   }
