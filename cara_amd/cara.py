@@ -263,4 +263,10 @@ def cara(config: Dict[str, Any]) -> th.nn.Module:
     if wd not in ("off", "exact"):
         raise CaraError("config['weight_dropout'] must be 'off' or 'exact'")
     model._cara_engine.weight_dropout = wd
+    # optional key: "bf16x3" makes eval-mode forwards under no_grad run split-bf16 products (cara_amd/precise.py), the
+    # parity instrument that meets north_star's 1e-3 on the logits; default "bf16" is the fast path
+    prec = config.get("precision", "bf16")
+    if prec not in ("bf16", "bf16x3"):
+        raise CaraError("config['precision'] must be 'bf16' or 'bf16x3'")
+    model._cara_engine.precision = prec
     return model

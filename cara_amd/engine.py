@@ -57,6 +57,10 @@ class CaraEngine:
         self.weight_dropout = "off"
         self.weight_dropout_p = 0.1
         self.weight_dropout_seed = None   # tests pin the mask seed; None = a fresh draw from torch's RNG per forward
+        # "bf16" (default): the fast path, bf16 MFMA operands.  "bf16x3": eval / no_grad forwards run every product as three
+        # split-bf16 MFMA products with fp32 activations (cara_amd/precise.py): a parity instrument that reaches north_star's
+        # 1e-3 on the logits at ~3x the GEMM work; training always runs the fast path.
+        self.precision = "bf16"
         self._ingested = None
         self._ingest_sig = None
         self._ws = {}
@@ -293,6 +297,11 @@ class CaraEngine:
             raise CaraError("model parameters and images must be on the same device")
         params = [model.head.weight, model.head.bias, *cp]
         self._need_backward = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if self.precision not in ("bf16", "bf16x3"):
+            raise CaraError(f"precision must be 'bf16' or 'bf16x3', not {self.precision!r}")
+        if self.precision == "bf16x3" and not model.training and not self._need_backward:
+            from . import precise
+            return precise.forward(model, images)
         return _VitFn.apply(self, images, droppath, *params)
 
     # ------------------------------------------------------------------ fused train step

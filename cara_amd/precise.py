@@ -1,0 +1,116 @@
+"""``precision = "bf16x3"``: the adapted ViT forward with every matrix product at fp32-like accuracy ON THE bf16 MATRIX CORES.
+
+north_star asks for logits within 1e-3 (relative) of the reference's fp32 CPU path.  The fast path cannot meet that:
+its MFMA operands are bf16 (8 significant bits), and the frozen weights in bf16 alone move the logits by 5e-3 at
+depth 12 (error budget in DESIGN.md section 2).  This module shows that the tolerance IS reachable on the same kernels
+with wider operands, and so bounds what that section argues: every operand is split into a bf16 head and a bf16 tail,
+
+    x = xh + xl,   W = Wh + Wl,       x W^T  ~=  xh Wh^T + xh Wl^T + xl Wh^T          (the xl Wl^T term is ~2^-18 relative)
+
+and the three products run on ``cara_gemm_bf16`` (``v_mfma_f32_16x16x32_bf16``, fp32 accumulation): the first two as ONE
+launch through the two-B-operand mechanism of the exact weight-dropout mode (``cara_gemm_args::B3``), the third added
+through the residual epilogue.  Three times the GEMM work of the fast path and fp32 activations throughout: a parity
+instrument (inference only, opt-in), not a speed path.
+
+What runs where: every product -- patch embedding, qkv / proj / fc1 / fc2 with the adapter merged as written
+(``W + s dW``, ``/root/reference/src/cara/cara.py:26-35,51-57,76-81,88-92`` in eval mode), Q K^T and P V per head, the
+classifier head -- on the HIP GEMM; LayerNorm, softmax, the exact GELU, bias / residual adds and the rank-R
+materialisation of dW (2 R |dW| flops) as fp32 torch ops on the device.  There is no CPU path here either.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from ._lib import CaraError
+
+
+def _split(t: torch.Tensor):
+    """fp32 -> (bf16 head, bf16 tail): t = head + tail up to 2^-17 relative."""
+    t = t.float().contiguous()
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+def _pad_k(t: torch.Tensor, k: int) -> torch.Tensor:
+    if t.shape[1] == k:
+        return t.contiguous()
+    out = torch.zeros(t.shape[0], k, dtype=t.dtype, device=t.device)
+    out[:, :t.shape[1]] = t
+    return out
+
+
+def matmul3(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
+    """a [M, K] @ w [N, K]^T (+ bias), fp32 in and out, as three bf16 MFMA products with fp32 accumulation."""
+    if a.ndim != 2 or w.ndim != 2 or a.shape[1] != w.shape[1]:
+        raise CaraError("matmul3: a [M, K], w [N, K]")
+    K = (a.shape[1] + 63) // 64 * 64          # the GEMM's K granule; zero columns change nothing
+    ah, al = (_pad_k(t, K) for t in _split(a))
+    wh, wl = (_pad_k(t, K) for t in _split(w))
+    out = torch.empty(a.shape[0], w.shape[0], dtype=torch.float32, device=a.device)
+    b = bias.float().contiguous() if bias is not None else None
+    L.gemm(ah, wh, out, epi=L.EPI_F32, bias=b, B3=wl)                 # xh Wh^T + xh Wl^T (+ b): one launch, two K loops
+    L.gemm(al, wh, out, epi=L.EPI_RESID, aux=out)                     # + xl Wh^T through the residual epilogue
+    return out
+
+
+def _cp_dense(model, l: int, s: float):
+    """(dW_qkv [3 dim, dim], dW_proj [dim, dim], dW_fc1 [4 dim, dim], dW_fc2 [dim, 4 dim]) of block l, times s: the tensors
+    cp_to_tensor materialises in cara.py:26-34,51-56,76-80,88-91, laid out like the nn.Linear weights they are added to."""
+    dim = model.embed_dim
+    R1, R2 = model.CP_R1.float(), model.CP_R2.float()
+    A1, A2, A3, A4 = (getattr(model, "CP_A%d" % i).float() for i in (1, 2, 3, 4))
+    P1, P2, P3 = (getattr(model, "CP_P%d" % i).float() for i in (1, 2, 3))
+    qkv = torch.einsum("r,kr,er,hr,dr->khde", R1, A1[3 * l:3 * l + 3], A2, A3, A4).reshape(3 * dim, dim)   # row k dim + h 64 + d
+    proj = torch.einsum("r,jr,cr->jc", R2 * P1[9 * l], P2, P3)                                              # x @ T^T: weight = T
+    fc1 = torch.einsum("r,ar,jr,cr->ajc", R2, P1[9 * l + 1:9 * l + 5], P2, P3).reshape(4 * dim, dim)
+    fc2 = torch.einsum("r,ar,jr,cr->ajc", R2, P1[9 * l + 5:9 * l + 9], P2, P3).reshape(4 * dim, dim).t()    # h @ T: weight = T^T
+    return s * qkv, s * proj, s * fc1, s * fc2.contiguous()
+
+
+@torch.no_grad()
+def forward(model, images: torch.Tensor) -> torch.Tensor:
+    """Eval-mode logits of the adapted model (cp_length 4) with split-bf16 products.  fp32 [B, classes]."""
+    eng = model.__dict__.get("_cara_engine")
+    if eng is None:
+        raise CaraError("precise.forward needs a model adapted by cara_amd.cara()")
+    if eng.cp_length != 4:
+        raise CaraError("the bf16x3 parity mode covers the default tensorisation (cp_length 4)")
+    if not images.is_cuda:
+        raise CaraError("cara_amd runs on the GPU only (no CPU fallback)")
+    s = float(eng.scale)
+    dev = images.device
+    with torch.cuda.device(dev):
+        x = images.float()
+        B = x.shape[0]
+        pe = model.patch_embed.proj
+        p, dim = pe.kernel_size[0], model.embed_dim
+        g = x.shape[2] // p
+        # Conv2d(k = s = p) as a product over im2col rows (column order = the flattening of weight [dim, C, p, p])
+        patches = x.reshape(B, x.shape[1], g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(B * g * g, -1)
+        t = matmul3(patches, pe.weight.reshape(dim, -1), pe.bias).reshape(B, g * g, dim)
+        t = torch.cat([model.cls_token.float().expand(B, -1, -1), t], dim=1) + model.pos_embed.float()
+        N = t.shape[1]
+        for l, blk in enumerate(model.blocks):
+            dq, dp, d1, d2 = _cp_dense(model, l, s)
+            at, ml = blk.attn, blk.mlp
+            H = at.num_heads
+            hd = dim // H
+            y = F.layer_norm(t, (dim,), blk.norm1.weight.float(), blk.norm1.bias.float(), blk.norm1.eps).reshape(B * N, dim)
+            qkv = matmul3(y, at.qkv.weight.float() + dq, at.qkv.bias).reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+            ao = torch.empty(B, N, H, hd, device=dev)
+            for b in range(B):
+                for h in range(H):
+                    q, k, v = (qkv[i, b, h].contiguous() for i in range(3))
+                    pr = torch.softmax(matmul3(q, k) * float(at.scale), dim=-1)
+                    ao[b, :, h] = matmul3(pr, v.t().contiguous())
+            o = matmul3(ao.reshape(B * N, dim), at.proj.weight.float() + dp, at.proj.bias.float() + s * model.CP_bias1.float())
+            t = t + o.reshape(B, N, dim)
+            y = F.layer_norm(t, (dim,), blk.norm2.weight.float(), blk.norm2.bias.float(), blk.norm2.eps).reshape(B * N, dim)
+            u = matmul3(y, ml.fc1.weight.float() + d1, ml.fc1.bias.float() + s * model.CP_bias2.float())
+            o = matmul3(F.gelu(u), ml.fc2.weight.float() + d2, ml.fc2.bias.float() + s * model.CP_bias3.float())
+            t = t + o.reshape(B, N, dim)
+        t = F.layer_norm(t, (dim,), model.norm.weight.float(), model.norm.bias.float(), model.norm.eps)
+        return matmul3(t[:, 0].contiguous(), model.head.weight.float(), model.head.bias)

@@ -883,3 +883,31 @@ def test_flax_layout_npz_with_resized_position_embedding_at_384(tmp_path):
     r = rel(got, want)
     print(f"\nflax-layout npz @384 (resized position embedding) -> device: logits rel-L2 {r:.2e}")
     assert r <= T.LOGITS_ABS and torch.equal(got.argmax(1).cpu(), want.argmax(1))
+
+
+def test_bf16x3_precision_mode_meets_the_1e3_logit_tolerance():
+    """north_star: "within 1e-3 relative on bf16 logits".  The fast path sits at 5.5e-3 on this case because its MFMA
+    operands carry 8 significant bits; precision = "bf16x3" runs every product as three split-bf16
+    MFMA products with fp32 accumulation and fp32 activations (cara_amd/precise.py) and must land inside the stated
+    tolerance against the logits the REFERENCE's own cara.py produced (golden case 6: depth 2, 197 tokens, rank 16)."""
+    from tests.golden.inputs import oracle_case
+    R, depth, imgsz, sb, sc, sx, sg = G["d2_cfg"].tolist()
+    w, cp = oracle_case(sg, sb, sc, R, depth, imgsz)
+    m = build(w, cp, R, 0.1, depth, imgsz).eval()
+    img = torch.randn(2, 3, imgsz, imgsz, generator=torch.Generator().manual_seed(sx)).to(DEV)
+    ref = torch.from_numpy(G["d2_logits"])
+    with torch.no_grad():
+        fast = m(img)
+        m._cara_engine.precision = "bf16x3"
+        wide = m(img)
+        m._cara_engine.precision = "bf16"
+    r_fast, r_wide = rel(fast, ref), rel(wide, ref)
+    print(f"\ndepth-2 golden logits vs the reference's fp32 output: bf16 fast path {r_fast:.2e}, bf16x3 {r_wide:.2e}")
+    assert r_wide <= 1.0e-3, r_wide                    # north_star's number, met by construction
+    assert r_wide < 0.1 * r_fast                       # ... and it is the operand width that does it
+    assert torch.equal(wide.argmax(1).cpu(), ref.argmax(1))
+    # a training forward is never routed there
+    m.train()
+    m._cara_engine.precision = "bf16x3"
+    out = m(img)
+    assert out.requires_grad
