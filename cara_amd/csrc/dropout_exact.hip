@@ -74,98 +74,140 @@ __device__ __forceinline__ float slab_sum(const float* __restrict__ dW, size_t e
   return g;
 }
 
+// Both contractions in ONE pass over dW.  A workgroup owns a 64 x 64 tile of dW: it sums the split-K slabs, applies the
+// regenerated mask and leaves the masked fp32 tile in LDS next to the tile's 64 rows of U and of Vs; every thread then
+// forms 8 outputs of each contraction (a row of the tile against 8 columns of U, a column against 8 columns of Vs) and the
+// tile's partial sums go to scratch -- dVs partials [in / 64][out][RP], dU partials [out / 64][in][RP] -- which
+// reduce_chunks_kernel adds in fixed order.  (The two separate passes read every slab twice, hashed every element twice and
+// ran at 1 TB/s: 72 us per linear at the headline shape, a seventh of the exact-mode step.)
 template <int RP>
-__global__ __launch_bounds__(256) void contract_rows_kernel(const float* __restrict__ dW, int nslab, size_t slab_stride,
-                                                            const bf16* __restrict__ U, float* __restrict__ dVs,
-                                                            int out, int in, unsigned seed, unsigned lin, unsigned thresh, float inv_keep) {
-  const int lane = threadIdx.x & 63, o = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (o >= out) return;
-  float acc[RP];
+__global__ __launch_bounds__(256) void contract_tile_kernel(const float* __restrict__ dW, int nslab, size_t slab_stride,
+                                                            const bf16* __restrict__ U, const bf16* __restrict__ Vs,
+                                                            float* __restrict__ pV, float* __restrict__ pU, int out, int in,
+                                                            unsigned seed, unsigned lin, unsigned thresh, float inv_keep) {
+  __shared__ float g[64][65];
+  __shared__ __attribute__((aligned(16))) float us[64][RP + 4];
+  __shared__ __attribute__((aligned(16))) float vs[64][RP + 4];
+  const int t = threadIdx.x;
+  const int i0 = blockIdx.x * 64, o0 = blockIdx.y * 64;
+  // the masked tile: thread -> row idx / 16, four consecutive columns
 #pragma unroll
-  for (int r = 0; r < RP; ++r) acc[r] = 0.f;
-  for (int i = lane; i < in; i += 64) {
-    const size_t e = (size_t)o * in + i;
-    const float k = keep_scale((unsigned)e, seed, lin, thresh, inv_keep);
-    const float g = k != 0.f ? slab_sum(dW, e, nslab, slab_stride) * k : 0.f;
-    if (g != 0.f) {
-#pragma unroll
-      for (int r = 0; r < RP; r += 8) {
-        const bf16x8 u = *reinterpret_cast<const bf16x8*>(U + (size_t)i * RP + r);
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) acc[r + kk] += g * (float)u[kk];
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < RP; ++r) {
-    const float s = wave_sum(acc[r]);
-    if (lane == 0) dVs[(size_t)o * RP + r] = s;
-  }
-}
-
-// dU[i,:] = sum_o m dW[o,i] Vs[o,:]: workgroup (x, y) owns 64 columns and the y-th of gridDim.y row chunks; thread
-// (column t%64, row group t/64) walks its rows with stride 4 (coalesced 256-byte row segments); the 4 row groups
-// are summed through LDS and the chunk's partial goes to scratch [chunk][in][RP]; reduce_chunks_kernel adds the
-// chunks in fixed order.
-constexpr int ROW_CHUNKS = 16;
-template <int RP>
-__global__ __launch_bounds__(256) void contract_cols_kernel(const float* __restrict__ dW, int nslab, size_t slab_stride,
-                                                            const bf16* __restrict__ Vs, float* __restrict__ scratch,
-                                                            int out, int in, unsigned seed, unsigned lin, unsigned thresh, float inv_keep) {
-  __shared__ float part[4][64][RP + 1];
-  const int ic = threadIdx.x & 63, og = threadIdx.x >> 6, i = blockIdx.x * 64 + ic;
-  const int per = (out + gridDim.y - 1) / gridDim.y, o_begin = blockIdx.y * per, o_end = min(out, o_begin + per);
-  float acc[RP];
-#pragma unroll
-  for (int r = 0; r < RP; ++r) acc[r] = 0.f;
-  if (i < in) {
-    for (int o = o_begin + og; o < o_end; o += 4) {
+  for (int k = 0; k < 4; ++k) {
+    const int idx = t + k * 256, r = idx >> 4, c = (idx & 15) * 4;
+    const int o = o0 + r, i = i0 + c;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (o < out) {
       const size_t e = (size_t)o * in + i;
-      const float k = keep_scale((unsigned)e, seed, lin, thresh, inv_keep);
-      const float g = k != 0.f ? slab_sum(dW, e, nslab, slab_stride) * k : 0.f;
-      if (g != 0.f) {
+      if (i + 4 <= in && (in & 3) == 0) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(dW + e);
+        for (int sidx = 1; sidx < nslab; ++sidx) a += *reinterpret_cast<const f32x4*>(dW + e + sidx * slab_stride);
 #pragma unroll
-        for (int r = 0; r < RP; r += 8) {
-          const bf16x8 v = *reinterpret_cast<const bf16x8*>(Vs + (size_t)o * RP + r);   // wave-uniform address: broadcast
+        for (int j = 0; j < 4; ++j) v[j] = a[j] * keep_scale((unsigned)(e + j), seed, lin, thresh, inv_keep);
+      } else {
 #pragma unroll
-          for (int kk = 0; kk < 8; ++kk) acc[r + kk] += g * (float)v[kk];
-        }
+        for (int j = 0; j < 4; ++j)
+          if (i + j < in) v[j] = slab_sum(dW, e + j, nslab, slab_stride) * keep_scale((unsigned)(e + j), seed, lin, thresh, inv_keep);
       }
     }
-  }
 #pragma unroll
-  for (int r = 0; r < RP; ++r) part[og][ic][r] = acc[r];
+    for (int j = 0; j < 4; ++j) g[r][c + j] = v[j];
+  }
+  for (int idx = t; idx < 64 * (RP / 8); idx += 256) {
+    const int r = idx / (RP / 8), c = (idx % (RP / 8)) * 8;
+    bf16x8 a = {}, b = {};
+    if (i0 + r < in) a = *reinterpret_cast<const bf16x8*>(U + (size_t)(i0 + r) * RP + c);
+    if (o0 + r < out) b = *reinterpret_cast<const bf16x8*>(Vs + (size_t)(o0 + r) * RP + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      us[r][c + j] = (float)a[j];
+      vs[r][c + j] = (float)b[j];
+    }
+  }
   __syncthreads();
-  float* dst = scratch + (size_t)blockIdx.y * in * RP;
-  for (int idx = threadIdx.x; idx < 64 * RP; idx += 256) {
-    const int r = idx % RP, c = idx / RP;
-    if (blockIdx.x * 64 + c < in)
-      dst[(size_t)(blockIdx.x * 64 + c) * RP + r] = ((part[0][c][r] + part[1][c][r]) + part[2][c][r]) + part[3][c][r];
+  // outputs: thread -> (row / column q, 8 of the RP columns starting at r0), RP / 8 threads per q, 256 / (RP / 8) q per pass
+  constexpr int TPQ = RP / 8, QPP = 256 / TPQ;
+  const int r0 = (t % TPQ) * 8;
+#pragma unroll
+  for (int pass = 0; pass < 64 / QPP; ++pass) {
+    const int q = pass * QPP + t / TPQ;
+    float av[8] = {}, au[8] = {};
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) {
+      const float gv = g[q][k], gu = g[k][q];      // dVs: row q against U rows k; dU: column q against Vs rows k
+      const f32x4 u0 = *reinterpret_cast<const f32x4*>(&us[k][r0]), u1 = *reinterpret_cast<const f32x4*>(&us[k][r0 + 4]);
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&vs[k][r0]), v1 = *reinterpret_cast<const f32x4*>(&vs[k][r0 + 4]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        av[j] += gv * u0[j]; av[4 + j] += gv * u1[j];
+        au[j] += gu * v0[j]; au[4 + j] += gu * v1[j];
+      }
+    }
+    if (o0 + q < out) {
+      float* d = pV + ((size_t)blockIdx.x * out + o0 + q) * RP + r0;
+      *reinterpret_cast<f32x4*>(d) = f32x4{av[0], av[1], av[2], av[3]};
+      *reinterpret_cast<f32x4*>(d + 4) = f32x4{av[4], av[5], av[6], av[7]};
+    }
+    if (i0 + q < in) {
+      float* d = pU + ((size_t)blockIdx.y * in + i0 + q) * RP + r0;
+      *reinterpret_cast<f32x4*>(d) = f32x4{au[0], au[1], au[2], au[3]};
+      *reinterpret_cast<f32x4*>(d + 4) = f32x4{au[4], au[5], au[6], au[7]};
+    }
   }
 }
 
 // out[j] = sum over `chunks` partial arrays of n floats each (fixed order)
+// (four interleaved partial sums keep four loads in flight per thread; the order is fixed: (s0 + s1) + (s2 + s3))
 __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restrict__ scratch, int chunks, size_t n, float* __restrict__ out) {
   const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
-  float s = scratch[j];
-  for (int c = 1; c < chunks; ++c) s += scratch[(size_t)c * n + j];
-  out[j] = s;
+  const float* p = scratch + j;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = 0;
+  for (; c + 4 <= chunks; c += 4) {
+    s0 += p[(size_t)c * n];
+    s1 += p[(size_t)(c + 1) * n];
+    s2 += p[(size_t)(c + 2) * n];
+    s3 += p[(size_t)(c + 3) * n];
+  }
+  if (c < chunks) s0 += p[(size_t)c * n];
+  if (c + 1 < chunks) s1 += p[(size_t)(c + 1) * n];
+  if (c + 2 < chunks) s2 += p[(size_t)(c + 2) * n];
+  out[j] = (s0 + s1) + (s2 + s3);
 }
 
-// column sums of a bf16 [M, ld] matrix (dc = sum_m dY): workgroup (x, y) owns 64 columns and the y-th row chunk,
-// 4 row groups summed in fixed order into scratch [chunk][N]; reduce_chunks_kernel finishes
+// column sums of a bf16 [M, ld] matrix (dc = sum_m dY): workgroup (x, y) owns 256 columns and the y-th row chunk; a wave
+// reads 128 columns of a row pair per instruction (16 bytes per lane: lanes 0..15 one row, 16..31 the next, ...), its four
+// row phases and the workgroup's four waves are summed in fixed order into scratch [chunk][N]; reduce_chunks_kernel
+// finishes.  (The first form read two bytes per lane: 32 us for 19 - 77 MB.)
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X, int ld, int M, int N, float* __restrict__ scratch) {
-  __shared__ float part[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  __shared__ float part[4][4][256];   // [wave][row phase][column]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cl = (lane & 31) * 8, rp = lane >> 5;           // 32 lanes x 8 columns = 256 columns; two rows per instruction
+  const int c0 = blockIdx.x * 256 + cl;
   const int per = (M + gridDim.y - 1) / gridDim.y, m_begin = blockIdx.y * per, m_end = min(M, m_begin + per);
-  float s = 0.f;
-  if (c < N)
-    for (int m = m_begin + g; m < m_end; m += 4) s += (float)X[(size_t)m * ld + c];
-  part[g][threadIdx.x & 63] = s;
+  float s[8] = {};
+  const bool vec = c0 + 8 <= N && (ld & 7) == 0;
+  for (int m = m_begin + wave * 2 + rp; m < m_end; m += 8) {
+    if (vec) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (size_t)m * ld + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (c0 + j < N) s[j] += (float)X[(size_t)m * ld + c0 + j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[wave][rp][cl + j] = s[j];
   __syncthreads();
-  if (g == 0 && c < N)
-    scratch[(size_t)blockIdx.y * N + c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < N) {
+    float tsum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) tsum += part[w][0][threadIdx.x] + part[w][1][threadIdx.x];
+    scratch[(size_t)blockIdx.y * N + c] = tsum;
+  }
 }
 
 bool mask_params(float p, unsigned* thresh, float* inv_keep) {
@@ -197,7 +239,11 @@ extern "C" int cara_materialize_merge(const void* W, const void* U, const void* 
   return CARA_OK;
 }
 
-extern "C" size_t cara_dropout_grad_scratch_bytes(int in, int Rp) { return (size_t)ROW_CHUNKS * in * Rp * sizeof(float); }
+// dVs partials [ceil(in / 64)][out][Rp] + dU partials [ceil(out / 64)][in][Rp], fp32
+extern "C" size_t cara_dropout_grad_scratch_bytes(int out, int in, int Rp) {
+  if (out <= 0 || in <= 0 || Rp <= 0) return 0;
+  return ((size_t)((in + 63) / 64) * out + (size_t)((out + 63) / 64) * in) * Rp * sizeof(float);
+}
 
 extern "C" int cara_dropout_grad_contract(const float* dW, int nslab, size_t slab_stride, const void* U, const void* Vs, int Rp, int out,
                                           int in, float p, unsigned seed, unsigned linear_id, float* dU, float* dVs, void* scratch,
@@ -209,28 +255,31 @@ extern "C" int cara_dropout_grad_contract(const float* dW, int nslab, size_t sla
     return CARA_E_ARG;
   if ((unsigned long long)out * in >= (1ull << 32)) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  float* sc = static_cast<float*>(scratch);
-  const dim3 gc((in + 63) / 64, ROW_CHUNKS);
-  if (Rp == 32) {
-    hipLaunchKernelGGL(contract_rows_kernel<32>, dim3((out + 3) / 4), dim3(256), 0, st, dW, nslab, slab_stride, (const bf16*)U, dVs, out, in, seed, linear_id, thresh, inv_keep);
-    hipLaunchKernelGGL(contract_cols_kernel<32>, gc, dim3(256), 0, st, dW, nslab, slab_stride, (const bf16*)Vs, sc, out, in, seed, linear_id, thresh, inv_keep);
-  } else {
-    hipLaunchKernelGGL(contract_rows_kernel<64>, dim3((out + 3) / 4), dim3(256), 0, st, dW, nslab, slab_stride, (const bf16*)U, dVs, out, in, seed, linear_id, thresh, inv_keep);
-    hipLaunchKernelGGL(contract_cols_kernel<64>, gc, dim3(256), 0, st, dW, nslab, slab_stride, (const bf16*)Vs, sc, out, in, seed, linear_id, thresh, inv_keep);
-  }
-  const size_t n = (size_t)in * Rp;
-  hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc, ROW_CHUNKS, n, dU);
+  const int ti = (in + 63) / 64, to = (out + 63) / 64;
+  float* pV = static_cast<float*>(scratch);               // [ti][out][Rp]
+  float* pU = pV + (size_t)ti * out * Rp;                  // [to][in][Rp]
+  const dim3 grid(ti, to);
+  if (Rp == 32)
+    hipLaunchKernelGGL(contract_tile_kernel<32>, grid, dim3(256), 0, st, dW, nslab, slab_stride, (const bf16*)U, (const bf16*)Vs, pV, pU, out, in, seed, linear_id, thresh, inv_keep);
+  else
+    hipLaunchKernelGGL(contract_tile_kernel<64>, grid, dim3(256), 0, st, dW, nslab, slab_stride, (const bf16*)U, (const bf16*)Vs, pV, pU, out, in, seed, linear_id, thresh, inv_keep);
+  const size_t nv = (size_t)out * Rp, nu = (size_t)in * Rp;
+  hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, pV, ti, nv, dVs);
+  hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, pU, to, nu, dU);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }
 
-extern "C" size_t cara_colsum_scratch_bytes(int N) { return (size_t)32 * N * sizeof(float); }
+extern "C" size_t cara_colsum_scratch_bytes(int N) { return (size_t)256 * N * sizeof(float); }
 
 extern "C" int cara_colsum_bf16(const void* X, int ld, int M, int N, float* out, void* scratch, void* stream) {
   if (!X || !out || !scratch || M <= 0 || N <= 0 || ld < N) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int chunks = M >= 2048 ? 32 : (M >= 256 ? 8 : 1);
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, (const bf16*)X, ld, M, N, static_cast<float*>(scratch));
+  // enough blocks to fill the chip: (N / 256 column groups) x chunks >= ~512; scratch holds up to 256 chunk rows
+  int chunks = M >= 256 ? (512 * 256 + N - 1) / N : 1;
+  chunks = chunks > 256 ? 256 : chunks;
+  while (chunks > 1 && M / chunks < 16) chunks >>= 1;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, chunks), dim3(256), 0, st, (const bf16*)X, ld, M, N, static_cast<float*>(scratch));
   hipLaunchKernelGGL(reduce_chunks_kernel, dim3((N + 255) / 256), dim3(256), 0, st, static_cast<const float*>(scratch), chunks, (size_t)N, out);
   CARA_CHECK_LAUNCH();
   return CARA_OK;

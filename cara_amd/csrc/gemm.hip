@@ -114,6 +114,27 @@ __device__ __forceinline__ void mma_tile32(const char* sA, const char* sB, f32x4
     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
 }
 
+// the same over TWO B tiles that share the A fragments: acc += A B^T + A B3^T (cara_gemm_args::B3)
+template <int MI>
+__device__ __forceinline__ void mma_tile32_2b(const char* sA, const char* sB, const char* sB3, f32x4 (&acc)[MI][4], int wr, int wc, int lane) {
+  const int fr = lane & 15, fq = lane >> 4;
+  bf16x8 a[MI], b[4], b3[4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sA + swz32(wr * (MI * 16) + i * 16 + fr, fq));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    b[j] = *reinterpret_cast<const bf16x8*>(sB + swz32(wc * 64 + j * 16 + fr, fq));
+    b3[j] = *reinterpret_cast<const bf16x8*>(sB3 + swz32(wc * 64 + j * 16 + fr, fq));
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b3[j], acc[i][j], 0, 0, 0);
+    }
+}
+
 // extension operands [rows, Rp] into 64-byte-row images, one image per 32 columns of Rp
 template <int ROWS, int NW = 4>
 __device__ __forceinline__ void stage_ext32(const bf16* __restrict__ P, int Rp, int r0, int rmax, int kk, char* lds_tile, int tid) {
@@ -130,13 +151,14 @@ __device__ __forceinline__ void stage_ext32(const bf16* __restrict__ P, int Rp, 
 // NW = waves per workgroup (NW/2 along M x 2 along N): 4, or 8 with MI = 2 for a 128-row tile made of
 // 32x64 wave tiles (more resident waves per CU)
 // one workgroup's tile; `block` = its index among the nwg tiles of the product, `zb` = product index of a batched launch
-// TWOB: the K loop runs twice, over B and then over B3 (cara_gemm_args::B3: same shape and ldb), A re-staged
+// TWOB: every K step stages B AND B3 (cara_gemm_args::B3: same shape and ldb) next to the A tile and runs both products on
+// the same A fragments (24 KiB slots: three workgroups per CU; the first form ran the K loop twice and staged A twice)
 template <int EPI, int MI, int NW, bool TWOB = false>
 __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int tiles_n, const int nwg, const int gm,
                                             const int block, const size_t zb_in, char* smem) {
   constexpr int TBM = MI * 16 * (NW / 2);
   constexpr int A_BYTES = TBM * BK32 * 2;
-  constexpr int SLOT = A_BYTES + B32_BYTES;
+  constexpr int SLOT = A_BYTES + (TWOB ? 2 : 1) * B32_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   STAMP(0);
@@ -205,21 +227,20 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
       cur ^= 1;
     }
   } else {
-    // steps 0 .. nk-1 over B, nk .. 2nk-1 over B3 (same row offsets: same shape and ldb; only the base pointer, a scalar,
-    // changes), A staged again from its first K step
+    // B3 has B's shape and ldb: the same row offsets, only the base pointer (a scalar) differs
     const bf16* __restrict__ B3 = static_cast<const bf16*>(p.B3);
-    for (int kt = 0; kt < 2 * nk; ++kt) {
+    stage_tile32_pre<BN, NW>(B3, 0, oB, smem + A_BYTES + B32_BYTES, uwave);
+    for (int kt = 0; kt < nk; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       char* sA = smem + cur * SLOT;
-      if (kt + 1 < 2 * nk) {
+      if (kt + 1 < nk) {
         char* nA = smem + (cur ^ 1) * SLOT;
-        const int kn = kt + 1, kk = kn < nk ? kn : kn - nk;
-        const bf16* __restrict__ Bn = kn < nk ? B : B3;
-        stage_tile32_pre<TBM, NW>(A, kk * kmulA, oA, nA, uwave);
-        stage_tile32_pre<BN, NW>(Bn, kk * kmulB, oB, nA + A_BYTES, uwave);
+        stage_tile32_pre<TBM, NW>(A, (kt + 1) * kmulA, oA, nA, uwave);
+        stage_tile32_pre<BN, NW>(B, (kt + 1) * kmulB, oB, nA + A_BYTES, uwave);
+        stage_tile32_pre<BN, NW>(B3, (kt + 1) * kmulB, oB, nA + A_BYTES + B32_BYTES, uwave);
       }
-      mma_tile32<MI>(sA, sA + A_BYTES, acc, wr, wc, lane);
+      mma_tile32_2b<MI>(sA, sA + A_BYTES, sA + A_BYTES + B32_BYTES, acc, wr, wc, lane);
       cur ^= 1;
     }
   }
@@ -291,7 +312,7 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
 // (the 160-row tile with an epilogue that reads a second operand and no riding products -- not a product of the model -- would spill
 // a few registers at four workgroups per CU: it gets three)
 template <int EPI, bool TWOB = false, int MI = 4>
-__global__ __launch_bounds__(256, (MI == 5 && (EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU)) ? 3 : 4) void gemm32_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
+__global__ __launch_bounds__(256, (TWOB || (MI == 5 && (EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU))) ? 3 : 4) void gemm32_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   gemm32_body<EPI, MI, 4, TWOB>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
 }
@@ -604,7 +625,8 @@ int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr
   // 9.22 -> 9.08 and 9.37 -> 9.28 ms per step on two boxes; for the N = 768 products, whose 594 / 474 tiles are a single
   // round either way, it made no difference in the step and stays off)
   static const int bm = [] { const char* e = getenv("CARA_GEMM_BM"); return e ? atoi(e) : 160; }();
-  if (bm == 160 && a->N >= 3072 && a->M > 1024 && a->batch <= 1 && !a->B3) {
+  static const int bm_minn = [] { const char* e = getenv("CARA_GEMM_BM_MINN"); return e ? atoi(e) : 3072; }();   // A/B: 2304 adds qkv forward
+  if (bm == 160 && a->N >= bm_minn && a->M > 1024 && a->batch <= 1 && !a->B3) {
     constexpr int LDS160 = 2 * (160 * BK32 * 2 + B32_BYTES);
     const int nwg5 = ((a->M + 159) / 160) * tiles_n;
     if (ts) {
@@ -634,7 +656,7 @@ int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr
     return CARA_OK;
   }
   const int nb = a->batch > 1 ? a->batch : 1;
-  if (a->B3) hipLaunchKernelGGL((gemm32_kernel<EPI, true>), dim3(nwg, nb), dim3(256), GEMM_LDS, st, *a, tiles_n, nwg, gm);
+  if (a->B3) hipLaunchKernelGGL((gemm32_kernel<EPI, true>), dim3(nwg, nb), dim3(256), GEMM_LDS + 2 * B32_BYTES, st, *a, tiles_n, nwg, gm);
   else hipLaunchKernelGGL((gemm32_kernel<EPI>), dim3(nwg, nb), dim3(256), GEMM_LDS, st, *a, tiles_n, nwg, gm);
   CARA_CHECK_LAUNCH();
   return CARA_OK;

@@ -126,7 +126,7 @@ bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
     w->dYt = c.take((size_t)4 * D * w->ldk * 2);
     w->Xt = c.take((size_t)4 * D * w->ldk * 2);
     w->dWd = c.take((size_t)w->nslab * 4 * D * D * 4);
-    w->xscratch = c.take(max_sz(cara_dropout_grad_scratch_bytes((int)(4 * D), (int)Rp), cara_colsum_scratch_bytes((int)(4 * D))));
+    w->xscratch = c.take(max_sz(cara_dropout_grad_scratch_bytes((int)(4 * D), (int)D, (int)Rp), cara_colsum_scratch_bytes((int)(4 * D))));
   }
   w->total = c.off;
   return true;

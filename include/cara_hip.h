@@ -265,8 +265,8 @@ int cara_materialize_merge(const void* W, const void* U, const void* Vs, int Rp,
 /* From the dense weight gradient dW (= dY^T X, given as `nslab` split-K partial slabs of fp32 [out,in], slab_stride
  * floats apart, summed on the fly) to the skinny quantities cara_factor_grad_reduce takes:
  * dVs[o,r] = sum_i keep/(1-p) dW[o,i] U[i,r], dU[i,r] = sum_o keep/(1-p) dW[o,i] Vs[o,r] (fp32 [out,Rp] / [in,Rp],
- * overwritten, fixed summation order).  scratch: cara_dropout_grad_scratch_bytes(in, Rp).                    */
-size_t cara_dropout_grad_scratch_bytes(int in, int Rp);
+ * overwritten, fixed summation order; ONE pass over dW for both).  scratch: cara_dropout_grad_scratch_bytes(out, in, Rp). */
+size_t cara_dropout_grad_scratch_bytes(int out, int in, int Rp);
 int cara_dropout_grad_contract(const float* dW, int nslab, size_t slab_stride, const void* U, const void* Vs, int Rp,
                                int out, int in, float p, unsigned seed, unsigned linear_id, float* dU, float* dVs,
                                void* scratch, void* stream);

@@ -97,7 +97,7 @@ def test_dropout_grad_contract_and_colsum(out, inn, Rp, p):
     dVs = torch.full((out, Rp), float("nan"), device=DEV)
     # the dense gradient arrives as split-K slabs that the kernels sum: hand it over in three pieces
     slabs = torch.stack([0.5 * dW, 0.25 * dW, 0.25 * dW]).contiguous()
-    scratch = torch.empty(lib.cara_dropout_grad_scratch_bytes(inn, Rp), dtype=torch.uint8, device=DEV)
+    scratch = torch.empty(lib.cara_dropout_grad_scratch_bytes(out, inn, Rp), dtype=torch.uint8, device=DEV)
     L.check(lib.cara_dropout_grad_contract(L.ptr(slabs), 3, C.c_size_t(out * inn), L.ptr(U), L.ptr(Vs), Rp, out, inn, C.c_float(p), 11, 5,
                                            L.ptr(dU), L.ptr(dVs), L.ptr(scratch), L.stream()), "contract")
     keep = torch.from_numpy(keep_mask(out, inn, p, seed=11, linear_id=5)).to(DEV)
