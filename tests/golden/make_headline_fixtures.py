@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Expected values of the two whole-model cases at the BASELINE.json sizes (ViT-B/16 depth 12, batch 64, 197 tokens:
+configs[1] rank 16 and configs[3] rank 64), computed ONCE in the build container by the CPU oracle's as-written fp32
+algorithm (oracle/cara_oracle.py, itself pinned to the reference by make_golden.py) and committed as small .npz files:
+
+    tests/golden/headline_b64_r16.npz, tests/golden/headline_b64_r64.npz
+        loss, logits [64, 100] (fp32 as written), logits_bf16_sim (the oracle with the device path's rounding points),
+        grad_<name> for the 12 CP tensors and the head, the DropPath multipliers that were used
+
+The GPU test (tests/test_model_gpu.py::test_headline_batch_64_whole_model) then needs no 100-second CPU forward +
+backward per rank on the GPU box.  Inputs are the seeded synthetic tensors of SURVEY 8d (oracle.synthetic_*), so the
+test regenerates them bit for bit.  Usage:  python tests/golden/make_headline_fixtures.py [16 64]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import cara_oracle as O  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def keep_masks(depth, B, seed=11):
+    """the same draw as tests/test_model_gpu.py::_keep"""
+    g = torch.Generator().manual_seed(seed)
+    rates = torch.linspace(0, 0.1, depth)
+    keep = (1 - rates).reshape(-1, 1, 1)
+    return ((keep + torch.rand(depth, 2, B, generator=g)).floor() / keep).float()
+
+
+def main():
+    ranks = [int(a) for a in sys.argv[1:]] or [16, 64]
+    B = 64
+    torch.set_num_threads(os.cpu_count() or 8)
+    w = O.synthetic_backbone()
+    x, y = O.synthetic_batch(batch=B)
+    keep = keep_masks(12, B)
+    head = {"weight": w["head.weight"], "bias": w["head.bias"]}
+    for rank in ranks:
+        t0 = time.time()
+        cp = O.synthetic_cp(rank=rank)
+        loss, logits, grads = O.train_step_as_written(x, y, w, cp, head, s=0.1, drop_path_keep=keep)
+        with torch.no_grad():
+            sim = O.vit_cara_forward(x, w, cp, s=0.1, drop_path_keep=keep, factored=True, bf16_sim=True)
+        out = {"loss": np.float64(loss.item()), "logits": logits.numpy(), "logits_bf16_sim": sim.numpy(), "droppath": keep.numpy(),
+               "rank": np.int64(rank), "batch": np.int64(B)}
+        for k, v in grads.items():
+            out["grad_" + k] = v.numpy()
+        path = os.path.join(HERE, f"headline_b64_r{rank}.npz")
+        np.savez_compressed(path, **out)
+        print(f"rank {rank}: loss {loss.item():.6f}, {os.path.getsize(path) / 1e6:.2f} MB, {time.time() - t0:.0f} s", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -540,10 +540,21 @@ def test_headline_batch_64_whole_model(rank):
     eng = m._cara_engine
     keep = _keep(12, B)
     loss = eng.train_step(x.to(DEV), y.to(DEV), None, droppath=keep.to(DEV))
-    head = {"weight": w["head.weight"], "bias": w["head.bias"]}
-    rloss, rlogits, gref = O.train_step_as_written(x, y, w, cp, head, s=0.1, drop_path_keep=keep)
+    # expected values: the CPU oracle's as-written fp32 train step on these very inputs, computed once in the build
+    # container (tests/golden/make_headline_fixtures.py: ~100 s of CPU per rank) and committed; recomputed here only if
+    # the fixture is missing
+    fx = os.path.join(os.path.dirname(__file__), "golden", f"headline_b64_r{rank}.npz")
+    if os.path.exists(fx):
+        F_ = np.load(fx)
+        assert torch.equal(torch.from_numpy(F_["droppath"]), keep)          # same masks as the fixture was made with
+        rloss, rlogits, sim = torch.tensor(float(F_["loss"])), torch.from_numpy(F_["logits"]), torch.from_numpy(F_["logits_bf16_sim"])
+        gref = {k[len("grad_"):]: torch.from_numpy(F_[k]) for k in F_.files if k.startswith("grad_")}
+    else:
+        head = {"weight": w["head.weight"], "bias": w["head.bias"]}
+        rloss, rlogits, gref = O.train_step_as_written(x, y, w, cp, head, s=0.1, drop_path_keep=keep)
+        with torch.no_grad():
+            sim = O.vit_cara_forward(x, w, cp, s=0.1, drop_path_keep=keep, factored=True, bf16_sim=True)
     with torch.no_grad():
-        sim = O.vit_cara_forward(x, w, cp, s=0.1, drop_path_keep=keep, factored=True, bf16_sim=True)
         logits = eng.forward(x.to(DEV), droppath=keep.to(DEV))
     r_ref, r_model = rel(logits, rlogits), rel(sim, rlogits)
     worst = max(rel(getattr(m, n).grad, gref[n]) for n in O.CP_NAMES)
