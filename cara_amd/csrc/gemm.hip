@@ -772,6 +772,150 @@ extern "C" int cara_pack_b_panels(const void* B, int ldb, int N, int K, void* ou
   return CARA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// C[z][m, n] (fp32) = sum over the rows k of slab z of At[k, m] * Bt[k, n]: the dense weight gradient dW = dY^T X of the exact
+// weight-dropout mode straight from the ROW-MAJOR activations (At = dY [K = tokens, M = out], Bt = X [tokens, N = in]),
+// split over `nslab` row ranges.  Both MFMA operands have their k axis along the image ROWS, so a K step stages 32 rows x
+// 128 columns of each operand (rows of 256 B: whole cache lines, one-KiB LDS-DMA pieces of 4 rows) and every fragment is
+// two transposing LDS reads (ds_read_b64_tr_b16: a lane receives 8 consecutive k of its column).  Image swizzle: the 32-byte
+// chunk c of row r sits at chunk c ^ (r & 7) ^ (((r >> 3) & 1) << 2) -- the two 16-lane groups of a half wave read rows 8 fq ..
+// 8 fq + 3 of one logical chunk and land on eight different physical chunks, 256 B = all 64 banks.  Replaces two
+// activation-sized transposes (16-byte tiles through LDS, a read and a write of every activation) plus their pad memsets per
+// linear: 143 us per block at the headline shape.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ int tn_swz(int r) { return (r & 7) ^ (((r >> 3) & 1) << 2); }
+
+__global__ __launch_bounds__(256, 4) void gemm_tn_kernel(const bf16* __restrict__ At, const int lda, const bf16* __restrict__ Bt, const int ldb,
+                                                         const cara_gemm_args p, const int K, const int kslab, const size_t slab_stride,
+                                                         const int tiles_n, const int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int IMG = 32 * 256, SLOT = 2 * IMG;   // one operand image: 32 rows x 128 columns bf16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int k_begin = blockIdx.y * kslab;
+  const int k_end = k_begin + kslab < K ? k_begin + kslab : K;
+  // staging: wave w issues pieces w, w + 4 of each image (piece = 4 rows); lane -> row l >> 4 of the piece, physical 16-byte
+  // slot l & 15; the source column comes from the swizzle (an involution)
+  unsigned offA[2], offB[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = (wave + 4 * t) * 4 + (lane >> 4);
+    const int pc = (lane & 15) >> 1, half = lane & 1;
+    const int col = ((pc ^ tn_swz(row)) << 4) + half * 8;
+    offA[t] = (unsigned)row * (unsigned)(lda * 2) + (unsigned)((m0 + col) * 2);
+    offB[t] = (unsigned)row * (unsigned)(ldb * 2) + (unsigned)((n0 + col) * 2);
+  }
+  auto stage = [&](int k0, char* dst) {
+    // rows beyond k_end - 1 are clamped (their products are masked out of the A fragments below)
+    const char* a = reinterpret_cast<const char*>(At);
+    const char* b = reinterpret_cast<const char*>(Bt);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = (wave + 4 * t) * 4 + (lane >> 4);
+      const int over = k0 + row - (k_end - 1);
+      const size_t ka = (size_t)(over > 0 ? k0 - over : k0);      // per-lane clamp of the row index to k_end - 1
+      glds16(a + ka * (size_t)(lda * 2) + offA[t], dst + (uwave + 4 * t) * 1024);
+      glds16(b + ka * (size_t)(ldb * 2) + offB[t], dst + IMG + (uwave + 4 * t) * 1024);
+    }
+  };
+  // fragment addresses inside an image: row 8 fq + (fr >> 2) (+ 4 for the second read), logical 32-byte chunk = the 16-column
+  // tile index, 8-byte piece fr & 3
+  int ofs_lo[8], ofs_hi[8];   // [column tile 0..7 of the 128 columns]
+  {
+    const int rlo = fq * 8 + (fr >> 2), rhi = rlo + 4;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      ofs_lo[c] = rlo * 256 + ((c ^ tn_swz(rlo)) << 5) + (fr & 3) * 8;
+      ofs_hi[c] = rhi * 256 + ((c ^ tn_swz(rhi)) << 5) + (fr & 3) * 8;
+    }
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = (k_end - k_begin + 31) / 32;
+  if (nk > 0) stage(k_begin, smem);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const char* sA = smem + cur * SLOT;
+    const char* sB = sA + IMG;
+    if (kt + 1 < nk) stage(k_begin + (kt + 1) * 32, smem + (cur ^ 1) * SLOT);
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = wr * 4 + i;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(sA + ofs_lo[c]));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(sA + ofs_hi[c]));
+      const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+      a[i] = bf16x8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = wc * 4 + j;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(sB + ofs_lo[c]));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(sB + ofs_hi[c]));
+      const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+      b[j] = bf16x8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+    }
+    const int kbase = k_begin + kt * 32;
+    if (kbase + 32 > k_end) {   // last, partial step of the slab (wave-uniform): rows >= k_end contribute nothing
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+          if (kbase + fq * 8 + jj >= k_end) a[i][jj] = (bf16)0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    cur ^= 1;
+  }
+  // epilogue: two 32-row halves through a wave-private [32][64] fp32 image, 16-byte stores
+  __syncthreads();
+  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+  const size_t coff = (size_t)blockIdx.y * slab_stride;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg[(i * 16 + fq * 4 + r) * 64 + j * 16 + fr] = acc[half * 2 + i][j][r];
+    asm volatile("" ::: "memory");
+    epilogue_rows<CARA_EPI_F32, 32>(p, stg, m0 + wr * 64 + half * 32, n0 + wc * 64, lane, coff);
+    asm volatile("" ::: "memory");
+  }
+}
+}  // namespace
+
+extern "C" int cara_gemm_tn_f32(const void* At, int lda, const void* Bt, int ldb, float* C, int ldc, int M, int N, int K, int nslab,
+                                size_t slab_stride, void* stream) {
+  if (!At || !Bt || !C || M <= 0 || N <= 0 || K <= 0 || nslab <= 0 || nslab > 65535) return CARA_E_ARG;
+  if ((M % 128) || (N % 128) || lda < M || ldb < N || (lda & 7) || (ldb & 7) || ldc < N || (ldc & 3)) return CARA_E_ARG;
+  if ((unsigned long long)K * lda * 2 >= (1ull << 32) || (unsigned long long)K * ldb * 2 >= (1ull << 32)) return CARA_E_ARG;
+  if (nslab > 1 && slab_stride < (size_t)M * ldc) return CARA_E_ARG;
+  const int kslab = ((K + nslab - 1) / nslab + 31) / 32 * 32;   // rows per slab, a multiple of the K step
+  if ((long long)kslab * (nslab - 1) >= K) return CARA_E_ARG;     // every slab must hold at least one row
+  cara_gemm_args p = {};
+  p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.epi = CARA_EPI_F32;
+  const int tiles_n = N / 128, nwg = (M / 128) * tiles_n;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(nwg, nslab), dim3(256), 2 * 2 * 32 * 256, static_cast<hipStream_t>(stream),
+                     static_cast<const bf16*>(At), lda, static_cast<const bf16*>(Bt), ldb, p, K, kslab, slab_stride, tiles_n, nwg);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
 static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* ts);
 extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) { return gemm_bf16_impl(a, stream, nullptr); }
 

@@ -380,20 +380,26 @@ int lin_bwd_exact(const Lin& L, const bf16* dY, const bf16* X, int Mr, int Rp, c
   const int ldk = W.ldk;
   if (want_dc)
     TRY(cara_colsum_bf16(dY, L.out, Mr, L.out, reinterpret_cast<float*>(ws + W.dc[L.slot]) + (size_t)layer * L.out, ws + W.xscratch, st));
-  if (ldk > Mr) {   // K of the dW product is Mr rounded up to 64: the pad columns of both transposes must be zero
-    if (hipMemset2DAsync(dYt + Mr, (size_t)ldk * 2, 0, (size_t)(ldk - Mr) * 2, L.out, hs) != hipSuccess) return CARA_E_LAUNCH;
-    if (hipMemset2DAsync(Xt + Mr, (size_t)ldk * 2, 0, (size_t)(ldk - Mr) * 2, L.in, hs) != hipSuccess) return CARA_E_LAUNCH;
-  }
-  TRY(cara_transpose_bf16_ld(dY, L.out, dYt, ldk, Mr, L.out, st));
-  TRY(cara_transpose_bf16_ld(X, L.in, Xt, ldk, Mr, L.in, st));
-  // split-K in one batched launch: slab z covers K columns [z * ldk/nslab, ...) of both transposes
+  // dW = dY^T X as split-K slabs.  Straight from the row-major activations through the transposing-read GEMM when the shapes
+  // allow (CARA_EXACT_TN=0: the first form -- two activation-sized transposes with zeroed pad columns, then one batched
+  // launch of the default GEMM over the transposed copies)
   const size_t slab_stride = (size_t)L.out * L.in;
   const int used = W.nslab;
-  cara_gemm_args d = {};
-  d.A = dYt; d.lda = ldk; d.B = Xt; d.ldb = ldk; d.M = L.out; d.N = L.in; d.K = ldk / used;
-  d.epi = CARA_EPI_F32; d.C = dWd; d.ldc = L.in;
-  d.batch = used; d.strideA = d.K; d.strideB = d.K; d.strideC = (long long)slab_stride;
-  TRY(cara_gemm_bf16(&d, st));
+  static const int use_tn = env_once("CARA_EXACT_TN", 1);
+  if (!(use_tn && cara_gemm_tn_f32(dY, L.out, X, L.in, dWd, L.in, L.out, L.in, Mr, used, slab_stride, st) == CARA_OK)) {
+    if (ldk > Mr) {   // K of the dW product is Mr rounded up to 64: the pad columns of both transposes must be zero
+      if (hipMemset2DAsync(dYt + Mr, (size_t)ldk * 2, 0, (size_t)(ldk - Mr) * 2, L.out, hs) != hipSuccess) return CARA_E_LAUNCH;
+      if (hipMemset2DAsync(Xt + Mr, (size_t)ldk * 2, 0, (size_t)(ldk - Mr) * 2, L.in, hs) != hipSuccess) return CARA_E_LAUNCH;
+    }
+    TRY(cara_transpose_bf16_ld(dY, L.out, dYt, ldk, Mr, L.out, st));
+    TRY(cara_transpose_bf16_ld(X, L.in, Xt, ldk, Mr, L.in, st));
+    // split-K in one batched launch: slab z covers K columns [z * ldk/nslab, ...) of both transposes
+    cara_gemm_args d = {};
+    d.A = dYt; d.lda = ldk; d.B = Xt; d.ldb = ldk; d.M = L.out; d.N = L.in; d.K = ldk / used;
+    d.epi = CARA_EPI_F32; d.C = dWd; d.ldc = L.in;
+    d.batch = used; d.strideA = d.K; d.strideB = d.K; d.strideC = (long long)slab_stride;
+    TRY(cara_gemm_bf16(&d, st));
+  }
   TRY(cara_dropout_grad_contract(dWd, used, slab_stride, L.U, L.Vs, Rp, L.out, L.in, s->wd_p, s->wd_seed, (unsigned)(4 * layer + L.slot),
                                  reinterpret_cast<float*>(ws + W.dU[L.slot]) + (size_t)layer * L.in * Rp,
                                  reinterpret_cast<float*>(ws + W.dVs[L.slot]) + (size_t)layer * L.out * Rp, ws + W.xscratch, st));

@@ -93,6 +93,14 @@ int cara_gemm_bf16(const cara_gemm_args* a, void* stream);
 int cara_pack_b_panels(const void* B, int ldb, int N, int K, void* out, void* stream);
 size_t cara_gemm_scratch_bytes(void);
 
+/* C[z] fp32 [M, ldc] = sum over the rows k of slab z of At[k, m] * Bt[k, n], z = 0 .. nslab - 1, slab z at C + z * slab_stride
+ * floats (rows [z * kslab, (z + 1) * kslab) with kslab = K / nslab rounded up to 32).  At bf16 [K, lda >= M], Bt bf16
+ * [K, ldb >= N], both ROW-major with the shared index k on the rows: dW = dY^T X (the dense weight gradient of the exact
+ * weight-dropout mode) from the activations as they are stored, without transposed copies.  M % 128 == N % 128 == 0,
+ * ld % 8 == 0, each operand < 4 GiB; CARA_E_ARG otherwise (callers then transpose and use cara_gemm_bf16).       */
+int cara_gemm_tn_f32(const void* At, int lda, const void* Bt, int ldb, float* C, int ldc, int M, int N, int K, int nslab,
+                     size_t slab_stride, void* stream);
+
 /* ---- skinny adapter contractions (HBM-bound) --------------------------------------------- */
 /* T[M,Rp] = X[M,K] * Ut[Rp,K]^T, bf16 out, also written transposed Tt[Rp,ldt] when Tt != NULL
  * (ldt >= M, multiple of 8).  Forward: T = X U; backward: G' = dY Vs.  K % 32 == 0.

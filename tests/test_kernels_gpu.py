@@ -308,6 +308,26 @@ def test_gemm_few_rows_split_k(M, N, K, Rp):
     close(dg, (acc - bias.double()) * ud.grad, 2 ** -8, 3e-3 * math.sqrt(K / 64), "few rows dgelu")
 
 
+@pytest.mark.parametrize("Kr,M,N,nslab", [(12608, 768, 768, 4), (12608, 3072, 768, 4), (12608, 768, 2304, 4), (1000, 256, 128, 1),
+                                          (333, 128, 384, 2), (64, 128, 128, 2)])
+def test_gemm_tn_from_row_major_operands(Kr, M, N, nslab):
+    """cara_gemm_tn_f32: C[z] = At[rows of slab z]^T Bt[rows of slab z] (dW = dY^T X) from ROW-major operands through
+    transposing LDS reads; the slabs sum to the full product, each slab matches its own row range, ragged last steps."""
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+    At, Bt = rnd(Kr, M + 8, seed=1), rnd(Kr, N + 16, seed=2)           # row strides larger than the widths
+    out = torch.full((nslab, M, N), float("nan"), dtype=torch.float32, device=DEV)
+    L().check(lib.cara_gemm_tn_f32(p(At), M + 8, p(Bt), N + 16, p(out), N, M, N, Kr, nslab, C.c_size_t(M * N), st()), "gemm_tn")
+    kslab = ((Kr + nslab - 1) // nslab + 31) // 32 * 32
+    for z in range(nslab):
+        a, b = At[z * kslab:(z + 1) * kslab, :M].double(), Bt[z * kslab:(z + 1) * kslab, :N].double()
+        close(out[z], a.t() @ b, 1e-5, 1e-3 * math.sqrt(kslab / 64), f"slab {z}")
+    close(out.double().sum(0), At[:, :M].double().t() @ Bt[:, :N].double(), 1e-5, 2e-3 * math.sqrt(Kr / 64), "sum of slabs")
+    # the same numbers as the transposed-copies route (cara_transpose_bf16_ld + batched cara_gemm_bf16) up to fp32 summation order
+    assert lib.cara_gemm_tn_f32(p(At), M + 8, p(Bt), N + 16, p(out), N, M - 8, N, Kr, nslab, C.c_size_t(M * N), st()) != 0   # M % 128
+    assert lib.cara_gemm_tn_f32(p(At), M + 8, p(Bt), N + 16, p(out), N, M, N, 32, 2, C.c_size_t(M * N), st()) != 0         # an empty slab
+
+
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,K,Rp", [(12608, 768, 32), (12608, 3072, 32), (197, 768, 64), (45, 2304, 32),
                                     (12608, 3072, 64), (12608, 2304, 64), (1001, 768, 64)])
