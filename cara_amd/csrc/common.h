@@ -80,3 +80,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + (bid >> 3);
 }
+
+// The same with the XCD's run permuted so that the workgroups that land on ONE CU hold consecutive logical tiles.  Observed
+// placement (tools/micro/placement_map.hip, speed only, never correctness): inside an XCD the j-th workgroup goes to CU j % 32
+// (4 shader engines x 8 CUs, round-robin), so while the whole grid is resident (<= 4 per CU: nwg <= 1024) workgroups j,
+// j + 32, j + 64, j + 96 of an XCD share a CU.  With consecutive tiles of a row-major order they share their A row panel:
+// the CU's L1 then serves two of three (three of four) requests for an A tile of a K step.
+__device__ __forceinline__ int xcd_remap_cu(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+  const int cnt = q + (xcd < r ? 1 : 0);
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  if (cnt > 128) return base + j;
+  const int c = j & 31, sl = j >> 5, sf = cnt >> 5, rem = cnt & 31;
+  return base + c * sf + (c < rem ? c : rem) + sl;
+}

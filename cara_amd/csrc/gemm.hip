@@ -167,7 +167,7 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
   // ~128 tiles an XCD keeps in flight touch about sqrt(128)+sqrt(128) operand panels instead of
   // 5 + tiles_n -- rocprofv3 FETCH_SIZE showed 9x re-fetch on the N = 3072 products with the plain
   // row-major order (their W panels alone exceed the XCD's 4 MiB L2).
-  const int tile = xcd_remap(block, nwg);
+  const int tile = gm < 0 ? xcd_remap_cu(block, nwg) : xcd_remap(block, nwg);   // (gm < 0: CARA_GEMM_CUSHARE, plain order)
   int tm, tn;
   if (gm <= 1) {
     tm = tile / tiles_n;
@@ -371,7 +371,7 @@ __device__ __forceinline__ void gemm32ft_body(const cara_gemm_args& p, const int
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int fr = lane & 15, fq = lane >> 4;
-  const int tile = xcd_remap(block, nwg);
+  const int tile = gm < 0 ? xcd_remap_cu(block, nwg) : xcd_remap(block, nwg);   // (gm < 0: CARA_GEMM_CUSHARE, plain order)
   int tm, tn;
   if (gm <= 1) {
     tm = tile / tiles_n;
@@ -548,7 +548,10 @@ static int group_m(int tiles_n) {
   // measured with rocprofv3 FETCH_SIZE (x2 gfx950 correction), per launch, plain order -> groups of 8:
   // fc1 fwd (24 column tiles) 224 -> 133 MB, fc2 bwd 297 -> 207 MB, but the 6-column products
   // 82 -> 113 MB and qkv (18 columns) flat: group only when there are many column tiles
-  return tiles_n >= 20 ? 8 : 1;
+  if (tiles_n >= 20) return 8;
+  // CARA_GEMM_CUSHARE=1: the narrow products (plain order) with the workgroups of a CU on consecutive tiles (xcd_remap_cu)
+  static const int cushare = [] { const char* e = getenv("CARA_GEMM_CUSHARE"); return e ? atoi(e) : 0; }();
+  return (cushare && tiles_n <= 8) ? -1 : 1;
 }
 
 // the transposed skinny products a GEMM launch can carry (cara_gemm_with_tskinny)
