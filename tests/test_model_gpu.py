@@ -922,3 +922,68 @@ def test_bf16x3_precision_mode_meets_the_1e3_logit_tolerance():
     m._cara_engine.precision = "bf16x3"
     out = m(img)
     assert out.requires_grad
+
+
+@pytest.mark.parametrize("rank,img,batch", [(48, 160, 3), (5, 96, 1), (33, 224, 2)])
+def test_odd_ranks_token_counts_and_batches(rank, img, batch):
+    """Shapes off the beaten path, whole model (depth 2) against the oracle: ranks that are no multiple of 16 and cross the
+    Rp = 32 / 64 boundary (5, 33, 48), token counts other than 197 (101 at 160 px, 37 at 96 px: the short-sequence attention
+    kernels, ragged row tiles everywhere), batch 1."""
+    from oracle import cara_oracle as O
+    depth = 2
+    w = O.synthetic_backbone(depth=depth, img=img)
+    cp = O.synthetic_cp(rank=rank, depth=depth)
+    x, y = O.synthetic_batch(batch=batch, img=img)
+    m = build(w, cp, rank, 0.1, depth, img).eval()
+    logits = m(x.to(DEV))
+    with torch.no_grad():
+        ref = O.vit_cara_forward(x, w, cp, s=0.1, depth=depth)
+        sim = O.vit_cara_forward(x, w, cp, s=0.1, depth=depth, factored=True, bf16_sim=True)
+    r_ref, r_model = rel(logits, ref), rel(sim, ref)
+    torch.nn.functional.cross_entropy(logits, y.to(DEV)).backward()
+    head = {"weight": w["head.weight"], "bias": w["head.bias"]}
+    _, _, gref = O.train_step_as_written(x, y, w, cp, head, s=0.1, depth=depth)
+    worst = max(rel(getattr(m, n).grad, gref[n]) for n in O.CP_NAMES)
+    print(f"\nrank {rank}, {img} px ({(img // 16) ** 2 + 1} tokens), batch {batch}: logits {r_ref:.2e} (rounding model {r_model:.2e}), worst CP gradient {worst:.2e}")
+    assert T.logits_ok(r_ref, r_model), (r_ref, r_model)
+    assert worst < T.CP_GRAD, worst
+
+
+def test_forward_and_backward_capture_into_a_hip_graph():
+    """include/cara_hip.h promises that cara_vit_forward / cara_vit_backward only enqueue work on the caller's stream (no
+    allocation, no synchronisation, no state): the pair must therefore capture into a hipGraph, and replaying the graph must
+    reproduce the eager results bitwise -- also after the parameters changed in place between replays."""
+    from oracle import cara_oracle as O
+    depth, B = 3, 4
+    w = O.synthetic_backbone(depth=depth)
+    cp = O.synthetic_cp(rank=16, depth=depth)
+    x, y = O.synthetic_batch(batch=B)
+    m = build(w, cp, 16, 0.1, depth, 224).train()
+    eng = m._cara_engine
+    keep = _keep(depth, B).to(DEV)
+    xd, yd = x.to(DEV), y.to(DEV)
+    eng.train_step(xd, yd, None, droppath=keep)                 # eager: ingests the weights, sizes workspace and grad buffers
+    want_loss = eng.train_step(xd, yd, None, droppath=keep).clone()
+    want = {n: getattr(m, n).grad.clone() for n in O.CP_NAMES}
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            loss = eng.train_step(xd, yd, None, droppath=keep)
+    torch.cuda.current_stream().wait_stream(side)
+    for n in O.CP_NAMES:
+        getattr(m, n).grad.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(loss, want_loss)
+    assert all(torch.equal(getattr(m, n).grad, want[n]) for n in O.CP_NAMES)
+    # parameters move in place (what an optimizer step does): the replay sees them
+    with torch.no_grad():
+        m.CP_P2.mul_(1.5)
+    g.replay()
+    torch.cuda.synchronize()
+    eager = eng.train_step(xd, yd, None, droppath=keep)
+    torch.cuda.synchronize()
+    assert torch.equal(loss, eager) and not torch.equal(loss, want_loss)
