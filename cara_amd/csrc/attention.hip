@@ -32,7 +32,17 @@ constexpr int HD = 64;        // head dim
 constexpr int NMAX = 224;     // 7 tiles of 32: the score rows of a wave fit in registers
 constexpr int NMAX_LONG = 608;  // 19 tiles: two [608][64] bf16 images + the row constants are 160 512 B of the 160 KiB
 
-__device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// Swizzle key of a row of a [rows][64] bf16 image (128-byte rows, eight 16-byte chunks): the BIT-REVERSED (row >> 1) & 7.
+// ds_read_b128 row fragments need the 8 even (and the 8 odd) rows of a 16-lane service group on different chunks: any
+// bijection of (row >> 1) & 7 does that.  The transposing reads (ds_read_b64_tr_b16: 32 lanes = rows R .. R + 3, four
+// consecutive chunks each) also need rows R and R + 2 -- the same 256-byte bank window -- on different 64-byte HALVES of their
+// rows: with the plain key their keys differ in bit 0 only and the two rows collide (2-way conflict on every transposing
+// read: SQ_LDS_BANK_CONFLICT was 26 % of SQ_LDS_IDX_ACTIVE); bit-reversed, keys of rows two apart always differ in bit 2.
+__device__ __forceinline__ int swzk(int row) {
+  const int t = (row >> 1) & 7;
+  return ((t & 1) << 2) | (t & 2) | (t >> 2);
+}
+__device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ swzk(row)) << 4); }
 // row of the 32x32 C/D layout held in register r of lane half h
 __device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -67,7 +77,7 @@ __device__ __forceinline__ bf16x8 tr_frag_rm(const char* img, int cbase, int bas
 
 // npad = N rounded up to a multiple of 32: the images hold npad rows (rows >= N duplicate row N-1)
 // Lane-constant byte offsets inside a 32-row block of a swizzled [rows][64] image (row stride 128 B): the swizzle
-// term ((row >> 1) & 7) only depends on the row's position inside its 32-row block, so the per-tile address of every
+// term swzk(row) only depends on the row's position inside its 32-row block, so the per-tile address of every
 // fragment is `block * 4096 + constant` -- computed once per kernel instead of ~10 VALU instructions per read
 // (rocprofv3 counted 2 300-2 450 VALU instructions per wave in these kernels, most of them address arithmetic
 // and mask selects: the matrix pipe was busy 8 % of a wave's life).
@@ -78,7 +88,7 @@ __device__ __forceinline__ RowOfs row_ofs(int lane) {
   const int ql = lane & 31, h = lane >> 5;
   RowOfs r;
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) r.o[ks] = ql * 128 + (((ks * 2 + h) ^ ((ql >> 1) & 7)) << 4);
+  for (int ks = 0; ks < 4; ++ks) r.o[ks] = ql * 128 + (((ks * 2 + h) ^ swzk(ql)) << 4);
   return r;
 }
 struct TrOfs {    // the two ds_read_b64_tr_b16 of tr_frag_rm(img, cbase = dt*32, base = block*32 + st*16)
@@ -94,8 +104,8 @@ __device__ __forceinline__ TrOfs tr_ofs(int lane) {
       const int rl = st * 16 + 4 * (g >> 1) + (i >> 2);
       const int chunk = ((dt * 32 + 16 * (g & 1)) >> 3) + ((i & 3) >> 1);
       const int sub = (i & 1) * 8;
-      t.lo[st][dt] = rl * 128 + ((chunk ^ ((rl >> 1) & 7)) << 4) + sub;
-      t.hi[st][dt] = (rl + 8) * 128 + ((chunk ^ (((rl + 8) >> 1) & 7)) << 4) + sub;
+      t.lo[st][dt] = rl * 128 + ((chunk ^ swzk(rl)) << 4) + sub;
+      t.hi[st][dt] = (rl + 8) * 128 + ((chunk ^ swzk(rl + 8)) << 4) + sub;
     }
   return t;
 }
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_persist_kernel(cons
     const int piece = isv ? q - 28 : q;
     const int row = piece * 8 + (lane >> 3);
     const int rr = row < N ? row : N - 1;
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const int c = (lane & 7) ^ swzk(row);
     kvoff[t] = (unsigned)rr * (unsigned)(ld * 2) + (unsigned)(c * 16) + (unsigned)((isv ? 2 : 1) * H * HD * 2);
     kvdst[t] = (unsigned)((isv ? IMG : 0) + piece * 1024);   // wave-uniform
   }
@@ -376,7 +386,7 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_persist_kernel(cons
     const int row = t * 8 + (lane >> 3);
     int gr = q0 + row;
     gr = gr < N ? gr : N - 1;
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const int c = (lane & 7) ^ swzk(row);
     qoff[t] = (unsigned)gr * (unsigned)(ld * 2) + (unsigned)(c * 16);
   }
   auto lds_of = [](const char* p) { return __builtin_amdgcn_readfirstlane((unsigned)(size_t)p); };   // LDS byte address
@@ -836,7 +846,7 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
   for (int t = 0; t < 4; ++t) {
     const int row = (wave + t * 7) * 8 + (lane >> 3);
     const int rr = row < N ? row : N - 1;
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const int c = (lane & 7) ^ swzk(row);
     off_qkv[t] = (unsigned)rr * (unsigned)(ld * 2) + (unsigned)(c * 16);
     off_o[t] = (unsigned)rr * (unsigned)(ldo * 2) + (unsigned)(c * 16);
   }
