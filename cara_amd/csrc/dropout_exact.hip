@@ -176,11 +176,11 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float* __restr
 }
 
 // column sums of a bf16 [M, ld] matrix (dc = sum_m dY): workgroup (x, y) owns 256 columns and the y-th row chunk; a wave
-// reads 128 columns of a row pair per instruction (16 bytes per lane: lanes 0..15 one row, 16..31 the next, ...), its four
-// row phases and the workgroup's four waves are summed in fixed order into scratch [chunk][N]; reduce_chunks_kernel
+// reads 256 columns of two rows per instruction (16 bytes per lane: lanes 0..31 one row, 32..63 the next); the two row
+// halves and the workgroup's four waves are summed in fixed order into scratch [chunk][N]; reduce_chunks_kernel
 // finishes.  (The first form read two bytes per lane: 32 us for 19 - 77 MB.)
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ X, int ld, int M, int N, float* __restrict__ scratch) {
-  __shared__ float part[4][4][256];   // [wave][row phase][column]
+  __shared__ float part[4][2][256];   // [wave][row of the instruction's pair][column]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cl = (lane & 31) * 8, rp = lane >> 5;           // 32 lanes x 8 columns = 256 columns; two rows per instruction
   const int c0 = blockIdx.x * 256 + cl;

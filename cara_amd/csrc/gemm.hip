@@ -829,13 +829,16 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_kernel(const bf16* __restrict_
   };
   // fragment addresses inside an image: row 8 fq + (fr >> 2) (+ 4 for the second read), logical 32-byte chunk = the 16-column
   // tile index, 8-byte piece fr & 3
-  int ofs_lo[8], ofs_hi[8];   // [column tile 0..7 of the 128 columns]
+  int oa_lo[4], oa_hi[4], ob_lo[4], ob_hi[4];   // this wave's four 16-column tiles of the A image (wr) and of the B image (wc)
   {
     const int rlo = fq * 8 + (fr >> 2), rhi = rlo + 4;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      ofs_lo[c] = rlo * 256 + ((c ^ tn_swz(rlo)) << 5) + (fr & 3) * 8;
-      ofs_hi[c] = rhi * 256 + ((c ^ tn_swz(rhi)) << 5) + (fr & 3) * 8;
+    for (int i = 0; i < 4; ++i) {
+      const int ca = wr * 4 + i, cb = wc * 4 + i;
+      oa_lo[i] = rlo * 256 + ((ca ^ tn_swz(rlo)) << 5) + (fr & 3) * 8;
+      oa_hi[i] = rhi * 256 + ((ca ^ tn_swz(rhi)) << 5) + (fr & 3) * 8;
+      ob_lo[i] = rlo * 256 + ((cb ^ tn_swz(rlo)) << 5) + (fr & 3) * 8;
+      ob_hi[i] = rhi * 256 + ((cb ^ tn_swz(rhi)) << 5) + (fr & 3) * 8;
     }
   }
   f32x4 acc[4][4];
@@ -855,17 +858,15 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_kernel(const bf16* __restrict_
     bf16x8 a[4], b[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int c = wr * 4 + i;
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(sA + ofs_lo[c]));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(sA + ofs_hi[c]));
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(sA + oa_lo[i]));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(sA + oa_hi[i]));
       const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
       a[i] = bf16x8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int c = wc * 4 + j;
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(sB + ofs_lo[c]));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(sB + ofs_hi[c]));
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(sB + ob_lo[j]));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(sB + ob_hi[j]));
       const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
       b[j] = bf16x8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
     }
