@@ -9,7 +9,8 @@ algorithm (oracle/cara_oracle.py, itself pinned to the reference by make_golden.
 
 The GPU test (tests/test_model_gpu.py::test_headline_batch_64_whole_model) then needs no 100-second CPU forward +
 backward per rank on the GPU box.  Inputs are the seeded synthetic tensors of SURVEY 8d (oracle.synthetic_*), so the
-test regenerates them bit for bit.  Usage:  python tests/golden/make_headline_fixtures.py [16 64]
+test regenerates them bit for bit.  Usage:  python tests/golden/make_headline_fixtures.py [16 64]   |   ... vitl
+(`vitl`: the expected values of the ViT-L/16 @384 parity test, tests/golden/vit_large_384_b2_r16.npz)
 """
 import os
 import sys
@@ -56,5 +57,31 @@ def main():
         print(f"rank {rank}: loss {loss.item():.6f}, {os.path.getsize(path) / 1e6:.2f} MB, {time.time() - t0:.0f} s", flush=True)
 
 
+def vit_large():
+    """tests/test_model_gpu.py::test_vit_large_384_against_oracle: ViT-L/16 @384 dimensioning, batch 2, rank 16, eval mode:
+    fp32 logits, bf16-rounded logits, gradients of the mean cross-entropy (60 s of CPU on the GPU box otherwise)."""
+    t0 = time.time()
+    dims = dict(depth=24, dim=1024, heads=16)
+    w = O.synthetic_backbone(img=384, **dims)
+    cp = O.synthetic_cp(rank=16, **dims)
+    x, y = O.synthetic_batch(batch=2, img=384)
+    head = {"weight": w["head.weight"], "bias": w["head.bias"]}
+    with torch.no_grad():
+        ref = O.vit_cara_forward(x, w, cp, s=0.1, depth=24, num_heads=16)
+        sim = O.vit_cara_forward(x, w, cp, s=0.1, depth=24, num_heads=16, factored=True, bf16_sim=True)
+    _, _, grads = O.train_step_as_written(x, y, w, cp, head, s=0.1, depth=24, num_heads=16)
+    out = {"logits": ref.numpy(), "logits_bf16_sim": sim.numpy()}
+    for k, v in grads.items():
+        if k != "head.bias":
+            out["grad_" + k] = v.numpy()
+    path = os.path.join(HERE, "vit_large_384_b2_r16.npz")
+    np.savez_compressed(path, **out)
+    print(f"ViT-L/16 @384: {os.path.getsize(path) / 1e6:.2f} MB, {time.time() - t0:.0f} s", flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["vitl"]:
+        torch.set_num_threads(os.cpu_count() or 8)
+        vit_large()
+    else:
+        main()

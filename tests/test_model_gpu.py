@@ -152,9 +152,16 @@ def test_vit_large_384_against_oracle():
     assert m.CP_A1.shape == (72, 16) and m.CP_A3.shape == (16, 16) and m.CP_P1.shape == (216, 16)
     assert m.CP_P2.shape == (1024, 16) and m.CP_bias2.shape == (4096,) and m.idx == 216 and m.attn_idx == 72
     logits = m(x.to(DEV))
-    with torch.no_grad():
-        ref = O.vit_cara_forward(x, w, cp, s=0.1, depth=24, num_heads=16)
-        sim = O.vit_cara_forward(x, w, cp, s=0.1, depth=24, num_heads=16, factored=True, bf16_sim=True)
+    # expected values from the committed fixture (the oracle on these very inputs, tests/golden/make_headline_fixtures.py vitl);
+    # recomputed on the spot only when the fixture is missing
+    fx = os.path.join(os.path.dirname(__file__), "golden", "vit_large_384_b2_r16.npz")
+    F_ = np.load(fx) if os.path.exists(fx) else None
+    if F_ is not None:
+        ref, sim = torch.from_numpy(F_["logits"]), torch.from_numpy(F_["logits_bf16_sim"])
+    else:
+        with torch.no_grad():
+            ref = O.vit_cara_forward(x, w, cp, s=0.1, depth=24, num_heads=16)
+            sim = O.vit_cara_forward(x, w, cp, s=0.1, depth=24, num_heads=16, factored=True, bf16_sim=True)
     r_ref, r_sim, r_model = rel(logits, ref), rel(logits, sim), rel(sim, ref)
     print(f"ViT-L/16@384 logits rel-L2: vs fp32 oracle {r_ref:.2e}, vs bf16-rounded oracle {r_sim:.2e} (rounding model {r_model:.2e})")
     assert T.logits_ok(r_ref, r_model), (r_ref, r_model)
@@ -162,8 +169,11 @@ def test_vit_large_384_against_oracle():
     safe = (top2[:, 0] - top2[:, 1]) > 4 * (logits.cpu() - ref).abs().max()
     assert torch.equal(logits.argmax(1).cpu()[safe], ref.argmax(1)[safe])
     torch.nn.functional.cross_entropy(logits, y.to(DEV)).backward()
-    head = {"weight": w["head.weight"], "bias": w["head.bias"]}
-    _, _, gref = O.train_step_as_written(x, y, w, cp, head, s=0.1, depth=24, num_heads=16)
+    if F_ is not None:
+        gref = {k[len("grad_"):]: torch.from_numpy(F_[k]) for k in F_.files if k.startswith("grad_")}
+    else:
+        head = {"weight": w["head.weight"], "bias": w["head.bias"]}
+        _, _, gref = O.train_step_as_written(x, y, w, cp, head, s=0.1, depth=24, num_heads=16)
     worst = 0.0
     for n in O.CP_NAMES:
         r = rel(getattr(m, n).grad, gref[n])
