@@ -22,6 +22,11 @@
 // (Other structures that were built and measured slower on this model's shapes -- a 64-deep double buffer,
 // 256x256 / 128x256 LDS-ring kernels, a persistent stream-K kernel, 256x128 tiles, a 208x256 one-workgroup-per-CU
 // tile with DMA-only loader waves -- live in tools/experimental/, outside the library.)
+// Also here: the adapter-inside form (gemm32ft_*: T = A Ut^T accumulated on the tiles the workgroup streams anyway, Rp = 32 or
+// 64), the forms that carry a pair of transposed skinny products behind their tiles (gemm32_ts_kernel, gemm32ft_ts_kernel),
+// the two-B-operand form of the exact weight-dropout mode (one K loop, both B tiles on the same A fragments), 8-wave
+// 192 / 256-row tiles (a switch: measured a tie), and gemm_tn_kernel (C = At^T Bt from row-major operands through
+// transposing LDS reads: the dense dW of the exact mode).
 #include <stdlib.h>
 
 #include "common.h"
