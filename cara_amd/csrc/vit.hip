@@ -46,6 +46,17 @@ struct Ws {
 
 size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
 
+// split-K slabs of the dense dW = dY^T X of one linear (cara_gemm_tn_f32): enough of them that (out / 128)(in / 128) tiles
+// times slabs fill the chip (proj: 36 tiles -- at four slabs each workgroup walked 98 K steps on a quarter of the CUs:
+// 73 us for 15 GF), at least 512 token rows per slab, at most 16
+int dw_slabs(int out, int in, int M) {
+  const int tiles = ((out + 127) / 128) * ((in + 127) / 128);
+  int n = (640 + tiles - 1) / tiles;
+  n = n > 16 ? 16 : n;
+  while (n > 1 && M / n < 512) --n;
+  return n < 1 ? 1 : n;
+}
+
 bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
   if (!g || !s || g->depth <= 0 || g->depth > 64 || g->dim % g->heads || g->dim / g->heads != 64) return false;
   if (!(g->Rp == 32 || g->Rp == 64) || g->rank > g->Rp || s->B <= 0 || s->tokens <= 1 || s->tokens > 608) return false;
@@ -125,7 +136,9 @@ bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
     }
     w->dYt = c.take((size_t)4 * D * w->ldk * 2);
     w->Xt = c.take((size_t)4 * D * w->ldk * 2);
-    w->dWd = c.take((size_t)w->nslab * 4 * D * D * 4);
+    size_t dwd = (size_t)w->nslab * 4 * D * D * 4;   // the transposed-copies route: nslab slabs of the largest product
+    for (int i = 0; i < 4; ++i) dwd = max_sz(dwd, (size_t)dw_slabs((int)outs[i], (int)ins[i], (int)M) * outs[i] * ins[i] * 4);
+    w->dWd = c.take(dwd);
     w->xscratch = c.take(max_sz(cara_dropout_grad_scratch_bytes((int)(4 * D), (int)D, (int)Rp), cara_colsum_scratch_bytes((int)(4 * D))));
   }
   w->total = c.off;
@@ -384,9 +397,10 @@ int lin_bwd_exact(const Lin& L, const bf16* dY, const bf16* X, int Mr, int Rp, c
   // allow (CARA_EXACT_TN=0: the first form -- two activation-sized transposes with zeroed pad columns, then one batched
   // launch of the default GEMM over the transposed copies)
   const size_t slab_stride = (size_t)L.out * L.in;
-  const int used = W.nslab;
+  int used = dw_slabs(L.out, L.in, Mr);
   static const int use_tn = env_once("CARA_EXACT_TN", 1);
   if (!(use_tn && cara_gemm_tn_f32(dY, L.out, X, L.in, dWd, L.in, L.out, L.in, Mr, used, slab_stride, st) == CARA_OK)) {
+    used = W.nslab;
     if (ldk > Mr) {   // K of the dW product is Mr rounded up to 64: the pad columns of both transposes must be zero
       if (hipMemset2DAsync(dYt + Mr, (size_t)ldk * 2, 0, (size_t)(ldk - Mr) * 2, L.out, hs) != hipSuccess) return CARA_E_LAUNCH;
       if (hipMemset2DAsync(Xt + Mr, (size_t)ldk * 2, 0, (size_t)(ldk - Mr) * 2, L.in, hs) != hipSuccess) return CARA_E_LAUNCH;
