@@ -249,8 +249,8 @@ CP_NAMES = ("CP_A1", "CP_A2", "CP_A3", "CP_A4", "CP_P1", "CP_P2", "CP_P3", "CP_R
 
 def cp_length_of(cp) -> int:
     """Order of the QKV tensorisation a CP dict carries (``image_classification/dim_experiment.py:264-295``):
-    5 has a CP_A5, 3 has no CP_A4, 4 is ``src/cara``'s."""
-    return 5 if "CP_A5" in cp else (4 if "CP_A4" in cp else 3)
+    5 has a CP_A5, 3 has no CP_A4, 2 has no CP_A3 either, 4 is ``src/cara``'s."""
+    return 5 if "CP_A5" in cp else (4 if "CP_A4" in cp else (3 if "CP_A3" in cp else 2))
 
 
 def cp_shapes(rank: int, dim: int = 768, heads: int = 12, depth: int = 12, cp_length: int = 4) -> Dict[str, Tuple[int, ...]]:
@@ -261,6 +261,8 @@ def cp_shapes(rank: int, dim: int = 768, heads: int = 12, depth: int = 12, cp_le
              "CP_A5": (dim // heads, rank)}
     elif cp_length == 3:
         a = {"CP_A1": (3 * depth, rank), "CP_A2": (dim, rank), "CP_A3": (dim, rank)}
+    elif cp_length == 2:   # dim_experiment.py:293-297: rank dense dim x dim matrices per projection
+        a = {"CP_A1": (3 * depth, rank), "CP_A2": (dim * dim, rank)}
     else:
         a = {"CP_A1": (3 * depth, rank), "CP_A2": (dim, rank), "CP_A3": (heads, rank), "CP_A4": (dim // heads, rank)}
     a.update({"CP_P1": (9 * depth, rank), "CP_P2": (dim, rank),
@@ -283,6 +285,8 @@ def init_cp_params(rank: int, l_mu: float, l_std: float, dim=768, heads=12, dept
     elif cp_length == 3:
         nn.init.zeros_(p["CP_A2"])
         nn.init.orthogonal_(p["CP_A3"])
+    elif cp_length == 2:
+        nn.init.zeros_(p["CP_A2"])
     else:
         nn.init.zeros_(p["CP_A2"])
         nn.init.orthogonal_(p["CP_A3"])
@@ -315,6 +319,10 @@ def qkv_adapter_tensor(cp, attn_idx: int) -> torch.Tensor:
     f1 = cp["CP_A1"][attn_idx:attn_idx + 3]
     if n == 3:   # :200-202
         return cp_to_tensor((cp["CP_R1"], (f1, cp["CP_A2"], cp["CP_A3"])))
+    if n == 2:   # :203-207: [3, dim * dim] -> [3, in, out]
+        t = cp_to_tensor((cp["CP_R1"], (f1, cp["CP_A2"])))
+        c = int(round(t.shape[1] ** 0.5))
+        return t.reshape(3, c, c)
     t = cp_to_tensor((cp["CP_R1"], (f1, cp["CP_A2"], cp["CP_A3"], cp["CP_A4"])))   # src/cara/cara.py:26-34
     K, E, H, D = t.shape
     return t.reshape(K, E, H * D)
@@ -475,14 +483,20 @@ def build_factored(cp: Dict[str, torch.Tensor], s: float, depth: int = 12, heads
     idxs = block_indices(depth)
     n = cp_length_of(cp)
     # out factor [dim, R] (row h*hd+d) and in factor [dim, R] of the QKV adapter, per order of tensorisation
-    kr_a = cp["CP_A3"] if n == 3 else (khatri_rao(cp["CP_A4"], cp["CP_A5"]) if n == 5 else khatri_rao(cp["CP_A3"], cp["CP_A4"]))
-    u_qkv = cp["CP_A3"] if n == 5 else cp["CP_A2"]
+    # (order 2 is not low-rank in (in, out): its QKV entry is the dense, scaled delta itself, ("dense", Dm [3 dim, dim]))
+    if n != 2:
+        kr_a = cp["CP_A3"] if n == 3 else (khatri_rao(cp["CP_A4"], cp["CP_A5"]) if n == 5 else khatri_rao(cp["CP_A3"], cp["CP_A4"]))
+        u_qkv = cp["CP_A3"] if n == 5 else cp["CP_A2"]
     for l in range(depth):
         a_idx, a_aidx, m_idx = idxs[l]
-        coef = cp["CP_A1"][l:l + 1] * cp["CP_A2"] if n == 5 else cp["CP_A1"][a_aidx:a_aidx + 3]   # [3,R]
-        g_qkv = cp["CP_R1"].unsqueeze(0) * coef  # [3,R]
-        v_qkv = (g_qkv.unsqueeze(1) * kr_a.unsqueeze(0)).reshape(-1, kr_a.shape[1]) * s  # [3*dim,R]
-        qkv = (u_qkv, v_qkv, None)
+        if n == 2:
+            t = qkv_adapter_tensor(cp, a_aidx)                                   # [3, in, out]
+            qkv = ("dense", s * t.permute(0, 2, 1).reshape(-1, t.shape[1]), None)   # rows k * dim + out, columns in
+        else:
+            coef = cp["CP_A1"][l:l + 1] * cp["CP_A2"] if n == 5 else cp["CP_A1"][a_aidx:a_aidx + 3]   # [3,R]
+            g_qkv = cp["CP_R1"].unsqueeze(0) * coef  # [3,R]
+            v_qkv = (g_qkv.unsqueeze(1) * kr_a.unsqueeze(0)).reshape(-1, kr_a.shape[1]) * s  # [3*dim,R]
+            qkv = (u_qkv, v_qkv, None)
         proj = (cp["CP_P3"], s * (cp["CP_R2"] * cp["CP_P1"][a_idx]).unsqueeze(0) * cp["CP_P2"], s * cp["CP_bias1"])
         fc1 = (cp["CP_P3"], s * cp["CP_R2"].unsqueeze(0) * khatri_rao(cp["CP_P1"][m_idx:m_idx + 4], cp["CP_P2"]),
                s * cp["CP_bias2"])
@@ -496,6 +510,8 @@ def adapter_linear(x, wgt, bias, fac, r=lambda t: t):
     """y = x W^T + b + (x U) Vs^T + c_s with the rank-R term carried as a K-extension
     ([x | T] [W | Vs]^T), T rounded like any other GEMM operand when ``r`` rounds."""
     U, Vs, cs = fac
+    if isinstance(U, str):   # ("dense", Dm, None): two products on the same operand, accumulated in fp32 (the device's B3 form)
+        return r(x) @ r(wgt).t() + r(x) @ r(Vs).t() + bias
     t = r(r(x) @ r(U))
     y = r(x) @ r(wgt).t() + t @ r(Vs).t() + bias
     if cs is not None:

@@ -60,3 +60,21 @@ def oracle_case_cp_length(cp_length):
             cp[k].copy_(0.02 * torch.randn(cp[k].shape, generator=g))
     img = torch.randn(2, 3, 224, 224, generator=torch.Generator(device="cpu").manual_seed(403))
     return O.vit_weights(vit), cp, img
+
+
+def oracle_case_cp_length2():
+    """Case 8 of make_golden.py: order 2 (CP_A2 [dim * dim, rank]), depth 2, 197 tokens, RANK 4 -- same RNG order and fills as
+    the script was run with.  Returns (weights, cp, images)."""
+    torch.manual_seed(14)
+    vit = O.create_vit("vit_base_patch16_224_in21k", drop_path_rate=0.1, depth=2, num_classes=100)
+    seeded_backbone_into(vit, 401)
+    torch.manual_seed(15)
+    cp = O.init_cp_params(4, 1.5, 0.1, cp_length=2)
+    g = torch.Generator(device="cpu").manual_seed(402)
+    with torch.no_grad():
+        cp["CP_A2"].copy_(0.02 * torch.randn(768 * 768, 4, generator=g))
+        cp["CP_P2"].copy_(0.05 * torch.randn(768, 4, generator=g))
+        for k in ("CP_bias1", "CP_bias2", "CP_bias3"):
+            cp[k].copy_(0.02 * torch.randn(cp[k].shape, generator=g))
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator(device="cpu").manual_seed(403))
+    return O.vit_weights(vit), cp, img

@@ -232,6 +232,49 @@ def main():
         for k in names:
             assert torch.allclose(cpv[k].grad, getattr(vit3, k).grad, rtol=1e-4, atol=1e-7), (n_, k)
 
+    # ---- 8. order 2 (dim_experiment.py:203-207,293-297): CP_A2 is [dim * dim, rank] -- `rank` dense dim x dim matrices per
+    # projection.  Rank 4 keeps the vectors small; of the 589 824 x 4 gradient of CP_A2 every 97th row is recorded, with
+    # the norm and the sum of the whole tensor.
+    torch.manual_seed(14)
+    vit2 = O.create_vit("vit_base_patch16_224_in21k", drop_path_rate=0.1, depth=2, num_classes=100)
+    seeded_backbone_into(vit2, 401)
+    dim.vit = vit2
+    torch.manual_seed(15)
+    dim.set_CP(vit2, dim=4, s=0.1, l_mu=1.5, l_std=0.1, cp_length=2)
+    names = [k for k, _ in vit2.named_parameters() if k.startswith("CP_")]
+    torch.manual_seed(15)
+    mine = O.init_cp_params(4, 1.5, 0.1, cp_length=2)
+    assert names == list(mine.keys()), (names, list(mine.keys()))
+    for k in names:
+        assert torch.equal(mine[k], getattr(vit2, k).detach()), (2, k)
+    assert [(b.attn.idx, b.attn.attn_idx, b.mlp.idx) for b in vit2.blocks] == [(0, 0, 1), (9, 3, 10)]
+    g = torch.Generator(device="cpu").manual_seed(402)
+    with torch.no_grad():
+        vit2.CP_A2.copy_(0.02 * torch.randn(768 * 768, 4, generator=g))
+        vit2.CP_P2.copy_(0.05 * torch.randn(768, 4, generator=g))
+        for k in ("CP_bias1", "CP_bias2", "CP_bias3"):
+            getattr(vit2, k).copy_(0.02 * torch.randn(getattr(vit2, k).shape, generator=g))
+    vit2.eval()
+    img4 = torch.randn(2, 3, 224, 224, generator=torch.Generator(device="cpu").manual_seed(403))
+    lg4 = vit2(img4)
+    torch.logsumexp(lg4, dim=1).sum().backward()
+    out["cpl2_cfg"] = np.array([4, 2, 224, 401, 402, 403, 14, 15], dtype=np.int64)
+    out["cpl2_logits"] = lg4.detach().numpy().copy()
+    for k in names:
+        gk = getattr(vit2, k).grad.detach()
+        if k == "CP_A2":
+            out["cpl2_grad_CP_A2_rows97"] = gk[::97].numpy().copy()
+            out["cpl2_grad_CP_A2_norm_sum"] = np.array([gk.double().norm().item(), gk.double().sum().item()])
+        else:
+            out[f"cpl2_grad_{k}"] = gk.numpy().copy()
+    cp4 = {k: getattr(vit2, k).detach().clone() for k in names}
+    cpv = {k: v.clone().requires_grad_(True) for k, v in cp4.items()}
+    mine4 = O.vit_cara_forward(img4, O.vit_weights(vit2), cpv, s=0.1, depth=2)
+    assert torch.allclose(mine4, lg4.detach(), rtol=1e-5, atol=5e-6), (mine4 - lg4).abs().max()
+    torch.logsumexp(mine4, dim=1).sum().backward()
+    for k in names:
+        assert torch.allclose(cpv[k].grad, getattr(vit2, k).grad, rtol=1e-4, atol=1e-7), (2, k)
+
     path = os.path.join(HERE, "cara_reference_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")

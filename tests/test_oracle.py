@@ -195,3 +195,29 @@ def test_other_orders_match_the_reference_script(cp_length):
     fac = O.vit_cara_forward(img.double(), {k: v.double() for k, v in w.items()}, {k: v.double() for k, v in cp.items()}, s=0.1,
                              depth=2, factored=True)
     assert torch.allclose(fac.float(), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_order_2_matches_the_reference_script():
+    """Golden case 8: the order-2 tensorisation (dim_experiment.py:203-207,293-297: CP_A2 [dim * dim, rank], a sum of `rank`
+    dense matrices per projection) -- logits, every small CP gradient, and of the 589 824 x 4 gradient of CP_A2 every 97th
+    row with the norm and sum of the whole, all recorded from the reference's own script; the oracle's "dense delta" form (two
+    products on the same operand: what the device runs) equals the as-written einsum."""
+    from tests.golden.inputs import oracle_case_cp_length2
+    w, cp, img = oracle_case_cp_length2()
+    assert O.cp_length_of(cp) == 2 and cp["CP_A2"].shape == (768 * 768, 4)
+    ref = torch.from_numpy(G["cpl2_logits"])
+    cpv = {k: v.clone().requires_grad_(True) for k, v in cp.items()}
+    logits = O.vit_cara_forward(img, w, cpv, s=0.1, depth=2)
+    assert torch.allclose(logits, ref, rtol=1e-5, atol=5e-6)
+    torch.logsumexp(logits, dim=1).sum().backward()
+    for k in cp:
+        if k == "CP_A2":
+            g2 = cpv[k].grad
+            assert torch.allclose(g2[::97], torch.from_numpy(G["cpl2_grad_CP_A2_rows97"]), rtol=1e-4, atol=1e-8)
+            n, sm = G["cpl2_grad_CP_A2_norm_sum"]
+            assert abs(g2.double().norm().item() - n) < 1e-5 * n and abs(g2.double().sum().item() - sm) < 1e-4 * abs(n)
+        else:
+            assert torch.allclose(cpv[k].grad, torch.from_numpy(G[f"cpl2_grad_{k}"]), rtol=1e-4, atol=1e-7), k
+    fac = O.vit_cara_forward(img.double(), {k: v.double() for k, v in w.items()}, {k: v.double() for k, v in cp.items()}, s=0.1,
+                             depth=2, factored=True)
+    assert torch.allclose(fac.float(), ref, rtol=1e-4, atol=1e-5)
