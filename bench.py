@@ -89,14 +89,15 @@ def site_work(M, D, R, B, H, N):
     }
 
 
-def build_model(rank, scale, num_classes, device, seed, name="vit_base_patch16_224_in21k"):
+def build_model(rank, scale, num_classes, device, seed, name="vit_base_patch16_224_in21k", cp_length=4):
     from cara_amd import cara, create_model
     torch.manual_seed(seed)
     vit = create_model(name, drop_path_rate=0.1, num_classes=num_classes)
-    vit = cara({"model": vit, "rank": rank, "scale": scale, "l_mu": 1.5, "l_std": 0.1})   # cifar row of vtab_config.py:2-8
+    vit = cara({"model": vit, "rank": rank, "scale": scale, "l_mu": 1.5, "l_std": 0.1,            # cifar row of vtab_config.py:2-8
+                "cp_length": cp_length})
     g = torch.Generator().manual_seed(3)
     with torch.no_grad():  # non-zero adapters (zero-init would make the K-extension trivially zero)
-        vit.CP_A2.copy_(0.05 * torch.randn(vit.CP_A2.shape, generator=g))
+        vit.CP_A2.copy_((0.05 if cp_length != 2 else 0.02) * torch.randn(vit.CP_A2.shape, generator=g))
         vit.CP_P2.copy_(0.05 * torch.randn(vit.CP_P2.shape, generator=g))
     vit = vit.to(device).train()
     trainable = []
@@ -429,6 +430,14 @@ def main():
         info["rank64_step_frac_of_mfma_peak"] = round(82.61 * args.batch / info["rank64_ms_per_step"] / PEAK_BF16_TFLOPS, 4)
         del m64, tr64, e64, o64
         torch.cuda.empty_cache()
+        # order 2 of dim_experiment.py (dense dim x dim QKV deltas, 9.4 M more parameters): the dense-delta form of the QKV linear
+        m2, tr2 = build_model(args.rank, scale, ncls, dev, seed=14, name=args.model, cp_length=2)
+        e2 = m2._cara_engine
+        e2.seed_rank_streams(2024, rank)
+        o2 = torch.optim.AdamW(tr2, lr=1e-3, weight_decay=1e-4, fused=True)
+        info["order2_qkv_ms_per_step"] = round(timed_steps(lambda: e2.train_step(x, y, o2)), 3)
+        del m2, tr2, e2, o2
+        torch.cuda.empty_cache()
 
     if rank == 0:
         ms_step = wall * 1e3 / args.steps
@@ -508,7 +517,7 @@ def main():
             # dropout and DropPath are live for 165 of its 1 500 steps, so a run of that recipe costs this per step on average
             info["recipe_blended_ms_per_step"] = round((165 * info["exact_dropout_ms_per_step"] + 1335 * ms_step) / 1500, 3)
             info["note"] = ("informational, 5 steps each after 2 warm-ups, same box and process: exact = the reference's train-mode "
-                            "Dropout(0.1) on the materialised dW (cara.py:35,57,81,92); rank64 = BASELINE.json configs[3] (82.61 GF/image); "
+                            "Dropout(0.1) on the materialised dW (cara.py:35,57,81,92); rank64 = BASELINE.json configs[3] (82.61 GF/image); order2_qkv = cp_length 2 of dim_experiment.py (dense dim x dim QKV deltas) at the headline rank and batch; "
                             "blended = (165 exact + 1335 factored) / 1500, the reference's stuck-in-eval recipe (SURVEY 3.3)")
             out["informational"] = info
         if world == 1 and not args.no_cpu_baseline and not large:

@@ -21,6 +21,7 @@ SYMBOLS = (
     "cara_tskinny_scratch_bytes", "cara_tskinny_xtg", "cara_tskinny_partial", "cara_tskinny_partial2", "cara_tskinny_reduce", "cara_tskinny_reduce_many", "cara_gemm_with_tskinny", "cara_layernorm_fwd", "cara_layernorm_bwd", "cara_layernorm_fwd_xu", "cara_layernorm_bwd_xu", "cara_layernorm_fwd_ex", "cara_layernorm_bwd_ex",
     "cara_attention_fwd", "cara_attention_bwd", "cara_im2col_patches", "cara_assemble_tokens",
     "cara_cross_entropy", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_transpose_bf16_ld", "cara_pack_offsets",
+    "cara_dense_delta_materialize", "cara_dense_delta_grad_scratch_bytes", "cara_dense_delta_grad", "cara_sum_slabs_f32",
     "cara_weight_dropout_hash", "cara_materialize_merge", "cara_dropout_grad_scratch_bytes", "cara_dropout_grad_contract", "cara_colsum_scratch_bytes", "cara_colsum_bf16", "cara_factor_prep", "cara_factor_grad_scratch_bytes", "cara_factor_grad_reduce", "cara_vit_workspace_bytes", "cara_vit_forward",
     "cara_vit_backward", "cara_head_backward", "cara_sizeof_struct", "cara_sizeof_gemm_args", "cara_profile_sites", "cara_profile_site_read", "cara_debug_tr_probe", "cara_debug_tr_frag",
 )
@@ -50,7 +51,9 @@ CP_FIELDS = ("A1", "A2", "A3", "A4", "P1", "P2", "P3", "R1", "R2", "bias1", "bia
 
 def cp_fields(cp_length: int = 4):
     """Names (without the CP_ prefix) of the CP tensors of a QKV tensorisation of order `cp_length`, in the order
-    the engine passes them around: order 3 has no A4, order 5 has an A5 (dim_experiment.py:264-295)."""
+    the engine passes them around: order 2 has neither A3 nor A4, order 3 no A4, order 5 an A5 (dim_experiment.py:264-297)."""
+    if cp_length == 2:
+        return tuple(n for n in CP_FIELDS if n not in ("A3", "A4"))
     if cp_length == 3:
         return tuple(n for n in CP_FIELDS if n != "A4")
     if cp_length == 5:
@@ -132,6 +135,7 @@ def lib() -> C.CDLL:
             _lib.cara_weight_dropout_hash.restype = C.c_uint
             _lib.cara_dropout_grad_scratch_bytes.restype = C.c_size_t
             _lib.cara_colsum_scratch_bytes.restype = C.c_size_t
+        _lib.cara_dense_delta_grad_scratch_bytes.restype = C.c_size_t
         _lib.cara_sizeof_struct.restype = C.c_size_t
         _lib.cara_sizeof_gemm_args.restype = C.c_size_t
         for which, mirror in enumerate(STRUCT_MIRRORS):   # a mirror that is short would make the library read past it

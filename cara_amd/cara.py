@@ -163,8 +163,9 @@ def _engine_forward(self, x):
 def set_cara(model: nn.Module, rank: int, scale: float, l_mu: float, l_std: float, _root=None, cp_length: int = 4) -> None:
     """Declare + initialise the CP tensors on the ViT and walk its children (``cara.py:98-166``).
 
-    ``cp_length`` selects the order of the QKV tensorisation as ``image_classification/dim_experiment.py:264-295``
-    (``set_CP``) does: 4 is ``src/cara``'s; 3 = ``[3L, dim, dim]`` (A3 ``[dim, R]``, no A4); 5 =
+    ``cp_length`` selects the order of the QKV tensorisation as ``image_classification/dim_experiment.py:264-297``
+    (``set_CP``) does: 4 is ``src/cara``'s; 2 = ``[3L, dim * dim]`` (A2 ``[dim * dim, R]``, no A3 / A4); 3 = ``[3L, dim, dim]``
+    (A3 ``[dim, R]``, no A4); 5 =
     ``[L, 3, dim, heads, dim/heads]`` (A1 ``[L, R]``, A2 ``[3, R]``, A3 ``[dim, R]``, A4 ``[heads, R]``, A5
     ``[dim/heads, R]``; ``attn_idx`` then advances by 1 per block, ``:334``).  Same initialisers in the same order."""
     root = _root
@@ -177,6 +178,7 @@ def set_cara(model: nn.Module, rank: int, scale: float, l_mu: float, l_std: floa
         qkv_factors = {
             4: (("A1", 3 * depth, xav), ("A2", dim, zero), ("A3", heads, orth), ("A4", dim // heads, orth)),   # cara.py:112-117
             3: (("A1", 3 * depth, xav), ("A2", dim, zero), ("A3", dim, orth)),                                 # dim_experiment.py:286-292
+            2: (("A1", 3 * depth, xav), ("A2", dim * dim, zero)),                                              # dim_experiment.py:293-297
             5: (("A1", depth, xav), ("A2", 3, orth), ("A3", dim, zero), ("A4", heads, orth),
                 ("A5", dim // heads, orth)),                                                                   # dim_experiment.py:266-276
         }[cp_length]
@@ -239,13 +241,14 @@ def cara(config: Dict[str, Any]) -> th.nn.Module:
         raise CaraError("rank must be in 1..64 (the K-extension is padded to 32 or 64 columns)")
     # optional sixth key, the `cp_length` of image_classification/dim_experiment.py (its `--dims`): order of the QKV
     # tensorisation.  4 (default) is src/cara's; 3 and 5 are rank-R in (in, out) too and run on the same kernels.
-    # 2 parametrises each projection as a sum of R DENSE dim x dim matrices: not an adapter the factored path can run.
+    # 2 parametrises each projection as a sum of R DENSE dim x dim matrices (CP_A2 [dim * dim, R], dim_experiment.py:203-207):
+    # not low-rank in (in, out), so the QKV linear runs in the dense-delta form (two products on the same operand,
+    # cara_gemm_args::B3; its gradient from the dense dW = X^T dY) while proj / fc1 / fc2 keep the factored kernels.
     cp_length = int(config.get("cp_length", 4))
-    if cp_length == 2:
-        raise CaraError("cp_length 2 is a sum of `rank` dense dim x dim matrices per projection (dim_experiment.py:203-207), "
-                        "not low-rank in (in, out): the factored HIP path cannot run it")
-    if cp_length not in (3, 4, 5):
-        raise CaraError("cp_length must be 3, 4 or 5")
+    if cp_length not in (2, 3, 4, 5):
+        raise CaraError("cp_length must be 2, 3, 4 or 5")
+    if cp_length == 2 and config.get("weight_dropout", "off") == "exact":
+        raise CaraError("cp_length 2 (dense QKV deltas) runs with weight_dropout = 'off' only")
     global global_model
     global_model = model
     set_cara(model, rank, scale, l_mu, l_std, cp_length=cp_length)

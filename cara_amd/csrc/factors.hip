@@ -10,7 +10,7 @@ namespace {
 struct PackDims {
   int depth, dim, heads, hd, rank, Rp;
   float s;
-  int cpl;   // order of the QKV tensorisation: 3, 4 or 5 (cara_geom::cp_length)
+  int cpl;   // order of the QKV tensorisation: 2, 3, 4 or 5 (cara_geom::cp_length)
 };
 
 // The QKV adapter of block l, projection k, in factored form for every supported order (cara_geom::cp_length):
@@ -40,6 +40,7 @@ __host__ __device__ inline int mat_rows(int m, int dim) {
 
 __device__ __forceinline__ float factor_value(const PackDims& g, const cara_cp& cp, int l, int m, int row, int r) {
   if (r >= g.rank) return 0.f;
+  if (g.cpl == 2 && (m == M_U_QKV || m == M_VS_QKV)) return 0.f;   // order 2: the QKV adapter is not low-rank (dense_delta.hip)
   const int R = g.rank, dim = g.dim;
   switch (m) {
     case M_U_QKV: return qkv_in(g, cp, row, r);
@@ -146,7 +147,7 @@ __device__ __forceinline__ void grad_rowwise(const PackDims& g, const cara_cp& c
     float a2 = 0.f, p3 = 0.f, p2 = 0.f, a3o = 0.f;
     const float sr2 = g.s * cp.R2[r];
     for (int l = 0; l < L; ++l) {
-      a2 += lg.dU_qkv[((size_t)l * dim + j) * Rp + r];
+      if (g.cpl != 2) a2 += lg.dU_qkv[((size_t)l * dim + j) * Rp + r];
       if (g.cpl == 3)   // order 3: the out factor A3 [dim, R] is a plain row-wise sum over blocks and projections
         for (int k = 0; k < 3; ++k) a3o += cp.A1[(3 * l + k) * R + r] * lg.dVs_qkv[((size_t)l * 3 * dim + k * dim + j) * Rp + r];
       p3 += lg.dU_proj[((size_t)l * dim + j) * Rp + r] + lg.dU_fc1[((size_t)l * dim + j) * Rp + r] +
@@ -157,7 +158,7 @@ __device__ __forceinline__ void grad_rowwise(const PackDims& g, const cara_cp& c
         p2 += cp.P1[(9 * l + 5 + a) * R + r] * lg.dU_fc2[((size_t)l * 4 * dim + a * dim + j) * Rp + r];
       }
     }
-    (g.cpl == 5 ? out.A3 : out.A2)[e] = a2;   // gradient of the in factor
+    if (g.cpl != 2) (g.cpl == 5 ? out.A3 : out.A2)[e] = a2;   // gradient of the in factor (order 2: cara_dense_delta_grad)
     if (g.cpl == 3) out.A3[e] = g.s * cp.R1[r] * a3o;
     out.P3[e] = p3;
     out.P2[e] = p2;
@@ -193,6 +194,7 @@ __device__ __forceinline__ void grad_colred_part(const PackDims& g, const cara_c
       for (int row = row0 + part; row < row1; row += 8) {
         float w, f;
         if (slot < 3) {
+          if (g.cpl == 2) break;   // (no factored QKV adapter)
           w = lg.dVs_qkv[((size_t)l * 3 * dim + slot * dim + row) * Rp + rr];
           f = g.s * qkv_out(g, cp, row, rr);
         } else if (slot == 3) {
@@ -229,7 +231,7 @@ __device__ __forceinline__ void grad_a34_part(const PackDims& g, const cara_cp& 
                                               const int lk, const int piece) {
   const int R = g.rank, Rp = g.Rp, dim = g.dim, H = g.heads, hd = g.hd;
   const int l = lk / 3, k = lk - 3 * l;
-  if (g.cpl == 3) return;   // no head / head-dim factors (grad_rowwise did A3)
+  if (g.cpl == 3 || g.cpl == 2) return;   // no head / head-dim factors (order 3: grad_rowwise did A3)
   const float* W = lg.dVs_qkv + ((size_t)l * 3 * dim + (size_t)k * dim) * Rp;   // [H*hd, Rp]
   const float* Fh = g.cpl == 5 ? cp.A4 : cp.A3;   // head factor [H, R]
   const float* Fd = g.cpl == 5 ? cp.A5 : cp.A4;   // head-dim factor [hd, R]
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp
   const GradScratch sc = grad_scratch(scratch, L, H, hd, R);
   if ((int)blockIdx.x < nb_a) {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (g.cpl != 3 && e < (H + hd) * R) {
+    if (g.cpl != 3 && g.cpl != 2 && e < (H + hd) * R) {
       const bool is3 = e < H * R;
       const int e2 = is3 ? e : e - H * R;
       const int r = e2 % R;
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp
       for (int sp = 0; sp < GS_SPLIT; ++sp) z += zp[sp * R];
       const int l = q / 12, slot = q - 12 * l;
       if (slot < 3) {
-        if (g.cpl == 5) continue;   // order 5: A1 [depth, R] and A2 [3, R] mix the three projections, below
+        if (g.cpl == 5 || g.cpl == 2) continue;   // order 5: A1 [depth, R] and A2 [3, R] mix the three projections, below; order 2: dense_delta.hip
         const int row = 3 * l + slot;
         d1 += cp.A1[row * R + r] * z;
         out.A1[row * R + r] = cp.R1[r] * z;
@@ -371,10 +373,12 @@ PackDims dims_of(const cara_geom* g) {
 bool geom_ok(const cara_geom* g) {
   return g && g->depth > 0 && g->dim > 0 && g->heads > 0 && g->dim % g->heads == 0 && g->rank > 0 &&
          g->rank <= g->Rp && (g->Rp == 32 || g->Rp == 64) &&
-         (g->cp_length == 0 || g->cp_length == 3 || g->cp_length == 4 || g->cp_length == 5);
+         (g->cp_length == 0 || g->cp_length == 2 || g->cp_length == 3 || g->cp_length == 4 || g->cp_length == 5);
 }
 bool cp_ok(const cara_geom* g, const cara_cp* c) {
-  if (!(c && c->A1 && c->A2 && c->A3 && c->P1 && c->P2 && c->P3 && c->R1 && c->R2 && c->bias1 && c->bias2 && c->bias3)) return false;
+  if (!(c && c->A1 && c->A2 && c->P1 && c->P2 && c->P3 && c->R1 && c->R2 && c->bias1 && c->bias2 && c->bias3)) return false;
+  if (g->cp_length == 2) return true;              // order 2: A1 [3 depth, R] and A2 [dim * dim, R] only
+  if (!c->A3) return false;
   if (g->cp_length != 3 && !c->A4) return false;   // order 3 has no fourth factor
   return g->cp_length != 5 || c->A5 != nullptr;
 }

@@ -38,6 +38,9 @@ struct Ws {
   size_t slabU[4], slabV[4], strideU[4], strideV[4];   // per linear: depth regions of tskinny slabs
   // exact weight-dropout mode: merged weights of every layer (and their transposes), transposed activations, dense dW
   size_t weff[4], wefft[4], dYt, Xt, dWd, xscratch;
+  // order-2 QKV tensorisation (cara_geom::cp_length == 2): the dense deltas of every layer and their transposes, the dense
+  // dD = x^T dY_k of every (layer, projection), split-K slabs of one such product, scratch of cara_dense_delta_grad
+  size_t dd, ddt, dD, dd_slabs, dd_scratch;
   int nslab;   // split-K slabs of the dense dW product
   int ldk;   // row stride of the transposed activations: M rounded up to the GEMM's K granule
   size_t total;
@@ -140,6 +143,15 @@ bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
     for (int i = 0; i < 4; ++i) dwd = max_sz(dwd, (size_t)dw_slabs((int)outs[i], (int)ins[i], (int)M) * outs[i] * ins[i] * 4);
     w->dWd = c.take(dwd);
     w->xscratch = c.take(max_sz(cara_dropout_grad_scratch_bytes((int)(4 * D), (int)D, (int)Rp), cara_colsum_scratch_bytes((int)(4 * D))));
+  }
+  w->dd = w->ddt = w->dD = w->dd_slabs = w->dd_scratch = 0;
+  if (g->cp_length == 2) {
+    if (s->wd_exact) return false;   // (the dense-delta QKV form and the exact weight-dropout mode are not combined)
+    w->dd = c.take((size_t)g->depth * 3 * D * D * 2);
+    w->ddt = c.take((size_t)g->depth * 3 * D * D * 2);
+    w->dD = c.take((size_t)g->depth * 3 * D * D * 4);
+    w->dd_slabs = c.take((size_t)dw_slabs((int)D, (int)D, (int)M) * D * D * 4);
+    w->dd_scratch = c.take(cara_dense_delta_grad_scratch_bytes(g));
   }
   w->total = c.off;
   return true;
@@ -357,6 +369,37 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
   return cara_tskinny_partial2(X, ldx, Gt, slabU, L.in, dY, lddy, Tt, slabV, L.out, want_dc ? 1 : 0, ldt, Mr, Rp, st);
 }
 
+// ---- order-2 QKV tensorisation: the QKV linear as y = x W^T + x Dm^T with the dense scaled delta Dm (cara_dense_delta_*) ----
+int lin_fwd_dense(const Lin& L, const bf16* X, int ldx, int Mr, const bf16* Dm, cara_gemm_args a, const Ctx& cx) {
+  a.A = X; a.lda = ldx; a.B = L.W; a.B3 = Dm; a.ldb = L.in; a.A2 = nullptr; a.B2 = nullptr; a.Rp = 0;
+  a.M = Mr; a.N = L.out; a.K = L.in; a.bias = L.bias;
+  if (a.ldc == 0) a.ldc = L.out;
+  with_scratch(a, cx);
+  SiteBracket b(SITE_FWD[L.slot], cx);
+  return cara_gemm_bf16(&a, cx.stream);
+}
+// backward: dX = dY W + dY Dm (optional), and dD[k] = X^T dY_k for the three projections (split-K slabs, summed)
+int lin_bwd_dense(const Lin& L, const bf16* dY, const bf16* X, int Mr, const bf16* Dmt, float* dD_l, float* slabs, bool want_dx,
+                  cara_gemm_args a, const Ctx& cx) {
+  void* st = cx.stream;
+  const int D = L.in;
+  if (want_dx) {
+    a.A = dY; a.lda = L.out; a.B = L.Wt; a.B3 = Dmt; a.ldb = L.out; a.A2 = nullptr; a.B2 = nullptr; a.Rp = 0;
+    a.M = Mr; a.N = L.in; a.K = L.out; a.bias = nullptr;
+    if (a.ldc == 0) a.ldc = L.in;
+    with_scratch(a, cx);
+    SiteBracket b(SITE_BWD[L.slot], cx);
+    TRY(cara_gemm_bf16(&a, st));
+  }
+  const int ns = dw_slabs(D, D, Mr);
+  const size_t dd = (size_t)D * D;
+  for (int k = 0; k < 3; ++k) {
+    TRY(cara_gemm_tn_f32(X, D, dY + (size_t)k * D, L.out, slabs, D, D, D, Mr, ns, dd, st));
+    TRY(cara_sum_slabs_f32(slabs, ns, dd, dd, dD_l + (size_t)k * dd, st));
+  }
+  return CARA_OK;
+}
+
 // ---- exact weight-dropout mode (cara_vit_shape::wd_exact): y = x W^T + x (keep/(1-p) dW)^T, two accumulated products ----
 // forward of one linear: materialise the masked delta (and its transpose, for dX) of this layer, then C = X (W + Dm)^T + bias
 int lin_fwd_exact(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, char* ws, const Ws& W, const cara_vit_shape* s,
@@ -554,6 +597,8 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
   cara_pack_layout pl;
   TRY(cara_pack_offsets(g, &pl));
   TRY(cara_factor_prep(g, cp, w->proj_b, w->fc1_b, w->fc2_b, ws + W.pack, stream));
+  const bool dense_qkv = g->cp_length == 2;   // order-2 tensorisation: the QKV linear in the dense-delta form
+  if (dense_qkv) TRY(cara_dense_delta_materialize(g, cp, ws + W.dd, ws + W.ddt, stream));
   TRY(cara_f32_to_bf16(head_w, ws + W.head_wb, (size_t)s->num_classes * D, stream));
   // patch embedding: Conv2d(k = s = patch) as a GEMM over im2col rows, then cls + pos_embed
   const int kp = s->chans * s->patch * s->patch;
@@ -594,16 +639,18 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
     cx_all.full = true;
     // K-panel-major activations (panel_acts): pa_x for what all M token rows produce (xn1), pa for the Mr rows of
     // the proj / MLP half of the block (xn2, h)
-    const bool pa_x = panel_acts(M, s, 2), pa = panel_acts(Mr, s, 1), pa_n = panel_acts(Mr, s, 2);
+    // (order 2: xn1 stays row-major -- the dense dD = xn1^T dY of the backward reads it with transposing LDS reads)
+    const bool pa_x = panel_acts(M, s, 2) && !dense_qkv, pa = panel_acts(Mr, s, 1), pa_n = panel_acts(Mr, s, 2);
     {
       SiteBracket sb(CARA_SITE_LN1_FWD, cx_all);
       TRY(cara_layernorm_fwd_ex(x_in, D, w->ln1_g + (size_t)l * D, w->ln1_b + (size_t)l * D, ws + lw.xn1,
                                 reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), M, D, s->eps,
-                                fx ? lin[0].Ut : nullptr, g->rank, Rp, ws + lw.T[0], ws + lw.Tt[0], W.ldt, pa_x ? M : 0, stream));
+                                (fx && !dense_qkv) ? lin[0].Ut : nullptr, g->rank, Rp, ws + lw.T[0], ws + lw.Tt[0], W.ldt, pa_x ? M : 0, stream));
     }
     cara_gemm_args e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + lw.qkv;
     if (ex) TRY(lin_fwd_exact(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), D, M, Rp, ws, W, s, e, cx_all));
+    else if (dense_qkv) TRY(lin_fwd_dense(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), D, M, reinterpret_cast<bf16*>(ws + W.dd) + (size_t)l * 3 * D * D, e, cx_all));
     else TRY(lin_fwd(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), pa_x ? -M : D, M, Rp, W.ldt, ws, lw, e, cx_all, fx));
     {
       SiteBracket sb(CARA_SITE_ATTN_FWD, cx_all);
@@ -666,6 +713,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
                          dp_last, 1, B, D, stream));
   const bool ex = s->wd_exact != 0;
   const bool fx = fuse_xu(g) && !ex;
+  const bool dense_qkv = g->cp_length == 2;
   bool have_G_fc2 = false;   // G' of this block's fc2 was left by the LayerNorm backward of the block above
   for (int l = g->depth - 1; l >= 0; --l) {
     const LayerWs& lw = W.layer[l];
@@ -692,7 +740,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     // K-panel-major activations, as the forward wrote them (xn1: pa_x; xn2, h: pa) and as the kernels here write
     // theirs: dH and dyp (pa), dyb of the block below (pa_x).  This block's own dyb came from the block above --
     // panels -- except in the last block, where the final norm's backward left it row-major on the cls rows.
-    const bool pa_x = panel_acts(M, s, 2), pa = panel_acts(Mr, s, 1), pa_n = panel_acts(Mr, s, 2);
+    const bool pa_x = panel_acts(M, s, 2) && !dense_qkv, pa = panel_acts(Mr, s, 1), pa_n = panel_acts(Mr, s, 2);
     const bool pa_dp = panel_acts(Mr, s, 4), pa_dx = panel_acts(M, s, 4);   // dyp here; dyb of the block below
     const bool pa_dyb = pa_dx && l < g->depth - 1;
     if (pa) { e.c_panels = Mr; e.ldc = 4 * D; }
@@ -726,6 +774,9 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
     // block 0 has nothing trainable upstream of it: its dX GEMM and LayerNorm backward are skipped
     if (ex) TRY(lin_bwd_exact(lin[0], dQKV, reinterpret_cast<bf16*>(ws + lw.xn1), M, Rp, ws, W, s, l > 0, e, false, cx_all));
+    else if (dense_qkv)
+      TRY(lin_bwd_dense(lin[0], dQKV, reinterpret_cast<bf16*>(ws + lw.xn1), M, reinterpret_cast<bf16*>(ws + W.ddt) + (size_t)l * 3 * D * D,
+                        reinterpret_cast<float*>(ws + W.dD) + (size_t)l * 3 * D * D, reinterpret_cast<float*>(ws + W.dd_slabs), l > 0, e, cx_all));
     else TRY(lin_bwd(lin[0], dQKV, 3 * D, reinterpret_cast<bf16*>(ws + lw.xn1), pa_x ? -M : D, M, Rp, W.ldt, ws, W, lw, l > 0, e, false, cx_all));
     if (l > 0) {
       // dyb = dY of fc2 of the block BELOW (all M rows there: only the last block runs on cls rows); this block's
@@ -747,6 +798,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     cara_ts_reduce red[CARA_TS_REDUCE_MAX];   // all slab sums of the pass in ONE launch (8 + 6 of them)
     int nred = 0;
     for (int i = 0; i < 4; ++i) {
+      if (i == 0 && dense_qkv) continue;   // order 2: the QKV linear wrote no skinny slabs (its gradient is dense, below)
       float* dU = reinterpret_cast<float*>(ws + W.dU[i]);
       float* dVs = reinterpret_cast<float*>(ws + W.dVs[i]);
       float* dc = i == 0 ? nullptr : reinterpret_cast<float*>(ws + W.dc[i]);
@@ -772,5 +824,8 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
   lg.dU_fc2 = reinterpret_cast<float*>(ws + W.dU[3]); lg.dVs_fc2 = reinterpret_cast<float*>(ws + W.dVs[3]);
   lg.dc_proj = reinterpret_cast<float*>(ws + W.dc[1]); lg.dc_fc1 = reinterpret_cast<float*>(ws + W.dc[2]);
   lg.dc_fc2 = reinterpret_cast<float*>(ws + W.dc[3]);
-  return cara_factor_grad_reduce(g, cp, &lg, grads, ws + W.gscratch, stream);
+  TRY(cara_factor_grad_reduce(g, cp, &lg, grads, ws + W.gscratch, stream));
+  if (dense_qkv)   // CP_A1 / CP_A2 / CP_R1 of the order-2 tensorisation, from the dense dD of every (layer, projection)
+    TRY(cara_dense_delta_grad(g, cp, reinterpret_cast<const float*>(ws + W.dD), grads, ws + W.dd_scratch, stream));
+  return CARA_OK;
 }

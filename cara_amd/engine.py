@@ -147,6 +147,8 @@ class CaraEngine:
         exact = self.weight_dropout == "exact"
         if self.weight_dropout not in ("off", "exact"):
             raise CaraError(f"weight_dropout must be 'off' or 'exact', not {self.weight_dropout!r}")
+        if exact and self.cp_length == 2:
+            raise CaraError("cp_length 2 (dense QKV deltas) runs with weight_dropout = 'off' only")
         key = (B, img, ncls, str(dev), exact)
         st = self._ws.get(key)
         if st is None:
@@ -374,6 +376,9 @@ class CaraEngine:
             raise CaraError("cara_amd runs on the GPU only (no CPU fallback)")
         if x.ndim != 3 or x.shape[2] != model.embed_dim or x.shape[1] > 608:
             raise CaraError("module-level forward expects x of shape [B, N <= 608, embed_dim]")
+        if self.cp_length == 2:
+            raise CaraError("with cp_length 2 (dense QKV deltas) call the whole model: the module-level Attention.forward / "
+                            "Mlp.forward entries run the factored adapters only")
         if self.weight_dropout == "exact" and model.training:
             raise CaraError("the module-level forwards (Attention.forward / Mlp.forward called on their own) run the factored "
                             "adapters only: with weight_dropout = 'exact' in train mode call the whole model, or switch to eval()")

@@ -77,7 +77,7 @@ def forward(model, images: torch.Tensor) -> torch.Tensor:
     if eng is None:
         raise CaraError("precise.forward needs a model adapted by cara_amd.cara()")
     if eng.cp_length != 4:
-        raise CaraError("the bf16x3 parity mode covers the default tensorisation (cp_length 4)")
+        raise CaraError("the bf16x3 parity instrument covers the default tensorisation (cp_length 4)")
     if not images.is_cuda:
         raise CaraError("cara_amd runs on the GPU only (no CPU fallback)")
     s = float(eng.scale)

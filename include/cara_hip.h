@@ -221,7 +221,10 @@ typedef struct {
    * 5: dW[k,e,h,d] = sum_r R1 A1[l] A2[k] A3[e] A4[h] A5[d],  A1 [depth,R], A2 [3,R], A3 [dim,R], A4 [heads,R],
    *    A5 [dim/heads,R].
    * All three are rank-R in (in, out) and run on the same factored kernels; only the factor pack and the
-   * gradient scatter differ.  (cp_length 2 is a sum of R dense dim x dim matrices, not low-rank: not supported.) */
+   * gradient scatter differ.
+   * 2: dW[k, e * dim + o] = sum_r R1 A1[3l+k] A2[e * dim + o],  A2 [dim * dim, R], no A3 / A4 (NULL): a sum of R DENSE
+   *    dim x dim matrices per projection, not low-rank -- the QKV linear then runs in the dense-delta form
+   *    (cara_dense_delta_* below; weight_dropout off only) while proj / fc1 / fc2 keep the factored kernels.           */
   int cp_length;
 } cara_geom;
 /* Pointers to the CP tensors (fp32, shapes of cara.py:112-125 for cp_length 4) or to their gradients.
@@ -259,6 +262,18 @@ typedef struct {
 size_t cara_factor_grad_scratch_bytes(const cara_geom* g);
 int cara_factor_grad_reduce(const cara_geom* g, const cara_cp* cp, const cara_layer_grads* lg,
                             const cara_cp* grads, void* scratch, void* stream);
+
+/* ---- order-2 QKV tensorisation (image_classification/dim_experiment.py:203-207,293-297; cara_geom::cp_length == 2) ---- */
+/* Dm bf16 [depth][3 dim, dim] with Dm[l][k dim + o][e] = s * sum_r R1[r] A1[3l+k, r] A2[e dim + o, r] (the second B operand,
+ * cara_gemm_args::B3, of the QKV linear next to the frozen weight) and Dmt bf16 [depth][dim, 3 dim] its transpose (for dX). */
+int cara_dense_delta_materialize(const cara_geom* g, const cara_cp* cp, void* Dm, void* Dmt, void* stream);
+/* From dD fp32 [depth][3][dim (e), dim (o)] = x^T dY_k per block and projection (cara_gemm_tn_f32 + cara_sum_slabs_f32) to the
+ * gradients of CP_A1, CP_A2, CP_R1 (OVERWRITTEN in `grads`; run it AFTER cara_factor_grad_reduce, which for this order leaves
+ * CP_A1 / CP_A2 alone and writes a zero CP_R1).  Fixed summation order.  scratch: cara_dense_delta_grad_scratch_bytes(g). */
+size_t cara_dense_delta_grad_scratch_bytes(const cara_geom* g);
+int cara_dense_delta_grad(const cara_geom* g, const cara_cp* cp, const float* dD, const cara_cp* grads, void* scratch, void* stream);
+/* out[j] = sum_z slabs[z * slab_stride + j], j < count (fixed order): the split-K slabs of cara_gemm_tn_f32 into one matrix */
+int cara_sum_slabs_f32(const float* slabs, int nslab, size_t slab_stride, size_t count, float* out, void* stream);
 
 /* ---- exact weight-space dropout mode (the reference's train-mode arithmetic, cara.py:35,57,81,92) ---- */
 /* keep(o,i) of linear `linear_id` = (cara_weight_dropout_hash(o*in + i, seed, linear_id) >> 8) >= p * 2^24

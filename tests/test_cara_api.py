@@ -90,10 +90,10 @@ def test_init_matches_reference_draws(rank):
     assert th.equal(m.CP_P3.detach()[:8], th.from_numpy(G[f"init_r{rank}_CP_P3_rows0_8"]))
 
 
-@pytest.mark.parametrize("cp_length", [3, 5])
+@pytest.mark.parametrize("cp_length", [2, 3, 5])
 def test_other_orders_of_the_qkv_tensorisation(cp_length):
     """config["cp_length"] = the `--dims` of image_classification/dim_experiment.py: parameter names, shapes, zero
-    factor and index walk of its set_CP (:264-295, :330-336); order 2 is refused with the reason."""
+    factor and index walk of its set_CP (:264-297, :330-336)."""
     cfg = _cfg(depth=3)
     cfg["cp_length"] = cp_length
     vit = cara(cfg)
@@ -102,16 +102,35 @@ def test_other_orders_of_the_qkv_tensorisation(cp_length):
         assert shapes == {"CP_A1": (3, 32), "CP_A2": (3, 32), "CP_A3": (768, 32), "CP_A4": (12, 32), "CP_A5": (64, 32)}
         assert th.count_nonzero(vit.CP_A3) == 0 and th.count_nonzero(vit.CP_A2) > 0
         assert [b.attn.attn_idx for b in vit.blocks] == [0, 1, 2] and vit.attn_idx == 3
-    else:
+    elif cp_length == 3:
         assert shapes == {"CP_A1": (9, 32), "CP_A2": (768, 32), "CP_A3": (768, 32)}
+        assert th.count_nonzero(vit.CP_A2) == 0
+        assert [b.attn.attn_idx for b in vit.blocks] == [0, 3, 6]
+    else:
+        assert shapes == {"CP_A1": (9, 32), "CP_A2": (768 * 768, 32)}            # dim_experiment.py:293-297
         assert th.count_nonzero(vit.CP_A2) == 0
         assert [b.attn.attn_idx for b in vit.blocks] == [0, 3, 6]
     assert [b.attn.idx for b in vit.blocks] == [0, 9, 18] and vit.idx == 27 and vit.cp_l == cp_length
     assert vit._cara_engine.cp_fields == _lib.cp_fields(cp_length)
-    cfg2 = _cfg(depth=2)
-    cfg2["cp_length"] = 2
-    with pytest.raises(CaraError, match="dense"):
-        cara(cfg2)
+
+
+def test_order_2_declaration_draws_and_limits():
+    """Order 2 (dense QKV deltas): the parameter draws are the reference script's (same initialisers, same order:
+    A1 xavier, A2 zeros, then P1, P3, R1, R2 -- dim_experiment.py:293-312, checked through the oracle's restatement,
+    itself pinned to the script in tests/test_oracle.py); the exact weight-dropout mode is refused by name."""
+    from oracle import cara_oracle as O
+    th.manual_seed(11)
+    want = O.init_cp_params(4, 1.5, 0.1, dim=256, heads=4, depth=2, cp_length=2)
+    model = _get_vit(embed_dim=256, num_heads=4, depth=2, num_classes=5)
+    th.manual_seed(11)
+    vit = cara({"model": model, "rank": 4, "scale": 2.0, "l_mu": 1.5, "l_std": 0.1, "cp_length": 2})
+    for k, v in want.items():
+        assert th.equal(getattr(vit, k).detach(), v), k
+    assert [n for n, _ in vit.named_parameters() if n.startswith("CP_")] == list(want.keys())
+    cfg = _cfg(depth=2)
+    cfg.update(cp_length=2, weight_dropout="exact")
+    with pytest.raises(CaraError, match="weight_dropout = 'off' only"):
+        cara(cfg)
 
 
 def test_state_dict_roundtrip_and_reset_classifier():
@@ -149,7 +168,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.cara_abi_version() == 5 and lib.cara_build_arch() == b"gfx950"
+    assert lib.cara_abi_version() == 6 and lib.cara_build_arch() == b"gfx950"
 
 
 # ---- drop-in on a FOREIGN timm-shaped model (vit_cp.py:13-15,155 builds it with timm.models.create_model) --------

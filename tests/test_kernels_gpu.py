@@ -832,3 +832,53 @@ def test_transposing_lds_read_semantics():
         rows = torch.tensor([[min(base + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3), N - 1) for j in range(8)] for l in range(64)])
         cols = torch.tensor([[cbase + (l & 31)] * 8 for l in range(64)])
         assert torch.equal(out.cpu(), Vb.cpu()[rows, cols]), (cbase, base)
+
+
+@pytest.mark.parametrize("dim,depth,rank", [(256, 2, 4), (768, 3, 16), (128, 1, 64)])
+def test_dense_delta_entry_points(dim, depth, rank):
+    """Order-2 QKV tensorisation (dim_experiment.py:203-207): cara_dense_delta_materialize against
+    s * sum_r R1 A1[3l+k] A2[e dim + o] in fp64 (bf16 outputs: half an ulp), and cara_dense_delta_grad against fp64 autograd of
+    sum(dD * tensor) through CP_A1 / CP_A2 / CP_R1; cara_sum_slabs_f32 bit-exact against the same fixed-order sum."""
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+    s = 0.3
+    g = torch.Generator().manual_seed(dim + rank)
+    A1 = torch.randn(3 * depth, rank, generator=g)
+    A2 = 0.1 * torch.randn(dim * dim, rank, generator=g)
+    R1 = 1.0 + 0.2 * torch.randn(rank, generator=g)
+    dD = torch.randn(depth, 3, dim, dim, generator=g)
+    d = {n: t.to(DEV).contiguous() for n, t in (("A1", A1), ("A2", A2), ("R1", R1))}
+    geom = L().Geom(depth, dim, 4, rank, 64 if rank > 32 else 32, s, 2)
+    cps = L().CpPtrs(A1=p(d["A1"]), A2=p(d["A2"]), R1=p(d["R1"]))
+    Dm = torch.empty(depth, 3 * dim, dim, dtype=torch.bfloat16, device=DEV)
+    Dmt = torch.empty(depth, dim, 3 * dim, dtype=torch.bfloat16, device=DEV)
+    L().check(lib.cara_dense_delta_materialize(C.byref(geom), C.byref(cps), p(Dm), p(Dmt), st()), "materialize")
+    v = {n: t.double().requires_grad_(True) for n, t in (("A1", A1), ("A2", A2), ("R1", R1))}
+    ten = s * torch.einsum("r,lkr,pr->lkp", v["R1"], v["A1"].reshape(depth, 3, rank), v["A2"]).reshape(depth, 3, dim, dim)   # [l][k][e][o]
+    want = ten.detach().permute(0, 1, 3, 2).reshape(depth, 3 * dim, dim)      # [l][k dim + o][e]
+    assert (Dm.double().cpu() - want).abs().max() <= 2.0 ** -8 * want.abs().max()
+    assert torch.equal(Dmt, Dm.transpose(1, 2).contiguous())
+    (ten * dD.double()).sum().backward()
+    gout = {n: torch.full_like(d[n], float("nan")) for n in d}
+    gp = L().CpPtrs(A1=p(gout["A1"]), A2=p(gout["A2"]), R1=p(gout["R1"]))
+    nb = lib.cara_dense_delta_grad_scratch_bytes(C.byref(geom))
+    assert nb > 0
+    scratch = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    dDd = dD.to(DEV)
+    L().check(lib.cara_dense_delta_grad(C.byref(geom), C.byref(cps), p(dDd), C.byref(gp), p(scratch), st()), "dense delta grad")
+    torch.cuda.synchronize()
+    for n in d:
+        ref = v[n].grad
+        close(gout[n], ref, 1e-4, 1e-4 * ref.abs().max().item(), "order-2 grad " + n)
+    # refusals: another order's geometry, a missing tensor
+    g4 = L().Geom(depth, dim, 4, rank, 32, s, 4)
+    assert lib.cara_dense_delta_materialize(C.byref(g4), C.byref(cps), p(Dm), p(Dmt), st()) != 0
+    assert lib.cara_dense_delta_grad_scratch_bytes(C.byref(g4)) == 0
+    assert lib.cara_dense_delta_grad(C.byref(geom), C.byref(cps), None, C.byref(gp), p(scratch), st()) != 0
+    # slabs
+    slabs = torch.randn(5, 1000, device=DEV)
+    out = torch.empty(777, device=DEV)
+    L().check(lib.cara_sum_slabs_f32(p(slabs), 5, C.c_size_t(1000), C.c_size_t(777), p(out), st()), "sum slabs")
+    ref = ((slabs[0] + slabs[2]) + slabs[4]) + (slabs[1] + slabs[3])
+    assert torch.equal(out, ref[:777])
+    assert lib.cara_sum_slabs_f32(p(slabs), 0, C.c_size_t(1000), C.c_size_t(777), p(out), st()) != 0

@@ -315,6 +315,90 @@ def test_other_orders_against_the_reference_script_vectors(cp_length):
     assert worst < T.CP_GRAD
 
 
+def test_order_2_against_the_reference_script_vectors():
+    """Golden case 8 of make_golden.py: order 2 of image_classification/dim_experiment.py (`--dims 2`: every QKV projection
+    gets a sum of R DENSE dim x dim matrices, CP_A2 [dim * dim, R], :203-207, :293-297) at depth 2, 197 tokens, rank 4 --
+    the dense-delta device path against the logits and CP gradients that script computed.  CP_A2's gradient is 590k x 4:
+    the fixture holds every 97th row plus the tensor's norm and sum."""
+    from oracle import cara_oracle as O
+    from tests.golden.inputs import oracle_case_cp_length2
+    from cara_amd import CaraError
+    w, cp, img = oracle_case_cp_length2()
+    m = build(w, {k: v.clone() for k, v in cp.items()}, 4, 0.1, 2, 224, cp_length=2).eval()
+    assert tuple(m.CP_A2.shape) == (768 * 768, 4) and not hasattr(m, "CP_A3")
+    logits = m(img.to(DEV))
+    ref = torch.from_numpy(G["cpl2_logits"])
+    with torch.no_grad():
+        sim = O.vit_cara_forward(img, w, cp, s=0.1, depth=2, factored=True, bf16_sim=True)
+    r_ref, r_model = rel(logits, ref), rel(sim, ref)
+    print(f"cp_length 2 vs dim_experiment.py: logits rel-L2 {r_ref:.2e} (rounding model {r_model:.2e})")
+    assert T.logits_ok(r_ref, r_model), (r_ref, r_model)
+    assert torch.equal(logits.argmax(1).cpu(), ref.argmax(1))
+    torch.logsumexp(logits, dim=1).sum().backward()
+    worst = 0.0
+    for k in cp:
+        g = getattr(m, k).grad
+        if k == "CP_A2":
+            e = rel(g[::97], torch.from_numpy(G["cpl2_grad_CP_A2_rows97"]))
+            nrm, tot = G["cpl2_grad_CP_A2_norm_sum"].tolist()
+            assert abs(g.double().norm().item() / nrm - 1) < T.CP_GRAD
+            assert abs(g.double().sum().item() - tot) < T.CP_GRAD * nrm          # a sum of 2.4 M terms of norm `nrm`
+        else:
+            gr = torch.from_numpy(G[f"cpl2_grad_{k}"])
+            if k in ("CP_A1", "CP_P1"):
+                assert torch.count_nonzero(gr[g.shape[0]:]) == 0
+                gr = gr[:g.shape[0]]
+            e = rel(g, gr)
+        print(f"  cp_length 2 grad {k}: rel-L2 {e:.2e}")
+        worst = max(worst, e)
+    assert worst < T.CP_GRAD
+    # the sub-module entries carry the factored adapters only
+    with pytest.raises(CaraError, match="whole model"):
+        m.blocks[0].attn(torch.zeros(1, 197, 768, device=DEV))
+
+
+def test_order_2_train_step_and_deeper_model():
+    """Order 2 through the optimiser step, in train mode (drop-path masks), at depth 3 / rank 8 / odd batch, against the oracle's
+    autograd on the same masks; then two AdamW steps lower the loss."""
+    from oracle import cara_oracle as O
+    depth, rank = 3, 8
+    w = O.synthetic_backbone(depth=depth)
+    torch.manual_seed(5)
+    cp = O.init_cp_params(rank, 1.0, 0.1, depth=depth, cp_length=2)
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        cp["CP_A2"].copy_(0.02 * torch.randn(cp["CP_A2"].shape, generator=g))
+        cp["CP_P2"].copy_(0.05 * torch.randn(cp["CP_P2"].shape, generator=g))
+    x, y = O.synthetic_batch(batch=3)
+    m = build(w, {k: v.clone() for k, v in cp.items()}, rank, 0.1, depth, 224, cp_length=2).train()
+    keep = torch.ones(depth, 2, 3)
+    keep[1, 0, 1] = 0.0
+    keep[2, 1, 2] = 0.0
+    logits = m._cara_engine.forward(x.to(DEV), droppath=keep.to(DEV))
+    cpv = {k: v.clone().requires_grad_(True) for k, v in cp.items()}
+    ref = O.vit_cara_forward(x, w, cpv, s=0.1, depth=depth, drop_path_keep=keep)
+    with torch.no_grad():
+        sim = O.vit_cara_forward(x, w, cp, s=0.1, depth=depth, drop_path_keep=keep, factored=True, bf16_sim=True)
+    assert T.logits_ok(rel(logits, ref.detach()), rel(sim, ref.detach()))
+    torch.nn.functional.cross_entropy(logits, y.to(DEV)).backward()
+    torch.nn.functional.cross_entropy(ref, y).backward()
+    for k in cp:
+        e = rel(getattr(m, k).grad, cpv[k].grad)
+        print(f"  order 2, depth 3: grad {k} rel-L2 {e:.2e}")
+        assert e < T.CP_GRAD, (k, e)
+    m.zero_grad()
+    m.eval()
+    opt = torch.optim.AdamW([p for n, p in m.named_parameters() if n.startswith("CP_") or n.startswith("head")], lr=1e-3)
+    losses = []
+    for _ in range(3):
+        loss = torch.nn.functional.cross_entropy(m(x.to(DEV)), y.to(DEV))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0], losses
+
+
 def test_drop_path_masks_and_train_mode():
     from oracle import cara_oracle as O
     w = O.synthetic_backbone(depth=3)
