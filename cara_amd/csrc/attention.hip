@@ -815,6 +815,20 @@ __device__ __forceinline__ void glds4_hidden(const char* base, unsigned voff, un
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory", "m0");
 }
 
+#ifdef CARA_ATTN_STAMPS
+// Diagnostic build (tools/attn_stamps.py): wave 0 of every workgroup records s_memrealtime (100 MHz) at eight points of
+// every head it walks, into a buffer of its own: [block][head slot (<= 4)][8].
+__device__ unsigned long long* g_attn_stamp_buf = nullptr;
+extern "C" int cara_debug_attn_stamps(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#define ATTN_STAMP(i)                                                                                              \
+  do {                                                                                                             \
+    if (g_attn_stamp_buf && tid == 0 && slot < 4) g_attn_stamp_buf[((size_t)blockIdx.x * 4 + slot) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define ATTN_STAMP(i)
+#endif
 __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                                 const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                                 bf16* __restrict__ dqkv, int N, int H, int BH, float scale) {
@@ -831,6 +845,7 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
   const int ld = 3 * H * HD, ldo = H * HD;
   const int l31 = lane & 31, h = lane >> 5;
   const float c2 = scale * 1.4426950408889634f;
+  const float nrscale = -1.f / scale;
   const RowOfs ro = row_ofs(lane);
   const TrOfs to = tr_ofs(lane);
   const int nt = (N + 31) >> 5;                 // query / key tiles (<= 7)
@@ -892,9 +907,16 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
     dma_lse(bh);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+#ifdef CARA_ATTN_STAMPS
+  int slot = -1;
+#endif
   for (; bh < BH; bh += gridDim.x) {
     const int nxt = bh + gridDim.x;
     const int b = bh / H, head = bh - b * H;
+#ifdef CARA_ATTN_STAMPS
+    ++slot;
+#endif
+    ATTN_STAMP(0);
     // T0: every wave is through with phase B of the previous head (K, V images free) and has seen its own pieces of this
     // head's Q, dO, O images land
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -911,11 +933,15 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
         for (int j = 0; j < 8; ++j) dl += (float)a[j] * (float)g[j];
       }
       dl += __shfl_xor(dl, 1, 64);
-      if (half == 0) del_s[row] = dl;
-      if (tid < NPAD) lse_s[tid] *= 1.4426950408889634f;   // (each element touched by exactly one thread)
+      // Row constants in the form the S and dP accumulators are SEEDED with (phase A reads them straight into the
+      // accumulator registers): S' = Q K^T - lse / scale, so p = exp2(c2 S') needs no subtraction, and dP' = dO V^T - delta,
+      // so dS = p dP'.  A padded query row (>= N) gets -1e30: its p is exactly 0, no select per element anywhere.
+      if (half == 0) del_s[row] = -dl;
+      if (tid < NPAD) lse_s[tid] = tid < N ? lse_s[tid] * nrscale : -1e30f;   // (each element touched by exactly one thread)
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // T1
     __builtin_amdgcn_sched_barrier(0);
+    ATTN_STAMP(1);
 
     // ================= phase A: dK, dV of keys t0 .. t0 + 31 =================
     f32x16 dkt[2], dvt[2];
@@ -931,9 +957,15 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
       const int q0 = qt * 32;
       const char* qblk = Qs + qt * 4096;
       const char* dblk = dOs + qt * 4096;
+      // accumulators seeded with the row constants: register 4 g4 + k of lane half h is query row q0 + 8 g4 + 4 h + k
       f32x16 sacc, pacc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + q0 + 8 * g4 + 4 * h);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + q0 + 8 * g4 + 4 * h);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sacc[4 * g4 + k] = l4[k]; pacc[4 * g4 + k] = d4[k]; }
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qblk + ro.o[ks]);
@@ -950,21 +982,15 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
         dma_image(qb + 2 * H * HD * 2, off_qkv, Vs);
         __builtin_amdgcn_sched_barrier(0);
       }
+      // (a lane whose key is padding -- t0 + l31 >= N, its K / V rows duplicates of row N - 1 -- carries finite values
+      // that only ever reach its OWN columns of dK^T / dV^T, which are not stored; a padded QUERY row has p = 0 through its
+      // seed: no select per element)
       f32x16 p, ds;
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + q0 + 8 * g4 + 4 * h);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + q0 + 8 * g4 + 4 * h);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int r = 4 * g4 + k;
-          float e = __builtin_amdgcn_exp2f(sacc[r] * c2 - l4[k]);
-          if (qt == nt - 1) e = crow(r, h) < last ? e : 0.f;
-          // (a lane whose key is padding -- t0 + l31 >= N, its K / V rows duplicates of row N - 1 -- carries finite values
-          // that only ever reach its OWN columns of dK^T / dV^T, which are not stored: no select per element needed)
-          p[r] = e;
-          ds[r] = e * (pacc[r] - d4[k]);
-        }
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sacc[r] * c2);
+        p[r] = e;
+        ds[r] = e * pacc[r];
       }
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
@@ -978,24 +1004,40 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
         }
       }
     }
+    ATTN_STAMP(2);
     // T2: this wave's pieces of K, V have landed (they are old by now); then every wave's
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (tvalid) {
-      bf16* dk = dqkv + (size_t)(b * N + t0 + l31) * ld + H * HD + head * HD;
-      bf16* dv = dk + H * HD;
+    ATTN_STAMP(3);
+    // dK, dV of this wave's 32 keys leave as WHOLE 128-byte rows: the accumulators hold them transposed (key on the lane, a
+    // lane's 4 consecutive d per register group), so a direct store is 32 instructions that touch 32 rows each (2.7 us of a
+    // head's 22: the stores are issue-bound per cache line touched).  Instead each matrix goes through this wave's 4 KiB of the
+    // O image (free between T1 and T3; swizzled like every image here) and out as 4 stores of 8 full rows.
+    {
+      char* stg = Os + wave * 4096;
+      const int srow = lane >> 3, schunk = lane & 7;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+      for (int m = 0; m < 2; ++m) {   // 0: dK (scaled), 1: dV
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d = dt * 32 + 8 * g + 4 * h;
-          bf16x4 a = {(bf16)(dkt[dt][4 * g] * scale), (bf16)(dkt[dt][4 * g + 1] * scale),
-                      (bf16)(dkt[dt][4 * g + 2] * scale), (bf16)(dkt[dt][4 * g + 3] * scale)};
-          bf16x4 c = {(bf16)dvt[dt][4 * g], (bf16)dvt[dt][4 * g + 1], (bf16)dvt[dt][4 * g + 2], (bf16)dvt[dt][4 * g + 3]};
-          *reinterpret_cast<bf16x4*>(dk + d) = a;
-          *reinterpret_cast<bf16x4*>(dv + d) = c;
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x16& acc = m == 0 ? dkt[dt] : dvt[dt];
+            const float f = m == 0 ? scale : 1.f;
+            const bf16x4 a = {(bf16)(acc[4 * g] * f), (bf16)(acc[4 * g + 1] * f), (bf16)(acc[4 * g + 2] * f), (bf16)(acc[4 * g + 3] * f)};
+            *reinterpret_cast<bf16x4*>(stg + swz128(l31, dt * 4 + g) + h * 8) = a;     // d = dt 32 + 8 g + 4 h ..+3
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        bf16* dst = dqkv + (size_t)(b * N + t0) * ld + (1 + m) * H * HD + head * HD + schunk * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint4 v = *reinterpret_cast<const uint4*>(stg + swz128(srow + 8 * i, schunk));
+          if (t0 + srow + 8 * i < N) *reinterpret_cast<uint4*>(dst + (size_t)(srow + 8 * i) * ld) = v;
         }
+        asm volatile("" ::: "memory");   // (the image is rewritten by the next matrix / the next head's DMA)
+      }
     }
 
     // ================= phase B: dQ of queries t0 .. t0 + 31 =================
@@ -1005,37 +1047,52 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
       qf[ks] = *reinterpret_cast<const bf16x8*>(Qs + wave * 4096 + ro.o[ks]);
       dof[ks] = *reinterpret_cast<const bf16x8*>(dOs + wave * 4096 + ro.o[ks]);
     }
-    const float lq = lse_s[t0 + l31], dl = del_s[t0 + l31];
+    const float lq = lse_s[t0 + l31] * c2, dl = del_s[t0 + l31];   // (-lse in log2 units | -delta; a padded query: -inf-like)
+    // seed of S^T in the LAST key tile: its padded key rows (duplicates of key N - 1) start at -1e30, so their p is exactly 0
+    f32x16 seed_last;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) seed_last[r] = crow(r, h) < last ? 0.f : -1e30f;
+    ATTN_STAMP(4);
     // T3: every wave holds its Q / dO rows and row constants: the Q, dO, O images may take the next head
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (nxt < BH) {
-      const char* qb = qkv_base(nxt);
-      dma_image(qb, off_qkv, Qs);
-      dma_image(o_base(dout, nxt), off_o, dOs);
-      dma_image(o_base(out, nxt), off_o, Os);
-      const bf16* kb = reinterpret_cast<const bf16*>(qb) + H * HD;
-      const bf16* vb = kb + H * HD;
+    ATTN_STAMP(5);
+    // The next head's images and key rows: 12 DMA pieces + 8 row loads + the LSE row per wave.  Issued in one go they hold the
+    // wave's instruction stream for 3-4 us (the CU's load path takes them at ~70 GB/s and a wave issues in order: the dQ sweep
+    // measured 9.0 us with them in front and 5.0 without); handed out over the key tiles -- slice j behind the MFMAs of tile j --
+    // they go out under the arithmetic.
+    const bool has_nxt = nxt < BH;
+    const char* nqb = qkv_base(has_nxt ? nxt : bh);
+    const char* ndob = o_base(dout, has_nxt ? nxt : bh);
+    const char* nob = o_base(out, has_nxt ? nxt : bh);
+    auto next_slice = [&](const int j) {   // j = 0 .. 5 (compile-time in the unrolled callers)
+      if (!has_nxt) return;
+      const int t = j & 3;
+      if (j < 4) {
+        glds16_hidden(nqb, off_qkv[t], lds_of(Qs) + (unsigned)((wave + t * 7) * 1024));
+        glds16_hidden(ndob, off_o[t], lds_of(dOs) + (unsigned)((wave + t * 7) * 1024));
+        glds16_hidden(nob, off_o[t], lds_of(Os) + (unsigned)((wave + t * 7) * 1024));
+        const bf16* kb = reinterpret_cast<const bf16*>(nqb) + H * HD;
+        kf[t] = *reinterpret_cast<const bf16x8*>(kb + (size_t)trow * ld + t * 16 + h * 8);
+      } else if (j == 4) {
+        const bf16* vb = reinterpret_cast<const bf16*>(nqb) + 2 * H * HD;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        kf[ks] = *reinterpret_cast<const bf16x8*>(kb + (size_t)trow * ld + ks * 16 + h * 8);
-        vf[ks] = *reinterpret_cast<const bf16x8*>(vb + (size_t)trow * ld + ks * 16 + h * 8);
+        for (int ks = 0; ks < 4; ++ks) vf[ks] = *reinterpret_cast<const bf16x8*>(vb + (size_t)trow * ld + ks * 16 + h * 8);
+      } else {
+        dma_lse(nxt);
       }
-      dma_lse(nxt);
-    }
+    };
     f32x16 dq[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 7; ++kt) {
-      if (kt >= nt) break;
+    auto tile_b = [&](const int kt, const f32x16& seed) {
       const char* kblk = Ks + kt * 4096;
       const char* vblk = Vs + kt * 4096;
-      f32x16 sT, dpT;
+      f32x16 sT = seed, dpT;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { sT[r] = 0.f; dpT[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) dpT[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kblk + ro.o[ks]);
@@ -1046,9 +1103,8 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
       f32x16 ds;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float e = __builtin_amdgcn_exp2f(sT[r] * c2 - lq);
-        if (kt == nt - 1) e = crow(r, h) < last ? e : 0.f;
-        ds[r] = e * (dpT[r] - dl);
+        const float e = __builtin_amdgcn_exp2f(sT[r] * c2 + lq);
+        ds[r] = e * (dpT[r] + dl);
       }
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
@@ -1059,11 +1115,30 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
           dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, a, dq[dt], 0, 0, 0);   // dQ^T = K^T dS^T
         }
       }
+    };
+    {
+      f32x16 zero;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+      // whole key tiles (unrolled: a tile's LDS fragments are requested under the previous tile's arithmetic), then the last
+      // one with its padded keys masked through the seed
+#pragma unroll
+      for (int kt = 0; kt < 6; ++kt) {
+        if (kt >= nt - 1) break;
+        next_slice(kt);
+        tile_b(kt, zero);
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j)   // (the slices of tiles this N does not have)
+        if (j >= nt - 1) next_slice(j);
+      tile_b(nt - 1, seed_last);
     }
+    ATTN_STAMP(6);
     // the next head's images and row fragments have landed (they are old by now): wait for them HERE, before this phase's
     // stores go out, so that no later wait ever has to cover a store
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    ATTN_STAMP(7);
     bf16* qrow_out = dqkv + (size_t)(b * N + trow) * ld + head * HD;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {

@@ -655,6 +655,8 @@ def attn_ref(qkv, B, N, H, scale):
 
 
 @pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 5, 2), (1, 64, 1), (2, 224, 3), (1, 33, 2),
+                                   # the persistent kernels (128 < N <= 224) at every tile count and ragged last tiles
+                                   (2, 129, 2), (1, 160, 3), (2, 161, 2), (1, 193, 1), (30, 197, 12),
                                    # above 224 tokens: two-sweep forward, key groups on grid.y (ViT-L/16 @384 has 577)
                                    (2, 577, 16), (1, 225, 2), (1, 608, 1), (2, 300, 3)])
 def test_attention_fwd_bwd(B, N, H):
