@@ -53,6 +53,9 @@ def main():
             gap = t[:, slot + 1, 0] - t[:, slot, 7]
             print(f"    dQ stores -> next loop top  mean {float(gap.mean()):6.2f} us")
     print(f"last stamp at {float((t[:, 2, 7] - t0).max()):.2f} us after the first")
+    raw = buf.cpu().reshape(256, 4, 8)[:, 3].double()
+    clk = (raw[:, 2] - raw[:, 0]) / ((raw[:, 3] - raw[:, 1]) / 100.0)      # shader-clock ticks per us = MHz
+    print(f"shader clock over the head loop: mean {float(clk.mean()):.0f} MHz (min {float(clk.min()):.0f}, max {float(clk.max()):.0f})")
 
 
 if __name__ == "__main__":

@@ -846,29 +846,28 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
   const int l31 = lane & 31, h = lane >> 5;
   const float c2 = scale * 1.4426950408889634f;
   const float nrscale = -1.f / scale;
-  const RowOfs ro = row_ofs(lane);
-  const TrOfs to = tr_ofs(lane);
   const int nt = (N + 31) >> 5;                 // query / key tiles (<= 7)
   const int last = N - (nt - 1) * 32;           // valid rows of the last tile
   const int t0 = wave * 32;                     // first key (phase A) / query (phase B) of this wave
   const int trow = t0 + l31 < N ? t0 + l31 : N - 1;
   const bool tvalid = t0 + l31 < N;
 
-  // per-lane 32-bit byte offsets of this wave's DMA pieces (head-independent; the head's base pointers are wave-uniform).
-  // An image = 28 pieces of 8 rows; wave w takes pieces w, w + 7, w + 14, w + 21 of every image.
-  unsigned off_qkv[4], off_o[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int row = (wave + t * 7) * 8 + (lane >> 3);
+  // per-lane 32-bit byte offsets of this wave's DMA pieces (the head's base pointers are wave-uniform).  An image = 28 pieces
+  // of 8 rows; wave w takes pieces w, w + 7, w + 14, w + 21 of every image.  Computed where a piece is issued (a dozen
+  // VALU instructions, ~50 pieces per head) rather than held in 12 registers across the sweeps, which run at the register
+  // limit; `lane` goes through an empty asm so that the compiler does not hoist them back out of the head loop.
+  auto piece_off = [&](const int t, const int rowbytes) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int row = (wave + t * 7) * 8 + (ln >> 3);
     const int rr = row < N ? row : N - 1;
-    const int c = (lane & 7) ^ swzk(row);
-    off_qkv[t] = (unsigned)rr * (unsigned)(ld * 2) + (unsigned)(c * 16);
-    off_o[t] = (unsigned)rr * (unsigned)(ldo * 2) + (unsigned)(c * 16);
-  }
+    const int c = (ln & 7) ^ swzk(row);
+    return (unsigned)rr * (unsigned)rowbytes + (unsigned)(c * 16);
+  };
   auto lds_of = [](const char* p) { return __builtin_amdgcn_readfirstlane((unsigned)(size_t)p); };
-  auto dma_image = [&](const char* base, const unsigned (&off)[4], char* img) {
+  auto dma_image = [&](const char* base, const int rowbytes, char* img) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) glds16_hidden(base, off[t], lds_of(img) + (unsigned)((wave + t * 7) * 1024));
+    for (int t = 0; t < 4; ++t) glds16_hidden(base, piece_off(t, rowbytes), lds_of(img) + (unsigned)((wave + t * 7) * 1024));
   };
   auto qkv_base = [&](int bh) { const int b = bh / H, hd = bh - b * H; return reinterpret_cast<const char*>(qkv + (size_t)b * N * ld + hd * HD); };
   auto o_base = [&](const bf16* p_, int bh) { const int b = bh / H, hd = bh - b * H; return reinterpret_cast<const char*>(p_ + (size_t)b * N * ldo + hd * HD); };
@@ -877,26 +876,24 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
   if (bh >= BH) return;
   // ---- prologue: what a "phase B" leaves behind for the next head ----
   bf16x8 kf[4], vf[4];
-  // the head's LSE row: wave 0, four pieces of 64 floats straight into lse_s (raw; scaled to log2 units in the delta step)
-  unsigned off_lse[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int i = t * 64 + lane;
-    off_lse[t] = (unsigned)((i < N ? i : N - 1) * 4);
-  }
+  // the head's LSE row: wave 0, four pieces of 64 floats straight into lse_s (raw; turned into seeds in the delta step)
   auto dma_lse = [&](int bh_) {
     if (wave == 0) {
       const char* base = reinterpret_cast<const char*>(lse + (size_t)bh_ * N);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        if (t * 64 < NPAD) glds4_hidden(base, off_lse[t], lds_of(reinterpret_cast<const char*>(lse_s)) + (unsigned)(t * 256));
+        if (t * 64 < NPAD) {
+          int i = t * 64 + lane;
+          asm volatile("" : "+v"(i));
+          glds4_hidden(base, (unsigned)((i < N ? i : N - 1) * 4), lds_of(reinterpret_cast<const char*>(lse_s)) + (unsigned)(t * 256));
+        }
     }
   };
   {
     const char* qb = qkv_base(bh);
-    dma_image(qb, off_qkv, Qs);
-    dma_image(o_base(dout, bh), off_o, dOs);
-    dma_image(o_base(out, bh), off_o, Os);
+    dma_image(qb, ld * 2, Qs);
+    dma_image(o_base(dout, bh), ldo * 2, dOs);
+    dma_image(o_base(out, bh), ldo * 2, Os);
     const bf16* kb = reinterpret_cast<const bf16*>(qb) + H * HD;
     const bf16* vb = kb + H * HD;
 #pragma unroll
@@ -909,12 +906,6 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
   }
 #ifdef CARA_ATTN_STAMPS
   int slot = -1;
-  // (head slot 3 is never walked at 3 heads per workgroup: its first entries take the shader-clock counter at both ends of the
-  // head loop, next to the 100-MHz one, so that the script can print the clock the kernel ran at)
-  if (g_attn_stamp_buf && tid == 0) {
-    g_attn_stamp_buf[((size_t)blockIdx.x * 4 + 3) * 8 + 0] = __builtin_amdgcn_s_memtime();
-    g_attn_stamp_buf[((size_t)blockIdx.x * 4 + 3) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
-  }
 #endif
   for (; bh < BH; bh += gridDim.x) {
     const int nxt = bh + gridDim.x;
@@ -928,7 +919,9 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // delta[row] = sum_d dO[row][d] O[row][d] from the images, two threads per row (4 chunks of 8 each); lse in log2 units
     {
-      const int row = tid >> 1, half = tid & 1;
+      int tid_d = tid;   // (laundered: the image offsets below are not to live in registers across the sweeps)
+      asm volatile("" : "+v"(tid_d));
+      const int row = tid_d >> 1, half = tid_d & 1;
       float dl = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -943,70 +936,127 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
       // accumulator registers): S' = Q K^T - lse / scale, so p = exp2(c2 S') needs no subtraction, and dP' = dO V^T - delta,
       // so dS = p dP'.  A padded query row (>= N) gets -1e30: its p is exactly 0, no select per element anywhere.
       if (half == 0) del_s[row] = -dl;
-      if (tid < NPAD) lse_s[tid] = tid < N ? lse_s[tid] * nrscale : -1e30f;   // (each element touched by exactly one thread)
+      if (tid_d < NPAD) lse_s[tid_d] = tid_d < N ? lse_s[tid_d] * nrscale : -1e30f;   // (each element touched by exactly one thread)
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // T1
     __builtin_amdgcn_sched_barrier(0);
     ATTN_STAMP(1);
 
     // ================= phase A: dK, dV of keys t0 .. t0 + 31 =================
+    // (fragment offsets recomputed per phase from a laundered lane id: as kernel-entry constants the compiler keeps a copy per
+    // 64-KiB window of the LDS images they are added to -- ~24 registers live through both sweeps, spilled and reloaded behind
+    // a vmcnt(0) inside the tile loops)
+    int lane_a = lane;
+    asm volatile("" : "+v"(lane_a));
+    const RowOfs ro = row_ofs(lane_a);
+    const TrOfs to = tr_ofs(lane_a);
     f32x16 dkt[2], dvt[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dkt[dt][r] = 0.f; dvt[dt][r] = 0.f; }
-    // (fully unrolled over the <= 7 tiles: the compiler then requests a tile's LDS fragments under the previous tile's
-    // arithmetic -- 68 -> 65 us per launch)
+    // Software-pipelined over the <= 7 query tiles, one MFMA per "gap" with the vector work that hides behind it written out by
+    // hand (a scheduling fence closes every gap): without that the two waves of a SIMD run in lock step -- both in their
+    // MFMAs, then both in their exponentials: 1 950 cycles per tile pair against 1 024 of MFMA.  Per tile t, 16 gaps:
+    //   gaps 0-7    S' of tile t + 1 and dP' of tile t, alternating (accumulators seeded with the row constants earlier)
+    //               || p = exp2(c2 S') of tile t, two accumulator registers per gap, kept in place and packed  || fragment reads
+    //   gaps 8-11   dV^T += dO^T p    || dS = p dP', four registers per gap, packed                             || fragment reads
+    //   gaps 12-15  dK^T += Q^T dS    || seeds of S'(t + 2) and dP'(t + 1) into the registers tile t has just left
+    // The S' of the tile after the last one is computed and dropped (4 of 112 MFMAs; its reads stay inside the LDS
+    // allocation): no tail variant of the body.
+    // (a lane whose key is padding -- t0 + l31 >= N, its K / V rows duplicates of row N - 1 -- carries finite values that only
+    // ever reach its OWN columns of dK^T / dV^T, which are not stored; a padded QUERY row has p = 0 through its seed)
+    {
+      f32x16 sx[2], dp;      // S' (then p) of tiles t, t + 1 (tile t in set t & 1); dP' of tile t
+      auto seed_s = [&](const int qt, f32x16& a, const int g4) {   // rows 8 g4 + 4 h .. + 3 of tile qt
+#ifdef ATTN_EXP_NOSEED
+        for (int k = 0; k < 4; ++k) a[4 * g4 + k] = -3.f;
+        return;
+#endif
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 32 + 8 * g4 + 4 * h);
 #pragma unroll
-    for (int qt = 0; qt < 7; ++qt) {
-      if (qt >= nt) break;
-      const int q0 = qt * 32;
-      const char* qblk = Qs + qt * 4096;
-      const char* dblk = dOs + qt * 4096;
-      // accumulators seeded with the row constants: register 4 g4 + k of lane half h is query row q0 + 8 g4 + 4 h + k
-      f32x16 sacc, pacc;
+        for (int k = 0; k < 4; ++k) a[4 * g4 + k] = l4[k];
+      };
+      auto seed_d = [&](const int qt, const int g4) {
+#ifdef ATTN_EXP_NOSEED
+        for (int k = 0; k < 4; ++k) dp[4 * g4 + k] = 0.5f;
+        return;
+#endif
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qt * 32 + 8 * g4 + 4 * h);
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + q0 + 8 * g4 + 4 * h);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + q0 + 8 * g4 + 4 * h);
+        for (int k = 0; k < 4; ++k) dp[4 * g4 + k] = d4[k];
+      };
+      auto frag_q = [&](const int qt, const int ks) { return *reinterpret_cast<const bf16x8*>(Qs + qt * 4096 + ro.o[ks]); };
+      auto frag_d = [&](const int qt, const int ks) { return *reinterpret_cast<const bf16x8*>(dOs + qt * 4096 + ro.o[ks]); };
+      // transposed fragment (st, dt) of a 32-row block: the st = 1 rows are 16 further down, same swizzle key -> +2048 B
+      auto frag_t = [&](const char* blk, const int st, const int dt) { return tr_frag_at(blk + st * 2048, to.lo[0][dt], to.hi[0][dt]); };
+      // The MFMA of gap i of tile t takes operand fragment (t, i): i < 8: Q rows of tile t + 1 (even i) / dO rows of tile t (odd i),
+      // K sub-step i >> 1; 8 <= i < 12: dO^T (st, dt) = ((i - 8) >> 1, (i - 8) & 1); i >= 12: Q^T likewise.  An LDS read takes
+      // ~120 cycles with seven waves at it, a gap 32: fragment (t, i) is requested FOUR gaps ahead into a ring of four
+      // (requested one gap ahead, every gap stalled on its read: 16 x ~115 cycles per tile is what the sweep measured).
+      bf16x8 fr[4];
+      auto request = [&](const int qt, const int i) {   // (compile-time arguments; tiles that do not exist: harmless reads)
+        const int t = qt + (i >> 4), j = i & 15;
+        bf16x8 f;
+        if (j < 8) f = (j & 1) ? frag_d(t, j >> 1) : frag_q(t + 1, j >> 1);
+        else if (j < 12) f = frag_t(dOs + t * 4096, (j - 8) >> 1, (j - 8) & 1);
+        else f = frag_t(Qs + t * 4096, (j - 12) >> 1, (j - 12) & 1);
+        fr[i & 3] = f;
+      };
+      bf16x8 pb[2], dsb[2];
+      // ---- prologue: tile 0's S', this head's K / V on their way, the seeds of S'(1) and dP'(0), the first four fragments
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { sacc[4 * g4 + k] = l4[k]; pacc[4 * g4 + k] = d4[k]; }
-      }
+      for (int g4 = 0; g4 < 4; ++g4) seed_s(0, sx[0], g4);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qblk + ro.o[ks]);
-        const bf16x8 da = *reinterpret_cast<const bf16x8*>(dblk + ro.o[ks]);
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], pacc, 0, 0, 0);
-      }
-      if (qt == 0) {
-        // K, V of THIS head into their images (needed by phase B): issued behind the LAST first-use of kf / vf (scheduling
-        // fence), so that none of the waits hipcc puts in front of those uses covers these pieces
-        __builtin_amdgcn_sched_barrier(0);
+      for (int ks = 0; ks < 4; ++ks) sx[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_q(0, ks), kf[ks], sx[0], 0, 0, 0);
+      // K, V of THIS head into their images (needed by phase B): issued behind a use of kf (scheduling fence), so that
+      // none of the waits hipcc puts in front of the kf / vf uses covers these pieces
+      __builtin_amdgcn_sched_barrier(0);
+      {
         const char* qb = qkv_base(bh);
-        dma_image(qb + H * HD * 2, off_qkv, Ks);
-        dma_image(qb + 2 * H * HD * 2, off_qkv, Vs);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // (a lane whose key is padding -- t0 + l31 >= N, its K / V rows duplicates of row N - 1 -- carries finite values
-      // that only ever reach its OWN columns of dK^T / dV^T, which are not stored; a padded QUERY row has p = 0 through its
-      // seed: no select per element)
-      f32x16 p, ds;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(sacc[r] * c2);
-        p[r] = e;
-        ds[r] = e * pacc[r];
+        dma_image(qb + H * HD * 2, ld * 2, Ks);
+        dma_image(qb + 2 * H * HD * 2, ld * 2, Vs);
       }
 #pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        const bf16x8 pb = pack8(p, st), dsb = pack8(ds, st);
+      for (int g4 = 0; g4 < 4; ++g4) { seed_s(1, sx[1], g4); seed_d(0, g4); }
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 doa = tr_frag_at(dblk, to.lo[st][dt], to.hi[st][dt]);
-          const bf16x8 qta = tr_frag_at(qblk, to.lo[st][dt], to.hi[st][dt]);
-          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa, pb, dvt[dt], 0, 0, 0);
-          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsb, dkt[dt], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) request(0, i);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int qt = 0; qt < 7; ++qt) {
+        if (qt >= nt) break;
+        const int c = qt & 1, n = c ^ 1;
+        // ---- gaps 0-7
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int ks = i >> 1;
+          if ((i & 1) == 0) sx[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 3], kf[ks], sx[n], 0, 0, 0);
+          else dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 3], vf[ks], dp, 0, 0, 0);
+          request(qt, i + 4);
+#pragma unroll
+          for (int r = 2 * i; r < 2 * i + 2; ++r) {
+            sx[c][r] = __builtin_amdgcn_exp2f(sx[c][r] * c2);
+            pb[r >> 3][r & 7] = (bf16)sx[c][r];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- gaps 8-11: dV^T += dO^T p  (st, dt) = (0,0) (0,1) (1,0) (1,1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dvt[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j & 3], pb[j >> 1], dvt[j & 1], 0, 0, 0);
+          request(qt, j + 12);
+#pragma unroll
+          for (int r = 4 * j; r < 4 * j + 4; ++r) dsb[r >> 3][r & 7] = (bf16)(sx[c][r] * dp[r]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- gaps 12-15: dK^T += Q^T dS; seeds of the next S' / dP' (tiles that do not exist: harmless reads)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dkt[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j & 3], dsb[j >> 1], dkt[j & 1], 0, 0, 0);
+          request(qt, j + 16);
+          if (j < 2) { seed_s(qt + 2, sx[c], 2 * j); seed_s(qt + 2, sx[c], 2 * j + 1); }       // (S' is the first to be used)
+          else { seed_d(qt + 1, 2 * j - 4); seed_d(qt + 1, 2 * j - 3); }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -1022,7 +1072,9 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
     // O image (free between T1 and T3; swizzled like every image here) and out as 4 stores of 8 full rows.
     {
       char* stg = Os + wave * 4096;
-      const int srow = lane >> 3, schunk = lane & 7;
+      int lane_s = lane;   // (laundered, as above)
+      asm volatile("" : "+v"(lane_s));
+      const int srow = lane_s >> 3, schunk = lane_s & 7, l31s = lane_s & 31, hs = lane_s >> 5;
 #pragma unroll
       for (int m = 0; m < 2; ++m) {   // 0: dK (scaled), 1: dV
 #pragma unroll
@@ -1032,7 +1084,7 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
             const f32x16& acc = m == 0 ? dkt[dt] : dvt[dt];
             const float f = m == 0 ? scale : 1.f;
             const bf16x4 a = {(bf16)(acc[4 * g] * f), (bf16)(acc[4 * g + 1] * f), (bf16)(acc[4 * g + 2] * f), (bf16)(acc[4 * g + 3] * f)};
-            *reinterpret_cast<bf16x4*>(stg + swz128(l31, dt * 4 + g) + h * 8) = a;     // d = dt 32 + 8 g + 4 h ..+3
+            *reinterpret_cast<bf16x4*>(stg + swz128(l31s, dt * 4 + g) + hs * 8) = a;     // d = dt 32 + 8 g + 4 h ..+3
           }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -1047,17 +1099,32 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
     }
 
     // ================= phase B: dQ of queries t0 .. t0 + 31 =================
+    // (the K and V images lie above 64 KiB, beyond the 16-bit offset field of an LDS read: their bases go into the lane offsets --
+    // opaque to the compiler, or it keeps one copy per 64-KiB window and tile -- and the tile / row-half offsets stay immediates)
+    int lane_b = lane;
+    asm volatile("" : "+v"(lane_b));
+    const RowOfs rob = row_ofs(lane_b);
+    const TrOfs tob = tr_ofs(lane_b);
+    int rk[4], rv[4], tk_lo[2], tk_hi[2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      rk[ks] = rob.o[ks] + 3 * IMG;
+      rv[ks] = rob.o[ks] + 4 * IMG;
+      asm volatile("" : "+v"(rk[ks]), "+v"(rv[ks]));
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      tk_lo[dt] = tob.lo[0][dt] + 3 * IMG;
+      tk_hi[dt] = tob.hi[0][dt] + 3 * IMG;
+      asm volatile("" : "+v"(tk_lo[dt]), "+v"(tk_hi[dt]));
+    }
     bf16x8 qf[4], dof[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      qf[ks] = *reinterpret_cast<const bf16x8*>(Qs + wave * 4096 + ro.o[ks]);
-      dof[ks] = *reinterpret_cast<const bf16x8*>(dOs + wave * 4096 + ro.o[ks]);
+      qf[ks] = *reinterpret_cast<const bf16x8*>(Qs + wave * 4096 + rob.o[ks]);
+      dof[ks] = *reinterpret_cast<const bf16x8*>(dOs + wave * 4096 + rob.o[ks]);
     }
     const float lq = lse_s[t0 + l31] * c2, dl = del_s[t0 + l31];   // (-lse in log2 units | -delta; a padded query: -inf-like)
-    // seed of S^T in the LAST key tile: its padded key rows (duplicates of key N - 1) start at -1e30, so their p is exactly 0
-    f32x16 seed_last;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) seed_last[r] = crow(r, h) < last ? 0.f : -1e30f;
     ATTN_STAMP(4);
     // T3: every wave holds its Q / dO rows and row constants: the Q, dO, O images may take the next head
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1075,9 +1142,10 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
       if (!has_nxt) return;
       const int t = j & 3;
       if (j < 4) {
-        glds16_hidden(nqb, off_qkv[t], lds_of(Qs) + (unsigned)((wave + t * 7) * 1024));
-        glds16_hidden(ndob, off_o[t], lds_of(dOs) + (unsigned)((wave + t * 7) * 1024));
-        glds16_hidden(nob, off_o[t], lds_of(Os) + (unsigned)((wave + t * 7) * 1024));
+        const unsigned oq = piece_off(t, ld * 2), oo = piece_off(t, ldo * 2);
+        glds16_hidden(nqb, oq, lds_of(Qs) + (unsigned)((wave + t * 7) * 1024));
+        glds16_hidden(ndob, oo, lds_of(dOs) + (unsigned)((wave + t * 7) * 1024));
+        glds16_hidden(nob, oo, lds_of(Os) + (unsigned)((wave + t * 7) * 1024));
         const bf16* kb = reinterpret_cast<const bf16*>(nqb) + H * HD;
         kf[t] = *reinterpret_cast<const bf16x8*>(kb + (size_t)trow * ld + t * 16 + h * 8);
       } else if (j == 4) {
@@ -1093,51 +1161,79 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-    auto tile_b = [&](const int kt, const f32x16& seed) {
-      const char* kblk = Ks + kt * 4096;
-      const char* vblk = Vs + kt * 4096;
-      f32x16 sT = seed, dpT;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dpT[r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kblk + ro.o[ks]);
-        const bf16x8 va = *reinterpret_cast<const bf16x8*>(vblk + ro.o[ks]);
-        sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], sT, 0, 0, 0);
-        dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dpT, 0, 0, 0);
-      }
-      f32x16 ds;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(sT[r] * c2 + lq);
-        ds[r] = e * (dpT[r] + dl);
-      }
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        const bf16x8 a = pack8(ds, st);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 kfr = tr_frag_at(kblk, to.lo[st][dt], to.hi[st][dt]);
-          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, a, dq[dt], 0, 0, 0);   // dQ^T = K^T dS^T
-        }
-      }
-    };
+    // The dQ sweep, pipelined like the dK / dV sweep: per key tile t, 12 gaps (one MFMA each, fences between them):
+    //   gaps 0-7   S^T of tile t + 1 and dP^T of tile t, alternating   || p = exp2(c2 S^T + lq) of tile t in place, 2 registers per gap
+    //   gaps 8-11  dQ^T += K^T dS^T                                     || dS = p dP'^T packed (dP^T is seeded with -delta), then the
+    //                                                                      seed of dP^T(t + 1); the padded keys of the last tile
+    //                                                                      have their p zeroed (one uniform branch per tile)
+    // with the operand fragments requested four gaps ahead into the same ring of four: slot i < 8: K rows of tile t + 1 (even) /
+    // V rows of tile t (odd), K sub-step i >> 1; slots 8-11: K^T (st, dt) of tile t.
     {
+      f32x16 sT[2], dpT;
+      bf16x8 fr[4], dsb[2];
+      auto request = [&](const int kt, const int i) {   // (compile-time arguments; tiles that do not exist: harmless reads)
+        const int t = kt + i / 12, j = i % 12;
+        bf16x8 f;
+        if (j < 8) f = (j & 1) ? *reinterpret_cast<const bf16x8*>(smem + t * 4096 + rv[j >> 1])
+                               : *reinterpret_cast<const bf16x8*>(smem + (t + 1) * 4096 + rk[j >> 1]);
+        else f = tr_frag_at(smem + t * 4096 + ((j - 8) >> 1) * 2048, tk_lo[(j - 8) & 1], tk_hi[(j - 8) & 1]);
+        fr[i & 3] = f;
+      };
+      // ---- prologue: S^T of tile 0, seeds, the first four fragments
       f32x16 zero;
 #pragma unroll
       for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-      // whole key tiles (unrolled: a tile's LDS fragments are requested under the previous tile's arithmetic), then the last
-      // one with its padded keys masked through the seed
+      sT[0] = zero;
 #pragma unroll
-      for (int kt = 0; kt < 6; ++kt) {
-        if (kt >= nt - 1) break;
-        next_slice(kt);
-        tile_b(kt, zero);
+      for (int ks = 0; ks < 4; ++ks)
+        sT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(smem + rk[ks]), qf[ks], sT[0], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dpT[r] = dl;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) request(0, i);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kt = 0; kt < 7; ++kt) {
+        if (kt >= nt) break;
+        const int c = kt & 1, n = c ^ 1;
+        if (kt < 6) next_slice(kt);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- gaps 0-7
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int ks = i >> 1;
+          if ((i & 1) == 0) sT[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 3], qf[ks], i == 0 ? zero : sT[n], 0, 0, 0);
+          else dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 3], dof[ks], dpT, 0, 0, 0);
+          request(kt, i + 4);
+#pragma unroll
+          for (int r = 2 * i; r < 2 * i + 2; ++r) sT[c][r] = __builtin_amdgcn_exp2f(sT[c][r] * c2 + lq);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // the last tile's padded keys (duplicates of key N - 1): their p is zeroed here, once per head
+        if (kt == nt - 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sT[c][r] = crow(r, h) < last ? sT[c][r] : 0.f;
+        }
+        // ---- gaps 8-11: dQ^T += K^T dS^T  (st, dt) = (0,0) (0,1) (1,0) (1,1)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dsb[0][r] = (bf16)(sT[c][r] * dpT[r]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dq[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j & 3], dsb[j >> 1], dq[j & 1], 0, 0, 0);
+          request(kt, j + 12);
+          if (j < 2) {
+#pragma unroll
+            for (int r = 8 + 4 * j; r < 12 + 4 * j; ++r) dsb[1][r - 8] = (bf16)(sT[c][r] * dpT[r]);
+          } else {
+#pragma unroll
+            for (int r = 8 * (j - 2); r < 8 * (j - 2) + 8; ++r) dpT[r] = dl;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 6; ++j)   // (the slices of tiles this N does not have)
-        if (j >= nt - 1) next_slice(j);
-      tile_b(nt - 1, seed_last);
+        if (j >= nt) next_slice(j);
     }
     ATTN_STAMP(6);
     // the next head's images and row fragments have landed (they are old by now): wait for them HERE, before this phase's
@@ -1173,12 +1269,6 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
       }
     }
   }
-#ifdef CARA_ATTN_STAMPS
-  if (g_attn_stamp_buf && tid == 0) {
-    g_attn_stamp_buf[((size_t)blockIdx.x * 4 + 3) * 8 + 2] = __builtin_amdgcn_s_memtime();
-    g_attn_stamp_buf[((size_t)blockIdx.x * 4 + 3) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-  }
-#endif
 }
 
 // diagnostic: stage a [N,64] matrix like the kernels do and return every lane's transposed fragment
@@ -1269,7 +1359,7 @@ extern "C" int cara_attention_bwd(const void* qkv, const void* out, const void* 
   static const int use_fused = [] { const char* e = getenv("CARA_ATTN_PERSIST"); return e ? atoi(e) : 1; }();
   if (use_fused && N > 128 && N <= NMAX) {
     const int BH = B * H, grid = BH < 256 ? BH : 256;
-    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(grid), dim3(448), 5 * 224 * 128 + (256 + 224) * 4, st, (const bf16*)qkv, (const bf16*)out,
+    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(grid), dim3(448), 5 * 224 * 128 + (256 + 256) * 4, st, (const bf16*)qkv, (const bf16*)out,
                        (const bf16*)dout, lse, (bf16*)dqkv, N, H, BH, scale);
     CARA_CHECK_LAUNCH();
     return CARA_OK;
