@@ -305,10 +305,12 @@ def main():
     eng.weight_dropout = args.weight_dropout
     cdist.broadcast_parameters(trainable)   # replicas identical by construction; this makes it a fact (outside the timed region)
     eng.seed_rank_streams(2024, rank)       # per-rank DropPath / weight-dropout masks
-    try:
+    # vit_cp.py:185's AdamW as one HIP launch (cara_amd/optim.py; CARA_BENCH_TORCH_ADAMW=1: torch's fused one, for A/B runs)
+    from cara_amd.optim import AdamW
+    if os.environ.get("CARA_BENCH_TORCH_ADAMW") == "1":
         opt = torch.optim.AdamW(trainable, lr=1e-3, weight_decay=1e-4, fused=True)
-    except Exception:
-        opt = torch.optim.AdamW(trainable, lr=1e-3, weight_decay=1e-4)
+    else:
+        opt = AdamW(trainable, lr=1e-3, weight_decay=1e-4)
     gx = torch.Generator().manual_seed(1000 + rank)   # each rank its own shard of the global batch
     # four different synthetic batches, resident in HBM before the timed region, fed in turn (one fixed batch would be
     # memorised within a few steps: loss 0.13 after 25 steps)
@@ -424,7 +426,7 @@ def main():
         m64, tr64 = build_model(64, scale, ncls, dev, seed=14, name=args.model)
         e64 = m64._cara_engine
         e64.seed_rank_streams(2024, rank)
-        o64 = torch.optim.AdamW(tr64, lr=1e-3, weight_decay=1e-4, fused=True)
+        o64 = AdamW(tr64, lr=1e-3, weight_decay=1e-4)
         info["rank64_ms_per_step"] = round(timed_steps(lambda: e64.train_step(x, y, o64)), 3)
         info["rank64_images_per_sec"] = round(args.batch / info["rank64_ms_per_step"] * 1e3, 1)
         info["rank64_step_frac_of_mfma_peak"] = round(82.61 * args.batch / info["rank64_ms_per_step"] / PEAK_BF16_TFLOPS, 4)
@@ -434,7 +436,7 @@ def main():
         m2, tr2 = build_model(args.rank, scale, ncls, dev, seed=14, name=args.model, cp_length=2)
         e2 = m2._cara_engine
         e2.seed_rank_streams(2024, rank)
-        o2 = torch.optim.AdamW(tr2, lr=1e-3, weight_decay=1e-4, fused=True)
+        o2 = AdamW(tr2, lr=1e-3, weight_decay=1e-4)
         info["order2_qkv_ms_per_step"] = round(timed_steps(lambda: e2.train_step(x, y, o2)), 3)
         del m2, tr2, e2, o2
         torch.cuda.empty_cache()

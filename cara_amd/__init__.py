@@ -7,3 +7,4 @@ Canonical-Polyadic adapters on a timm-named ViT container; the arithmetic lives 
 from .cara import cara, set_cara  # noqa: F401
 from .vit import VisionTransformer, create_model  # noqa: F401
 from ._lib import CaraError  # noqa: F401
+from . import optim  # noqa: F401

@@ -21,7 +21,7 @@ SYMBOLS = (
     "cara_tskinny_scratch_bytes", "cara_tskinny_xtg", "cara_tskinny_partial", "cara_tskinny_partial2", "cara_tskinny_reduce", "cara_tskinny_reduce_many", "cara_gemm_with_tskinny", "cara_layernorm_fwd", "cara_layernorm_bwd", "cara_layernorm_fwd_xu", "cara_layernorm_bwd_xu", "cara_layernorm_fwd_ex", "cara_layernorm_bwd_ex",
     "cara_attention_fwd", "cara_attention_bwd", "cara_im2col_patches", "cara_assemble_tokens",
     "cara_cross_entropy", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_transpose_bf16_ld", "cara_pack_offsets",
-    "cara_dense_delta_materialize", "cara_dense_delta_grad_scratch_bytes", "cara_dense_delta_grad", "cara_sum_slabs_f32",
+    "cara_dense_delta_materialize", "cara_dense_delta_grad_scratch_bytes", "cara_dense_delta_grad", "cara_sum_slabs_f32", "cara_adamw_step",
     "cara_weight_dropout_hash", "cara_materialize_merge", "cara_dropout_grad_scratch_bytes", "cara_dropout_grad_contract", "cara_colsum_scratch_bytes", "cara_colsum_bf16", "cara_factor_prep", "cara_factor_grad_scratch_bytes", "cara_factor_grad_reduce", "cara_vit_workspace_bytes", "cara_vit_forward",
     "cara_vit_backward", "cara_head_backward", "cara_sizeof_struct", "cara_sizeof_gemm_args", "cara_profile_sites", "cara_profile_site_read", "cara_debug_tr_probe", "cara_debug_tr_frag",
 )
@@ -106,8 +106,22 @@ class TsReduce(C.Structure):
                 ("batch", C.c_int), ("M", C.c_int), ("K1", C.c_int), ("Rp", C.c_int)]
 
 
+ADAMW_MAX_TENSORS, ADAMW_MAX_GROUPS = 32, 4
+
+
+class AdamWTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_size_t), ("group", C.c_int)]
+
+
+class AdamWArgs(C.Structure):
+    _fields_ = [("t", AdamWTensor * ADAMW_MAX_TENSORS), ("ntensors", C.c_int), ("step", C.c_int),
+                ("lr", C.c_float * ADAMW_MAX_GROUPS), ("weight_decay", C.c_float * ADAMW_MAX_GROUPS),
+                ("one_minus_beta1", C.c_float), ("beta2", C.c_float), ("one_minus_beta2", C.c_float), ("eps", C.c_float),
+                ("bias_correction1", C.c_float), ("bias_correction2_sqrt", C.c_float)]
+
+
 # CARA_STRUCT_* of include/cara_hip.h -> the mirror above (lib() asserts that every size agrees with the library's)
-STRUCT_MIRRORS = (GemmArgs, Geom, CpPtrs, PackLayout, LayerGrads, VitWeights, VitShape, TsReduce)
+STRUCT_MIRRORS = (GemmArgs, Geom, CpPtrs, PackLayout, LayerGrads, VitWeights, VitShape, TsReduce, AdamWArgs)
 
 
 class CaraError(RuntimeError):

@@ -3,7 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libcara_hip.so
-SRCS="lib.hip gemm.hip skinny.hip norm_misc.hip attention.hip factors.hip dropout_exact.hip dense_delta.hip"
+SRCS="lib.hip gemm.hip skinny.hip norm_misc.hip attention.hip factors.hip dropout_exact.hip dense_delta.hip optim.hip"
 [ -f vit.hip ] && SRCS="$SRCS vit.hip"
 OBJS=""
 mkdir -p build

@@ -1,7 +1,7 @@
 // Library identification for libcara_hip.so.
 #include "common.h"
 
-extern "C" int cara_abi_version(void) { return 6; }
+extern "C" int cara_abi_version(void) { return 7; }
 extern "C" const char* cara_build_arch(void) { return "gfx950"; }
 
 extern "C" size_t cara_sizeof_struct(int which) {
@@ -14,6 +14,7 @@ extern "C" size_t cara_sizeof_struct(int which) {
     case CARA_STRUCT_VIT_WEIGHTS: return sizeof(cara_vit_weights);
     case CARA_STRUCT_VIT_SHAPE: return sizeof(cara_vit_shape);
     case CARA_STRUCT_TS_REDUCE: return sizeof(cara_ts_reduce);
+    case CARA_STRUCT_ADAMW_ARGS: return sizeof(cara_adamw_args);
     default: return 0;
   }
 }

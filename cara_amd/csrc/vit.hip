@@ -351,6 +351,9 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
       if (defer) carry = (pend->valid && pend->Rp == Rp) ? pend : nullptr;
       else if (!inside) carry = &mine;
     }
+#ifdef CARA_ABLATE_TS   // timing experiment only (tools/build_variant.sh): the dX GEMMs WITHOUT their riding products (wrong gradients)
+    if (carry) { TRY(cara_gemm_bf16(&a, st)); return CARA_OK; }
+#endif
     if (carry) {
       TRY(cara_gemm_with_tskinny(&a, carry->Xa, carry->ldxa, carry->Gta, carry->slabs_a, carry->K1a, carry->Xb, carry->ldxb, carry->Gtb,
                                  carry->slabs_b, carry->K1b, carry->want_cs, carry->ldg, carry->M, carry->Rp, st));

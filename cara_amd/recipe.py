@@ -123,10 +123,9 @@ def fit(model, train_batches: Callable[[int], Iterable], test_batches: Optional[
         model._cara_engine.seed_rank_streams(run_seed, cdist.get_rank(group))
     if seed is None:
         seed = int(torch.initial_seed() % (1 << 31))   # (only names the checkpoint file below, like args.seed in vit_cp.py:65)
-    try:
-        opt = torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, fused=True)
-    except Exception:
-        opt = torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
+    # vit_cp.py:185's torch.optim.AdamW, as one HIP launch over the 14 trainable tensors (cara_amd/optim.py: same arithmetic)
+    from .optim import AdamW
+    opt = AdamW(params, lr=lr, weight_decay=weight_decay)
     sched = CosineLRScheduler(opt, t_initial=100, warmup_t=10, lr_min=1e-5, warmup_lr_init=1e-6, decay_rate=0.1)
     eng = model._cara_engine
     best = 0.0

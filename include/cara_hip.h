@@ -275,6 +275,30 @@ int cara_dense_delta_grad(const cara_geom* g, const cara_cp* cp, const float* dD
 /* out[j] = sum_z slabs[z * slab_stride + j], j < count (fixed order): the split-K slabs of cara_gemm_tn_f32 into one matrix */
 int cara_sum_slabs_f32(const float* slabs, int nslab, size_t slab_stride, size_t count, float* out, void* stream);
 
+/* ---- optimiser step (image_classification/vit_cp.py:185 `torch.optim.AdamW(trainable, ...)`, :50 `opt.step()`) ---- */
+/* torch.optim.AdamW's arithmetic (amsgrad off, maximize off) over up to 32 fp32 tensors in ONE launch:
+ *   p *= 1 - lr wd;  m += (1 - beta1)(g - m);  v = beta2 v + (1 - beta2) g g;
+ *   p -= lr / bias_correction1 * m / (sqrt(v) / bias_correction2_sqrt + eps)
+ * with bias_correction1 = 1 - beta1^step and bias_correction2_sqrt = sqrt(1 - beta2^step) computed by the caller (in double, as
+ * torch does on the host).  `group` picks the tensor's lr / weight_decay (param groups; betas and eps are shared).
+ * The struct travels by value into the kernel: nothing lives in device memory, a changed lr costs nothing.          */
+#define CARA_ADAMW_MAX_TENSORS 32
+#define CARA_ADAMW_MAX_GROUPS 4
+typedef struct {
+  float* p; const float* g; float* m; float* v;   /* parameter, gradient, exp_avg, exp_avg_sq: n fp32 each */
+  size_t n;
+  int group;
+} cara_adamw_tensor;
+typedef struct {
+  cara_adamw_tensor t[CARA_ADAMW_MAX_TENSORS];
+  int ntensors;
+  int step;                                        /* 1-based step count (validation only; the corrections come below) */
+  float lr[CARA_ADAMW_MAX_GROUPS], weight_decay[CARA_ADAMW_MAX_GROUPS];
+  float one_minus_beta1, beta2, one_minus_beta2, eps;
+  float bias_correction1, bias_correction2_sqrt;
+} cara_adamw_args;
+int cara_adamw_step(const cara_adamw_args* a, void* stream);
+
 /* ---- exact weight-space dropout mode (the reference's train-mode arithmetic, cara.py:35,57,81,92) ---- */
 /* keep(o,i) of linear `linear_id` = (cara_weight_dropout_hash(o*in + i, seed, linear_id) >> 8) >= p * 2^24
  * (host-callable mirror of the device hash, so that tests and the oracle can rebuild the masks).             */
@@ -358,7 +382,7 @@ int cara_head_backward(const float* dlogits, const void* xn_bf16, const float* h
  * unknown id.                                                                                                   */
 enum {
   CARA_STRUCT_GEMM_ARGS = 0, CARA_STRUCT_GEOM, CARA_STRUCT_CP, CARA_STRUCT_PACK_LAYOUT, CARA_STRUCT_LAYER_GRADS,
-  CARA_STRUCT_VIT_WEIGHTS, CARA_STRUCT_VIT_SHAPE, CARA_STRUCT_TS_REDUCE,
+  CARA_STRUCT_VIT_WEIGHTS, CARA_STRUCT_VIT_SHAPE, CARA_STRUCT_TS_REDUCE, CARA_STRUCT_ADAMW_ARGS,
   CARA_STRUCT_COUNT
 };
 size_t cara_sizeof_struct(int which);

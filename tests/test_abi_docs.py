@@ -58,9 +58,21 @@ def test_every_ctypes_mirror_matches_the_header_field_by_field():
 def test_struct_ids_of_the_header_follow_the_mirror_table():
     m = re.search(r"CARA_STRUCT_GEMM_ARGS\s*=\s*0(.*?)CARA_STRUCT_COUNT", _strip_comments(HDR), flags=re.S)
     ids = ["CARA_STRUCT_GEMM_ARGS"] + re.findall(r"CARA_STRUCT_[A-Z_]+", m.group(1))
-    names = ["CARA_STRUCT_" + n[len("cara_"):].upper() for n in MIRRORS]
+    # (cara_adamw_args holds arrays and a nested struct, which the field parser above does not read: its element struct is
+    # compared field by field below, the whole by sizeof -- lib() and test_library_reports_the_same_struct_sizes)
+    names = ["CARA_STRUCT_" + n[len("cara_"):].upper() for n in MIRRORS] + ["CARA_STRUCT_ADAMW_ARGS"]
     assert ids == names, (ids, names)
-    assert tuple(MIRRORS.values()) == _lib.STRUCT_MIRRORS
+    assert tuple(MIRRORS.values()) + (_lib.AdamWArgs,) == _lib.STRUCT_MIRRORS
+
+
+def test_adamw_tensor_entry_matches_the_header():
+    want = header_struct("cara_adamw_tensor")
+    got = list(_lib.AdamWTensor._fields_)
+    assert [n for n, _ in got] == [n for n, _ in want]
+    for (n, tg), (_, tw) in zip(got, want):
+        assert C.sizeof(tg) == C.sizeof(tw) and (tg is C.c_void_p) == (tw is C.c_void_p), (n, tg, tw)
+    m = re.search(r"#define\s+CARA_ADAMW_MAX_TENSORS\s+(\d+).*?#define\s+CARA_ADAMW_MAX_GROUPS\s+(\d+)", HDR, flags=re.S)
+    assert (int(m.group(1)), int(m.group(2))) == (_lib.ADAMW_MAX_TENSORS, _lib.ADAMW_MAX_GROUPS)
 
 
 def test_library_reports_the_same_struct_sizes():

@@ -884,3 +884,44 @@ def test_dense_delta_entry_points(dim, depth, rank):
     ref = ((slabs[0] + slabs[2]) + slabs[4]) + (slabs[1] + slabs[3])
     assert torch.equal(out, ref[:777])
     assert lib.cara_sum_slabs_f32(p(slabs), 0, C.c_size_t(1000), C.c_size_t(777), p(out), st()) != 0
+
+
+def test_adamw_step_against_torch():
+    """cara_amd.optim.AdamW (one cara_adamw_step launch over all tensors) against torch.optim.AdamW on the CPU: five steps, two
+    parameter groups with their own lr / weight decay, an lr that a scheduler changes between steps, sizes on both sides of the
+    1024-element chunk; then torch's state_dict layout and a reload."""
+    from cara_amd.optim import AdamW
+    g = torch.Generator().manual_seed(21)
+    shapes = [(36, 16), (768, 16), (16,), (3072,), (100, 768), (1,), (1025,), (1024,)]
+    ref = [torch.randn(*s_, generator=g).requires_grad_(True) for s_ in shapes]
+    dev = [r.detach().clone().to(DEV).requires_grad_(True) for r in ref]
+    groups = lambda ps: [{"params": ps[:5], "lr": 1e-3, "weight_decay": 1e-4}, {"params": ps[5:], "lr": 3e-3, "weight_decay": 0.0}]  # noqa: E731
+    ropt = torch.optim.AdamW(groups(ref), betas=(0.9, 0.999), eps=1e-8)
+    dopt = AdamW(groups(dev), betas=(0.9, 0.999), eps=1e-8)
+    for step in range(5):
+        for r, d in zip(ref, dev):
+            r.grad = torch.randn(r.shape, generator=g) * (10.0 ** (step - 2))
+            d.grad = r.grad.to(DEV)
+        for o in (ropt, dopt):
+            o.param_groups[0]["lr"] = 1e-3 * (0.5 ** step)
+        ropt.step()
+        dopt.step()
+        for r, d in zip(ref, dev):
+            close(d.detach(), r.detach(), 2e-6, 2e-7, f"AdamW step {step}")
+    sd = dopt.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 5.0
+    close(sd["state"][4]["exp_avg_sq"], ropt.state_dict()["state"][4]["exp_avg_sq"], 2e-6, 1e-12, "exp_avg_sq")
+    d2 = AdamW(groups(dev))
+    d2.load_state_dict(sd)
+    for r, d in zip(ref, dev):
+        r.grad = torch.ones_like(r)
+        d.grad = torch.ones_like(d)
+    ropt.step()
+    d2.step()
+    for r, d in zip(ref, dev):
+        close(d.detach(), r.detach(), 2e-6, 2e-7, "AdamW after reload")
+    # no CPU path
+    c = torch.zeros(4, requires_grad=True)
+    c.grad = torch.ones(4)
+    with pytest.raises(L().CaraError, match="GPU"):
+        AdamW([c]).step()

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../cara_amd/csrc"
 mkdir -p build_stamps
 OBJS=""
 pids=()
-for s in lib gemm skinny norm_misc attention factors dropout_exact vit; do
+for s in lib gemm skinny norm_misc attention factors dropout_exact dense_delta optim vit; do
   o=build_stamps/$s.o
   OBJS="$OBJS $o"
   if [ ! -f "$o" ] || [ "$s.hip" -nt "$o" ] || [ gemm_epilogue.h -nt "$o" ] || [ common.h -nt "$o" ] || [ tskinny_body.h -nt "$o" ]; then
