@@ -84,21 +84,29 @@ __host__ inline PackOffsets make_offsets(int dim, int Rp) {
   return o;
 }
 
-// grid.y = layer * M_COUNT + matrix; grid.x covers 2 * rows * Rp elements: first half writes the
-// row-major copy (r fastest), second half the transposed copy (row fastest) -> both coalesced.
+// grid.y = layer * M_COUNT + matrix; grid.x covers 2 * rows * Rp / 8 threads of EIGHT elements each: the first half writes the
+// row-major copy (8 consecutive r of a row), the second half the transposed copy (8 consecutive rows of an r) -> one 16-byte
+// store per thread, both coalesced.  (One element per thread: 30 us per step for 19 MB of output.)
 __global__ __launch_bounds__(256) void prep_kernel(PackDims g, cara_cp cp, PackOffsets po, char* __restrict__ pack) {
   const int l = blockIdx.y / M_COUNT, m = blockIdx.y - l * M_COUNT;
   const int rows = mat_rows(m, g.dim);
-  const int n = rows * g.Rp;
+  const int n8 = rows * g.Rp / 8;          // (rows and Rp are multiples of 8)
   int e = blockIdx.x * 256 + threadIdx.x;
   char* base = pack + (size_t)l * po.layer_stride;
-  if (e < n) {
-    const int row = e / g.Rp, r = e - row * g.Rp;
-    reinterpret_cast<bf16*>(base + po.rm[m])[e] = (bf16)factor_value(g, cp, l, m, row, r);
-  } else if (e < 2 * n) {
-    e -= n;
-    const int r = e / rows, row = e - r * rows;
-    reinterpret_cast<bf16*>(base + po.tr[m])[e] = (bf16)factor_value(g, cp, l, m, row, r);
+  bf16x8 v;
+  if (e < n8) {
+    const int rp8 = g.Rp / 8;
+    const int row = e / rp8, r0 = (e - row * rp8) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16)factor_value(g, cp, l, m, row, r0 + j);
+    reinterpret_cast<bf16x8*>(base + po.rm[m])[e] = v;
+  } else if (e < 2 * n8) {
+    e -= n8;
+    const int rows8 = rows / 8;
+    const int r = e / rows8, row0 = (e - r * rows8) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16)factor_value(g, cp, l, m, row0 + j, r);
+    reinterpret_cast<bf16x8*>(base + po.tr[m])[e] = v;
   }
 }
 
@@ -371,7 +379,7 @@ PackDims dims_of(const cara_geom* g) {
   return d;
 }
 bool geom_ok(const cara_geom* g) {
-  return g && g->depth > 0 && g->dim > 0 && g->heads > 0 && g->dim % g->heads == 0 && g->rank > 0 &&
+  return g && g->depth > 0 && g->dim > 0 && g->dim % 8 == 0 && g->heads > 0 && g->dim % g->heads == 0 && g->rank > 0 &&
          g->rank <= g->Rp && (g->Rp == 32 || g->Rp == 64) &&
          (g->cp_length == 0 || g->cp_length == 2 || g->cp_length == 3 || g->cp_length == 4 || g->cp_length == 5);
 }
@@ -404,7 +412,7 @@ extern "C" int cara_factor_prep(const cara_geom* g, const cara_cp* cp, const flo
   hipStream_t st = static_cast<hipStream_t>(stream);
   const PackDims d = dims_of(g);
   const PackOffsets po = make_offsets(g->dim, g->Rp);
-  const int maxn = 2 * 4 * g->dim * g->Rp;
+  const int maxn = 2 * 4 * g->dim * g->Rp / 8;   // threads of eight elements, both copies of the tallest matrix
   hipLaunchKernelGGL(prep_kernel, dim3((maxn + 255) / 256, g->depth * M_COUNT), dim3(256), 0, st, d, *cp, po, (char*)pack);
   CARA_CHECK_LAUNCH();
   hipLaunchKernelGGL(prep_bias_kernel, dim3((4 * g->dim + 255) / 256, g->depth), dim3(256), 0, st, d, *cp, po,

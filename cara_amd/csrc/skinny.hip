@@ -31,7 +31,7 @@ template <int NT>
 __global__ __launch_bounds__(1024) void skinny_xu_sliced_kernel(const bf16* __restrict__ X, int ldx,
                                                                 const bf16* __restrict__ Ut,
                                                                 bf16* __restrict__ T, bf16* __restrict__ Tt,
-                                                                int ldt, int M, int K, const int ldT) {
+                                                                int ldt, int M, int K, const int ldT, const int groups) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* red = reinterpret_cast<f32x4*>(smem);   // [nwaves][NT][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(1024) void skinny_xu_sliced_kernel(const bf16* __re
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
     for (int j = 0; j < NT; ++j) u[ks][j] = *reinterpret_cast<const bf16x8*>(Ut + (size_t)(j * 16 + fr) * K + k0 + ks * 32);
-  const int mblk = blockIdx.x * (16 * XU_GROUPS);
+  const int mblk = blockIdx.x * (16 * groups);   // groups = XU_GROUPS row groups of 16 per workgroup; 1 for few-row products
   bf16x8 a[KS], an[KS];
   // ldx < 0: X is K-panel-major, [K/32][-ldx rows][32] (cara_gemm_args::c_panels): element (r, k0 + 32 ks) sits at
   // ((wave * KS + ks) * rows + r) * 32 + fq * 8 -- a wave's load is one contiguous KiB
@@ -63,8 +63,9 @@ __global__ __launch_bounds__(1024) void skinny_xu_sliced_kernel(const bf16* __re
   }
 #pragma unroll
   for (int g = 0; g < XU_GROUPS; ++g) {
+    if (g >= groups) break;
     const int m0 = mblk + g * 16;
-    if (g + 1 < XU_GROUPS) {
+    if (g + 1 < groups) {
       int r = m0 + 16 + fr;
       r = r < M ? r : M - 1;
 #pragma unroll
@@ -293,9 +294,12 @@ extern "C" int cara_skinny_xu(const void* X, int ldx, const void* Ut, void* T, v
   // (Rp = 64: two workgroups per row block, 32 columns each -- see the kernel)
   if ((Rp == 32 || Rp == 64) && K % XU_KSLICE == 0 && K / XU_KSLICE <= 16 && M >= 64) {
     const int nw = K / XU_KSLICE;
-    const dim3 g2((M + 16 * XU_GROUPS - 1) / (16 * XU_GROUPS), Rp / 32), b2(nw * 64);
+    // a few rows (the cls-row-only linears of the last block: M = batch): one row group per workgroup, or a single CU
+    // walks all of them one after the other (20 us for 64 rows x 3072 columns; 6 us as four workgroups)
+    const int groups = M <= 16 * XU_GROUPS * 8 ? 1 : XU_GROUPS;
+    const dim3 g2((M + 16 * groups - 1) / (16 * groups), Rp / 32), b2(nw * 64);
     const size_t lds = (size_t)nw * 2 * 64 * sizeof(f32x4);
-    hipLaunchKernelGGL(skinny_xu_sliced_kernel<2>, g2, b2, lds, st, x, ldx, u, (bf16*)T, (bf16*)Tt, ldt, M, K, Rp);
+    hipLaunchKernelGGL(skinny_xu_sliced_kernel<2>, g2, b2, lds, st, x, ldx, u, (bf16*)T, (bf16*)Tt, ldt, M, K, Rp, groups);
     CARA_CHECK_LAUNCH();
     return CARA_OK;
   }

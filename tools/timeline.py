@@ -10,6 +10,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--skip-last", type=int, default=0,
                 help="training steps to leave out at the end of the trace (bench.py ends with 3 steps in which EVERY kernel "
                      "site is bracketed by HIP events: ~15 us of idle chip per bracket, not part of the timed region)")
+ap.add_argument("--list", action="store_true", help="also print the ordered kernels of the last step of the window")
 a = ap.parse_args()
 f = glob.glob(a.path + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
@@ -48,3 +49,12 @@ qs = collections.Counter(q for _, _, _, q in win)
 print("queues:", dict(qs))
 for k, v in gaps.most_common(25):
     print(f"{v/1e3/a.steps:8.1f} us/step  x{gapn[k]/a.steps:5.1f}  {k}")
+
+if a.list:   # the ordered kernels of the LAST step of the window: offset, duration, gap before, name
+    lp = [i for i, e in enumerate(win) if "prep_kernel" in e[2]][-1]
+    step = win[lp:]
+    s0, prev_end = step[0][0], step[0][0]
+    print(f"\nlast step: {len(step)} kernels, {(max(e[1] for e in step) - s0) / 1e3:.1f} us")
+    for s_, e_, n_, q_ in step:
+        print(f"{(s_ - s0) / 1e3:9.1f} us  {(e_ - s_) / 1e3:7.1f} us  gap {max(0, s_ - prev_end) / 1e3:5.1f}  {n_[:90]}")
+        prev_end = max(prev_end, e_)
