@@ -350,6 +350,20 @@ __device__ __forceinline__ void glds16_hidden(const char* base, unsigned voff, u
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory", "m0");
 }
 
+#ifdef CARA_ATTN_STAMPS
+// Diagnostic build (tools/attn_stamps.py): wave 0 of every workgroup records s_memrealtime (100 MHz) at eight points of
+// every head it walks, into a buffer of its own: [block][head slot (<= 4)][8].
+__device__ unsigned long long* g_attn_stamp_buf = nullptr;
+extern "C" int cara_debug_attn_stamps(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#define ATTN_STAMP(i)                                                                                              \
+  do {                                                                                                             \
+    if (g_attn_stamp_buf && tid == 0 && slot < 4) g_attn_stamp_buf[((size_t)blockIdx.x * 4 + slot) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define ATTN_STAMP(i)
+#endif
 __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_persist_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                                             float* __restrict__ lse, int N, int H, int BH, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -411,18 +425,23 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_persist_kernel(cons
   stage_kv(bh, 0);
   stage_q(bh);
   int cur = 0;
+#ifdef CARA_ATTN_STAMPS
+  int slot = -1;
+#endif
   for (; bh < BH; bh += gridDim.x) {
     const int nxt = bh + gridDim.x;
-    // every wave is through with the images of the head before this one: refill them with the next head
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (nxt < BH) {
-      stage_kv(nxt, cur ^ 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all but the 8 pieces just issued: this head's K, V, Q have landed
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    asm volatile("s_barrier" ::: "memory");               // ... for every wave
+#ifdef CARA_ATTN_STAMPS
+    ++slot;
+#endif
+    ATTN_STAMP(0);
+    // ONE barrier per head: behind it every wave's pieces of this head's K, V and Q have landed (they were issued during the
+    // previous head -- everything this wave has outstanding, its output stores included, is old by now) AND every wave is
+    // through with the previous head, whose K / V images the next head's pieces may therefore overwrite.  Those pieces are
+    // handed out over the key tiles of the S^T loop below: issued between two barriers, as they used to be, the 56 pieces
+    // of a head held all seven waves for 1.6 us while the CU's load path accepted them (time stamps, tools/attn_stamps.py).
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    ATTN_STAMP(1);
     const char* Ks = smem + cur * 2 * IMG;
     const char* Vs = Ks + IMG;
     const int b = bh / H, head = bh - b * H;
@@ -436,10 +455,14 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_persist_kernel(cons
     bf16x8 ka[2][4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) ka[0][ks] = *reinterpret_cast<const bf16x8*>(Ks + ro.o[ks]);
+    const char* nbase = head_base(nxt < BH ? nxt : bh);
+    const unsigned nimg = lds_of(smem + (cur ^ 1) * 2 * IMG);
 #pragma unroll
     for (int kt = 0; kt < 7; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      if (nxt < BH && (kt & 1) == 0)   // the next head's K / V: pieces 0-3 behind the even tiles here, 4-7 in the P V loop
+        glds16_hidden(nbase, kvoff[kt >> 1], nimg + __builtin_amdgcn_readfirstlane(kvdst[kt >> 1]));
       if (kt < nkt) {
         if (kt + 1 < nkt) {
           const char* kb_ = Ks + (kt + 1) * 4096;
@@ -450,6 +473,7 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_persist_kernel(cons
         for (int ks = 0; ks < 4; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[kt & 1][ks], qf[ks], s[kt], 0, 0, 0);
       }
     }
+    ATTN_STAMP(2);
     // the Q fragments are in registers: the wave's Q image may take the next head's rows
     if (nxt < BH) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -470,6 +494,7 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_persist_kernel(cons
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    ATTN_STAMP(3);
     const float mxc = mx * c2;
     float sum = 0.f;
     f32x16 o[2];
@@ -482,6 +507,8 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_persist_kernel(cons
       if (kt < nkt) {
         // the four V fragments of this key tile are requested first: the exponentials below cover their latency
         const char* vb_ = Vs + kt * 4096;
+        if (nxt < BH && (kt & 1) == 0)
+          glds16_hidden(nbase, kvoff[4 + (kt >> 1)], nimg + __builtin_amdgcn_readfirstlane(kvdst[4 + (kt >> 1)]));
         bf16x8 vf[2][2];
 #pragma unroll
         for (int st = 0; st < 2; ++st)
@@ -501,7 +528,13 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_persist_kernel(cons
         }
       }
     }
+    if (nxt < BH) {
+#pragma unroll
+      for (int kt = 0; kt < 7; kt += 2)   // (the pieces of tiles this N does not have)
+        if (kt >= nkt) glds16_hidden(nbase, kvoff[4 + (kt >> 1)], nimg + __builtin_amdgcn_readfirstlane(kvdst[4 + (kt >> 1)]));
+    }
     sum += __shfl_xor(sum, 32, 64);
+    ATTN_STAMP(4);
     const float inv = 1.0f / sum;
     // O^T layout: column (lane & 31) = QUERY, register r of lane half h = d = 32 dt + 8 (r >> 2) + 4 h + (r & 3): a lane
     // holds its query's row in runs of four d, and 1 / sum of that query is the lane's own.  Lane halves swap runs
@@ -546,6 +579,7 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_persist_kernel(cons
       }
       if (h == 0 && q0 + ql < N) lse[(size_t)bh * N + q0 + ql] = mx * scale + __logf(sum);
     }
+    ATTN_STAMP(5);
     cur ^= 1;
   }
 }
@@ -815,20 +849,6 @@ __device__ __forceinline__ void glds4_hidden(const char* base, unsigned voff, un
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory", "m0");
 }
 
-#ifdef CARA_ATTN_STAMPS
-// Diagnostic build (tools/attn_stamps.py): wave 0 of every workgroup records s_memrealtime (100 MHz) at eight points of
-// every head it walks, into a buffer of its own: [block][head slot (<= 4)][8].
-__device__ unsigned long long* g_attn_stamp_buf = nullptr;
-extern "C" int cara_debug_attn_stamps(void* buf) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
-}
-#define ATTN_STAMP(i)                                                                                              \
-  do {                                                                                                             \
-    if (g_attn_stamp_buf && tid == 0 && slot < 4) g_attn_stamp_buf[((size_t)blockIdx.x * 4 + slot) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
-  } while (0)
-#else
-#define ATTN_STAMP(i)
-#endif
 __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                                 const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                                 bf16* __restrict__ dqkv, int N, int H, int BH, float scale) {

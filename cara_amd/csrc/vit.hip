@@ -661,6 +661,9 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
     }
     e = {};
     e.epi = CARA_EPI_RESID; e.C = x_mid; e.aux = x_in; e.rowscale = dp1; e.rows_per_sample = rps; e.ldc = ldr;
+#ifdef CARA_ABLATE_RESID   // timing experiment only: the residual products with a plain bf16 epilogue (wrong results)
+    e = {}; e.epi = CARA_EPI_BF16; e.C = ws + lw.u;
+#endif
     if (ex) TRY(lin_fwd_exact(lin[1], reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, ws, W, s, e, cx));
     else TRY(lin_fwd(lin[1], reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, lw, e, cx));
     // x = x + drop_path(mlp(norm2(x)))
@@ -678,6 +681,9 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
     else TRY(lin_fwd(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), pa_n ? -Mr : D, Mr, Rp, W.ldt, ws, lw, e, cx, fx));
     e = {};
     e.epi = CARA_EPI_RESID; e.C = x_out; e.aux = x_mid; e.rowscale = dp2; e.rows_per_sample = rps; e.ldc = ldr;
+#ifdef CARA_ABLATE_RESID
+    e = {}; e.epi = CARA_EPI_BF16; e.C = ws + lw.u;
+#endif
     if (ex) TRY(lin_fwd_exact(lin[3], reinterpret_cast<bf16*>(ws + lw.h), 4 * D, Mr, Rp, ws, W, s, e, cx));
     else TRY(lin_fwd(lin[3], reinterpret_cast<bf16*>(ws + lw.h), pa ? -Mr : 4 * D, Mr, Rp, W.ldt, ws, lw, e, cx));
   }
