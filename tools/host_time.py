@@ -9,7 +9,11 @@ import bench
 dev = torch.device("cuda", 0)
 model, trainable = bench.build_model(16, 0.1, 100, dev, seed=14, name="vit_base_patch16_224_in21k")
 eng = model._cara_engine
-opt = torch.optim.AdamW(trainable, lr=1e-3, weight_decay=1e-4, fused=True)
+if os.environ.get("CARA_BENCH_TORCH_ADAMW") == "1":
+    opt = torch.optim.AdamW(trainable, lr=1e-3, weight_decay=1e-4, fused=True)
+else:
+    from cara_amd.optim import AdamW
+    opt = AdamW(trainable, lr=1e-3, weight_decay=1e-4)
 x = torch.randn(64, 3, 224, 224, device=dev)
 y = torch.randint(0, 100, (64,), device=dev)
 for _ in range(5):
