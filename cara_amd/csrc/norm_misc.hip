@@ -60,7 +60,7 @@ __device__ __forceinline__ UtFrags<V4, NT> load_ut_frags(const bf16* __restrict_
 }
 template <int V4, int NT>
 __device__ __forceinline__ void block_contract(XuLds<V4, NT>& L, const UtFrags<V4, NT>& uf, bf16* __restrict__ T,
-                                               bf16* __restrict__ Tt, const int ldt, const int row_base, const int M) {
+                                               bf16* __restrict__ Tt, const int ldt, const int row_base, const int M, const int Rp) {
   constexpr int LDY = XuLds<V4, NT>::LDY;
   static_assert(XU_WAVES == 8, "K steps per wave = C / 32 / 8 = V4");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -88,7 +88,7 @@ __device__ __forceinline__ void block_contract(XuLds<V4, NT>& L, const UtFrags<V
     const bf16x4 o = {(bf16)t[0], (bf16)t[1], (bf16)t[2], (bf16)t[3]};
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (m0 + r < M) T[(size_t)(m0 + r) * (NT * 16) + col] = o[r];
+      if (m0 + r < M) T[(size_t)(m0 + r) * Rp + col] = o[r];
     if (Tt) {
       if (m0 + 4 <= M) {
         *reinterpret_cast<bf16x4*>(Tt + (size_t)col * ldt + m0) = o;
@@ -97,6 +97,17 @@ __device__ __forceinline__ void block_contract(XuLds<V4, NT>& L, const UtFrags<V
         for (int r = 0; r < 4; ++r)
           if (m0 + r < M) Tt[(size_t)col * ldt + m0 + r] = o[r];
       }
+    }
+  }
+  else if (wave < Rp / 16) {
+    // NT * 16 < Rp (rank <= 16 at Rp = 32: only the first column tile is computed, the rows of Ut beyond the rank are
+    // zero): the tiles that were skipped are written as the zeros they are
+    const int col = wave * 16 + fr, m0 = row_base + fq * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (m0 + r >= M) continue;
+      T[(size_t)(m0 + r) * Rp + col] = (bf16)0.f;
+      if (Tt) Tt[(size_t)col * ldt + m0 + r] = (bf16)0.f;
     }
   }
 }
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_fwd_kernel(const 
   // (NT = 4: twice the fragments; they are requested behind the row loop, as in the backward kernel, so that the kernel
   // keeps its occupancy)
   UtFrags<XU ? V4 : 1, XU ? NT : 1> uf;
-  if constexpr (XU && NT == 2) uf = load_ut_frags<V4, NT>(Ut);
+  if constexpr (XU && NT <= 2) uf = load_ut_frags<V4, NT>(Ut);
   // all of a wave's rows are requested before anything is reduced: a wave keeps RPW x V4 16-byte loads in flight
   // instead of V4 (the kernel is latency-bound: one row at a time reached 3.4 TB/s)
   float4 v[RPW][V4];
@@ -178,8 +189,8 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_fwd_kernel(const 
       __syncthreads();
       panel_store<V4, NT>(L, y, yp, blockIdx.x * 16, M);
     }
-    if constexpr (NT != 2) uf = load_ut_frags<V4, NT>(Ut);
-    block_contract<V4, NT>(L, uf, T, Tt, ldt, blockIdx.x * 16, M);   // T = LN(x) U of the next linear
+    if constexpr (NT > 2) uf = load_ut_frags<V4, NT>(Ut);
+    block_contract<V4, NT>(L, uf, T, Tt, ldt, blockIdx.x * 16, M, Rp);   // T = LN(x) U of the next linear
   }
 }
 
@@ -279,7 +290,7 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_bwd_kernel(const 
     }
     // (the B fragments are requested here, not at the top: holding them through the row loop costs the backward kernel a
     // workgroup of occupancy -- 138 VGPRs, 36 us instead of 31)
-    block_contract<V4, NT>(L, load_ut_frags<V4, NT>(Vst), G, Gt, ldt, blockIdx.x * 16, M);   // G' = dY Vs of the linear below
+    block_contract<V4, NT>(L, load_ut_frags<V4, NT>(Vst), G, Gt, ldt, blockIdx.x * 16, M, Rp);   // G' = dY Vs of the linear below
   }
 }
 
@@ -446,10 +457,16 @@ int ln_fwd_launch(const float* x, long ldx, const float* gamma, const float* bet
                                      a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp)
 #define LNF4(V) hipLaunchKernelGGL((ln_fwd_kernel<V, true, 4>), grid, block, 0, st, x, ldx, gamma, beta, (bf16*)y, mean, rstd, M, eps, \
                                    a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp)
+#define LNF1(V) hipLaunchKernelGGL((ln_fwd_kernel<V, true, 1>), grid, block, 0, st, x, ldx, gamma, beta, (bf16*)y, mean, rstd, M, eps, \
+                                   a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp)
   if (a.Ut && a.Rp == 64) {
     if (C == 768) LNF4(3);
     else if (C == 1024) LNF4(4);
     else LNF4(1);
+  } else if (a.Ut && a.rank <= 16) {   // half of the padded rank is structurally zero: one column tile of the contraction
+    if (C == 768) LNF1(3);
+    else if (C == 1024) LNF1(4);
+    else LNF1(1);
   } else if (a.Ut) {
     if (C == 768) LNF(3, true);
     else if (C == 1024) LNF(4, true);
@@ -460,6 +477,7 @@ int ln_fwd_launch(const float* x, long ldx, const float* gamma, const float* bet
   else return CARA_E_ARG;
 #undef LNF
 #undef LNF4
+#undef LNF1
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }
@@ -478,10 +496,16 @@ int ln_bwd_launch(const void* dy, const float* x, long ldx, const float* gamma, 
                                      dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M, a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp)
 #define LNB4(V) hipLaunchKernelGGL((ln_bwd_kernel<V, true, 4>), grid, block, 0, st, (const bf16*)dy, x, ldx, gamma, mean, rstd, \
                                    dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M, a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp)
+#define LNB1(V) hipLaunchKernelGGL((ln_bwd_kernel<V, true, 1>), grid, block, 0, st, (const bf16*)dy, x, ldx, gamma, mean, rstd, \
+                                   dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M, a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp)
   if (a.Ut && a.Rp == 64) {
     if (C == 768) LNB4(3);
     else if (C == 1024) LNB4(4);
     else LNB4(1);
+  } else if (a.Ut && a.rank <= 16) {
+    if (C == 768) LNB1(3);
+    else if (C == 1024) LNB1(4);
+    else LNB1(1);
   } else if (a.Ut) {
     if (C == 768) LNB(3, true);
     else if (C == 1024) LNB(4, true);
@@ -492,6 +516,7 @@ int ln_bwd_launch(const void* dy, const float* x, long ldx, const float* gamma, 
   else return CARA_E_ARG;
 #undef LNB
 #undef LNB4
+#undef LNB1
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }

@@ -83,6 +83,18 @@ __global__ __launch_bounds__(1024) void skinny_xu_sliced_kernel(const bf16* __re
     for (int j = 0; j < NT; ++j) red[(wave * NT + j) * 64 + lane] = acc[j];
     __syncthreads();
     if (m0 < M) {
+      // (rank <= 16 at Rp = 32: NT = 1 computes the first 16 columns only -- the rows of Ut beyond the rank are zero -- and the
+      // column tiles it skips are written as the zeros they are, by the waves behind the summing ones)
+      for (int nt = NT + wave; nt < Rp / 16 && gridDim.y == 1; nt += nwaves) {
+        const int n = nt * 16 + fr;
+        const int mb = m0 + fq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (mb + r >= M) continue;
+          T[(size_t)(mb + r) * Rp + n] = (bf16)0.f;
+          if (Tt) Tt[(size_t)n * ldt + mb + r] = (bf16)0.f;
+        }
+      }
       for (int nt = wave; nt < NT; nt += nwaves) {
         f32x4 s = red[nt * 64 + lane];
         for (int w = 1; w < nwaves; ++w) {
@@ -277,7 +289,12 @@ extern "C" int cara_tskinny_reduce_many(const cara_ts_reduce* probs, int n, void
 
 extern "C" int cara_skinny_xu(const void* X, int ldx, const void* Ut, void* T, void* Tt, int ldt,
                               int M, int K, int Rp, void* stream) {
-  if (!X || !Ut || !T || M <= 0 || K <= 0 || (K & 31)) return CARA_E_ARG;
+  return cara_skinny_xu_r(X, ldx, Ut, T, Tt, ldt, M, K, Rp, Rp, stream);
+}
+
+extern "C" int cara_skinny_xu_r(const void* X, int ldx, const void* Ut, void* T, void* Tt, int ldt,
+                                int M, int K, int Rp, int rank, void* stream) {
+  if (!X || !Ut || !T || M <= 0 || K <= 0 || (K & 31) || rank <= 0 || rank > Rp) return CARA_E_ARG;
   // ldx < 0: X is K-panel-major with -ldx >= M rows per panel (sliced kernel only)
   const bool xpanels = ldx < 0;
   if (xpanels ? -ldx < M : ((ldx & 7) || ldx < K)) return CARA_E_ARG;
@@ -299,7 +316,10 @@ extern "C" int cara_skinny_xu(const void* X, int ldx, const void* Ut, void* T, v
     const int groups = M <= 16 * XU_GROUPS * 8 ? 1 : XU_GROUPS;
     const dim3 g2((M + 16 * groups - 1) / (16 * groups), Rp / 32), b2(nw * 64);
     const size_t lds = (size_t)nw * 2 * 64 * sizeof(f32x4);
-    hipLaunchKernelGGL(skinny_xu_sliced_kernel<2>, g2, b2, lds, st, x, ldx, u, (bf16*)T, (bf16*)Tt, ldt, M, K, Rp, groups);
+    if (Rp == 32 && rank <= 16)   // half of the padded rank is structurally zero: one column tile, half the Ut fragments
+      hipLaunchKernelGGL(skinny_xu_sliced_kernel<1>, dim3(g2.x, 1), b2, lds, st, x, ldx, u, (bf16*)T, (bf16*)Tt, ldt, M, K, Rp, groups);
+    else
+      hipLaunchKernelGGL(skinny_xu_sliced_kernel<2>, g2, b2, lds, st, x, ldx, u, (bf16*)T, (bf16*)Tt, ldt, M, K, Rp, groups);
     CARA_CHECK_LAUNCH();
     return CARA_OK;
   }

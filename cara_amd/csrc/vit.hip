@@ -192,6 +192,7 @@ struct Ctx {
   int layer;
   bool full;       // this block runs on all token rows (not the cls-row-only last block)
   TsPending* pend = nullptr;   // backward: the pair of products waiting for a carrier
+  int rank = 0;                // the adapter's rank (0: unknown, the skinny passes compute all Rp columns)
 };
 
 int flush_pending(const Ctx& cx) {
@@ -295,7 +296,7 @@ int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char*
   const bool inside = !have_T && fuse_gemm_t(Mr, Rp, false);   // T computed by the GEMM itself
   if (!have_T && !inside) {
     SiteBracket b(CARA_SITE_SKINNY_FWD, cx);
-    TRY(cara_skinny_xu(X, ldx, L.Ut, T, Tt, ldt, Mr, L.in, Rp, st));
+    TRY(cara_skinny_xu_r(X, ldx, L.Ut, T, Tt, ldt, Mr, L.in, Rp, cx.rank > 0 ? cx.rank : Rp, st));
   }
   a.A = X; a.lda = ldx; a.B = L.W; a.Bp = L.Wp; a.ldb = L.in; a.A2 = inside ? nullptr : T; a.B2 = L.Vs; a.Rp = Rp;
   if (ldx < 0) { a.a_panels = -ldx; a.lda = 0; }   // (ldx < 0: X is K-panel-major with -ldx rows per panel, as in cara_skinny_xu)
@@ -330,7 +331,7 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
   const bool inside = !have_G && want_dx && fuse_gemm_t(Mr, Rp, true) && defer && a.epi == CARA_EPI_BF16;
   if (!have_G && !inside) {
     SiteBracket b(CARA_SITE_SKINNY_BWD, cx);
-    TRY(cara_skinny_xu(dY, lddy, L.Vst, G, Gt, ldt, Mr, L.out, Rp, st));
+    TRY(cara_skinny_xu_r(dY, lddy, L.Vst, G, Gt, ldt, Mr, L.out, Rp, cx.rank > 0 ? cx.rank : Rp, st));
   }
   TsPending mine;
   mine.valid = true;
@@ -610,6 +611,7 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
   a.A = ws + W.patches; a.lda = kp; a.B = w->patch_w; a.ldb = kp; a.M = B * P; a.N = D; a.K = kp;
   a.bias = w->patch_b; a.epi = CARA_EPI_F32; a.C = ws + W.emb; a.ldc = D;
   Ctx cx{stream, ws + W.gemm_scratch, 0, false};
+  cx.rank = g->rank;
   with_scratch(a, cx);
   TRY(cara_gemm_bf16(&a, stream));
   TRY(cara_assemble_tokens(reinterpret_cast<float*>(ws + W.emb), w->cls, w->pos,
@@ -704,6 +706,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
   char* ws = static_cast<char*>(workspace);
   TsPending pending;
   Ctx cx{stream, ws + W.gemm_scratch, 0, false, &pending};
+  cx.rank = g->rank;
   hipStream_t hs = static_cast<hipStream_t>(stream);
   const int D = g->dim, M = W.M, Rp = g->Rp, B = s->B, N = s->tokens;
   const float att_scale = 1.0f / sqrtf((float)(D / g->heads));

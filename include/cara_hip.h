@@ -108,6 +108,11 @@ int cara_gemm_tn_f32(const void* At, int lda, const void* Bt, int ldb, float* C,
  * with -ldx >= M rows per panel (what a GEMM with cara_gemm_args::c_panels = -ldx wrote).                  */
 int cara_skinny_xu(const void* X, int ldx, const void* Ut, void* T, void* Tt, int ldt,
                    int M, int K, int Rp, void* stream);
+/* The same with the adapter's rank stated (1 <= rank <= Rp; rows >= rank of Ut are zero): at Rp = 32 and rank <= 16 only the
+ * first 16 columns are computed (half the Ut fragments and MFMAs of a pass that is bound by what a workgroup pays once) and
+ * columns 16 .. 31 of T / rows 16 .. 31 of Tt are written as the zeros they are.  Same results, bit for bit.          */
+int cara_skinny_xu_r(const void* X, int ldx, const void* Ut, void* T, void* Tt, int ldt,
+                     int M, int K, int Rp, int rank, void* stream);
 /* D[K1,Rp] (fp32) = sum_m X[m,K1] * G[m,Rp]  given Gt[Rp,ldg] (= G transposed, bf16); optional
  * colsum[K1] (fp32) = sum_m X[m,:].  Outputs are OVERWRITTEN.  `slabs` is caller scratch of
  * cara_tskinny_scratch_bytes(M, K1, Rp) bytes.  Gives dU = X^T G' and dVs = dY^T T (A.4).      */

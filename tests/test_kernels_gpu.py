@@ -925,3 +925,27 @@ def test_adamw_step_against_torch():
     c.grad = torch.ones(4)
     with pytest.raises(L().CaraError, match="GPU"):
         AdamW([c]).step()
+
+
+@pytest.mark.parametrize("M,K,rank", [(12608, 3072, 16), (12608, 768, 16), (333, 2304, 5), (64, 3072, 16), (12608, 768, 17), (70, 768, 32)])
+def test_skinny_xu_with_the_rank_stated(M, K, rank):
+    """cara_skinny_xu_r: at Rp = 32 and rank <= 16 only the first column tile is computed and the rest is WRITTEN as zeros (the
+    outputs start as NaN here); bit for bit the result of cara_skinny_xu, transposed copy included."""
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+    X = rnd(M, K, seed=1)
+    Ut = rnd(32, K, seed=2, scale=0.1)
+    Ut[rank:] = 0
+    ldt = (M + 31) // 32 * 32
+    out = []
+    for fn, extra in ((lib.cara_skinny_xu, ()), (lib.cara_skinny_xu_r, (rank,))):
+        T = torch.full((M, 32), float("nan"), dtype=torch.bfloat16, device=DEV)
+        Tt = torch.full((32, ldt), float("nan"), dtype=torch.bfloat16, device=DEV)
+        L().check(fn(p(X), K, p(Ut), p(T), p(Tt), ldt, M, K, 32, *extra, st()), "skinny")
+        out.append((T, Tt))
+    (T0, Tt0), (T1, Tt1) = out
+    assert torch.equal(T0, T1) and torch.equal(Tt0[:, :M], Tt1[:, :M])
+    assert torch.count_nonzero(T1[:, rank:]) == 0 and torch.equal(Tt1[:, :M], T1.t())
+    close(T1, X.double() @ Ut.double().t(), 2 ** -8, 1e-3, "T")
+    assert lib.cara_skinny_xu_r(p(X), K, p(Ut), p(T), p(Tt), ldt, M, K, 32, 0, st()) != 0
+    assert lib.cara_skinny_xu_r(p(X), K, p(Ut), p(T), p(Tt), ldt, M, K, 32, 33, st()) != 0
