@@ -1201,6 +1201,206 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// The LAST block: only the cls row of its attention output can reach the logits (the proj / MLP half of that block
+// already runs on the cls rows alone), i.e. ONE query per (batch, head) against all N keys.  The full kernels spend
+// 20 + 53 us on 197 queries there; this pair is two streaming passes over K and V: a workgroup of four waves per
+// (batch, head), lane = head dimension d, the waves share the key rows n = wave, wave + 4, ...; dot products over d are
+// wave reductions.  Same rounding points as the MFMA kernels (P and dS go through bf16 before they multiply V / dO / K / q,
+// the row sum is taken of the unrounded exponentials, outputs are bf16).
+// Forward writes out[b * N + 0, head] and lse[b, head, 0] only; backward reads those rows only and writes ALL of this
+// layer's dqkv (dQ of the other rows is zero: they had no query in play).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block4_reduce(float v, float* red, const bool is_max) {   // 256 threads, result to all
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();   // (red may still be read from a previous reduction)
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// lane = (row of a group of eight, 16-byte chunk of the 128-byte head row): a wave instruction moves eight whole rows, a dot
+// product over d is 8 multiply-adds per lane + a reduction over the 8 lanes of a row; all of a wave's loads of a sweep are
+// requested before anything is reduced (as one row per wave instruction with 2-byte lanes the pair took 42 + 37 us: every
+// row a dependent load -> reduce chain)
+__device__ __forceinline__ float row8_sum(float v) {   // sum over the 8 lanes (chunks) of a row
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  return v;
+}
+__device__ __forceinline__ float rows_sum(float v) {   // sum over the 8 row slots of a wave (same chunk)
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void attn_cls_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse,
+                                                           const int N, const int H, const float scale) {
+  __shared__ float sc[NMAX_LONG + 32];
+  __shared__ float red[4];
+  __shared__ float part[4][64];
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r8 = lane >> 3, c = lane & 7;
+  const int ld = 3 * H * HD;
+  const bf16* base = qkv + (size_t)b * N * ld + h * HD + c * 8;
+  const bf16* kb = base + H * HD;
+  const bf16* vb = kb + H * HD;
+  float q8[8];
+  {
+    const bf16x8 qv = *reinterpret_cast<const bf16x8*>(base);   // the cls row is row 0 of the sample
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q8[j] = (float)qv[j] * scale;
+  }
+  const int nit = (N + 31) / 32;                                // this wave's row groups: rows (it * 4 + wave) * 8 + r8
+  // in batches of eight row groups (all of N <= 256 in one): eight 16-byte loads per lane in flight, fragments in registers
+  // (indexed by a loop that can end early they went to scratch memory)
+  for (int it0 = 0; it0 < nit; it0 += 8) {
+    bf16x8 kv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int n = ((it0 + u) * 4 + wave) * 8 + r8;
+      kv[u] = *reinterpret_cast<const bf16x8*>(kb + (size_t)(n < N ? n : N - 1) * ld);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += q8[j] * (float)kv[u][j];
+      s = row8_sum(s);
+      const int n = ((it0 + u) * 4 + wave) * 8 + r8;
+      if (c == 0 && it0 + u < nit) sc[n] = n < N ? s : -3.0e38f;   // (padded rows: exp -> 0)
+    }
+  }
+  __syncthreads();
+  const int npad = nit * 32;
+  float mx = -3.0e38f;
+  for (int n = threadIdx.x; n < npad; n += 256) mx = fmaxf(mx, sc[n]);
+  mx = block4_reduce(mx, red, true);
+  float sum = 0.f;
+  for (int n = threadIdx.x; n < npad; n += 256) {
+    const float e = __expf(sc[n] - mx);
+    sum += e;                                                   // (unrounded, as in the MFMA kernels)
+    sc[n] = (float)(bf16)e;                                     // P as the bf16 operand of P V
+  }
+  sum = block4_reduce(sum, red, false);                         // (its barriers also publish the rounded P)
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int it0 = 0; it0 < nit; it0 += 8) {
+    bf16x8 vv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int n = ((it0 + u) * 4 + wave) * 8 + r8;
+      vv[u] = *reinterpret_cast<const bf16x8*>(vb + (size_t)(n < N ? n : N - 1) * ld);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float pn = it0 + u < nit ? sc[((it0 + u) * 4 + wave) * 8 + r8] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += pn * (float)vv[u][j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float t = rows_sum(acc[j]);
+    if (r8 == 0) part[wave][c * 8 + j] = t;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float o = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) / sum;
+    out[(size_t)b * N * (H * HD) + h * HD + lane] = (bf16)o;
+    if (lane == 0) lse[(size_t)bh * N] = mx + __logf(sum);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                           bf16* __restrict__ dqkv, const int N, const int H, const float scale) {
+  __shared__ float part[4][64];
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r8 = lane >> 3, c = lane & 7;
+  const int ld = 3 * H * HD;
+  const size_t row0 = (size_t)b * N;
+  const bf16* base = qkv + row0 * ld + h * HD + c * 8;
+  const bf16* kb = base + H * HD;
+  const bf16* vb = kb + H * HD;
+  bf16* dq = dqkv + row0 * ld + h * HD + c * 8;
+  bf16* dk = dq + H * HD;
+  bf16* dv = dk + H * HD;
+  float qs8[8], do8[8];
+  float delta;
+  {
+    const bf16x8 qv = *reinterpret_cast<const bf16x8*>(base);
+    const bf16x8 ov = *reinterpret_cast<const bf16x8*>(out + row0 * (H * HD) + h * HD + c * 8);
+    const bf16x8 gv = *reinterpret_cast<const bf16x8*>(dout + row0 * (H * HD) + h * HD + c * 8);
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      qs8[j] = (float)qv[j] * scale;
+      do8[j] = (float)gv[j];
+      d += do8[j] * (float)ov[j];
+    }
+    delta = row8_sum(d);                                        // (every row slot its own copy)
+  }
+  const float L = lse[(size_t)bh * N];
+  const int nit = (N + 31) / 32;
+  float dqa[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dqa[j] = 0.f;
+  // in batches of four row groups: 8 loads of 16 bytes per lane in flight
+  for (int it0 = 0; it0 < nit; it0 += 4) {
+    bf16x8 kk[4], vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = ((it0 + u) * 4 + wave) * 8 + r8;
+      const size_t ro = (size_t)(n < N ? n : N - 1) * ld;
+      kk[u] = *reinterpret_cast<const bf16x8*>(kb + ro);
+      vv[u] = *reinterpret_cast<const bf16x8*>(vb + ro);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = ((it0 + u) * 4 + wave) * 8 + r8;
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s += qs8[j] * (float)kk[u][j];
+        dp += do8[j] * (float)vv[u][j];
+      }
+      s = row8_sum(s);
+      dp = row8_sum(dp);
+      const float p = __expf(s - L);
+      const float pb = (float)(bf16)p;                          // P and dS as the bf16 operands they are in the MFMA kernels
+      const float dsb = (float)(bf16)(p * (dp - delta));
+      if (n < N && it0 + u < nit) {
+        bf16x8 ov, kv, zv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ov[j] = (bf16)(pb * do8[j]);
+          kv[j] = (bf16)(dsb * qs8[j]);
+          zv[j] = (bf16)0.f;
+          dqa[j] += dsb * (float)kk[u][j];
+        }
+        *reinterpret_cast<bf16x8*>(dv + (size_t)n * ld) = ov;
+        *reinterpret_cast<bf16x8*>(dk + (size_t)n * ld) = kv;
+        if (n > 0) *reinterpret_cast<bf16x8*>(dq + (size_t)n * ld) = zv;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float t = rows_sum(dqa[j]);
+    if (r8 == 0) part[wave][c * 8 + j] = t;
+  }
+  __syncthreads();
+  if (wave == 0)
+    dqkv[row0 * ld + h * HD + lane] = (bf16)(((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) * scale);
+}
+
 // diagnostic: stage a [N,64] matrix like the kernels do and return every lane's transposed fragment
 __global__ void tr_frag_probe_kernel(const bf16* __restrict__ src, bf16* __restrict__ out, int N, int cbase, int base) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1303,6 +1503,24 @@ extern "C" int cara_attention_bwd(const void* qkv, const void* out, const void* 
   else
     hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, dim3(B * H, (N + 127) / 128), dim3(256), lds, st, (const bf16*)qkv,
                        (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale, npad);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
+
+extern "C" int cara_attention_cls_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, void* stream) {
+  if (!qkv || !out || !lse || B <= 0 || H <= 0 || N <= 0 || N > NMAX_LONG) return CARA_E_ARG;
+  hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(B * H), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16*)qkv, (bf16*)out, lse, N, H,
+                     scale);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
+
+extern "C" int cara_attention_cls_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                      int B, int N, int H, float scale, void* stream) {
+  if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || H <= 0 || N <= 0 || N > NMAX_LONG) return CARA_E_ARG;
+  hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(B * H), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16*)qkv, (const bf16*)out,
+                     (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
 }

@@ -505,6 +505,12 @@ bool cls_shortcut_enabled() {
   return v != 0;
 }
 
+// CARA_CLS_ATTN=0: the last block runs the full attention kernels although only its cls query matters (A/B measurements only)
+bool cls_attention_enabled() {
+  static const int v = env_once("CARA_CLS_ATTN", 1);
+  return v != 0;
+}
+
 // tiny classifier-head backward (B x classes x D, fp32 VALU).  The three outputs are independent: blocks
 // [0, nbw) take dW (and db), the rest dxn, so the two long loops run side by side instead of one after the other in
 // every thread (58 -> ~25 us; it sits alone at the head of the backward pass)
@@ -659,7 +665,11 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
     else TRY(lin_fwd(lin[0], reinterpret_cast<bf16*>(ws + lw.xn1), pa_x ? -M : D, M, Rp, W.ldt, ws, lw, e, cx_all, fx));
     {
       SiteBracket sb(CARA_SITE_ATTN_FWD, cx_all);
-      TRY(cara_attention_fwd(ws + lw.qkv, ws + lw.ao, reinterpret_cast<float*>(ws + lw.lse), B, N, g->heads, att_scale, stream));
+      // (the last block: only the cls row of the attention output is read -- by proj on the cls rows -- so only the cls query runs)
+      if (cls_only && cls_attention_enabled())
+        TRY(cara_attention_cls_fwd(ws + lw.qkv, ws + lw.ao, reinterpret_cast<float*>(ws + lw.lse), B, N, g->heads, att_scale, stream));
+      else
+        TRY(cara_attention_fwd(ws + lw.qkv, ws + lw.ao, reinterpret_cast<float*>(ws + lw.lse), B, N, g->heads, att_scale, stream));
     }
     e = {};
     e.epi = CARA_EPI_RESID; e.C = x_mid; e.aux = x_in; e.rowscale = dp1; e.rows_per_sample = rps; e.ldc = ldr;
@@ -774,13 +784,18 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     // ---- attention branch ----
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dAO; e.ldc = ldr;
-    if (cls_only && hipMemsetAsync(ws + W.dAO, 0, (size_t)M * D * 2, hs) != hipSuccess) return CARA_E_LAUNCH;
+    const bool cls_attn = cls_only && cls_attention_enabled();   // (then only the cls rows of dAO are ever read)
+    if (cls_only && !cls_attn && hipMemsetAsync(ws + W.dAO, 0, (size_t)M * D * 2, hs) != hipSuccess) return CARA_E_LAUNCH;
     if (ex) TRY(lin_bwd_exact(lin[1], dyp, reinterpret_cast<bf16*>(ws + lw.ao), Mr, Rp, ws, W, s, true, e, true, cx));
     else TRY(lin_bwd(lin[1], dyp, pa_dp ? -Mr : ldr, reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, W, lw, true, e, true, cx, fx));
     {
       SiteBracket sb(CARA_SITE_ATTN_BWD, cx_all);
-      TRY(cara_attention_bwd(ws + lw.qkv, ws + lw.ao, ws + W.dAO, reinterpret_cast<float*>(ws + lw.lse), dQKV, B, N,
-                             g->heads, att_scale, stream));
+      if (cls_attn)
+        TRY(cara_attention_cls_bwd(ws + lw.qkv, ws + lw.ao, ws + W.dAO, reinterpret_cast<float*>(ws + lw.lse), dQKV, B, N,
+                                   g->heads, att_scale, stream));
+      else
+        TRY(cara_attention_bwd(ws + lw.qkv, ws + lw.ao, ws + W.dAO, reinterpret_cast<float*>(ws + lw.lse), dQKV, B, N,
+                               g->heads, att_scale, stream));
     }
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;

@@ -195,6 +195,14 @@ int cara_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int
                        void* stream);
 int cara_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                        void* dqkv, int B, int N, int H, float scale, void* stream);
+/* The same for the cls query alone (row 0 of every sample) -- all the LAST block needs: only the cls row of its attention
+ * output reaches the logits (timm's `x[:, 0]` behind the final norm; cara.py:43-48 computes every row).  _fwd writes
+ * out[b N + 0, :] and lse[b, h, 0] and leaves the other rows alone; _bwd reads those rows (and dout[b N + 0, :]) and writes
+ * ALL of dqkv: dK / dV of every key row, dQ of the cls row, zeros for the dQ of the other rows.  Same rounding points as the
+ * full kernels.  N <= 608.                                                                                             */
+int cara_attention_cls_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, void* stream);
+int cara_attention_cls_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                           void* dqkv, int B, int N, int H, float scale, void* stream);
 
 /* ---- small pieces of the ViT around the blocks -------------------------------------------- */
 /* patches bf16 [B*gh*gw, C*p*p] <- images fp32 [B,C,Hi,Wi]  (Conv2d k=s=p as a GEMM operand)  */

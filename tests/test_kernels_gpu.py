@@ -949,3 +949,44 @@ def test_skinny_xu_with_the_rank_stated(M, K, rank):
     close(T1, X.double() @ Ut.double().t(), 2 ** -8, 1e-3, "T")
     assert lib.cara_skinny_xu_r(p(X), K, p(Ut), p(T), p(Tt), ldt, M, K, 32, 0, st()) != 0
     assert lib.cara_skinny_xu_r(p(X), K, p(Ut), p(T), p(Tt), ldt, M, K, 32, 33, st()) != 0
+
+
+@pytest.mark.parametrize("B,N,H", [(3, 197, 12), (2, 5, 2), (1, 577, 16), (64, 197, 12)])
+def test_attention_for_the_cls_query_alone(B, N, H):
+    """cara_attention_cls_fwd / _bwd (what the last block needs: only the cls row of its attention output reaches the logits)
+    against the full kernels' cls rows and against fp64; the backward with a gradient on the cls rows only, all of dqkv."""
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+    scale = 64 ** -0.5
+    qkv = rnd(B * N, 3 * H * 64, seed=1, scale=1.0)
+    out_full = torch.empty(B * N, H * 64, dtype=torch.bfloat16, device=DEV)
+    lse_full = torch.empty(B, H, N, device=DEV)
+    L().check(lib.cara_attention_fwd(p(qkv), p(out_full), p(lse_full), B, N, H, C.c_float(scale), st()), "attn fwd")
+    out = torch.full((B * N, H * 64), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lse = torch.full((B, H, N), float("nan"), device=DEV)
+    L().check(lib.cara_attention_cls_fwd(p(qkv), p(out), p(lse), B, N, H, C.c_float(scale), st()), "attn cls fwd")
+    cls = torch.arange(B, device=DEV) * N
+    qd = qkv.double().requires_grad_(True)
+    ref, ref_lse = attn_ref(qd, B, N, H, scale)
+    close(out[cls], ref[cls], 2 ** -7, 4e-3, "cls out")
+    close(out[cls], out_full[cls].double(), 2 ** -7, 2e-3, "cls out vs the full kernel")
+    close(lse[:, :, 0], ref_lse[:, :, 0], 1e-4, 1e-4, "cls lse")
+    mask = torch.ones(B * N, dtype=torch.bool, device=DEV)
+    mask[cls] = False
+    assert torch.isnan(out[mask]).all() and torch.isnan(lse[:, :, 1:]).all()          # nothing else is written
+    dout = torch.zeros(B * N, H * 64, dtype=torch.bfloat16, device=DEV)
+    dout[cls] = rnd(B, H * 64, seed=2)
+    ref.backward(dout.double())
+    dqkv = torch.full_like(qkv, float("nan"))
+    L().check(lib.cara_attention_cls_bwd(p(qkv), p(out), p(dout), p(lse), p(dqkv), B, N, H, C.c_float(scale), st()), "attn cls bwd")
+    g = qd.grad
+    assert not torch.isnan(dqkv).any()
+    err = (dqkv.double() - g).abs()
+    assert (err <= 2 ** -6 * g.abs() + 0.02 * g.abs().max()).all(), f"max err {err.max():.3e} vs grad max {g.abs().max():.3e}"
+    assert (dqkv.double() - g).norm() / g.norm() < 8e-3
+    if N > 1:
+        qblock = dqkv.reshape(B, N, 3, H * 64)[:, 1:, 0]
+        assert torch.count_nonzero(qblock) == 0                                          # no query but the cls one was in play
+    dfull = torch.empty_like(qkv)
+    L().check(lib.cara_attention_bwd(p(qkv), p(out_full), p(dout), p(lse_full), p(dfull), B, N, H, C.c_float(scale), st()), "attn bwd")
+    assert (dqkv.double() - dfull.double()).norm() / dfull.double().norm() < 8e-3
