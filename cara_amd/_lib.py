@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("CARA_LIB_PATH") or os.path.join(_HERE, "libcara_hip.s
 
 # every symbol include/cara_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "cara_abi_version", "cara_build_arch", "cara_gemm_bf16", "cara_gemm_tn_f32", "cara_pack_b_panels", "cara_gemm_scratch_bytes", "cara_skinny_xu", "cara_skinny_xu_r",
+    "cara_abi_version", "cara_build_arch", "cara_gemm_bf16", "cara_gemm_tn_f32", "cara_pack_b_panels", "cara_gemm_scratch_bytes", "cara_skinny_xu", "cara_skinny_xu_r", "cara_tskinny_partial2_r", "cara_gemm_with_tskinny_r",
     "cara_tskinny_scratch_bytes", "cara_tskinny_xtg", "cara_tskinny_partial", "cara_tskinny_partial2", "cara_tskinny_reduce", "cara_tskinny_reduce_many", "cara_gemm_with_tskinny", "cara_layernorm_fwd", "cara_layernorm_bwd", "cara_layernorm_fwd_xu", "cara_layernorm_bwd_xu", "cara_layernorm_fwd_ex", "cara_layernorm_bwd_ex",
     "cara_attention_fwd", "cara_attention_bwd", "cara_attention_cls_fwd", "cara_attention_cls_bwd", "cara_im2col_patches", "cara_assemble_tokens",
     "cara_cross_entropy", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_transpose_bf16_ld", "cara_pack_offsets",
@@ -103,7 +103,7 @@ class VitShape(C.Structure):
 
 class TsReduce(C.Structure):
     _fields_ = [("slabs", C.c_void_p), ("slab_stride", C.c_size_t), ("D", C.c_void_p), ("colsum", C.c_void_p),
-                ("batch", C.c_int), ("M", C.c_int), ("K1", C.c_int), ("Rp", C.c_int)]
+                ("batch", C.c_int), ("M", C.c_int), ("K1", C.c_int), ("Rp", C.c_int), ("Rc", C.c_int)]
 
 
 ADAMW_MAX_TENSORS, ADAMW_MAX_GROUPS = 32, 4

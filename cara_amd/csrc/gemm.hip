@@ -343,7 +343,7 @@ __global__ __launch_bounds__(512, 4) void gemm32w8_kernel(const cara_gemm_args p
 // accumulator tiles take the kernel to 136 VGPRs, three workgroups per CU -- still far better than the products as a
 // launch of their own behind the GEMM, 55 us per pair at rank 64)
 template <int EPI, bool COLSUM, int MI = 4, int NT = 2>
-__global__ __launch_bounds__(256, NT == 2 ? 4 : 3) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
+__global__ __launch_bounds__(256, NT <= 2 ? 4 : 3) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
                                                            const TsProblem t0, const TsProblem t1, const int ldg, const int Mts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // the products' blocks sit BEHIND the GEMM tiles: they fill the slots the GEMM's last, partly filled round leaves
@@ -564,7 +564,7 @@ struct TsPair {
   TsProblem a, b;
   int ldg, M;
   bool any_cs;
-  int nt;   // Rp / 16 of the products: 2 or 4
+  int nt;   // column tiles of 16 the products compute: Rp / 16 = 2 or 4, or 1 at Rp = 32 and rank <= 16
 };
 
 // one launch of the GEMM-with-riders kernel: COLSUM and NT (the products' Rp / 16) picked at run time
@@ -580,6 +580,8 @@ void launch_ts(const cara_gemm_args* a, hipStream_t st, const TsPair* ts, int ti
   } while (0)
   if (ts->nt == 4) {
     if (ts->any_cs) TS_GO(true, 4); else TS_GO(false, 4);
+  } else if (ts->nt == 1) {   // rank <= 16: the products compute 16 of their 32 columns (16-wide slabs)
+    if (ts->any_cs) TS_GO(true, 1); else TS_GO(false, 1);
   } else {
     if (ts->any_cs) TS_GO(true, 2); else TS_GO(false, 2);
   }
@@ -931,11 +933,18 @@ extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) { return ge
 extern "C" int cara_gemm_with_tskinny(const cara_gemm_args* a, const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
                                       const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b, int ldg,
                                       int M, int Rp, void* stream) {
+  return cara_gemm_with_tskinny_r(a, Xa, ldxa, Gta, slabs_a, K1a, Xb, ldxb, Gtb, slabs_b, K1b, want_colsum_b, ldg, M, Rp, Rp, stream);
+}
+
+extern "C" int cara_gemm_with_tskinny_r(const cara_gemm_args* a, const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
+                                        const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b, int ldg,
+                                        int M, int Rp, int rank, void* stream) {
+  if (rank <= 0 || rank > Rp) return CARA_E_ARG;
   if (!(Rp == 32 || Rp == 64) || !ts_args_ok(Xa, ldxa, Gta, ldg, slabs_a, M, K1a, Rp) || !ts_args_ok(Xb, ldxb, Gtb, ldg, slabs_b, M, K1b, Rp)) return CARA_E_ARG;
   TsPair ts;
   ts.a = ts_problem(Xa, ldxa, Gta, slabs_a, 0, M, K1a, Rp);
   ts.b = ts_problem(Xb, ldxb, Gtb, slabs_b, want_colsum_b, M, K1b, Rp);
-  ts.ldg = ldg; ts.M = M; ts.any_cs = want_colsum_b != 0; ts.nt = Rp / 16;
+  ts.ldg = ldg; ts.M = M; ts.any_cs = want_colsum_b != 0; ts.nt = (Rp == 32 && rank <= 16 && !a->Ut) ? 1 : Rp / 16;
   return gemm_bf16_impl(a, stream, &ts);
 }
 

@@ -248,6 +248,7 @@ __global__ void tskinny_reduce_many_kernel(const TsReduceTable t) {
   const cara_ts_reduce& q = t.p[blockIdx.z];
   if ((int)blockIdx.y >= q.batch) return;
   const int K1 = q.K1, Rp = q.Rp, nchunks = t.nchunks[blockIdx.z];
+  const int Rc = q.Rc > 0 ? q.Rc : Rp;   // columns the slabs hold (16 when the products ran at rank <= 16): the rest of D is zero
   const int colblocks = K1 / TS_COLS;
   const int nblk = colblocks * nchunks;
   const float* slabs = reinterpret_cast<const float*>(static_cast<const char*>(q.slabs) + (size_t)blockIdx.y * q.slab_stride);
@@ -257,7 +258,7 @@ __global__ void tskinny_reduce_many_kernel(const TsReduceTable t) {
   if (idx < total) {
     const int i = idx / Rp, r = idx - i * Rp;
     const int cb = i / TS_COLS, il = i - cb * TS_COLS;
-    const float s = strided_sum4(slabs + ((size_t)cb * TS_COLS + il) * Rp + r, (size_t)colblocks * TS_COLS * Rp, nchunks);
+    const float s = r < Rc ? strided_sum4(slabs + ((size_t)cb * TS_COLS + il) * Rc + r, (size_t)colblocks * TS_COLS * Rc, nchunks) : 0.f;
     q.D[(size_t)blockIdx.y * total + idx] = s;
   }
   if (q.colsum && idx < K1) {
@@ -276,6 +277,7 @@ extern "C" int cara_tskinny_reduce_many(const cara_ts_reduce* probs, int n, void
   for (int i = 0; i < n; ++i) {
     const cara_ts_reduce& q = probs[i];
     if (!q.slabs || !q.D || q.batch <= 0 || q.M <= 0 || q.K1 <= 0 || (q.K1 % TS_COLS) || !(q.Rp == 32 || q.Rp == 64)) return CARA_E_ARG;
+    if (!(q.Rc == 0 || q.Rc == q.Rp || (q.Rc == 16 && q.Rp == 32))) return CARA_E_ARG;
     t.p[i] = q;
     t.nchunks[i] = ts_chunks(q.M, q.K1);
     const int blocks = (q.K1 * q.Rp + 255) / 256;
@@ -341,7 +343,7 @@ extern "C" size_t cara_tskinny_scratch_bytes(int M, int K1, int Rp) {
 }
 
 namespace {
-int ts_launch(const TsProblem& a, const TsProblem& b, int ldg, int M, int Rp, bool any_cs, hipStream_t st) {
+int ts_launch(const TsProblem& a, const TsProblem& b, int ldg, int M, int Rp, bool any_cs, hipStream_t st, bool half = false) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tskinny_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TsRing<4>::WAVE_BYTES);
@@ -351,7 +353,11 @@ int ts_launch(const TsProblem& a, const TsProblem& b, int ldg, int M, int Rp, bo
     attr_set = true;
   }
   const dim3 grid(a.nblk + b.nblk), block(256);
-  if (Rp == 32) {
+  if (Rp == 32 && half) {   // rank <= 16: one r-tile (16 of the 32 columns), 16-wide slabs
+    const size_t lds = TsRing<1>::BLOCK_BYTES;
+    if (any_cs) hipLaunchKernelGGL((tskinny_kernel<1, true>), grid, block, lds, st, a, b, ldg, M);
+    else hipLaunchKernelGGL((tskinny_kernel<1, false>), grid, block, lds, st, a, b, ldg, M);
+  } else if (Rp == 32) {
     const size_t lds = 4 * TsRing<2>::WAVE_BYTES;
     if (any_cs) hipLaunchKernelGGL((tskinny_kernel<2, true>), grid, block, lds, st, a, b, ldg, M);
     else hipLaunchKernelGGL((tskinny_kernel<2, false>), grid, block, lds, st, a, b, ldg, M);
@@ -381,6 +387,18 @@ extern "C" int cara_tskinny_partial2(const void* Xa, int ldxa, const void* Gta, 
   const TsProblem a = ts_problem(Xa, ldxa, Gta, slabs_a, 0, M, K1a, Rp);
   const TsProblem b = ts_problem(Xb, ldxb, Gtb, slabs_b, want_colsum_b, M, K1b, Rp);
   return ts_launch(a, b, ldg, M, Rp, want_colsum_b != 0, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int cara_tskinny_partial2_r(const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
+                                       const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b,
+                                       int ldg, int M, int Rp, int rank, void* stream) {
+  if (rank <= 0 || rank > Rp) return CARA_E_ARG;
+  if (!(Rp == 32 && rank <= 16))
+    return cara_tskinny_partial2(Xa, ldxa, Gta, slabs_a, K1a, Xb, ldxb, Gtb, slabs_b, K1b, want_colsum_b, ldg, M, Rp, stream);
+  if (!ts_args_ok(Xa, ldxa, Gta, ldg, slabs_a, M, K1a, Rp) || !ts_args_ok(Xb, ldxb, Gtb, ldg, slabs_b, M, K1b, Rp)) return CARA_E_ARG;
+  const TsProblem a = ts_problem(Xa, ldxa, Gta, slabs_a, 0, M, K1a, Rp);
+  const TsProblem b = ts_problem(Xb, ldxb, Gtb, slabs_b, want_colsum_b, M, K1b, Rp);
+  return ts_launch(a, b, ldg, M, Rp, want_colsum_b != 0, static_cast<hipStream_t>(stream), true);
 }
 
 extern "C" int cara_tskinny_reduce(const void* slabs, size_t slab_stride, float* D, float* colsum, int batch, int M,

@@ -32,7 +32,7 @@ struct TsRing {
   static constexpr int WAVE_BYTES = NSTAGE * STAGE;
   // the end-of-block combine runs in passes of 8 accumulator tiles (two r-tiles x four i-tiles): [4 waves][8][64] f32x4
   // + [4 waves][4][64] floats, whatever NT (Rp = 64 as one pass would be 68 KiB: two workgroups per CU for the GEMM
-  // the products ride in)
+  // the products ride in; NT = 1 -- rank <= 16, one r-tile -- uses half of a pass)
   static constexpr int COMBINE_BYTES = 4 * 8 * 64 * 16 + 4 * 4 * 64 * 4;
   static constexpr int BLOCK_BYTES = 4 * WAVE_BYTES > COMBINE_BYTES ? 4 * WAVE_BYTES : COMBINE_BYTES;
 };
@@ -63,7 +63,9 @@ __device__ __forceinline__ void ts_issue(const bf16* __restrict__ X, int ldx, co
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -168,13 +170,14 @@ __device__ __forceinline__ void tskinny_body(const TsProblem& p0, const TsProble
   f32x4* red = reinterpret_cast<f32x4*>(smem);  // [wave][8][64]
   float* cred = reinterpret_cast<float*>(smem + 4 * 8 * 64 * 16);  // [wave][4 it][64 lanes]
   float* slab = slabs + (size_t)bid * TS_COLS * (NT * 16);
+  constexpr int RPP = NT >= 2 ? 2 : 1;   // r-tiles per pass
 #pragma unroll
-  for (int h = 0; h < NT / 2; ++h) {
+  for (int h = 0; h < NT / RPP; ++h) {
     if (h) __syncthreads();   // the previous pass's sums have been read
 #pragma unroll
-    for (int r2 = 0; r2 < 2; ++r2)
+    for (int r2 = 0; r2 < RPP; ++r2)
 #pragma unroll
-      for (int it = 0; it < 4; ++it) red[(wave * 8 + r2 * 4 + it) * 64 + lane] = acc[h * 2 + r2][it];
+      for (int it = 0; it < 4; ++it) red[(wave * 8 + r2 * 4 + it) * 64 + lane] = acc[h * RPP + r2][it];
     if constexpr (COLSUM) {
       if (h == 0) {
 #pragma unroll
@@ -182,14 +185,14 @@ __device__ __forceinline__ void tskinny_body(const TsProblem& p0, const TsProble
       }
     }
     __syncthreads();
-    for (int t = wave; t < 8; t += 4) {
+    for (int t = wave; t < 4 * RPP; t += 4) {
       f32x4 s = red[t * 64 + lane];
 #pragma unroll
       for (int w = 1; w < 4; ++w) {
         const f32x4 v = red[(w * 8 + t) * 64 + lane];
         s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
       }
-      const int rt = h * 2 + (t >> 2), it = t & 3;
+      const int rt = h * RPP + (t >> 2), it = t & 3;
       // C layout: row (= r) = rt*16 + fq*4 + reg, col (= i) = it*16 + fr  ->  slab[i][r..r+3]
       *reinterpret_cast<f32x4*>(slab + (size_t)(it * 16 + fr) * (NT * 16) + rt * 16 + fq * 4) = s;
     }
@@ -215,6 +218,7 @@ inline bool ts_args_ok(const void* X, int ldx, const void* Gt, int ldg, void* sl
   if ((ldg & 7) || ldg < ((M + 31) / 32) * 32) return false;
   return Rp == 32 || Rp == 64;
 }
+// (the column sums sit behind nblk slabs of the FULL width Rp whatever the rank: the place cara_tskinny_reduce* looks for them)
 inline TsProblem ts_problem(const void* X, int ldx, const void* Gt, void* slabs, int want_colsum, int M, int K1, int Rp) {
   TsProblem p;
   p.X = (const bf16*)X; p.Gt = (const bf16*)Gt; p.ldx = ldx; p.K1 = K1;

@@ -195,12 +195,21 @@ struct Ctx {
   int rank = 0;                // the adapter's rank (0: unknown, the skinny passes compute all Rp columns)
 };
 
+// the rank the transposed skinny products are told (0 in the context = unknown: all Rp columns).  Deferred products
+// (CARA_DEFER_TS) ride in adapter-inside GEMMs, whose kernel has no 16-column form: they keep all columns.
+bool defer_ts();
+int env_once(const char* name, int dflt);
+inline int ts_rank(const Ctx& cx, int Rp) {
+  static const int full = env_once("CARA_TS_ALL_COLUMNS", 0);   // 1: the products compute all Rp columns whatever the rank (A/B runs)
+  return (cx.rank > 0 && !defer_ts() && !full) ? cx.rank : Rp;
+}
+
 int flush_pending(const Ctx& cx) {
   TsPending* q = cx.pend;
   if (!q || !q->valid) return CARA_OK;
   q->valid = false;
-  return cara_tskinny_partial2(q->Xa, q->ldxa, q->Gta, q->slabs_a, q->K1a, q->Xb, q->ldxb, q->Gtb, q->slabs_b, q->K1b, q->want_cs,
-                               q->ldg, q->M, q->Rp, cx.stream);
+  return cara_tskinny_partial2_r(q->Xa, q->ldxa, q->Gta, q->slabs_a, q->K1a, q->Xb, q->ldxb, q->Gtb, q->slabs_b, q->K1b, q->want_cs,
+                                 q->ldg, q->M, q->Rp, ts_rank(cx, q->Rp), cx.stream);
 }
 
 struct SiteBracket {   // RAII: event 0 .. kernel(s) .. event 1, event 2 (an empty bracket: the markers' own cost)
@@ -356,8 +365,8 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
     if (carry) { TRY(cara_gemm_bf16(&a, st)); return CARA_OK; }
 #endif
     if (carry) {
-      TRY(cara_gemm_with_tskinny(&a, carry->Xa, carry->ldxa, carry->Gta, carry->slabs_a, carry->K1a, carry->Xb, carry->ldxb, carry->Gtb,
-                                 carry->slabs_b, carry->K1b, carry->want_cs, carry->ldg, carry->M, carry->Rp, st));
+      TRY(cara_gemm_with_tskinny_r(&a, carry->Xa, carry->ldxa, carry->Gta, carry->slabs_a, carry->K1a, carry->Xb, carry->ldxb, carry->Gtb,
+                                   carry->slabs_b, carry->K1b, carry->want_cs, carry->ldg, carry->M, carry->Rp, ts_rank(cx, carry->Rp), st));
       if (carry == pend) pend->valid = false;
       if (carry == &mine) return CARA_OK;
     } else {
@@ -370,7 +379,7 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
     return CARA_OK;
   }
   if (pend) TRY(flush_pending(cx));
-  return cara_tskinny_partial2(X, ldx, Gt, slabU, L.in, dY, lddy, Tt, slabV, L.out, want_dc ? 1 : 0, ldt, Mr, Rp, st);
+  return cara_tskinny_partial2_r(X, ldx, Gt, slabU, L.in, dY, lddy, Tt, slabV, L.out, want_dc ? 1 : 0, ldt, Mr, Rp, ts_rank(cx, Rp), st);
 }
 
 // ---- order-2 QKV tensorisation: the QKV linear as y = x W^T + x Dm^T with the dense scaled delta Dm (cara_dense_delta_*) ----
@@ -824,6 +833,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     const int L = g->depth;
     cara_ts_reduce red[CARA_TS_REDUCE_MAX];   // all slab sums of the pass in ONE launch (8 + 6 of them)
     int nred = 0;
+    const int Rc = (Rp == 32 && ts_rank(cx, Rp) <= 16) ? 16 : 0;   // (every product of the pass was told the same rank)
     for (int i = 0; i < 4; ++i) {
       if (i == 0 && dense_qkv) continue;   // order 2: the QKV linear wrote no skinny slabs (its gradient is dense, below)
       float* dU = reinterpret_cast<float*>(ws + W.dU[i]);
@@ -833,13 +843,13 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
       // so that block's slabs have their own chunking
       const int full = (i == 0 || !cls_shortcut_enabled()) ? L : L - 1;   // (not reached in the exact mode)
       if (full > 0) {
-        red[nred++] = cara_ts_reduce{ws + W.slabU[i], W.strideU[i], dU, nullptr, full, M, ins[i], Rp};
-        red[nred++] = cara_ts_reduce{ws + W.slabV[i], W.strideV[i], dVs, dc, full, M, outs[i], Rp};
+        red[nred++] = cara_ts_reduce{ws + W.slabU[i], W.strideU[i], dU, nullptr, full, M, ins[i], Rp, Rc};
+        red[nred++] = cara_ts_reduce{ws + W.slabV[i], W.strideV[i], dVs, dc, full, M, outs[i], Rp, Rc};
       }
       if (i != 0 && cls_shortcut_enabled()) {
         const size_t l = L - 1;
-        red[nred++] = cara_ts_reduce{ws + W.slabU[i] + l * W.strideU[i], 0, dU + l * ins[i] * Rp, nullptr, 1, B, ins[i], Rp};
-        red[nred++] = cara_ts_reduce{ws + W.slabV[i] + l * W.strideV[i], 0, dVs + l * outs[i] * Rp, dc + l * outs[i], 1, B, outs[i], Rp};
+        red[nred++] = cara_ts_reduce{ws + W.slabU[i] + l * W.strideU[i], 0, dU + l * ins[i] * Rp, nullptr, 1, B, ins[i], Rp, Rc};
+        red[nred++] = cara_ts_reduce{ws + W.slabV[i] + l * W.strideV[i], 0, dVs + l * outs[i] * Rp, dc + l * outs[i], 1, B, outs[i], Rp, Rc};
       }
     }
     TRY(cara_tskinny_reduce_many(red, nred, stream));

@@ -141,11 +141,22 @@ int cara_gemm_with_tskinny(const cara_gemm_args* a, const void* Xa, int ldxa, co
                            int ldg, int M, int Rp, void* stream);
 int cara_tskinny_reduce(const void* slabs, size_t slab_stride, float* D, float* colsum, int batch,
                         int M, int K1, int Rp, void* stream);
+/* cara_tskinny_partial2 / cara_gemm_with_tskinny with the adapter's rank stated (1 <= rank <= Rp): at Rp = 32 and rank <= 16
+ * the products compute the first 16 of their 32 columns only (the others are zero by construction: rows >= rank of Gt are
+ * zero) and write 16-WIDE slabs -- reduce them with cara_ts_reduce::Rc = 16 (cara_tskinny_reduce_many), which sums those
+ * columns and writes the other columns of D as zeros.  Otherwise identical to the functions without _r.                  */
+int cara_tskinny_partial2_r(const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
+                            const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b,
+                            int ldg, int M, int Rp, int rank, void* stream);
+int cara_gemm_with_tskinny_r(const cara_gemm_args* a, const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
+                             const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b,
+                             int ldg, int M, int Rp, int rank, void* stream);
 /* Up to CARA_TS_REDUCE_MAX of those reductions in ONE launch (each entry = the arguments of cara_tskinny_reduce). */
 #define CARA_TS_REDUCE_MAX 16
 typedef struct {
   const void* slabs; size_t slab_stride; float* D; float* colsum;   /* colsum may be NULL */
   int batch, M, K1, Rp;
+  int Rc;   /* columns the slabs hold: 0 or Rp = all; 16 (at Rp = 32) = slabs written by the _r functions at rank <= 16 */
 } cara_ts_reduce;
 int cara_tskinny_reduce_many(const cara_ts_reduce* probs, int n, void* stream);
 

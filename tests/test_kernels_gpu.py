@@ -488,9 +488,7 @@ def test_tskinny_reductions_in_one_launch():
     lib = L().lib()
     p, st = L().ptr, L().stream
 
-    class Red(C.Structure):
-        _fields_ = [("slabs", C.c_void_p), ("slab_stride", C.c_size_t), ("D", C.c_void_p), ("colsum", C.c_void_p),
-                    ("batch", C.c_int), ("M", C.c_int), ("K1", C.c_int), ("Rp", C.c_int)]
+    Red = L().TsReduce       # (the mirror the library's struct size is checked against at load time; Rc stays 0 = all columns)
 
     lib.cara_tskinny_scratch_bytes.restype = C.c_size_t
     probs, keep = [], []
@@ -990,3 +988,42 @@ def test_attention_for_the_cls_query_alone(B, N, H):
     dfull = torch.empty_like(qkv)
     L().check(lib.cara_attention_bwd(p(qkv), p(out_full), p(dout), p(lse_full), p(dfull), B, N, H, C.c_float(scale), st()), "attn bwd")
     assert (dqkv.double() - dfull.double()).norm() / dfull.double().norm() < 8e-3
+
+
+@pytest.mark.parametrize("M,K1a,K1b,rank", [(12608, 768, 3072, 16), (333, 768, 2304, 7), (64, 3072, 768, 16)])
+def test_transposed_skinny_products_with_the_rank_stated(M, K1a, K1b, rank):
+    """cara_tskinny_partial2_r + cara_tskinny_reduce_many with Rc = 16: at Rp = 32 and rank <= 16 the products compute 16 of their
+    32 columns into 16-wide slabs; the reduced D equals the all-columns path bit for bit on those columns, the rest is written
+    as zeros; column sums unchanged."""
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+    Rp = 32
+    ldg = (M + 31) // 32 * 32
+    Xa, Xb = rnd(M, K1a, seed=1), rnd(M, K1b, seed=2)
+    Ga = torch.zeros(Rp, ldg, dtype=torch.bfloat16, device=DEV)
+    Gb = torch.zeros(Rp, ldg, dtype=torch.bfloat16, device=DEV)
+    Ga[:rank, :M] = rnd(rank, M, seed=3)
+    Gb[:rank, :M] = rnd(rank, M, seed=4)
+    res = []
+    for half in (False, True):
+        sa = torch.empty(lib.cara_tskinny_scratch_bytes(M, K1a, Rp), dtype=torch.uint8, device=DEV)
+        sb = torch.empty(lib.cara_tskinny_scratch_bytes(M, K1b, Rp), dtype=torch.uint8, device=DEV)
+        Da = torch.full((K1a, Rp), float("nan"), device=DEV)
+        Db = torch.full((K1b, Rp), float("nan"), device=DEV)
+        cs = torch.full((K1b,), float("nan"), device=DEV)
+        if half:
+            L().check(lib.cara_tskinny_partial2_r(p(Xa), K1a, p(Ga), p(sa), K1a, p(Xb), K1b, p(Gb), p(sb), K1b, 1, ldg, M, Rp, rank, st()), "partial2_r")
+        else:
+            L().check(lib.cara_tskinny_partial2(p(Xa), K1a, p(Ga), p(sa), K1a, p(Xb), K1b, p(Gb), p(sb), K1b, 1, ldg, M, Rp, st()), "partial2")
+        tab = (L().TsReduce * 2)(L().TsReduce(p(sa), 0, p(Da), None, 1, M, K1a, Rp, 16 if half else 0),
+                                 L().TsReduce(p(sb), 0, p(Db), p(cs), 1, M, K1b, Rp, 16 if half else 0))
+        L().check(lib.cara_tskinny_reduce_many(tab, 2, st()), "reduce many")
+        torch.cuda.synchronize()
+        res.append((Da, Db, cs))
+    (Da0, Db0, cs0), (Da1, Db1, cs1) = res
+    assert torch.equal(Da0, Da1) and torch.equal(Db0, Db1) and torch.equal(cs0, cs1)
+    assert torch.count_nonzero(Da1[:, rank:]) == 0 and torch.count_nonzero(Db1[:, rank:]) == 0
+    close(Da1[:, :rank], Xa.double().t() @ Ga[:rank, :M].double().t(), 1e-3, 1e-2, "dU")
+    close(cs1, Xb.double().sum(0), 1e-3, 1e-2, "colsum")
+    bad = (L().TsReduce * 1)(L().TsReduce(p(sa), 0, p(Da), None, 1, M, K1a, Rp, 8))
+    assert lib.cara_tskinny_reduce_many(bad, 1, st()) != 0
