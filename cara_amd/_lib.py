@@ -38,7 +38,7 @@ class GemmArgs(C.Structure):
                 ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
                 ("batch", C.c_int), ("strideA", C.c_longlong), ("strideB", C.c_longlong), ("strideC", C.c_longlong),
                 ("Ut", C.c_void_p), ("T_out", C.c_void_p), ("Tt_out", C.c_void_p), ("ldt", C.c_int),
-                ("Bp", C.c_void_p), ("a_panels", C.c_int), ("c_panels", C.c_int), ("B3", C.c_void_p)]
+                ("Bp", C.c_void_p), ("a_panels", C.c_int), ("c_panels", C.c_int), ("B3", C.c_void_p), ("Ut_rank", C.c_int)]
 
 
 class Geom(C.Structure):
@@ -186,8 +186,9 @@ def stream(device=None) -> C.c_void_p:
 
 def gemm(A, B, out, *, epi, bias=None, A2=None, B2=None, C2=None, aux=None, rowscale=None,
          rows_per_sample=0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, scratch=None, Ut=None, T_out=None,
-         Tt_out=None, Bp=None, a_panels=0, c_panels=0, B3=None):
+         Tt_out=None, Bp=None, a_panels=0, c_panels=0, B3=None, Ut_rank=0):
     a = GemmArgs()
+    a.Ut_rank = Ut_rank   # with Ut: the adapter's rank if known (<= 16 at Rp = 32: 16 of the 32 columns of T are computed)
     a.B3 = ptr(B3)   # optional second B operand: C = A B^T + A B3^T, accumulated in fp32
     a.Bp = ptr(Bp)   # optional K-panel-major image of B (pack_b_panels)
     a.a_panels, a.c_panels = a_panels, c_panels   # A given / C written as [K/32][P][32] panels

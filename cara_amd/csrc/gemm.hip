@@ -368,9 +368,15 @@ __global__ __launch_bounds__(256, NT <= 2 ? 4 : 3) void gemm32_ts_kernel(const c
 // ---------------------------------------------------------------------------------------------
 // NU = Rp / 32: 1 (rank <= 32) or 2 (rank <= 64: a 4-KiB slab of Ut per K step, eight T tiles per wave, two extension steps; 140
 // VGPRs, three workgroups per CU -- the kernel serves the N = 768 products, whose 594 tiles never put more than three on a CU)
-template <int EPI, int NU = 1>
+// HALFT (NU = 1 only; cara_gemm_args::Ut_rank <= 16): columns 16 .. 31 of T are zero by construction (rows >= rank of Ut are zero),
+// so a workgroup stages 16 rows of Ut per K step instead of 32 and every wave computes TWO T tiles (rows of its wave row:
+// tiles 2 wc, 2 wc + 1; columns 0 .. 15) instead of four: 18 MFMAs per K step instead of 20, one 1-KiB piece less.  All four
+// waves keep the same instruction stream (skipping the second wave column's T tiles behind a branch cost 57 %).
+template <int EPI, int NU = 1, bool HALFT = false>
 __device__ __forceinline__ void gemm32ft_body(const cara_gemm_args& p, const int tiles_n, const int nwg, const int gm, const int block, char* smem) {
+  static_assert(!HALFT || NU == 1, "the 16-column form exists for Rp = 32 only");
   constexpr int TBM = 128;
+  constexpr int NTT = HALFT ? 2 : 4;   // T tiles per wave
   constexpr int A_BYTES = TBM * BK32 * 2, U_BYTES = NU * 32 * BK32 * 2;
   constexpr int SLOT = A_BYTES + B32_BYTES + U_BYTES;   // 18 KiB; two slots = 36 KiB, still 4 workgroups per CU (NU = 2: 20 / 40 KiB)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -396,20 +402,22 @@ __device__ __forceinline__ void gemm32ft_body(const cara_gemm_args& p, const int
   const bf16* __restrict__ B = static_cast<const bf16*>(packed ? p.Bp : p.B);
   const int kmulB = packed ? p.N * BK32 : BK32;
   const bf16* __restrict__ Ut = static_cast<const bf16*>(p.Ut);
-  f32x4 acc[4][4], accg[4][NU];
+  f32x4 acc[4][4], accg[NTT][NU];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int c = 0; c < NU; ++c) accg[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+#pragma unroll
+  for (int i = 0; i < NTT; ++i)
+#pragma unroll
+    for (int c = 0; c < NU; ++c) accg[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   // the Rp x 32 slab of Ut of one K step = 2 NU one-KiB pieces (16 rows x 64 B), issued by waves 0 .. 2 NU - 1
   const int uwave = __builtin_amdgcn_readfirstlane(wave);
   const unsigned offU = (unsigned)((wave & (2 * NU - 1)) * 16 + (lane >> 2)) * (unsigned)(p.K * 2) +
                         (unsigned)((((lane & 3) ^ ((((lane >> 2) >> 3) & 1) * 3))) * 16);
   auto stage_u = [&](int k0, char* dst) {
-    if (uwave < 2 * NU) glds16(reinterpret_cast<const char*>(Ut + k0) + offU, dst + uwave * 1024);
+    if (uwave < (HALFT ? 1 : 2 * NU)) glds16(reinterpret_cast<const char*>(Ut + k0) + offU, dst + uwave * 1024);
   };
   const int nk = p.K / BK32;
   const TileOfs<TBM, 4> oA = tile_ofs<TBM, 4>(p.a_panels ? BK32 : p.lda, m0, p.M - 1, wave, lane);
@@ -442,13 +450,25 @@ __device__ __forceinline__ void gemm32ft_body(const cara_gemm_args& p, const int
 #pragma unroll
     for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sB + swz32(wc * 64 + j * 16 + fr, fq));
 #pragma unroll
-    for (int c = 0; c < NU; ++c) bu[c] = *reinterpret_cast<const bf16x8*>(sU + swz32((wc * NU + c) * 16 + fr, fq));   // this wave's 16 NU columns of T
+    for (int c = 0; c < NU; ++c) bu[c] = *reinterpret_cast<const bf16x8*>(sU + swz32(((HALFT ? 0 : wc) * NU + c) * 16 + fr, fq));   // this wave's 16 NU columns of T
+    if constexpr (HALFT) {
+      // T tiles (2 wc, 2 wc + 1) x column tile 0: the A fragments picked by a wave-uniform select, no branch
+      const bf16x8 ah0 = wc ? a[2] : a[0], ah1 = wc ? a[3] : a[1];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        if (i == 1) accg[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bu[0], accg[0][0], 0, 0, 0);
+        if (i == 3) accg[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bu[0], accg[1][0], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
-      for (int c = 0; c < NU; ++c) accg[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bu[c], accg[i][c], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NU; ++c) accg[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bu[c], accg[i][c], 0, 0, 0);
+      }
     }
     cur ^= 1;
   }
@@ -469,13 +489,14 @@ __device__ __forceinline__ void gemm32ft_body(const cara_gemm_args& p, const int
     bf16* Tt = static_cast<bf16*>(p.Tt_out);
     char* img = (NU == 2 && wc == 1) ? sO : sE;   // the image that holds this wave's T columns
 #pragma unroll
-    for (int c = 0; c < NU; ++c) {
-      const int icol = (NU == 2 ? c : wc) * 16 + fr;      // column inside its 32-column image
+    for (int c = 0; c < (HALFT ? 2 : NU); ++c) {            // (HALFT: c = 0 the computed columns 0 .. 15, c = 1 the zero columns 16 .. 31)
+      const int icol = HALFT ? c * 16 + fr : (NU == 2 ? c : wc) * 16 + fr;      // column inside its 32-column image
       const int col = NU == 2 ? wc * 32 + icol : icol;     // column of T
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row0 = wr * 64 + i * 16 + fq * 4;
-        bf16x4 tv = {(bf16)accg[i][c][0], (bf16)accg[i][c][1], (bf16)accg[i][c][2], (bf16)accg[i][c][3]};
+      for (int i = 0; i < NTT; ++i) {
+        const int row0 = wr * 64 + (HALFT ? wc * 2 + i : i) * 16 + fq * 4;
+        const f32x4 av = (HALFT && c == 1) ? f32x4{0.f, 0.f, 0.f, 0.f} : accg[i][HALFT ? 0 : c];
+        bf16x4 tv = {(bf16)av[0], (bf16)av[1], (bf16)av[2], (bf16)av[3]};
 #pragma unroll
         for (int r = 0; r < 4; ++r) *reinterpret_cast<bf16*>(img + swz32(row0 + r, icol >> 3) + (icol & 7) * 2) = tv[r];
         if (tn == 0) {
@@ -526,10 +547,10 @@ __device__ __forceinline__ void gemm32ft_body(const cara_gemm_args& p, const int
   }
 }
 
-template <int EPI, int NU = 1>
+template <int EPI, int NU = 1, bool HALFT = false>
 __global__ __launch_bounds__(256, NU == 1 ? 4 : 3) void gemm32ft_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm32ft_body<EPI, NU>(p, tiles_n, nwg, gm, blockIdx.x, smem);
+  gemm32ft_body<EPI, NU, HALFT>(p, tiles_n, nwg, gm, blockIdx.x, smem);
 }
 
 // the adapter-inside GEMM carrying a pair of transposed skinny products (of ANOTHER linear: this launch only now produces
@@ -619,6 +640,7 @@ int launch32ft(const cara_gemm_args* a, hipStream_t st, const TsPair* ts) {
     }
   }
   if (a->Rp == 64) hipLaunchKernelGGL((gemm32ft_kernel<EPI, 2>), dim3(nwg), dim3(256), lds2, st, *a, tiles_n, nwg, gm);
+  else if (a->Ut_rank > 0 && a->Ut_rank <= 16) hipLaunchKernelGGL((gemm32ft_kernel<EPI, 1, true>), dim3(nwg), dim3(256), lds1, st, *a, tiles_n, nwg, gm);
   else hipLaunchKernelGGL((gemm32ft_kernel<EPI>), dim3(nwg), dim3(256), lds1, st, *a, tiles_n, nwg, gm);
   CARA_CHECK_LAUNCH();
   return CARA_OK;

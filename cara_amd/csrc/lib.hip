@@ -1,7 +1,7 @@
 // Library identification for libcara_hip.so.
 #include "common.h"
 
-extern "C" int cara_abi_version(void) { return 10; }
+extern "C" int cara_abi_version(void) { return 11; }
 extern "C" const char* cara_build_arch(void) { return "gfx950"; }
 
 extern "C" size_t cara_sizeof_struct(int which) {

@@ -309,7 +309,10 @@ int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char*
   }
   a.A = X; a.lda = ldx; a.B = L.W; a.Bp = L.Wp; a.ldb = L.in; a.A2 = inside ? nullptr : T; a.B2 = L.Vs; a.Rp = Rp;
   if (ldx < 0) { a.a_panels = -ldx; a.lda = 0; }   // (ldx < 0: X is K-panel-major with -ldx rows per panel, as in cara_skinny_xu)
-  if (inside) { a.Ut = L.Ut; a.T_out = T; a.Tt_out = Tt; a.ldt = ldt; }
+  if (inside) {
+    static const int t_all = env_once("CARA_GEMM_T_ALL_COLUMNS", 0);   // 1: T inside the GEMM with all Rp columns whatever the rank (A/B runs)
+    a.Ut = L.Ut; a.T_out = T; a.Tt_out = Tt; a.ldt = ldt; a.Ut_rank = t_all ? 0 : cx.rank;
+  }
   a.M = Mr; a.N = L.out; a.K = L.in; a.bias = L.bias;
   if (a.ldc == 0) a.ldc = L.out;
   with_scratch(a, cx);

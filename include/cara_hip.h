@@ -87,6 +87,9 @@ typedef struct {
   /* operand -- the exact weight-dropout mode's masked adapter delta against the frozen weight -- that a pre-merged bf16      */
   /* B + B3 would round away.  Plain product only: no Bp, batch, Ut, a_panels or tskinny with it.                            */
   const void* B3;
+  /* With Ut: the adapter's rank, if the caller knows it (0 = not stated).  At Rp = 32 and 1 <= Ut_rank <= 16 the kernel computes  */
+  /* columns 0 .. 15 of T only (rows >= rank of Ut are zero) and writes columns 16 .. 31 as zeros: same results, bit for bit.      */
+  int Ut_rank;
 } cara_gemm_args;
 int cara_gemm_bf16(const cara_gemm_args* a, void* stream);
 /* B bf16 [N, K] (row stride ldb) -> out bf16 [K/32][N][32] (cara_gemm_args::Bp); K % 32 == 0 */

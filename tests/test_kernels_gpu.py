@@ -1027,3 +1027,34 @@ def test_transposed_skinny_products_with_the_rank_stated(M, K1a, K1b, rank):
     close(cs1, Xb.double().sum(0), 1e-3, 1e-2, "colsum")
     bad = (L().TsReduce * 1)(L().TsReduce(p(sa), 0, p(Da), None, 1, M, K1a, Rp, 8))
     assert lib.cara_tskinny_reduce_many(bad, 1, st()) != 0
+
+
+@pytest.mark.parametrize("M,N,K,rank,epi", [(12608, 768, 3072, 16, "resid"), (12608, 768, 768, 16, "resid"), (333, 768, 768, 5, "bf16"),
+                                            (12608, 768, 3072, 17, "resid")])
+def test_adapter_inside_gemm_with_the_rank_stated(M, N, K, rank, epi):
+    """cara_gemm_args.Ut_rank: at Rp = 32 and rank <= 16 the adapter-inside GEMM computes 16 of the 32 columns of T (two T tiles
+    per wave instead of four, 16 rows of Ut per K step) and writes the rest as zeros -- outputs, T and its transpose bit for
+    bit those of the all-columns kernel."""
+    Rp = 32
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    Ut, Vs = rnd(Rp, K, seed=3, scale=0.1), rnd(N, Rp, seed=4, scale=0.3)
+    Ut[rank:] = 0
+    Vs[:, rank:] = 0
+    ldt = (M + 31) // 32 * 32
+    bias = rnd(N, seed=5, dtype=torch.float32)
+    res = []
+    for r in (0, rank):
+        T = torch.full((M, Rp), float("nan"), dtype=torch.bfloat16, device=DEV)
+        Tt = torch.full((Rp, ldt), float("nan"), dtype=torch.bfloat16, device=DEV)
+        if epi == "resid":
+            aux = rnd(M, N, seed=6, dtype=torch.float32)
+            out = torch.full((M, N), float("nan"), device=DEV)
+            L().gemm(A, W, out, epi=L().EPI_RESID, bias=bias, B2=Vs, aux=aux, Ut=Ut, T_out=T, Tt_out=Tt, Ut_rank=r)
+        else:
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            L().gemm(A, W, out, epi=L().EPI_BF16, bias=bias, B2=Vs, Ut=Ut, T_out=T, Tt_out=Tt, Ut_rank=r)
+        res.append((out, T, Tt[:, :M].clone()))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    assert torch.count_nonzero(res[1][1][:, rank:]) == 0 and torch.equal(res[1][2], res[1][1].t())
+    close(res[1][1], A.double() @ Ut.double().t(), 2 ** -8, 1e-3 * math.sqrt(K / 64), "T inside")
