@@ -962,9 +962,11 @@ extern "C" int cara_gemm_with_tskinny_r(const cara_gemm_args* a, const void* Xa,
                                         const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b, int ldg,
                                         int M, int Rp, int rank, void* stream) {
   if (rank <= 0 || rank > Rp) return CARA_E_ARG;
-  if (!(Rp == 32 || Rp == 64) || !ts_args_ok(Xa, ldxa, Gta, ldg, slabs_a, M, K1a, Rp) || !ts_args_ok(Xb, ldxb, Gtb, ldg, slabs_b, M, K1b, Rp)) return CARA_E_ARG;
+  // (Xa == NULL: the launch carries the second product only)
+  if (!(Rp == 32 || Rp == 64) || (Xa && !ts_args_ok(Xa, ldxa, Gta, ldg, slabs_a, M, K1a, Rp)) || !ts_args_ok(Xb, ldxb, Gtb, ldg, slabs_b, M, K1b, Rp)) return CARA_E_ARG;
   TsPair ts;
-  ts.a = ts_problem(Xa, ldxa, Gta, slabs_a, 0, M, K1a, Rp);
+  ts.a = ts_problem(Xa ? Xa : Xb, Xa ? ldxa : ldxb, Xa ? Gta : Gtb, Xa ? slabs_a : slabs_b, 0, M, Xa ? K1a : K1b, Rp);
+  if (!Xa) ts.a.nblk = 0;
   ts.b = ts_problem(Xb, ldxb, Gtb, slabs_b, want_colsum_b, M, K1b, Rp);
   ts.ldg = ldg; ts.M = M; ts.any_cs = want_colsum_b != 0; ts.nt = (Rp == 32 && rank <= 16 && !a->Ut) ? 1 : Rp / 16;
   return gemm_bf16_impl(a, stream, &ts);

@@ -393,12 +393,12 @@ extern "C" int cara_tskinny_partial2_r(const void* Xa, int ldxa, const void* Gta
                                        const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b,
                                        int ldg, int M, int Rp, int rank, void* stream) {
   if (rank <= 0 || rank > Rp) return CARA_E_ARG;
-  if (!(Rp == 32 && rank <= 16))
-    return cara_tskinny_partial2(Xa, ldxa, Gta, slabs_a, K1a, Xb, ldxb, Gtb, slabs_b, K1b, want_colsum_b, ldg, M, Rp, stream);
-  if (!ts_args_ok(Xa, ldxa, Gta, ldg, slabs_a, M, K1a, Rp) || !ts_args_ok(Xb, ldxb, Gtb, ldg, slabs_b, M, K1b, Rp)) return CARA_E_ARG;
-  const TsProblem a = ts_problem(Xa, ldxa, Gta, slabs_a, 0, M, K1a, Rp);
+  // (Xa == NULL: the second product alone)
+  if ((Xa && !ts_args_ok(Xa, ldxa, Gta, ldg, slabs_a, M, K1a, Rp)) || !ts_args_ok(Xb, ldxb, Gtb, ldg, slabs_b, M, K1b, Rp)) return CARA_E_ARG;
+  TsProblem a = ts_problem(Xa ? Xa : Xb, Xa ? ldxa : ldxb, Xa ? Gta : Gtb, Xa ? slabs_a : slabs_b, 0, M, Xa ? K1a : K1b, Rp);
+  if (!Xa) a.nblk = 0;
   const TsProblem b = ts_problem(Xb, ldxb, Gtb, slabs_b, want_colsum_b, M, K1b, Rp);
-  return ts_launch(a, b, ldg, M, Rp, want_colsum_b != 0, static_cast<hipStream_t>(stream), true);
+  return ts_launch(a, b, ldg, M, Rp, want_colsum_b != 0, static_cast<hipStream_t>(stream), Rp == 32 && rank <= 16);
 }
 
 extern "C" int cara_tskinny_reduce(const void* slabs, size_t slab_stride, float* D, float* colsum, int batch, int M,

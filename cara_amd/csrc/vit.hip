@@ -204,10 +204,15 @@ inline int ts_rank(const Ctx& cx, int Rp) {
   return (cx.rank > 0 && !defer_ts() && !full) ? cx.rank : Rp;
 }
 
+bool defer_du();
+
 int flush_pending(const Ctx& cx) {
   TsPending* q = cx.pend;
   if (!q || !q->valid) return CARA_OK;
   q->valid = false;
+  if (defer_du())   // (only the dU half of a linear waits in this mode: the first product of the entry)
+    return cara_tskinny_partial2_r(nullptr, 0, nullptr, nullptr, 0, q->Xa, q->ldxa, q->Gta, q->slabs_a, q->K1a, 0, q->ldg, q->M, q->Rp,
+                                   ts_rank(cx, q->Rp), cx.stream);
   return cara_tskinny_partial2_r(q->Xa, q->ldxa, q->Gta, q->slabs_a, q->K1a, q->Xb, q->ldxb, q->Gtb, q->slabs_b, q->K1b, q->want_cs,
                                  q->ldg, q->M, q->Rp, ts_rank(cx, q->Rp), cx.stream);
 }
@@ -358,6 +363,18 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
     if (a.ldc == 0) a.ldc = L.in;
     with_scratch(a, cx);
     SiteBracket b(SITE_BWD[L.slot], cx);
+    // (CARA_DEFER_DU, default on) this launch carries its linear's dVs = dY^T T (which reads the dY the GEMM is streaming) and the dU = X^T G'
+    // of the PREVIOUS linear of the pass (a dU never shares an operand with its own dX GEMM, so it loses nothing by riding
+    // elsewhere): fc2's dU, the 77-MB read of h, leaves the two-round fc2 dX launch for the single-round fc1 dX launch
+    if (can_carry && defer_du() && pend && !inside) {
+      const bool take = pend->valid && pend->Rp == Rp && pend->M == Mr && pend->ldg == ldt;
+      if (pend->valid && !take) TRY(flush_pending(cx));
+      TRY(cara_gemm_with_tskinny_r(&a, take ? pend->Xa : nullptr, take ? pend->ldxa : 0, take ? pend->Gta : nullptr, take ? pend->slabs_a : nullptr,
+                                   take ? pend->K1a : 0, mine.Xb, mine.ldxb, mine.Gtb, mine.slabs_b, mine.K1b, mine.want_cs, ldt, Mr, Rp,
+                                   ts_rank(cx, Rp), st));
+      *pend = mine;   // (its dU half waits for the next dX GEMM of the pass; flush_pending runs it alone otherwise)
+      return CARA_OK;
+    }
     // which pair this launch carries: the one that waits (deferred), else its own
     const TsPending* carry = nullptr;
     if (can_carry) {
@@ -521,6 +538,12 @@ bool cls_shortcut_enabled() {
 bool cls_attention_enabled() {
   static const int v = env_once("CARA_CLS_ATTN", 1);
   return v != 0;
+}
+
+// A linear's dU = X^T G' rides in the NEXT dX GEMM of the pass, its dVs in its own (lin_bwd); CARA_DEFER_DU=0: both in its own
+bool defer_du() {
+  static const int v = env_once("CARA_DEFER_DU", 1);
+  return v != 0 && !defer_ts();
 }
 
 // tiny classifier-head backward (B x classes x D, fp32 VALU).  The three outputs are independent: blocks
