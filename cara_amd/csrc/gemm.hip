@@ -555,13 +555,14 @@ __global__ __launch_bounds__(256, NU == 1 ? 4 : 3) void gemm32ft_kernel(const ca
 
 // the adapter-inside GEMM carrying a pair of transposed skinny products (of ANOTHER linear: this launch only now produces
 // the G' its own products would read) behind its tiles, as gemm32_ts_kernel does
-template <int EPI, int NU, bool COLSUM>
+// (NTS: column tiles of 16 the riding products compute -- 2 NU, or 1 at rank <= 16; HALFT: the 16-column form of the adapter inside)
+template <int EPI, int NU, bool COLSUM, int NTS = 2 * NU, bool HALFT = false>
 __global__ __launch_bounds__(256, NU == 1 ? 4 : 3) void gemm32ft_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
                                                                            const TsProblem t0, const TsProblem t1, const int ldg, const int Mts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x;
-  if (b >= nwg) tskinny_body<2 * NU, COLSUM, 1>(t0, t1, ldg, Mts, b - nwg, smem);
-  else gemm32ft_body<EPI, NU>(p, tiles_n, nwg, gm, b, smem);
+  if (b >= nwg) tskinny_body<NTS, COLSUM, 1>(t0, t1, ldg, Mts, b - nwg, smem);
+  else gemm32ft_body<EPI, NU, HALFT>(p, tiles_n, nwg, gm, b, smem);
 }
 
 static int group_m(int tiles_n);
@@ -622,15 +623,19 @@ int launch32ft(const cara_gemm_args* a, hipStream_t st, const TsPair* ts) {
   const int lds1 = 2 * (128 * BK32 * 2 + B32_BYTES + 32 * BK32 * 2), lds2 = 2 * (128 * BK32 * 2 + B32_BYTES + 64 * BK32 * 2);
   if (ts) {   // (plain bf16 output only: the backward's fc1 / qkv dX)
     if constexpr (EPI == CARA_EPI_BF16) {
-      if (ts->nt != a->Rp / 16) return CARA_E_ARG;
+      const bool half = a->Rp == 32 && ts->nt == 1;   // rank <= 16: one r-tile in the riding products, 16 columns of the adapter inside
+      if (ts->nt != a->Rp / 16 && !half) return CARA_E_ARG;
+      if (half && !(a->Ut_rank > 0 && a->Ut_rank <= 16)) return CARA_E_ARG;
       const dim3 grid(nwg + ts->a.nblk + ts->b.nblk), block(256);
       constexpr int RB = TsRing<2, 1>::BLOCK_BYTES;   // the same for every NT (two-pass combine)
-#define FT_GO(NU, CS, L)                                                                                                    \
-      hipLaunchKernelGGL((gemm32ft_ts_kernel<EPI, NU, CS>), grid, block, (RB > L ? RB : L), st, *a, tiles_n, nwg, gm, ts->a, ts->b, ts->ldg, ts->M)
+#define FT_GO(NU, CS, L, NTS, HT)                                                                                           \
+      hipLaunchKernelGGL((gemm32ft_ts_kernel<EPI, NU, CS, NTS, HT>), grid, block, (RB > L ? RB : L), st, *a, tiles_n, nwg, gm, ts->a, ts->b, ts->ldg, ts->M)
       if (a->Rp == 64) {
-        if (ts->any_cs) FT_GO(2, true, lds2); else FT_GO(2, false, lds2);
+        if (ts->any_cs) FT_GO(2, true, lds2, 4, false); else FT_GO(2, false, lds2, 4, false);
+      } else if (half) {
+        if (ts->any_cs) FT_GO(1, true, lds1, 1, true); else FT_GO(1, false, lds1, 1, true);
       } else {
-        if (ts->any_cs) FT_GO(1, true, lds1); else FT_GO(1, false, lds1);
+        if (ts->any_cs) FT_GO(1, true, lds1, 2, false); else FT_GO(1, false, lds1, 2, false);
       }
 #undef FT_GO
       CARA_CHECK_LAUNCH();
@@ -968,7 +973,7 @@ extern "C" int cara_gemm_with_tskinny_r(const cara_gemm_args* a, const void* Xa,
   ts.a = ts_problem(Xa ? Xa : Xb, Xa ? ldxa : ldxb, Xa ? Gta : Gtb, Xa ? slabs_a : slabs_b, 0, M, Xa ? K1a : K1b, Rp);
   if (!Xa) ts.a.nblk = 0;
   ts.b = ts_problem(Xb, ldxb, Gtb, slabs_b, want_colsum_b, M, K1b, Rp);
-  ts.ldg = ldg; ts.M = M; ts.any_cs = want_colsum_b != 0; ts.nt = (Rp == 32 && rank <= 16 && !a->Ut) ? 1 : Rp / 16;
+  ts.ldg = ldg; ts.M = M; ts.any_cs = want_colsum_b != 0; ts.nt = (Rp == 32 && rank <= 16 && (!a->Ut || (a->Ut_rank > 0 && a->Ut_rank <= 16))) ? 1 : Rp / 16;
   return gemm_bf16_impl(a, stream, &ts);
 }
 

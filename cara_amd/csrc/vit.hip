@@ -205,6 +205,7 @@ inline int ts_rank(const Ctx& cx, int Rp) {
 }
 
 bool defer_du();
+bool g_inside_enabled();
 
 int flush_pending(const Ctx& cx) {
   TsPending* q = cx.pend;
@@ -346,7 +347,11 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
   const bool can_carry = fuse_ts(Mr, Rp);
   const bool defer = pend && defer_ts() && can_carry;
   const bool inside = !have_G && want_dx && fuse_gemm_t(Mr, Rp, true) && defer && a.epi == CARA_EPI_BF16;
-  if (!have_G && !inside) {
+  // with the dU products riding one launch later (CARA_DEFER_DU) nothing in a linear's own dX launch reads its G', so the GEMM
+  // can compute it inside and the separate pass over dY goes (CARA_GEMM_G_INSIDE=0 keeps the pass)
+  const bool g_inside = !inside && !have_G && want_dx && can_carry && defer_du() && pend && g_inside_enabled() &&
+                        fuse_gemm_t(Mr, Rp, false) && a.epi == CARA_EPI_BF16;
+  if (!have_G && !inside && !g_inside) {
     SiteBracket b(CARA_SITE_SKINNY_BWD, cx);
     TRY(cara_skinny_xu_r(dY, lddy, L.Vst, G, Gt, ldt, Mr, L.out, Rp, cx.rank > 0 ? cx.rank : Rp, st));
   }
@@ -369,6 +374,9 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
     if (can_carry && defer_du() && pend && !inside) {
       const bool take = pend->valid && pend->Rp == Rp && pend->M == Mr && pend->ldg == ldt;
       if (pend->valid && !take) TRY(flush_pending(cx));
+      if (g_inside) {   // G' = dY Vs computed by this GEMM on the tiles it streams (its own dVs does not read G'; its dU rides later)
+        a.A2 = nullptr; a.Ut = L.Vst; a.T_out = G; a.Tt_out = Gt; a.ldt = ldt; a.Ut_rank = ts_rank(cx, Rp) <= 16 ? ts_rank(cx, Rp) : 0;
+      }
       TRY(cara_gemm_with_tskinny_r(&a, take ? pend->Xa : nullptr, take ? pend->ldxa : 0, take ? pend->Gta : nullptr, take ? pend->slabs_a : nullptr,
                                    take ? pend->K1a : 0, mine.Xb, mine.ldxb, mine.Gtb, mine.slabs_b, mine.K1b, mine.want_cs, ldt, Mr, Rp,
                                    ts_rank(cx, Rp), st));
@@ -537,6 +545,11 @@ bool cls_shortcut_enabled() {
 // CARA_CLS_ATTN=0: the last block runs the full attention kernels although only its cls query matters (A/B measurements only)
 bool cls_attention_enabled() {
   static const int v = env_once("CARA_CLS_ATTN", 1);
+  return v != 0;
+}
+
+bool g_inside_enabled() {
+  static const int v = env_once("CARA_GEMM_G_INSIDE", 1);
   return v != 0;
 }
 
