@@ -205,7 +205,7 @@ inline int ts_rank(const Ctx& cx, int Rp) {
 }
 
 bool defer_du();
-bool g_inside_enabled();
+bool g_inside_enabled(int slot);
 
 int flush_pending(const Ctx& cx) {
   TsPending* q = cx.pend;
@@ -349,7 +349,7 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
   const bool inside = !have_G && want_dx && fuse_gemm_t(Mr, Rp, true) && defer && a.epi == CARA_EPI_BF16;
   // with the dU products riding one launch later (CARA_DEFER_DU) nothing in a linear's own dX launch reads its G', so the GEMM
   // can compute it inside and the separate pass over dY goes (CARA_GEMM_G_INSIDE=0 keeps the pass)
-  const bool g_inside = !inside && !have_G && want_dx && can_carry && defer_du() && pend && g_inside_enabled() &&
+  const bool g_inside = !inside && !have_G && want_dx && can_carry && defer_du() && pend && g_inside_enabled(L.slot) &&
                         fuse_gemm_t(Mr, Rp, false) && a.epi == CARA_EPI_BF16;
   if (!have_G && !inside && !g_inside) {
     SiteBracket b(CARA_SITE_SKINNY_BWD, cx);
@@ -548,9 +548,9 @@ bool cls_attention_enabled() {
   return v != 0;
 }
 
-bool g_inside_enabled() {
-  static const int v = env_once("CARA_GEMM_G_INSIDE", 1);
-  return v != 0;
+bool g_inside_enabled(int slot) {   // CARA_GEMM_G_INSIDE: bit 0 qkv, bit 1 fc1 (default 3: both)
+  static const int v = env_once("CARA_GEMM_G_INSIDE", 3);
+  return (v & (slot == 0 ? 1 : 2)) != 0;
 }
 
 // A linear's dU = X^T G' rides in the NEXT dX GEMM of the pass, its dVs in its own (lin_bwd); CARA_DEFER_DU=0: both in its own
