@@ -57,14 +57,14 @@ SITE_KERNEL = {
     "proj_fwd": "gemm32ft_kernel<RESID> (proj forward, T = X U inside)",
     "fc1_fwd": "gemm32_kernel<GELU, MI=5> (fc1 forward, 160 x 128 tiles, two bf16 outputs u and gelu(u))",
     "fc2_fwd": "gemm32ft_kernel<RESID> (fc2 forward, T = X U inside)",
-    "qkv_bwd": "gemm32_ts_kernel<BF16,false> (qkv dX + its dU / dVs products in one launch)",
-    "proj_bwd": "gemm32_ts_kernel<BF16,true> (proj dX + dU / dVs / dc)",
-    "fc1_bwd": "gemm32_ts_kernel<BF16,true> (fc1 dX + dU / dVs / dc)",
-    "fc2_bwd": "gemm32_ts_kernel<DGELU,true, MI=5> (fc2 dX, 160 x 128 tiles, gelu' epilogue + dU / dVs / dc)",
+    "qkv_bwd": "gemm32ft_ts_kernel<BF16> (qkv dX with G' = dY Vs inside + its dVs + proj's dU riding in the launch)",
+    "proj_bwd": "gemm32_ts_kernel<BF16,true> (proj dX + its dVs / dc + fc1's dU riding in the launch)",
+    "fc1_bwd": "gemm32ft_ts_kernel<BF16,true> (fc1 dX with G' = dY Vs inside + its dVs / dc + fc2's dU riding in the launch)",
+    "fc2_bwd": "gemm32_ts_kernel<DGELU,true, MI=5> (fc2 dX, 160 x 128 tiles, gelu' epilogue + its dVs / dc + the dU of the qkv above)",
     "attn_fwd": "attn_fwd_persist_kernel (3 heads per CU)", "attn_bwd": "attn_bwd_fused_kernel (dK/dV sweep then dQ sweep per head)",
     "ln1_fwd": "ln_fwd_kernel<XU> (LayerNorm 1 + T = LN(x) U of qkv)", "ln2_fwd": "ln_fwd_kernel<XU> (LayerNorm 2 + T of fc1)",
     "ln1_bwd": "ln_bwd_kernel<XU> (LayerNorm 1 backward + G' of the fc2 below)", "ln2_bwd": "ln_bwd_kernel<XU> (LayerNorm 2 backward + G' of proj)",
-    "skinny_fwd": "skinny_xu_sliced_kernel (T = X U)", "skinny_bwd": "skinny_xu_sliced_kernel (G' = dY Vs of fc1 / qkv)",
+    "skinny_fwd": "skinny_xu_sliced_kernel (T = X U)", "skinny_bwd": "skinny_xu_sliced_kernel (G' = dY Vs where no dX GEMM computes it: block 0's qkv)",
 }
 
 
@@ -73,19 +73,22 @@ def site_work(M, D, R, B, H, N):
     def fwd(i, o, t_inside):   # [X | T][W | Vs]^T, plus T = X U when the GEMM computes it
         return 2.0 * M * o * (i + R) + (2.0 * M * i * R if t_inside else 0.0)
 
-    def bwd(i, o):             # dX = [dY | G'][W^T | U]^T plus the riding dU = X^T G', dVs = dY^T T
-        return 2.0 * M * i * (o + R) + 2.0 * M * R * (i + o)
+    # what a dX launch carries with the default switches: dX = [dY | G'][W^T | U]^T, its OWN dVs = dY^T T
+    # (K1 = o), the dU = X^T G' of the PREVIOUS linear of the pass (K1 = du_k), and -- fc1 / qkv -- its own G' = dY Vs inside
+    def bwd(i, o, du_k, g_inside):
+        return 2.0 * M * i * (o + R) + 2.0 * M * R * (o + du_k) + (2.0 * M * o * R if g_inside else 0.0)
     att = 4.0 * B * H * N * N * 64
     return {
         "qkv_fwd": ("mfma", fwd(D, 3 * D, False)), "proj_fwd": ("mfma", fwd(D, D, True)),
         "fc1_fwd": ("mfma", fwd(D, 4 * D, False)), "fc2_fwd": ("mfma", fwd(4 * D, D, True)),
-        "qkv_bwd": ("mfma", bwd(D, 3 * D)), "proj_bwd": ("mfma", bwd(D, D)), "fc1_bwd": ("mfma", bwd(D, 4 * D)), "fc2_bwd": ("mfma", bwd(4 * D, D)),
+        "qkv_bwd": ("mfma", bwd(D, 3 * D, D, True)), "proj_bwd": ("mfma", bwd(D, D, D, False)),
+        "fc1_bwd": ("mfma", bwd(D, 4 * D, 4 * D, True)), "fc2_bwd": ("mfma", bwd(4 * D, D, D, False)),
         "attn_fwd": ("mfma", att), "attn_bwd": ("mfma", 2.5 * att),     # S, dP, dV, dK, dQ: five products of 2 B H N^2 64
         # LayerNorm forward: read x fp32, write xn bf16; backward: read dy bf16 + x fp32 + dx fp32, write dx fp32 + dyb bf16
         "ln1_fwd": ("hbm", M * D * 6.0), "ln2_fwd": ("hbm", M * D * 6.0), "ln1_bwd": ("hbm", M * D * 16.0), "ln2_bwd": ("hbm", M * D * 16.0),
-        # skinny contractions read their [M, K] operand once (bf16): forward K = D or 4 D (unused by default), backward
-        # the dY of fc1 (K = 4 D) and of qkv (K = 3 D) alternate -> mean
-        "skinny_fwd": ("hbm", M * 2.5 * D * 2.0), "skinny_bwd": ("hbm", M * 3.5 * D * 2.0),
+        # skinny contractions read their [M, K] operand once (bf16): forward K = D or 4 D (unused by default); backward, with the
+        # default switches, only block 0's qkv (K = 3 D) still runs the pass (the other G' come out of dX GEMMs / LayerNorms)
+        "skinny_fwd": ("hbm", M * 2.5 * D * 2.0), "skinny_bwd": ("hbm", M * 3.0 * D * 2.0),
     }
 
 
