@@ -3,13 +3,13 @@
 WRITE_SIZE need separate passes: TCC slots).  gfx950 correction of MI355X_MICROARCH.md (section HBM): FETCH_SIZE counts
 half the bytes of wide coalesced reads -> bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  The i-th launch of a kernel name
 is the same launch in both passes.  Usage: pmc_sites.py <fetch dir> <write dir> <out.json>"""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 
 
 def series(path, counter):
-    f = glob.glob(path + "/**/*counter_collection.csv", recursive=True)
+    f = sorted(glob.glob(path + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)   # (the newest run's file)
     out = collections.defaultdict(list)
-    for r in csv.DictReader(open(f[0])):
+    for r in csv.DictReader(open(f[-1])):
         if r["Counter_Name"] == counter:
             out[r["Kernel_Name"]].append(float(r["Counter_Value"]) * 1024)
     return out
@@ -21,12 +21,14 @@ MB = 1e6
 SITES = {
     "fc1_fwd": ("gemm32_kernel<2,", lambda r, w: w > 120 * MB),                 # two bf16 outputs of [12608, 3072]
     "qkv_fwd": ("gemm32_kernel<0,", lambda r, w: w > 50 * MB),
-    "fc2_fwd": ("gemm32ft_kernel<3>", lambda r, w: r > 100 * MB),               # reads h (77 MB) + the fp32 residual
-    "proj_fwd": ("gemm32ft_kernel<3>", lambda r, w: 30 * MB < r <= 100 * MB),
+    "fc2_fwd": ("gemm32ft_kernel<3", lambda r, w: r > 100 * MB),               # reads h (77 MB) + the fp32 residual
+    "proj_fwd": ("gemm32ft_kernel<3", lambda r, w: 30 * MB < r <= 100 * MB),
     "fc2_bwd": ("gemm32_ts_kernel<4, true", lambda r, w: w > 50 * MB),
-    "fc1_bwd": ("gemm32_ts_kernel<0, true", lambda r, w: r > 150 * MB),        # dH as GEMM operand and as the products' operand
+    # (with G' inside -- the default since round 3 -- fc1 / qkv dX run gemm32ft_ts_kernel<BF16, NU = 1, COLSUM, ...>: COLSUM tells them apart)
+    "fc1_bwd": [("gemm32ft_ts_kernel<0, 1, true", lambda r, w: w > 10 * MB),
+                ("gemm32_ts_kernel<0, true", lambda r, w: r > 150 * MB)],       # dH as GEMM operand and as the products' operand
     "proj_bwd": ("gemm32_ts_kernel<0, true", lambda r, w: 20 * MB < r <= 150 * MB),
-    "qkv_bwd": ("gemm32_ts_kernel<0, false", lambda r, w: w > 10 * MB),
+    "qkv_bwd": [("gemm32ft_ts_kernel<0, 1, false", lambda r, w: w > 10 * MB), ("gemm32_ts_kernel<0, false", lambda r, w: w > 10 * MB)],
     "attn_fwd": ("attn_fwd_persist_kernel", lambda r, w: True),
     "attn_bwd": ("attn_bwd_fused_kernel", lambda r, w: True),
     "ln_fwd": ("ln_fwd_kernelILi3ELb1", lambda r, w: w > 15 * MB),
@@ -34,13 +36,14 @@ SITES = {
     "skinny_bwd": ("skinny_xu_sliced_kernel", lambda r, w: r > 40 * MB),
 }
 out = {}
-for site, (key, pick) in SITES.items():
+for site, pats in SITES.items():
     rows = []
-    for name in fetch:
-        if key in name and name in write:
-            for f, w in zip(fetch[name], write[name]):
-                if pick(2 * f, w):
-                    rows.append((2 * f, w))
+    for key, pick in (pats if isinstance(pats, list) else [pats]):
+        for name in fetch:
+            if key in name and name in write:
+                for f, w in zip(fetch[name], write[name]):
+                    if pick(2 * f, w):
+                        rows.append((2 * f, w))
     if rows:
         n = len(rows)
         r, w = sum(x for x, _ in rows) / n, sum(y for _, y in rows) / n
@@ -49,7 +52,6 @@ for site, (key, pick) in SITES.items():
 meta = {"_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes over bench.py --steps 2 (tools/pmc_traffic.sh); "
                    "read = 2 x FETCH_SIZE (gfx950 reports half the bytes of wide coalesced reads)"}
 # which kernels this was measured on (bench.py compares it with the sources of the run that quotes the number)
-import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 try:
     from bench import kernel_source_sha16
