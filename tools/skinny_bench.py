@@ -4,7 +4,6 @@
 Round-3 finding (profiles/r03_f_skinny_bench.txt): 128, 197 and 256 workgroups of 64 rows take the same 22-24 us, 243 workgroups
 of 52 rows too -- a launch is dominated by what every workgroup pays once (its 196 KiB of Ut fragments + the first row group, at
 the ~35 GB/s one 16-wave workgroup draws), not by rows per workgroup or by how many CUs take part."""
-import ctypes as C
 import os
 import sys
 
