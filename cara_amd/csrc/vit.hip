@@ -822,12 +822,14 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
     if (ex) TRY(lin_bwd_exact(lin[2], dH, reinterpret_cast<bf16*>(ws + lw.xn2), Mr, Rp, ws, W, s, true, e, true, cx));
     else TRY(lin_bwd(lin[2], dH, pa ? -Mr : 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), pa_n ? -Mr : D, Mr, Rp, W.ldt, ws, W, lw, true, e, true, cx));
-    // dyp = dY of this block's proj: its G' = dY Vs comes out of the same kernel
+    // dyp = dY of this block's proj: its G' = dY Vs comes out of the same kernel (CARA_LN2B_XU=0: out of proj's dX GEMM instead)
+    static const int ln2b_xu = env_once("CARA_LN2B_XU", 1);
+    const bool fxp = fx && (ln2b_xu != 0 || cls_only);
     {
       SiteBracket sb(CARA_SITE_LN2_BWD, cx);
       TRY(cara_layernorm_bwd_ex(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_mid), ldr, w->ln2_g + (size_t)l * D,
                                 reinterpret_cast<float*>(ws + lw.mean2), reinterpret_cast<float*>(ws + lw.rstd2), dx, dx, dyp, dp1,
-                                rps, Mr, D, fx ? lin[1].Vst : nullptr, g->rank, Rp, ws + R.G[1], ws + R.Gt[1], W.ldt, pa_dp ? Mr : 0, stream));
+                                rps, Mr, D, fxp ? lin[1].Vst : nullptr, g->rank, Rp, ws + R.G[1], ws + R.Gt[1], W.ldt, pa_dp ? Mr : 0, stream));
     }
     // ---- attention branch ----
     e = {};
@@ -835,7 +837,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     const bool cls_attn = cls_only && cls_attention_enabled();   // (then only the cls rows of dAO are ever read)
     if (cls_only && !cls_attn && hipMemsetAsync(ws + W.dAO, 0, (size_t)M * D * 2, hs) != hipSuccess) return CARA_E_LAUNCH;
     if (ex) TRY(lin_bwd_exact(lin[1], dyp, reinterpret_cast<bf16*>(ws + lw.ao), Mr, Rp, ws, W, s, true, e, true, cx));
-    else TRY(lin_bwd(lin[1], dyp, pa_dp ? -Mr : ldr, reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, W, lw, true, e, true, cx, fx));
+    else TRY(lin_bwd(lin[1], dyp, pa_dp ? -Mr : ldr, reinterpret_cast<bf16*>(ws + lw.ao), ldr, Mr, Rp, W.ldt, ws, W, lw, true, e, true, cx, fxp));
     {
       SiteBracket sb(CARA_SITE_ATTN_BWD, cx_all);
       if (cls_attn)
