@@ -3,7 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libcara_hip.so
-SRCS="lib.hip gemm.hip skinny.hip norm_misc.hip attention.hip factors.hip dropout_exact.hip dense_delta.hip optim.hip"
+SRCS="lib.hip gemm.hip gemm8.hip skinny.hip norm_misc.hip attention.hip factors.hip dropout_exact.hip dense_delta.hip optim.hip"
 [ -f vit.hip ] && SRCS="$SRCS vit.hip"
 OBJS=""
 mkdir -p build
@@ -11,7 +11,7 @@ pids=()
 for s in $SRCS; do
   o=build/${s%.hip}.o
   OBJS="$OBJS $o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ gemm_epilogue.h -nt "$o" ] || [ tskinny_body.h -nt "$o" ] || [ ../../include/cara_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ gemm_epilogue.h -nt "$o" ] || [ tskinny_body.h -nt "$o" ] || [ gemm8.h -nt "$o" ] || [ ../../include/cara_hip.h -nt "$o" ]; then
     hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -c "$s" -o "$o" &
     pids+=($!)
   fi

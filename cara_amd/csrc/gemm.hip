@@ -32,6 +32,7 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "tskinny_body.h"
+#include "gemm8.h"
 
 #ifdef CARA_GEMM_STAMPS
 // Diagnostic build (tools/gemm_stamps.py): wave 0 of every workgroup records s_memrealtime (100 MHz) at its start, at the
@@ -955,6 +956,9 @@ extern "C" int cara_gemm_tn_f32(const void* At, int lda, const void* Bt, int ldb
 }
 
 static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* ts);
+// measurement tools only (tools/gemm8_bench.py): pick the tile family per call sequence inside one process (-1: the environment decides)
+static int g_gemm8_override = -1;
+extern "C" int cara_debug_set_gemm8(int mt) { g_gemm8_override = mt; return CARA_OK; }
 extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) { return gemm_bf16_impl(a, stream, nullptr); }
 
 extern "C" int cara_gemm_with_tskinny(const cara_gemm_args* a, const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
@@ -999,6 +1003,13 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
   if (a->epi == CARA_EPI_DGELU && !a->aux) return CARA_E_ARG;
   if (ts && (a->batch > 1 || a->M <= 128 || a->B3 || (a->Ut && a->epi != CARA_EPI_BF16))) return CARA_E_ARG;
   if (a->B3 && (a->Bp || a->Ut || a->batch > 1 || a->a_panels)) return CARA_E_ARG;
+  // CARA_GEMM8 = 160 / 256: the MT x 256 x 64 one-workgroup-per-CU tile (gemm8.hip) for the products it takes
+  static const int g8_env = [] { const char* e = getenv("CARA_GEMM8"); return e ? atoi(e) : 0; }();
+  const int g8 = g_gemm8_override >= 0 ? g_gemm8_override : g8_env;
+  if (g8 && !ts) {
+    const int rc = cara_gemm8_launch(a, st, g8);
+    if (rc >= 0) return rc;
+  }
   if (a->Ut) {   // whole adapter inside the GEMM: Rp = 32, T produced here
     if (a->A2 || !a->B2 || !(a->Rp == 32 || a->Rp == 64) || !a->T_out || a->batch > 1 || (a->Tt_out && (a->ldt < a->M || (a->ldt & 7)))) return CARA_E_ARG;
     switch (a->epi) {

@@ -394,7 +394,7 @@ def vit_cara_forward(images, w: Dict[str, torch.Tensor], cp: Dict[str, torch.Ten
                      depth: int = 12, num_heads: int = 12, patch: int = 16, eps: float = 1e-6,
                      drop_path_keep: Optional[torch.Tensor] = None, factored: bool = False,
                      bf16_sim: bool = False, train: Optional[dict] = None,
-                     keep_masks=None, keep_p: float = 0.1):
+                     keep_masks=None, keep_p: float = 0.1, sim_dtype: Optional[torch.dtype] = None):
     """Whole adapted forward (timm VisionTransformer.forward with cp_attn/cp_mlp patched in),
     functional form over the state-dict ``w`` and CP tensors ``cp``.
 
@@ -421,7 +421,11 @@ def vit_cara_forward(images, w: Dict[str, torch.Tensor], cp: Dict[str, torch.Ten
         m1 = keep_masks(layer, "fc1").to(torch.float32).t() * sc                            # [c(in), o]
         m2 = keep_masks(layer, "fc2").to(torch.float32).t() * sc                            # [i(in), o]
         return ({"qkv": lambda t: t * mq, "proj": lambda t: t * mp}, {"fc1": lambda t: t * m1, "fc2": lambda t: t * m2})
-    r = (lambda t: t.to(torch.bfloat16).to(t.dtype)) if bf16_sim else (lambda t: t)
+    # ``sim_dtype``: the operand type of the rounding model (``bf16_sim`` = torch.bfloat16; torch.float16 asks what the SAME
+    # rounding points would cost with fp16 MFMA operands -- 10 mantissa bits at the bf16 MFMA rate)
+    if bf16_sim and sim_dtype is None:
+        sim_dtype = torch.bfloat16
+    r = (lambda t: t.to(sim_dtype).to(t.dtype)) if sim_dtype is not None else (lambda t: t)
     B = images.shape[0]
     dim = w["cls_token"].shape[-1]
     hd = dim // num_heads
