@@ -56,8 +56,8 @@ SITE_KERNEL = {
     "qkv_fwd": "gemm32_kernel<BF16> (qkv forward, [xn1 | T][W | Vs]^T)",
     "proj_fwd": "gemm32ft_kernel<RESID> (proj forward, T = X U inside)",
     "fc1_fwd": "gemm32_kernel<GELU, MI=5> (fc1 forward, 160 x 128 tiles, two bf16 outputs u and gelu(u))",
-    "fc2_fwd": "gemm32ft_kernel<RESID> (fc2 forward, T = X U inside)",
-    "qkv_bwd": "gemm32ft_ts_kernel<BF16> (qkv dX with G' = dY Vs inside + its dVs + proj's dU riding in the launch)",
+    "fc2_fwd": "gemm8_kernel<G8<3,2>, RESID, MODE 2> (fc2 forward on the 160 x 256 x 64 tile, one workgroup per CU, T = X U inside)",
+    "qkv_bwd": "gemm8_ts_kernel<G8<3,2>, BF16, MODE 2> (qkv dX on the 160 x 256 x 64 tile with G' = dY Vs inside; its dVs + proj's dU as workgroups behind the tiles)",
     "proj_bwd": "gemm32_ts_kernel<BF16,true> (proj dX + its dVs / dc + fc1's dU riding in the launch)",
     "fc1_bwd": "gemm32ft_ts_kernel<BF16,true> (fc1 dX with G' = dY Vs inside + its dVs / dc + fc2's dU riding in the launch)",
     "fc2_bwd": "gemm32_ts_kernel<DGELU,true, MI=5> (fc2 dX, 160 x 128 tiles, gelu' epilogue + its dVs / dc + the dU of the qkv above)",
@@ -90,6 +90,26 @@ def site_work(M, D, R, B, H, N):
         # default switches, only block 0's qkv (K = 3 D) still runs the pass (the other G' come out of dX GEMMs / LayerNorms)
         "skinny_fwd": ("hbm", M * 2.5 * D * 2.0), "skinny_bwd": ("hbm", M * 3.0 * D * 2.0),
     }
+
+
+def executed_gflop(gf_per_img, batch, D, R, H, N, depth):
+    """What the device EXECUTES of the algorithmic work (SURVEY 8d counts every block on every token): the last block's proj /
+    fc1 / fc2 (forward and dX) and its attention run for the cls rows only -- only that row reaches the logits, logits bitwise
+    unchanged -- and block 0, which has nothing trainable upstream, skips its qkv dX.  Returns (fwd, step) GFLOP per batch: the
+    honest numerators of the utilisation figures (images/sec is unaffected)."""
+    M, B = batch * N, batch
+    lin = lambda i, o: 2.0 * i * o + 2.0 * R * (i + o)                     # per row: base product + factored adapter
+    rows_saved = (M - B) * (lin(D, D) + lin(D, 4 * D) + lin(4 * D, D))     # proj + fc1 + fc2 of the last block on B rows instead of M
+    att = 4.0 * B * H * N * N * 64
+    att_saved = att * (1.0 - 1.0 / N)                                      # one query per (sample, head) in the last block
+    fwd_saved = rows_saved + att_saved
+    bwd_saved = rows_saved + 2.5 * att_saved                               # dX of the same three linears, attention backward
+    # (the adapter-gradient products of the skipped rows -- 2 x the adapter forward -- go with them)
+    bwd_saved += (M - B) * 2.0 * (2.0 * R * (D + D) + 2.0 * R * (D + 4 * D) + 2.0 * R * (4 * D + D))
+    bwd_saved += M * lin(3 * D, D)                                         # block 0's qkv dX
+    fwd = gf_per_img["fwd"] * batch - fwd_saved / 1e9
+    step = gf_per_img["step"] * batch - (fwd_saved + bwd_saved) / 1e9
+    return fwd, step
 
 
 def build_model(rank, scale, num_classes, device, seed, name="vit_base_patch16_224_in21k", cp_length=4):
@@ -240,7 +260,9 @@ def self_launch(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this host driver
-    env.setdefault("OMP_NUM_THREADS", "4")
+    # eight Python enqueuers share the cgroup's cores with their helper threads: cap the host-side thread pools per rank
+    env.setdefault("OMP_NUM_THREADS", "2")
+    env.setdefault("MKL_NUM_THREADS", "2")
     print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks through torch.distributed.run", file=sys.stderr, flush=True)
     return subprocess.call(cmd, env=env)
 
@@ -296,6 +318,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if world > 1:   # (the enqueue of a step is single-threaded Python; intra-op CPU pools only fight over the cores)
+        torch.set_num_threads(1 if rank > 0 else 2)
 
     from cara_amd import _lib
     from cara_amd import dist as cdist
@@ -421,28 +445,43 @@ def main():
             b.record()
             torch.cuda.synchronize()
             return a.elapsed_time(b) / n
-        eng.weight_dropout = "exact"
-        info["exact_dropout_ms_per_step"] = round(timed_steps(step), 3)
-        eng.weight_dropout = "off"
-        eng._ws.clear()
-        torch.cuda.empty_cache()
-        m64, tr64 = build_model(64, scale, ncls, dev, seed=14, name=args.model)
-        e64 = m64._cara_engine
-        e64.seed_rank_streams(2024, rank)
-        o64 = AdamW(tr64, lr=1e-3, weight_decay=1e-4)
-        info["rank64_ms_per_step"] = round(timed_steps(lambda: e64.train_step(x, y, o64)), 3)
-        info["rank64_images_per_sec"] = round(args.batch / info["rank64_ms_per_step"] * 1e3, 1)
-        info["rank64_step_frac_of_mfma_peak"] = round(82.61 * args.batch / info["rank64_ms_per_step"] / PEAK_BF16_TFLOPS, 4)
-        del m64, tr64, e64, o64
-        torch.cuda.empty_cache()
-        # order 2 of dim_experiment.py (dense dim x dim QKV deltas, 9.4 M more parameters): the dense-delta form of the QKV linear
-        m2, tr2 = build_model(args.rank, scale, ncls, dev, seed=14, name=args.model, cp_length=2)
-        e2 = m2._cara_engine
-        e2.seed_rank_streams(2024, rank)
-        o2 = AdamW(tr2, lr=1e-3, weight_decay=1e-4)
-        info["order2_qkv_ms_per_step"] = round(timed_steps(lambda: e2.train_step(x, y, o2)), 3)
-        del m2, tr2, e2, o2
-        torch.cuda.empty_cache()
+        # every leg on its own: a failure there (memory on a shared box, an environment switch the leg does not support) is
+        # recorded and must not cost the headline line, which is already measured
+        def leg(name, fn):
+            try:
+                fn()
+            except Exception as exc:   # noqa: BLE001 -- diagnostics behind the measurement
+                info[name + "_error"] = f"{type(exc).__name__}: {exc}"[:300]
+            finally:
+                eng.weight_dropout = "off"
+                torch.cuda.empty_cache()
+
+        def leg_exact():
+            eng.weight_dropout = "exact"
+            info["exact_dropout_ms_per_step"] = round(timed_steps(step), 3)
+            eng.weight_dropout = "off"
+            eng._ws.clear()
+
+        def leg_rank64():
+            m64, tr64 = build_model(64, scale, ncls, dev, seed=14, name=args.model)
+            e64 = m64._cara_engine
+            e64.seed_rank_streams(2024, rank)
+            o64 = AdamW(tr64, lr=1e-3, weight_decay=1e-4)
+            info["rank64_ms_per_step"] = round(timed_steps(lambda: e64.train_step(x, y, o64)), 3)
+            info["rank64_images_per_sec"] = round(args.batch / info["rank64_ms_per_step"] * 1e3, 1)
+            info["rank64_step_frac_of_mfma_peak"] = round(82.61 * args.batch / info["rank64_ms_per_step"] / PEAK_BF16_TFLOPS, 4)
+
+        def leg_order2():
+            # order 2 of dim_experiment.py (dense dim x dim QKV deltas, 9.4 M more parameters): the dense-delta form of the QKV linear
+            m2, tr2 = build_model(args.rank, scale, ncls, dev, seed=14, name=args.model, cp_length=2)
+            e2 = m2._cara_engine
+            e2.seed_rank_streams(2024, rank)
+            o2 = AdamW(tr2, lr=1e-3, weight_decay=1e-4)
+            info["order2_qkv_ms_per_step"] = round(timed_steps(lambda: e2.train_step(x, y, o2)), 3)
+
+        leg("exact_dropout", leg_exact)
+        leg("rank64", leg_rank64)
+        leg("order2_qkv", leg_order2)
 
     if rank == 0:
         ms_step = wall * 1e3 / args.steps
@@ -460,6 +499,7 @@ def main():
                 d.update(algorithmic_mb=round(amount / 1e6, 1), achieved_gbs=round(amount / us / 1e3, 1),
                          frac_of_hbm_peak=round(amount / us / 1e3 / PEAK_HBM_GBS, 4))
             return d
+        ex_fwd, ex_step = executed_gflop(gf, args.batch, dim, args.rank, heads, tokens, 24 if large else 12)
         per_step = {n: v["brackets"] // 3 for n, v in post.items()}
         ranked = sorted((n for n in post if work[n][0] == "mfma"), key=lambda n: -post[n]["avg_ms"] * per_step[n])
         top = [entry(n, post[n], per_step[n]) for n in (ranked if args.all_sites else ranked[:3])]
@@ -506,7 +546,13 @@ def main():
                        "gpu_event_ms_per_step": round(ev_ms / args.steps, 3), "loss": float(loss),
                        "forward_only_ms": round(fwd_ms, 3),
                        "forward_only_images_per_sec_per_gpu": round(args.batch / fwd_ms * 1e3, 1),
-                       "forward_frac_of_mfma_peak": round(gf["fwd"] * args.batch / fwd_ms / PEAK_BF16_TFLOPS, 4)},
+                       "forward_frac_of_mfma_peak": round(gf["fwd"] * args.batch / fwd_ms / PEAK_BF16_TFLOPS, 4),
+                       # the same two fractions over what the device EXECUTES (executed_gflop: the cls-row shortcut of the last block
+                       # and block 0's skipped qkv dX taken out of the numerator): hardware utilisation, not algorithmic throughput
+                       "step_executed_gflop": round(ex_step, 1),
+                       "step_frac_of_mfma_peak_executed": round(ex_step / ms_step / PEAK_BF16_TFLOPS, 4),
+                       "forward_executed_gflop": round(ex_fwd, 1),
+                       "forward_frac_of_mfma_peak_executed": round(ex_fwd / fwd_ms / PEAK_BF16_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": f"{SITE_KERNEL[dominant]}; site {dominant}: the largest time share of the step among the "
@@ -517,10 +563,14 @@ def main():
             "roofline_top": top,
             "roofline_hbm": hbm,
         }
-        if info:
+        if info.get("exact_dropout_ms_per_step"):
             # the reference's own recipe keeps the model in eval mode after the first evaluation (vit_cp.py:60,75): weight-space
             # dropout and DropPath are live for 165 of its 1 500 steps, so a run of that recipe costs this per step on average
             info["recipe_blended_ms_per_step"] = round((165 * info["exact_dropout_ms_per_step"] + 1335 * ms_step) / 1500, 3)
+            # ... and that, not `value`, is the throughput of the reference's recipe AS WRITTEN (vit_cp.py:19-70 + cara.py:35,57,81,92)
+            out["config"]["recipe_blended_ms_per_step"] = info["recipe_blended_ms_per_step"]
+            out["config"]["recipe_blended_images_per_sec"] = round(world * args.batch / info["recipe_blended_ms_per_step"] * 1e3, 1)
+        if info:
             info["note"] = ("informational, 5 steps each after 2 warm-ups, same box and process: exact = the reference's train-mode "
                             "Dropout(0.1) on the materialised dW (cara.py:35,57,81,92); rank64 = BASELINE.json configs[3] (82.61 GF/image); order2_qkv = cp_length 2 of dim_experiment.py (dense dim x dim QKV deltas) at the headline rank and batch; "
                             "blended = (165 exact + 1335 factored) / 1500, the reference's stuck-in-eval recipe (SURVEY 3.3)")

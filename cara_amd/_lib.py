@@ -14,10 +14,12 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CARA_LIB_PATH (diagnostic) points at another build of the same ABI for same-box A/B timing
 LIB_PATH = os.environ.get("CARA_LIB_PATH") or os.path.join(_HERE, "libcara_hip.so")
+# the same sources with IEEE-half MFMA operands (cara_amd/csrc/build.sh f16): `precision = "fp16"`
+LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libcara_hip_f16.so")}
 
 # every symbol include/cara_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "cara_abi_version", "cara_build_arch", "cara_gemm_bf16", "cara_gemm_tn_f32", "cara_pack_b_panels", "cara_gemm_scratch_bytes", "cara_skinny_xu", "cara_skinny_xu_r", "cara_tskinny_partial2_r", "cara_gemm_with_tskinny_r",
+    "cara_abi_version", "cara_build_arch", "cara_operand_type", "cara_gemm_bf16", "cara_gemm_tn_f32", "cara_pack_b_panels", "cara_gemm_scratch_bytes", "cara_skinny_xu", "cara_skinny_xu_r", "cara_tskinny_partial2_r", "cara_gemm_with_tskinny_r", "cara_gemm_rider_slab_format", "cara_linear_fwd", "cara_linear_bwd",
     "cara_tskinny_scratch_bytes", "cara_tskinny_xtg", "cara_tskinny_partial", "cara_tskinny_partial2", "cara_tskinny_reduce", "cara_tskinny_reduce_many", "cara_gemm_with_tskinny", "cara_layernorm_fwd", "cara_layernorm_bwd", "cara_layernorm_fwd_xu", "cara_layernorm_bwd_xu", "cara_layernorm_fwd_ex", "cara_layernorm_bwd_ex",
     "cara_attention_fwd", "cara_attention_bwd", "cara_attention_cls_fwd", "cara_attention_cls_bwd", "cara_im2col_patches", "cara_assemble_tokens",
     "cara_cross_entropy", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_transpose_bf16_ld", "cara_pack_offsets",
@@ -103,7 +105,12 @@ class VitShape(C.Structure):
 
 class TsReduce(C.Structure):
     _fields_ = [("slabs", C.c_void_p), ("slab_stride", C.c_size_t), ("D", C.c_void_p), ("colsum", C.c_void_p),
-                ("batch", C.c_int), ("M", C.c_int), ("K1", C.c_int), ("Rp", C.c_int), ("Rc", C.c_int)]
+                ("batch", C.c_int), ("M", C.c_int), ("K1", C.c_int), ("Rp", C.c_int), ("Rc", C.c_int), ("wave_slabs", C.c_int)]
+
+
+class Linear(C.Structure):   # cara_linear: one adapted linear per call (cara_linear_fwd / cara_linear_bwd)
+    _fields_ = [("W", C.c_void_p), ("Wt", C.c_void_p), ("Ut", C.c_void_p), ("U", C.c_void_p), ("Vs", C.c_void_p), ("Vst", C.c_void_p),
+                ("bias", C.c_void_p), ("in", C.c_int), ("out", C.c_int), ("Rp", C.c_int), ("rank", C.c_int)]
 
 
 ADAMW_MAX_TENSORS, ADAMW_MAX_GROUPS = 32, 4
@@ -121,42 +128,51 @@ class AdamWArgs(C.Structure):
 
 
 # CARA_STRUCT_* of include/cara_hip.h -> the mirror above (lib() asserts that every size agrees with the library's)
-STRUCT_MIRRORS = (GemmArgs, Geom, CpPtrs, PackLayout, LayerGrads, VitWeights, VitShape, TsReduce, AdamWArgs)
+STRUCT_MIRRORS = (GemmArgs, Geom, CpPtrs, PackLayout, LayerGrads, VitWeights, VitShape, TsReduce, Linear, AdamWArgs)
 
 
 class CaraError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
 
 
-def lib() -> C.CDLL:
-    """Load libcara_hip.so or raise.  Never falls back to another implementation."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise CaraError(
-                f"{LIB_PATH} not found: build it with cara_amd/csrc/build.sh (or __graft_entry__.build()). "
-                "cara_amd has no CPU or eager fallback.")
-        _lib = C.CDLL(LIB_PATH)
-        _lib.cara_build_arch.restype = C.c_char_p
-        _lib.cara_tskinny_scratch_bytes.restype = C.c_size_t
-        _lib.cara_factor_grad_scratch_bytes.restype = C.c_size_t
-        if hasattr(_lib, "cara_vit_workspace_bytes"):
-            _lib.cara_vit_workspace_bytes.restype = C.c_size_t
-            _lib.cara_gemm_scratch_bytes.restype = C.c_size_t
-            _lib.cara_weight_dropout_hash.restype = C.c_uint
-            _lib.cara_dropout_grad_scratch_bytes.restype = C.c_size_t
-            _lib.cara_colsum_scratch_bytes.restype = C.c_size_t
-        _lib.cara_dense_delta_grad_scratch_bytes.restype = C.c_size_t
-        _lib.cara_sizeof_struct.restype = C.c_size_t
-        _lib.cara_sizeof_gemm_args.restype = C.c_size_t
-        for which, mirror in enumerate(STRUCT_MIRRORS):   # a mirror that is short would make the library read past it
-            want = int(_lib.cara_sizeof_struct(which))
-            if want != C.sizeof(mirror):
-                raise CaraError(f"{LIB_PATH}: sizeof({mirror.__name__}) is {C.sizeof(mirror)} here, {want} in the library: "
-                                "cara_amd/_lib.py and include/cara_hip.h disagree (rebuild, or update the mirror)")
+def lib(operands: str = "bf16") -> C.CDLL:
+    """Load libcara_hip.so (operands = "bf16", the product) or libcara_hip_f16.so ("fp16": the same sources and ABI with IEEE-half
+    MFMA operands) or raise.  Never falls back to another implementation."""
+    got = _libs.get(operands)
+    if got is not None:
+        return got
+    if operands not in LIB_PATHS:
+        raise CaraError(f"no library for operand type {operands!r}")
+    path = LIB_PATHS[operands]
+    if not os.path.exists(path):
+        raise CaraError(
+            f"{path} not found: build it with cara_amd/csrc/build.sh{' f16' if operands == 'fp16' else ''} (or __graft_entry__.build()). "
+            "cara_amd has no CPU or eager fallback.")
+    _lib = C.CDLL(path)
+    _lib.cara_build_arch.restype = C.c_char_p
+    _lib.cara_operand_type.restype = C.c_char_p
+    if _lib.cara_operand_type() != operands.encode():
+        raise CaraError(f"{path} was built for {_lib.cara_operand_type()!r} operands, not {operands!r}")
+    _lib.cara_tskinny_scratch_bytes.restype = C.c_size_t
+    _lib.cara_factor_grad_scratch_bytes.restype = C.c_size_t
+    if hasattr(_lib, "cara_vit_workspace_bytes"):
+        _lib.cara_vit_workspace_bytes.restype = C.c_size_t
+        _lib.cara_gemm_scratch_bytes.restype = C.c_size_t
+        _lib.cara_weight_dropout_hash.restype = C.c_uint
+        _lib.cara_dropout_grad_scratch_bytes.restype = C.c_size_t
+        _lib.cara_colsum_scratch_bytes.restype = C.c_size_t
+    _lib.cara_dense_delta_grad_scratch_bytes.restype = C.c_size_t
+    _lib.cara_sizeof_struct.restype = C.c_size_t
+    _lib.cara_sizeof_gemm_args.restype = C.c_size_t
+    for which, mirror in enumerate(STRUCT_MIRRORS):   # a mirror that is short would make the library read past it
+        want = int(_lib.cara_sizeof_struct(which))
+        if want != C.sizeof(mirror):
+            raise CaraError(f"{path}: sizeof({mirror.__name__}) is {C.sizeof(mirror)} here, {want} in the library: "
+                            "cara_amd/_lib.py and include/cara_hip.h disagree (rebuild, or update the mirror)")
+    _libs[operands] = _lib
     return _lib
 
 

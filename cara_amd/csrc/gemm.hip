@@ -956,9 +956,27 @@ extern "C" int cara_gemm_tn_f32(const void* At, int lda, const void* Bt, int ldb
 }
 
 static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* ts);
-// measurement tools only (tools/gemm8_bench.py): pick the tile family per call sequence inside one process (-1: the environment decides)
+// measurement tools only (tools/gemm8_bench.py): pick the tile family per call sequence inside one process -- 160 / 256: that tile for
+// every product it takes; 0: never; -1: the policy below decides (the default)
 static int g_gemm8_override = -1;
 extern "C" int cara_debug_set_gemm8(int mt) { g_gemm8_override = mt; return CARA_OK; }
+// Which products run on the 160 x 256 x 64 tile (same-box A/Bs of the step, profiles/r04_b_*): the long-K, narrow-N ones --
+//   * fc2 forward (K = 4 dim, N = dim, the adapter inside: 86 -> 74 us) and qkv dX (K = 3 dim, with its riding products as
+//     workgroups behind the tiles: 64.7 -> 60.3 us);
+//   * NOT a dX launch that carries long riders: fc1 dX carries 154 MB of transposed skinny products (its dVs reads dH, fc2's dU
+//     reads h) that the 128 x 128 x 32 kernel streams under its four resident workgroups per CU (87 us in all); one tile per CU
+//     leaves them to the end (100 us) or to helper waves that cost the tile more than they hide (92 us).  riders = 1 asks for a
+//     launch that carries products: K <= CARA_GEMM8_MAXK_TS (2304) then.
+// CARA_GEMM8=0 turns the tile off, CARA_GEMM8_MINK / _MAXN / _MAXK_TS move the bounds (A/B runs).  Callers that lay activations
+// out for a GEMM (vit.hip: K-panel-major h / dH) ask here first: the tile reads row-major operands.
+bool cara_gemm8_policy(int M, int N, int K, int riders) {
+  static const int on = [] { const char* e = getenv("CARA_GEMM8"); return e ? atoi(e) : 160; }();
+  static const int mink = [] { const char* e = getenv("CARA_GEMM8_MINK"); return e ? atoi(e) : 2048; }();
+  static const int maxn = [] { const char* e = getenv("CARA_GEMM8_MAXN"); return e ? atoi(e) : 1024; }();
+  static const int maxk_ts = [] { const char* e = getenv("CARA_GEMM8_MAXK_TS"); return e ? atoi(e) : 2304; }();
+  return on == 160 && M >= 4096 && (M % 16) == 0 && (N % 16) == 0 && N <= maxn && K >= mink && (!riders || K <= maxk_ts);
+}
+
 extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) { return gemm_bf16_impl(a, stream, nullptr); }
 
 extern "C" int cara_gemm_with_tskinny(const cara_gemm_args* a, const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
@@ -979,6 +997,17 @@ extern "C" int cara_gemm_with_tskinny_r(const cara_gemm_args* a, const void* Xa,
   ts.b = ts_problem(Xb, ldxb, Gtb, slabs_b, want_colsum_b, M, K1b, Rp);
   ts.ldg = ldg; ts.M = M; ts.any_cs = want_colsum_b != 0; ts.nt = (Rp == 32 && rank <= 16 && (!a->Ut || (a->Ut_rank > 0 && a->Ut_rank <= 16))) ? 1 : Rp / 16;
   return gemm_bf16_impl(a, stream, &ts);
+}
+
+static int g8_choice(const cara_gemm_args* a, bool riders) {
+  return g_gemm8_override > 0 ? g_gemm8_override : (g_gemm8_override < 0 && cara_gemm8_policy(a->M, a->N, a->K, riders ? 1 : 0) ? 160 : 0);
+}
+extern "C" int cara_gemm_rider_slab_format(const cara_gemm_args* a, int Rp, int rank) {
+  if (!a || !(Rp == 32 || Rp == 64) || rank <= 0 || rank > Rp) return 0;
+  const int g8 = g8_choice(a, true);
+  if (!g8) return 0;
+  const int nt = (Rp == 32 && rank <= 16 && (!a->Ut || (a->Ut_rank > 0 && a->Ut_rank <= 16))) ? 1 : Rp / 16;
+  return cara_gemm8_plan(a, g8, nt) == 2 ? 1 : 0;
 }
 
 // ts != NULL: the launch also carries a pair of transposed skinny products; only the default 128 x 128 x 32 kernel can
@@ -1003,11 +1032,15 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
   if (a->epi == CARA_EPI_DGELU && !a->aux) return CARA_E_ARG;
   if (ts && (a->batch > 1 || a->M <= 128 || a->B3 || (a->Ut && a->epi != CARA_EPI_BF16))) return CARA_E_ARG;
   if (a->B3 && (a->Bp || a->Ut || a->batch > 1 || a->a_panels)) return CARA_E_ARG;
-  // CARA_GEMM8 = 160 / 256: the MT x 256 x 64 one-workgroup-per-CU tile (gemm8.hip) for the products it takes
-  static const int g8_env = [] { const char* e = getenv("CARA_GEMM8"); return e ? atoi(e) : 0; }();
-  const int g8 = g_gemm8_override >= 0 ? g_gemm8_override : g8_env;
-  if (g8 && !ts) {
-    const int rc = cara_gemm8_launch(a, st, g8);
+  // The MT x 256 x 64 one-workgroup-per-CU tile (gemm8.hip) where the policy asks for it (cara_gemm8_policy) and the tile takes the product
+  const int g8 = g8_choice(a, ts != nullptr);
+  if (g8) {
+    cara_g8_riders rd;
+    if (ts) {
+      auto cp = [](const TsProblem& t) { return cara_g8_product{t.X, t.Gt, t.slabs, t.cs_slabs, t.ldx, t.K1, t.nchunks, t.nblk}; };
+      rd.a = cp(ts->a); rd.b = cp(ts->b); rd.ldg = ts->ldg; rd.M = ts->M; rd.any_cs = ts->any_cs ? 1 : 0; rd.nt = ts->nt;
+    }
+    const int rc = cara_gemm8_launch(a, st, g8, ts ? &rd : nullptr);
     if (rc >= 0) return rc;
   }
   if (a->Ut) {   // whole adapter inside the GEMM: Rp = 32, T produced here

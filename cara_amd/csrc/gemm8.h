@@ -2,6 +2,26 @@
 #pragma once
 #include "common.h"
 
+// one transposed skinny product riding in the launch (the fields of TsProblem, tskinny_body.h)
+struct cara_g8_product {
+  const void* X; const void* Gt;
+  float* slabs; float* cs_slabs;
+  int ldx, K1, nchunks, nblk;
+};
+struct cara_g8_riders {
+  cara_g8_product a, b;
+  int ldg, M, any_cs, nt;
+};
+
 // CARA_OK when the product was launched, CARA_E_LAUNCH on a failed launch, -1 when this tile does not take the
-// product (the caller then runs the 128 x 128 x 32 kernel).  mt = rows per tile: 160 or 256.
-int cara_gemm8_launch(const cara_gemm_args* a, hipStream_t st, int mt);
+// product (the caller then runs the 128 x 128 x 32 kernel).  mt = rows per tile: 160 or 256.  ts: the pair of
+// transposed skinny products the launch carries behind its tiles, or NULL.
+int cara_gemm8_launch(const cara_gemm_args* a, hipStream_t st, int mt, const cara_g8_riders* ts);
+// what cara_gemm8_launch would do with the product: 0 = not taken; 1 = taken, riding products (riders_nt = their column tiles of
+// 16, 0 = none) as workgroups behind the tiles: one slab per tskinny BLOCK; 2 = taken with helper waves: the riding products write
+// one slab per WAVE (cara_ts_reduce::wave_slabs)
+int cara_gemm8_plan(const cara_gemm_args* a, int mt, int riders_nt);
+
+// the dispatcher's policy (gemm.hip): does a product of this shape go to the tile?  riders: the launch carries transposed skinny
+// products.  (Callers that choose activation layouts ask.)
+bool cara_gemm8_policy(int M, int N, int K, int riders);

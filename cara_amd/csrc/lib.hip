@@ -1,8 +1,9 @@
 // Library identification for libcara_hip.so.
 #include "common.h"
 
-extern "C" int cara_abi_version(void) { return 11; }
+extern "C" int cara_abi_version(void) { return 12; }
 extern "C" const char* cara_build_arch(void) { return "gfx950"; }
+extern "C" const char* cara_operand_type(void) { return CARA_OPERAND_TYPE; }
 
 extern "C" size_t cara_sizeof_struct(int which) {
   switch (which) {
@@ -14,6 +15,7 @@ extern "C" size_t cara_sizeof_struct(int which) {
     case CARA_STRUCT_VIT_WEIGHTS: return sizeof(cara_vit_weights);
     case CARA_STRUCT_VIT_SHAPE: return sizeof(cara_vit_shape);
     case CARA_STRUCT_TS_REDUCE: return sizeof(cara_ts_reduce);
+    case CARA_STRUCT_LINEAR: return sizeof(cara_linear);
     case CARA_STRUCT_ADAMW_ARGS: return sizeof(cara_adamw_args);
     default: return 0;
   }

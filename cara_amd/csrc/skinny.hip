@@ -279,7 +279,8 @@ extern "C" int cara_tskinny_reduce_many(const cara_ts_reduce* probs, int n, void
     if (!q.slabs || !q.D || q.batch <= 0 || q.M <= 0 || q.K1 <= 0 || (q.K1 % TS_COLS) || !(q.Rp == 32 || q.Rp == 64)) return CARA_E_ARG;
     if (!(q.Rc == 0 || q.Rc == q.Rp || (q.Rc == 16 && q.Rp == 32))) return CARA_E_ARG;
     t.p[i] = q;
-    t.nchunks[i] = ts_chunks(q.M, q.K1);
+    if (q.wave_slabs && !(q.Rc == 16 && q.Rp == 32)) return CARA_E_ARG;   // (only the one-r-tile products are written per wave)
+    t.nchunks[i] = ts_chunks(q.M, q.K1) * (q.wave_slabs ? 4 : 1);   // slab (chunk * 4 + wave) of a column block
     const int blocks = (q.K1 * q.Rp + 255) / 256;
     maxblocks = blocks > maxblocks ? blocks : maxblocks;
     maxbatch = q.batch > maxbatch ? q.batch : maxbatch;
@@ -338,7 +339,8 @@ extern "C" int cara_skinny_xu_r(const void* X, int ldx, const void* Ut, void* T,
 
 extern "C" size_t cara_tskinny_scratch_bytes(int M, int K1, int Rp) {
   if (M <= 0 || K1 <= 0 || (K1 % TS_COLS) || !(Rp == 32 || Rp == 64)) return 0;
-  const size_t nblk = (size_t)(K1 / TS_COLS) * ts_chunks(M, K1);
+  // (four times the blocks: a product that rides in a launch of the 160 x 256 x 64 tile writes one slab per wave, cara_ts_reduce::wave_slabs)
+  const size_t nblk = (size_t)4 * (K1 / TS_COLS) * ts_chunks(M, K1);
   return nblk * TS_COLS * Rp * sizeof(float) + nblk * TS_COLS * sizeof(float);
 }
 

@@ -81,11 +81,13 @@ struct TsProblem {
 
 // one block's share; `block` = its index among the p0.nblk + p1.nblk blocks of the pair.  NSTAGE = 3: two K steps
 // of prefetch per wave; NSTAGE = 1: load, wait, multiply (enough when the CU holds many other waves)
+// tid_in / active: a workgroup of more than 256 threads runs one block per 256 threads (the 512-thread GEMM tile of gemm8.hip
+// that carries the products); a surplus group passes active = false: it keeps the barrier count and touches no memory
 template <int NT, bool COLSUM, int NSTAGE>
 __device__ __forceinline__ void tskinny_body(const TsProblem& p0, const TsProblem& p1, const int ldg, const int M, const int block,
-                                             char* smem) {
+                                             char* smem, const int tid_in = -1, const bool active = true) {
   using R = TsRing<NT, NSTAGE>;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = tid_in < 0 ? (int)threadIdx.x : tid_in, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const bool second = block >= p0.nblk;
@@ -113,7 +115,7 @@ __device__ __forceinline__ void tskinny_body(const TsProblem& p0, const TsProble
 
   // this wave's steps: s_begin + wave, +4, ...
   const int first = s_begin + wave;
-  const int nmine = first < s_end ? (s_end - first + 3) / 4 : 0;
+  const int nmine = (active && first < s_end) ? (s_end - first + 3) / 4 : 0;
   if constexpr (NSTAGE == 3) {
     if (nmine > 0) ts_issue<NT>(X, ldx, Gt, ldg, i0, first * 32, M, ring, lane);
     if (nmine > 1) ts_issue<NT>(X, ldx, Gt, ldg, i0, (first + 4) * 32, M, ring + R::STAGE, lane);
@@ -185,7 +187,7 @@ __device__ __forceinline__ void tskinny_body(const TsProblem& p0, const TsProble
       }
     }
     __syncthreads();
-    for (int t = wave; t < 4 * RPP; t += 4) {
+    for (int t = wave; active && t < 4 * RPP; t += 4) {
       f32x4 s = red[t * 64 + lane];
 #pragma unroll
       for (int w = 1; w < 4; ++w) {
@@ -198,7 +200,7 @@ __device__ __forceinline__ void tskinny_body(const TsProblem& p0, const TsProble
     }
   }
   if constexpr (COLSUM) {
-    if (want_cs && tid < TS_COLS) {
+    if (active && want_cs && tid < TS_COLS) {
       const int it = tid >> 4, f = tid & 15;
       float s = 0.f;
 #pragma unroll

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm8.h"
 
 namespace {
 
@@ -183,6 +184,14 @@ struct TsPending {
   const void *Xa, *Gta, *Xb, *Gtb;
   void *slabs_a, *slabs_b;
   int ldxa, K1a, ldxb, K1b, want_cs, ldg, M, Rp;
+  int slot = 0, layer = 0;   // the linear the pair belongs to
+};
+
+// How a linear's transposed skinny products left their partial sums, per layer: 0 = one slab per block, 1 = one per wave
+// (cara_gemm_rider_slab_format: the launches of the 160 x 256 x 64 tile stream their riding products with helper waves).
+// The end-of-pass reduction groups the layers of a linear by it.
+struct SlabFormats {
+  unsigned char U[4][64] = {}, V[4][64] = {};
 };
 
 // per-call context: what lin_fwd / lin_bwd need besides their operands (nothing here outlives the call)
@@ -193,6 +202,7 @@ struct Ctx {
   bool full;       // this block runs on all token rows (not the cls-row-only last block)
   TsPending* pend = nullptr;   // backward: the pair of products waiting for a carrier
   int rank = 0;                // the adapter's rank (0: unknown, the skinny passes compute all Rp columns)
+  SlabFormats* fmt = nullptr;  // backward: where the launches note the slab format of the products they carry
 };
 
 // the rank the transposed skinny products are told (0 in the context = unknown: all Rp columns).  Deferred products
@@ -359,7 +369,7 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
   mine.valid = true;
   mine.Xa = X; mine.ldxa = ldx; mine.Gta = Gt; mine.slabs_a = slabU; mine.K1a = L.in;
   mine.Xb = dY; mine.ldxb = lddy; mine.Gtb = Tt; mine.slabs_b = slabV; mine.K1b = L.out; mine.want_cs = want_dc ? 1 : 0;
-  mine.ldg = ldt; mine.M = Mr; mine.Rp = Rp;
+  mine.ldg = ldt; mine.M = Mr; mine.Rp = Rp; mine.slot = L.slot; mine.layer = cx.layer;
   if (want_dx) {
     a.A = dY; a.lda = lddy; a.B = L.Wt; a.Bp = L.Wtp; a.ldb = L.out; a.A2 = inside ? nullptr : G; a.B2 = L.U; a.Rp = Rp;
     if (lddy < 0) { a.a_panels = -lddy; a.lda = 0; }
@@ -377,6 +387,11 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
       if (g_inside) {   // G' = dY Vs computed by this GEMM on the tiles it streams (its own dVs does not read G'; its dU rides later)
         a.A2 = nullptr; a.Ut = L.Vst; a.T_out = G; a.Tt_out = Gt; a.ldt = ldt; a.Ut_rank = ts_rank(cx, Rp) <= 16 ? ts_rank(cx, Rp) : 0;
       }
+      if (cx.fmt) {   // (depends on the arguments only: asked before the launch, valid for it)
+        const unsigned char f = (unsigned char)cara_gemm_rider_slab_format(&a, Rp, ts_rank(cx, Rp));
+        if (take) cx.fmt->U[pend->slot][pend->layer] = f;
+        cx.fmt->V[L.slot][cx.layer] = f;
+      }
       TRY(cara_gemm_with_tskinny_r(&a, take ? pend->Xa : nullptr, take ? pend->ldxa : 0, take ? pend->Gta : nullptr, take ? pend->slabs_a : nullptr,
                                    take ? pend->K1a : 0, mine.Xb, mine.ldxb, mine.Gtb, mine.slabs_b, mine.K1b, mine.want_cs, ldt, Mr, Rp,
                                    ts_rank(cx, Rp), st));
@@ -392,6 +407,11 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
 #ifdef CARA_ABLATE_TS   // timing experiment only (tools/build_variant.sh): the dX GEMMs WITHOUT their riding products (wrong gradients)
     if (carry) { TRY(cara_gemm_bf16(&a, st)); return CARA_OK; }
 #endif
+    if (carry && cx.fmt) {
+      const unsigned char f = (unsigned char)cara_gemm_rider_slab_format(&a, carry->Rp, ts_rank(cx, carry->Rp));
+      cx.fmt->U[carry->slot][carry->layer] = f;
+      cx.fmt->V[carry->slot][carry->layer] = f;
+    }
     if (carry) {
       TRY(cara_gemm_with_tskinny_r(&a, carry->Xa, carry->ldxa, carry->Gta, carry->slabs_a, carry->K1a, carry->Xb, carry->ldxb, carry->Gtb,
                                    carry->slabs_b, carry->K1b, carry->want_cs, carry->ldg, carry->M, carry->Rp, ts_rank(cx, carry->Rp), st));
@@ -699,7 +719,8 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
     // K-panel-major activations (panel_acts): pa_x for what all M token rows produce (xn1), pa for the Mr rows of
     // the proj / MLP half of the block (xn2, h)
     // (order 2: xn1 stays row-major -- the dense dD = xn1^T dY of the backward reads it with transposing LDS reads)
-    const bool pa_x = panel_acts(M, s, 2) && !dense_qkv, pa = panel_acts(Mr, s, 1), pa_n = panel_acts(Mr, s, 2);
+    // (h stays row-major where fc2 forward / fc1 dX run on the 160 x 256 x 64 tile, which stages whole 128-byte lines of row-major operands)
+    const bool pa_x = panel_acts(M, s, 2) && !dense_qkv, pa = panel_acts(Mr, s, 1) && !cara_gemm8_policy(Mr, D, 4 * D, 0), pa_n = panel_acts(Mr, s, 2);
     {
       SiteBracket sb(CARA_SITE_LN1_FWD, cx_all);
       TRY(cara_layernorm_fwd_ex(x_in, D, w->ln1_g + (size_t)l * D, w->ln1_b + (size_t)l * D, ws + lw.xn1,
@@ -763,8 +784,10 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
   if (!layout(g, s, &W) || !w || !cp || !head_w || !dlogits || !workspace || !grads || !dhead_w || !dhead_b) return CARA_E_ARG;
   char* ws = static_cast<char*>(workspace);
   TsPending pending;
+  SlabFormats formats;
   Ctx cx{stream, ws + W.gemm_scratch, 0, false, &pending};
   cx.rank = g->rank;
+  cx.fmt = &formats;
   hipStream_t hs = static_cast<hipStream_t>(stream);
   const int D = g->dim, M = W.M, Rp = g->Rp, B = s->B, N = s->tokens;
   const float att_scale = 1.0f / sqrtf((float)(D / g->heads));
@@ -810,10 +833,12 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     // K-panel-major activations, as the forward wrote them (xn1: pa_x; xn2, h: pa) and as the kernels here write
     // theirs: dH and dyp (pa), dyb of the block below (pa_x).  This block's own dyb came from the block above --
     // panels -- except in the last block, where the final norm's backward left it row-major on the cls rows.
-    const bool pa_x = panel_acts(M, s, 2) && !dense_qkv, pa = panel_acts(Mr, s, 1), pa_n = panel_acts(Mr, s, 2);
+    // (h as the forward wrote it: row-major where fc2 forward runs on the 160 x 256 x 64 tile; dH: row-major where fc1 dX does)
+    const bool pa_x = panel_acts(M, s, 2) && !dense_qkv, pa = panel_acts(Mr, s, 1) && !cara_gemm8_policy(Mr, D, 4 * D, 0), pa_n = panel_acts(Mr, s, 2);
+    const bool pa_dh = panel_acts(Mr, s, 1) && !cara_gemm8_policy(Mr, D, 4 * D, 1);
     const bool pa_dp = panel_acts(Mr, s, 4), pa_dx = panel_acts(M, s, 4);   // dyp here; dyb of the block below
     const bool pa_dyb = pa_dx && l < g->depth - 1;
-    if (pa) { e.c_panels = Mr; e.ldc = 4 * D; }
+    if (pa_dh) { e.c_panels = Mr; e.ldc = 4 * D; }
     if (ex) TRY(lin_bwd_exact(lin[3], dyb, reinterpret_cast<bf16*>(ws + lw.h), Mr, Rp, ws, W, s, true, e, true, cx));
     else TRY(lin_bwd(lin[3], dyb, pa_dyb ? -M : ldr, reinterpret_cast<bf16*>(ws + lw.h), pa ? -Mr : 4 * D, Mr, Rp, W.ldt, ws, W, lw, true, e, true, cx,
                      have_G_fc2));
@@ -821,7 +846,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
     if (ex) TRY(lin_bwd_exact(lin[2], dH, reinterpret_cast<bf16*>(ws + lw.xn2), Mr, Rp, ws, W, s, true, e, true, cx));
-    else TRY(lin_bwd(lin[2], dH, pa ? -Mr : 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), pa_n ? -Mr : D, Mr, Rp, W.ldt, ws, W, lw, true, e, true, cx));
+    else TRY(lin_bwd(lin[2], dH, pa_dh ? -Mr : 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), pa_n ? -Mr : D, Mr, Rp, W.ldt, ws, W, lw, true, e, true, cx));
     // dyp = dY of this block's proj: its G' = dY Vs comes out of the same kernel (CARA_LN2B_XU=0: out of proj's dX GEMM instead)
     static const int ln2b_xu = env_once("CARA_LN2B_XU", 1);
     const bool fxp = fx && (ln2b_xu != 0 || cls_only);
@@ -872,9 +897,17 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
   if (!ex) {   // (the exact mode wrote dU / dVs / dc of every layer directly)
     const int ins[4] = {D, D, D, 4 * D}, outs[4] = {3 * D, D, 4 * D, D};
     const int L = g->depth;
-    cara_ts_reduce red[CARA_TS_REDUCE_MAX];   // all slab sums of the pass in ONE launch (8 + 6 of them)
+    cara_ts_reduce red[CARA_TS_REDUCE_MAX];   // all slab sums of the pass in ONE launch (8 + 6 of them, more where a linear's layers differ in slab format)
     int nred = 0;
     const int Rc = (Rp == 32 && ts_rank(cx, Rp) <= 16) ? 16 : 0;   // (every product of the pass was told the same rank)
+    auto push = [&](const cara_ts_reduce& e) -> int {
+      if (nred == CARA_TS_REDUCE_MAX) {
+        TRY(cara_tskinny_reduce_many(red, nred, stream));
+        nred = 0;
+      }
+      red[nred++] = e;
+      return CARA_OK;
+    };
     for (int i = 0; i < 4; ++i) {
       if (i == 0 && dense_qkv) continue;   // order 2: the QKV linear wrote no skinny slabs (its gradient is dense, below)
       float* dU = reinterpret_cast<float*>(ws + W.dU[i]);
@@ -883,14 +916,25 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
       // qkv (i == 0) sees all tokens in every block; proj / fc1 / fc2 of the last block ran on B rows,
       // so that block's slabs have their own chunking
       const int full = (i == 0 || !cls_shortcut_enabled()) ? L : L - 1;   // (not reached in the exact mode)
-      if (full > 0) {
-        red[nred++] = cara_ts_reduce{ws + W.slabU[i], W.strideU[i], dU, nullptr, full, M, ins[i], Rp, Rc};
-        red[nred++] = cara_ts_reduce{ws + W.slabV[i], W.strideV[i], dVs, dc, full, M, outs[i], Rp, Rc};
+      // runs of layers whose products left the same slab format (one per block / one per wave: SlabFormats)
+      for (int l0 = 0; l0 < full;) {
+        int l1 = l0 + 1;
+        while (l1 < full && formats.U[i][l1] == formats.U[i][l0]) ++l1;
+        TRY(push(cara_ts_reduce{ws + W.slabU[i] + (size_t)l0 * W.strideU[i], W.strideU[i], dU + (size_t)l0 * ins[i] * Rp, nullptr, l1 - l0, M, ins[i], Rp, Rc,
+                                formats.U[i][l0]}));
+        l0 = l1;
+      }
+      for (int l0 = 0; l0 < full;) {
+        int l1 = l0 + 1;
+        while (l1 < full && formats.V[i][l1] == formats.V[i][l0]) ++l1;
+        TRY(push(cara_ts_reduce{ws + W.slabV[i] + (size_t)l0 * W.strideV[i], W.strideV[i], dVs + (size_t)l0 * outs[i] * Rp, dc ? dc + (size_t)l0 * outs[i] : nullptr,
+                                l1 - l0, M, outs[i], Rp, Rc, formats.V[i][l0]}));
+        l0 = l1;
       }
       if (i != 0 && cls_shortcut_enabled()) {
         const size_t l = L - 1;
-        red[nred++] = cara_ts_reduce{ws + W.slabU[i] + l * W.strideU[i], 0, dU + l * ins[i] * Rp, nullptr, 1, B, ins[i], Rp, Rc};
-        red[nred++] = cara_ts_reduce{ws + W.slabV[i] + l * W.strideV[i], 0, dVs + l * outs[i] * Rp, dc + l * outs[i], 1, B, outs[i], Rp, Rc};
+        TRY(push(cara_ts_reduce{ws + W.slabU[i] + l * W.strideU[i], 0, dU + l * ins[i] * Rp, nullptr, 1, B, ins[i], Rp, Rc, 0}));
+        TRY(push(cara_ts_reduce{ws + W.slabV[i] + l * W.strideV[i], 0, dVs + l * outs[i] * Rp, dc + l * outs[i], 1, B, outs[i], Rp, Rc, 0}));
       }
     }
     TRY(cara_tskinny_reduce_many(red, nred, stream));

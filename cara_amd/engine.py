@@ -60,6 +60,10 @@ class CaraEngine:
         # "bf16" (default): the fast path, bf16 MFMA operands.  "bf16x3": eval / no_grad forwards run every product as three
         # split-bf16 MFMA products with fp32 activations (cara_amd/precise.py): a parity instrument that reaches north_star's
         # 1e-3 on the logits at ~3x the GEMM work; training always runs the fast path.
+        # "fp16": the SAME kernels compiled with IEEE-half MFMA operands (libcara_hip_f16.so: 11 significand bits at the bf16 MFMA
+        # rate) for forward AND backward -- logits inside north_star's 1e-3 of the fp32 reference (measured: tests/test_model_gpu.py,
+        # DESIGN.md section 2); the backward runs under a static loss scale (FP16_LOSS_SCALE: gradients need half's range, not its
+        # precision) that is divided out of the flat fp32 gradient buffer before the all-reduce.  Whole-model calls only.
         self.precision = "bf16"
         self._ingested = None
         self._ingest_sig = None
@@ -80,12 +84,21 @@ class CaraEngine:
         from .modules import FactorPack
         self._factors = FactorPack(self)
 
+    FP16_LOSS_SCALE = 1024.0
+
+    def _operands(self) -> str:
+        return "fp16" if self.precision == "fp16" else "bf16"
+
+    def _lib(self):
+        return L.lib(self._operands())
+
     # ------------------------------------------------------------------ frozen weights -> HBM layout
     def _backbone_params(self, model):
         return [p for n, p in model.named_parameters() if not n.startswith("CP_") and not n.startswith("head.")]
 
     def _signature(self, model):
-        return tuple((p.data_ptr(), p._version) for p in self._backbone_params(model))
+        # (the operand type is part of it: the 16-bit images of the frozen weights are written by the library in use)
+        return (self._operands(),) + tuple((p.data_ptr(), p._version) for p in self._backbone_params(model))
 
     def _ingest(self, model, dev):
         with torch.cuda.device(dev):
@@ -94,7 +107,7 @@ class CaraEngine:
     def _ingest_on(self, model, dev):
         """One-time (and after any in-place change / load_state_dict): frozen fp32 parameters ->
         bf16 [depth, out, in] stacks plus transposed copies for the dX GEMMs, fp32 vectors stacked."""
-        lib = L.lib()
+        lib = self._lib()
         stream = lambda: L.stream(dev)   # noqa: E731  (everything below enqueues on dev's current stream)
         blocks = list(model.blocks)
         depth, D = len(blocks), model.embed_dim
@@ -149,7 +162,7 @@ class CaraEngine:
             raise CaraError(f"weight_dropout must be 'off' or 'exact', not {self.weight_dropout!r}")
         if exact and self.cp_length == 2:
             raise CaraError("cp_length 2 (dense QKV deltas) runs with weight_dropout = 'off' only")
-        key = (B, img, ncls, str(dev), exact)
+        key = (B, img, ncls, str(dev), exact, self._operands())
         st = self._ws.get(key)
         if st is None:
             pe = model.patch_embed
@@ -160,7 +173,7 @@ class CaraEngine:
             patch = pe.proj.kernel_size[0]
             shape = L.VitShape(B, img, patch, pe.proj.in_channels, (img // patch) ** 2 + 1, ncls,
                                float(model.norm.eps), 1 if exact else 0, float(self.weight_dropout_p), 0)
-            nbytes = L.lib().cara_vit_workspace_bytes(C.byref(geom), C.byref(shape))
+            nbytes = self._lib().cara_vit_workspace_bytes(C.byref(geom), C.byref(shape))
             if nbytes == 0:
                 raise CaraError(f"unsupported geometry for the HIP path: {geom.depth=} {geom.dim=} {geom.heads=} "
                                 f"{shape.tokens=} (needs head dim 64, tokens <= 608, dim % 256 == 0)")
@@ -204,7 +217,7 @@ class CaraEngine:
         st["shape"].inference = 0 if need_backward else 1
         cps = self._cp_ptrs([t.detach().contiguous() for t in cp])
         logits = torch.empty_like(st["logits"])
-        check(L.lib().cara_vit_forward(C.byref(st["geom"]), C.byref(st["shape"]), C.byref(self._ingested[1]), C.byref(cps),
+        check(self._lib().cara_vit_forward(C.byref(st["geom"]), C.byref(st["shape"]), C.byref(self._ingested[1]), C.byref(cps),
                                        ptr(head_w.detach().contiguous()), ptr(head_b.detach().contiguous()), ptr(images),
                                        ptr(droppath), ptr(st["ws"]), ptr(logits), stream(dev)), "cara_vit_forward")
         self._fwd_serial += 1
@@ -230,10 +243,16 @@ class CaraEngine:
         g = self._grad_buffers(model, dev)
         cps = self._cp_ptrs([t.detach().contiguous() for t in cp])
         gps = L.cp_ptrs(self.cp_fields, [g[n] for n in self.cp_fields])
-        check(L.lib().cara_vit_backward(C.byref(st["geom"]), C.byref(st["shape"]), C.byref(self._ingested[1]), C.byref(cps),
-                                        ptr(head_w.detach().contiguous()), ptr(dlogits.contiguous().float()), ptr(droppath),
-                                        ptr(st["ws"]), C.byref(gps), ptr(g["head_w"]), ptr(g["head_b"]), stream(dev)),
+        dl = dlogits.contiguous().float()
+        scaled = self.precision == "fp16"
+        if scaled:   # static loss scale: every 16-bit gradient of the pass is FP16_LOSS_SCALE times larger, the fp32 sums are scaled back
+            dl = dl * self.FP16_LOSS_SCALE
+        check(self._lib().cara_vit_backward(C.byref(st["geom"]), C.byref(st["shape"]), C.byref(self._ingested[1]), C.byref(cps),
+                                            ptr(head_w.detach().contiguous()), ptr(dl), ptr(droppath),
+                                            ptr(st["ws"]), C.byref(gps), ptr(g["head_w"]), ptr(g["head_b"]), stream(dev)),
               "cara_vit_backward")
+        if scaled:
+            self._flat_grad.mul_(1.0 / self.FP16_LOSS_SCALE)
         self._bwd_ready = -1
         return g
 
@@ -299,8 +318,10 @@ class CaraEngine:
             raise CaraError("model parameters and images must be on the same device")
         params = [model.head.weight, model.head.bias, *cp]
         self._need_backward = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        if self.precision not in ("bf16", "bf16x3"):
-            raise CaraError(f"precision must be 'bf16' or 'bf16x3', not {self.precision!r}")
+        if self.precision not in ("bf16", "bf16x3", "fp16"):
+            raise CaraError(f"precision must be 'bf16', 'fp16' or 'bf16x3', not {self.precision!r}")
+        if self.precision == "fp16" and (self.weight_dropout == "exact" or self.cp_length == 2):
+            raise CaraError("precision = 'fp16' runs the factored adapters (weight_dropout = 'off', cp_length 3 / 4 / 5)")
         if self.precision == "bf16x3" and not model.training and not self._need_backward:
             from . import precise
             return precise.forward(model, images)
@@ -347,6 +368,8 @@ class CaraEngine:
         hw, hb = model.head.weight, model.head.bias
         if hw.device != dev or any(t.device != dev for t in cp):
             raise CaraError("model parameters and images must be on the same device")
+        if self.precision == "fp16" and (self.weight_dropout == "exact" or self.cp_length == 2):
+            raise CaraError("precision = 'fp16' runs the factored adapters (weight_dropout = 'off', cp_length 3 / 4 / 5)")
         with torch.no_grad(), torch.cuda.device(dev):
             if droppath is None:
                 droppath = self.draw_droppath(model, images.shape[0], dev)
@@ -357,7 +380,7 @@ class CaraEngine:
                 self._dlogits = torch.empty(B, ncls, device=dev)
             if self._dlogits.shape != logits.shape:
                 self._dlogits = torch.empty(B, ncls, device=dev)
-            check(L.lib().cara_cross_entropy(ptr(logits), ptr(labels.contiguous()), ptr(self._loss_buf), ptr(self._dlogits),
+            check(self._lib().cara_cross_entropy(ptr(logits), ptr(labels.contiguous()), ptr(self._loss_buf), ptr(self._dlogits),
                                              B, ncls, stream(dev)), "cara_cross_entropy")
             self._run_backward(self._dlogits, droppath, hw, cp)
             self._apply_gradients(optimizer, group)
@@ -376,6 +399,8 @@ class CaraEngine:
             raise CaraError("cara_amd runs on the GPU only (no CPU fallback)")
         if x.ndim != 3 or x.shape[2] != model.embed_dim or x.shape[1] > 608:
             raise CaraError("module-level forward expects x of shape [B, N <= 608, embed_dim]")
+        if self.precision == "fp16":
+            raise CaraError("precision = 'fp16' is a whole-model mode: call model(x) / train_step, not a block's Attention.forward / Mlp.forward")
         if self.cp_length == 2:
             raise CaraError("with cp_length 2 (dense QKV deltas) call the whole model: the module-level Attention.forward / "
                             "Mlp.forward entries run the factored adapters only")

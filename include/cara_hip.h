@@ -31,6 +31,9 @@ extern "C" {
 /* ---- library info ------------------------------------------------------------------------ */
 int cara_abi_version(void);              /* bumped on any signature change */
 const char* cara_build_arch(void);       /* "gfx950" */
+/* The 16-bit operand type of this build: "bf16" (libcara_hip.so) or "fp16" (libcara_hip_f16.so: the same sources compiled with
+ * IEEE-half operands at the same MFMA rate -- every "bf16" below then reads "fp16"; same ABI, struct for struct).           */
+const char* cara_operand_type(void);
 
 /* ---- GEMM with rank-R K-extension -------------------------------------------------------- */
 /* C = A[M,K] * B[N,K]^T  (+ A2[M,Rp] * B2[N,Rp]^T)  then an epilogue.  bf16 in, fp32 accumulate.
@@ -154,14 +157,46 @@ int cara_tskinny_partial2_r(const void* Xa, int ldxa, const void* Gta, void* sla
 int cara_gemm_with_tskinny_r(const cara_gemm_args* a, const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
                              const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b,
                              int ldg, int M, int Rp, int rank, void* stream);
+/* How the products that ride in cara_gemm_with_tskinny_r(a, ..., Rp, rank, ...) leave their partial sums: 0 = one slab per block
+ * (every other entry point of this section), 1 = one slab per WAVE, four per block -- the long-K, narrow-N dX products run on a
+ * 160 x 256 x 64 tile, one workgroup per CU, whose riding products are streamed by helper waves UNDER the tile's K loop: a helper
+ * wave owns one wave's steps of a block and writes its own slab (no combine through LDS).  Pass the answer as
+ * cara_ts_reduce::wave_slabs.  cara_tskinny_scratch_bytes() covers both forms.  Depends on the arguments only.            */
+int cara_gemm_rider_slab_format(const cara_gemm_args* a, int Rp, int rank);
 /* Up to CARA_TS_REDUCE_MAX of those reductions in ONE launch (each entry = the arguments of cara_tskinny_reduce). */
-#define CARA_TS_REDUCE_MAX 16
+#define CARA_TS_REDUCE_MAX 24
 typedef struct {
   const void* slabs; size_t slab_stride; float* D; float* colsum;   /* colsum may be NULL */
   int batch, M, K1, Rp;
   int Rc;   /* columns the slabs hold: 0 or Rp = all; 16 (at Rp = 32) = slabs written by the _r functions at rank <= 16 */
+  int wave_slabs;   /* 1: the product wrote one slab per WAVE of its blocks (four per block): what cara_gemm_with_tskinny_r does  */
+                    /* where cara_gemm_rider_slab_format() says so; 0: one slab per block                                        */
 } cara_ts_reduce;
 int cara_tskinny_reduce_many(const cara_ts_reduce* probs, int n, void* stream);
+
+/* ---- one adapted linear per call (cara_linear_fwd / cara_linear_bwd) -------------------------------- */
+/* The adapter linear of cara.py:25-42 (qkv), :50-58 (proj), :75-82 (fc1), :87-93 (fc2) in factored form as ONE call each way:
+ * compositions of the entry points above, for an integrator who patches one nn.Linear at a time (cara_vit_forward /
+ * cara_vit_backward schedule the same pieces with more fusion).  The per-layer factor images come from cara_factor_prep:
+ * Ut [Rp, in] = U^T, U [in, Rp], Vs [out, Rp] = s g (.) V, Vst [Rp, out] (bf16, columns / rows >= rank zero), bias = b + s c.  */
+typedef struct {
+  const void* W;  const void* Wt;     /* bf16 [out, in] frozen weight; [in, out] its transpose (backward only)             */
+  const void* Ut; const void* U;      /* bf16 [Rp, in], [in, Rp]                                                           */
+  const void* Vs; const void* Vst;    /* bf16 [out, Rp], [Rp, out]                                                         */
+  const float* bias;                  /* fp32 [out] or NULL                                                                */
+  int in, out, Rp, rank;              /* Rp in {32, 64}, 1 <= rank <= Rp                                                   */
+} cara_linear;
+/* Y = epilogue(X W^T + bias + (X U) Vs^T): T [M, Rp] = X U (bf16) and its transpose Tt [Rp, ldt] (ldt >= M rounded up to 32,
+ * multiple of 8) are WRITTEN -- the backward reads Tt.  epi / Y / Y2 / aux / rowscale / rows_per_sample: the epilogue fields of
+ * cara_gemm_args -- C, C2, aux, ...; ldy = 0: dense.  X bf16 [M, ldx].                                                     */
+int cara_linear_fwd(const cara_linear* L, const void* X, int ldx, int M, void* T, void* Tt, int ldt, int epi, void* Y, int ldy,
+                    void* Y2, const void* aux, const float* rowscale, int rows_per_sample, void* stream);
+/* Given dY bf16 [M, lddy], the saved input X and the forward's Tt: G [M, Rp] = dY Vs and Gt (scratch, written);
+ * dX bf16 [M, lddx] = dY W + G U^T (skipped when NULL); dU fp32 [in, Rp] = X^T G, dVs fp32 [out, Rp] = dY^T T, dc fp32 [out] =
+ * column sums of dY (NULL: not wanted) -- the gradients cara_factor_grad_reduce takes per layer.  slabs_u / slabs_v:
+ * cara_tskinny_scratch_bytes(M, in, Rp) / (M, out, Rp) bytes of caller scratch.                                             */
+int cara_linear_bwd(const cara_linear* L, const void* dY, int lddy, const void* X, int ldx, const void* Tt, int M, void* G, void* Gt,
+                    int ldt, void* dX, int lddx, void* slabs_u, void* slabs_v, float* dU, float* dVs, float* dc, void* stream);
 
 /* ---- LayerNorm (eps inside the sqrt, biased variance; timm Block norm1/norm2/norm) ------- */
 /* y bf16 [M,C] = (x - mean) * rstd * gamma + beta; saves mean, rstd fp32 [M].  x fp32 rows with
@@ -409,7 +444,7 @@ int cara_head_backward(const float* dlogits, const void* xn_bf16, const float* h
  * unknown id.                                                                                                   */
 enum {
   CARA_STRUCT_GEMM_ARGS = 0, CARA_STRUCT_GEOM, CARA_STRUCT_CP, CARA_STRUCT_PACK_LAYOUT, CARA_STRUCT_LAYER_GRADS,
-  CARA_STRUCT_VIT_WEIGHTS, CARA_STRUCT_VIT_SHAPE, CARA_STRUCT_TS_REDUCE, CARA_STRUCT_ADAMW_ARGS,
+  CARA_STRUCT_VIT_WEIGHTS, CARA_STRUCT_VIT_SHAPE, CARA_STRUCT_TS_REDUCE, CARA_STRUCT_LINEAR, CARA_STRUCT_ADAMW_ARGS,
   CARA_STRUCT_COUNT
 };
 size_t cara_sizeof_struct(int which);

@@ -42,7 +42,7 @@ def header_struct(name):
 MIRRORS = {
     "cara_gemm_args": _lib.GemmArgs, "cara_geom": _lib.Geom, "cara_cp": _lib.CpPtrs, "cara_pack_layout": _lib.PackLayout,
     "cara_layer_grads": _lib.LayerGrads, "cara_vit_weights": _lib.VitWeights, "cara_vit_shape": _lib.VitShape,
-    "cara_ts_reduce": _lib.TsReduce,
+    "cara_ts_reduce": _lib.TsReduce, "cara_linear": _lib.Linear,
 }
 
 

@@ -1058,3 +1058,60 @@ def test_adapter_inside_gemm_with_the_rank_stated(M, N, K, rank, epi):
         assert torch.equal(x, y)
     assert torch.count_nonzero(res[1][1][:, rank:]) == 0 and torch.equal(res[1][2], res[1][1].t())
     close(res[1][1], A.double() @ Ut.double().t(), 2 ** -8, 1e-3 * math.sqrt(K / 64), "T inside")
+
+
+@pytest.mark.parametrize("M,din,dout,rank,epi", [(1000, 768, 2304, 16, "bf16"), (394, 3072, 768, 8, "resid"), (12608, 3072, 768, 16, "resid")])
+def test_one_adapted_linear_per_call(M, din, dout, rank, epi):
+    """cara_linear_fwd / cara_linear_bwd (SURVEY 8b's minimum export set): the adapter linear of cara.py:25-42 / :50-58 / :75-82 /
+    :87-93 in factored form as ONE call each way, against the as-written arithmetic in fp64 -- y = x W^T + b + (x U) Vs^T and the
+    gradients dX, dU = X^T (dY Vs), dVs = dY^T (X U), dc = colsum dY that cara_factor_grad_reduce takes."""
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+    lib.cara_tskinny_scratch_bytes.restype = C.c_size_t
+    Rp = 32
+    X, W = rnd(M, din, seed=1), rnd(dout, din, seed=2, scale=0.05)
+    U, Vs = rnd(din, Rp, seed=3, scale=0.1), rnd(dout, Rp, seed=4, scale=0.3)
+    U[:, rank:] = 0
+    Vs[:, rank:] = 0
+    bias = rnd(dout, seed=5, dtype=torch.float32)
+    lin = L().Linear()
+    lin.W, lin.Wt, lin.Ut, lin.U, lin.Vs, lin.Vst = p(W), p(W.t().contiguous()), p(U.t().contiguous()), p(U), p(Vs), p(Vs.t().contiguous())
+    keep = [W.t().contiguous(), U.t().contiguous(), Vs.t().contiguous()]
+    lin.W, lin.Wt, lin.Ut, lin.Vst = p(W), p(keep[0]), p(keep[1]), p(keep[2])
+    lin.bias = p(bias)
+    setattr(lin, "in", din)
+    lin.out, lin.Rp, lin.rank = dout, Rp, rank
+    ldt = (M + 31) // 32 * 32
+    T = torch.full((M, Rp), float("nan"), dtype=torch.bfloat16, device=DEV)
+    Tt = torch.zeros(Rp, ldt, dtype=torch.bfloat16, device=DEV)
+    if epi == "bf16":
+        Y = torch.full((M, dout), float("nan"), dtype=torch.bfloat16, device=DEV)
+        L().check(lib.cara_linear_fwd(C.byref(lin), p(X), din, M, p(T), p(Tt), ldt, L().EPI_BF16, p(Y), 0, None, None, None, 0, st()), "cara_linear_fwd")
+        ref = X.double() @ W.double().t() + bias.double() + T.double() @ Vs.double().t()
+        close(Y, ref, 2 ** -8, 2e-3 * math.sqrt(din / 64), "linear forward")
+    else:
+        aux = rnd(M, dout, seed=6, dtype=torch.float32)
+        rs = (torch.arange((M + 196) // 197, device=DEV) % 2).float() * 1.1
+        Y = torch.full((M, dout), float("nan"), device=DEV)
+        L().check(lib.cara_linear_fwd(C.byref(lin), p(X), din, M, p(T), p(Tt), ldt, L().EPI_RESID, p(Y), 0, None, p(aux), p(rs), 197, st()), "cara_linear_fwd")
+        ref = aux.double() + rs.double().repeat_interleave(197)[:M, None] * (X.double() @ W.double().t() + bias.double() + T.double() @ Vs.double().t())
+        close(Y, ref, 1e-5, 2e-3 * math.sqrt(din / 64), "linear forward (residual epilogue)")
+    close(T, X.double() @ U.double(), 2 ** -8, 1e-3 * math.sqrt(din / 64), "T = X U")
+    assert torch.equal(Tt[:, :M], T.t())
+    # backward
+    dY = rnd(M, dout, seed=7, scale=0.1)
+    G = torch.full((M, Rp), float("nan"), dtype=torch.bfloat16, device=DEV)
+    Gt = torch.zeros(Rp, ldt, dtype=torch.bfloat16, device=DEV)
+    dX = torch.full((M, din), float("nan"), dtype=torch.bfloat16, device=DEV)
+    su = torch.zeros(int(lib.cara_tskinny_scratch_bytes(M, din, Rp)), dtype=torch.uint8, device=DEV)
+    sv = torch.zeros(int(lib.cara_tskinny_scratch_bytes(M, dout, Rp)), dtype=torch.uint8, device=DEV)
+    dU, dVs, dc = torch.empty(din, Rp, device=DEV), torch.empty(dout, Rp, device=DEV), torch.empty(dout, device=DEV)
+    L().check(lib.cara_linear_bwd(C.byref(lin), p(dY), dout, p(X), din, p(Tt), M, p(G), p(Gt), ldt, p(dX), 0, p(su), p(sv), p(dU), p(dVs), p(dc), st()),
+              "cara_linear_bwd")
+    close(G, dY.double() @ Vs.double(), 2 ** -8, 1e-3 * math.sqrt(dout / 64), "G' = dY Vs")
+    close(dX, dY.double() @ W.double() + G.double() @ U.double().t(), 2 ** -8, 2e-3 * math.sqrt(dout / 64), "dX")
+    close(dU, X.double().t() @ G.double(), 1e-3, 2e-2 * math.sqrt(M / 1000), "dU")
+    close(dVs, dY.double().t() @ T.double(), 1e-3, 2e-2 * math.sqrt(M / 1000), "dVs")
+    close(dc, dY.double().sum(0), 1e-3, 1e-2 * math.sqrt(M / 1000), "dc")
+    bad = L().Linear()
+    assert lib.cara_linear_fwd(C.byref(bad), p(X), din, M, p(T), p(Tt), ldt, L().EPI_BF16, p(Y), 0, None, None, None, 0, st()) != 0
