@@ -479,6 +479,18 @@ def main():
             o2 = AdamW(tr2, lr=1e-3, weight_decay=1e-4)
             info["order2_qkv_ms_per_step"] = round(timed_steps(lambda: e2.train_step(x, y, o2)), 3)
 
+        def leg_fp16():
+            # precision = "fp16": the same kernels with IEEE-half MFMA operands (same MFMA rate), forward and backward -- the mode
+            # whose logits sit inside north_star's 1e-3 of the fp32 reference (tests/test_model_gpu.py::test_fp16_precision_*)
+            try:
+                eng.precision = "fp16"
+                info["fp16_ms_per_step"] = round(timed_steps(step), 3)
+                info["fp16_images_per_sec"] = round(args.batch / info["fp16_ms_per_step"] * 1e3, 1)
+            finally:
+                eng.precision = "bf16"
+                eng._ws.clear()
+
+        leg("fp16", leg_fp16)
         leg("exact_dropout", leg_exact)
         leg("rank64", leg_rank64)
         leg("order2_qkv", leg_order2)
@@ -573,7 +585,8 @@ def main():
         if info:
             info["note"] = ("informational, 5 steps each after 2 warm-ups, same box and process: exact = the reference's train-mode "
                             "Dropout(0.1) on the materialised dW (cara.py:35,57,81,92); rank64 = BASELINE.json configs[3] (82.61 GF/image); order2_qkv = cp_length 2 of dim_experiment.py (dense dim x dim QKV deltas) at the headline rank and batch; "
-                            "blended = (165 exact + 1335 factored) / 1500, the reference's stuck-in-eval recipe (SURVEY 3.3)")
+                            "blended = (165 exact + 1335 factored) / 1500, the reference's stuck-in-eval recipe (SURVEY 3.3); fp16 = precision 'fp16' "
+                            "(libcara_hip_f16.so: the same kernels with IEEE-half MFMA operands, logits within 1e-3 of the fp32 reference)")
             out["informational"] = info
         if world == 1 and not args.no_cpu_baseline and not large:
             out["cpu_baseline"] = cpu_baseline(scale)
