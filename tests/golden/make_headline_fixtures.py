@@ -10,7 +10,9 @@ algorithm (oracle/cara_oracle.py, itself pinned to the reference by make_golden.
 The GPU test (tests/test_model_gpu.py::test_headline_batch_64_whole_model) then needs no 100-second CPU forward +
 backward per rank on the GPU box.  Inputs are the seeded synthetic tensors of SURVEY 8d (oracle.synthetic_*), so the
 test regenerates them bit for bit.  Usage:  python tests/golden/make_headline_fixtures.py [16 64]   |   ... vitl
-(`vitl`: the expected values of the ViT-L/16 @384 parity test, tests/golden/vit_large_384_b2_r16.npz)
+(`vitl`: the expected values of the ViT-L/16 @384 parity test, tests/golden/vit_large_384_b2_r16.npz;
+ `vitl32`: the eval logits of BASELINE.json configs[4] at its REAL per-GPU batch, 32 x 577 = 18 464 token rows,
+ tests/golden/vit_large_384_b32_r16_logits.npz)
 """
 import os
 import sys
@@ -57,6 +59,25 @@ def main():
         print(f"rank {rank}: loss {loss.item():.6f}, {os.path.getsize(path) / 1e6:.2f} MB, {time.time() - t0:.0f} s", flush=True)
 
 
+def vit_large_b32():
+    """BASELINE.json configs[4] at its real batch (32 images @384: M = 18 464 token rows, 115.4 row tiles of 160): eval-mode logits
+    of the fp32 as-written oracle and of its bf16-rounded form, 8 samples at a time (samples are independent in eval mode)."""
+    t0 = time.time()
+    dims = dict(depth=24, dim=1024, heads=16)
+    w = O.synthetic_backbone(img=384, **dims)
+    cp = O.synthetic_cp(rank=16, **dims)
+    x, _ = O.synthetic_batch(batch=32, img=384)
+    ref, sim = [], []
+    with torch.no_grad():
+        for i in range(0, 32, 8):
+            ref.append(O.vit_cara_forward(x[i:i + 8], w, cp, s=0.1, depth=24, num_heads=16))
+            sim.append(O.vit_cara_forward(x[i:i + 8], w, cp, s=0.1, depth=24, num_heads=16, factored=True, bf16_sim=True))
+            print(f"  samples {i}..{i + 7}: {time.time() - t0:.0f} s", flush=True)
+    path = os.path.join(HERE, "vit_large_384_b32_r16_logits.npz")
+    np.savez_compressed(path, logits=torch.cat(ref).numpy(), logits_bf16_sim=torch.cat(sim).numpy())
+    print(f"ViT-L/16 @384, batch 32: {os.path.getsize(path) / 1e6:.2f} MB, {time.time() - t0:.0f} s", flush=True)
+
+
 def vit_large():
     """tests/test_model_gpu.py::test_vit_large_384_against_oracle: ViT-L/16 @384 dimensioning, batch 2, rank 16, eval mode:
     fp32 logits, bf16-rounded logits, gradients of the mean cross-entropy (60 s of CPU on the GPU box otherwise)."""
@@ -79,6 +100,10 @@ def vit_large():
     print(f"ViT-L/16 @384: {os.path.getsize(path) / 1e6:.2f} MB, {time.time() - t0:.0f} s", flush=True)
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "vitl32":
+    torch.set_num_threads(os.cpu_count() or 8)
+    vit_large_b32()
+    sys.exit(0)
 if __name__ == "__main__":
     if sys.argv[1:] == ["vitl"]:
         torch.set_num_threads(os.cpu_count() or 8)

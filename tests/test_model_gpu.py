@@ -183,6 +183,35 @@ def test_vit_large_384_against_oracle():
     assert rel(m.head.weight.grad, gref["head.weight"]) < T.CP_GRAD
 
 
+def test_vit_large_384_at_its_real_batch():
+    """BASELINE.json configs[4] at its REAL per-GPU batch: ViT-L/16 @384, 32 images -> M = 18 464 token rows (115.4 row tiles of
+    160, 144.25 of 128: the 160 x 256 x 64 tile's edge workgroups, the two-sweep attention at 32 x 16 heads), rank 16, eval mode.
+    Logits against the fp32 as-written oracle and its bf16-rounded form, committed by tests/golden/make_headline_fixtures.py vitl32
+    (115 s of CPU); the class index of every sample, no margin filter; and the same with precision = "fp16"."""
+    from oracle import cara_oracle as O
+    fx = os.path.join(os.path.dirname(__file__), "golden", "vit_large_384_b32_r16_logits.npz")
+    if not os.path.exists(fx):
+        pytest.skip("the committed ViT-L batch-32 fixture is missing")
+    F_ = np.load(fx)
+    ref, sim = torch.from_numpy(F_["logits"]), torch.from_numpy(F_["logits_bf16_sim"])
+    dims = dict(depth=24, dim=1024, heads=16)
+    w = O.synthetic_backbone(img=384, **dims)
+    cp = O.synthetic_cp(rank=16, **dims)
+    x, _ = O.synthetic_batch(batch=32, img=384)
+    m = build(w, cp, 16, 0.1, 24, 384, name="vit_large_patch16_384").eval()
+    with torch.no_grad():
+        logits = m(x.to(DEV))
+        m._cara_engine.precision = "fp16"
+        half = m(x.to(DEV))
+    r_ref, r_model, r_half = rel(logits, ref), rel(sim, ref), rel(half, ref)
+    differ = int((logits.argmax(1).cpu() != ref.argmax(1)).sum()), int((half.argmax(1).cpu() != ref.argmax(1)).sum())
+    print(f"\nViT-L/16@384, batch 32 (M = 18464): logits rel-L2 vs fp32 oracle bf16 {r_ref:.2e} (rounding model {r_model:.2e}), fp16 {r_half:.2e}; "
+          f"class indices that differ of 32: bf16 {differ[0]}, fp16 {differ[1]}")
+    assert T.logits_ok(r_ref, r_model), (r_ref, r_model)
+    assert r_half < 0.25 * r_ref and r_half <= 1.5e-3      # (24 blocks deep: the fp16 rounding model gives ~1.2e-3)
+    assert differ[1] == 0
+
+
 def test_depth12_headline_shapes_against_oracle():
     """ViT-B/16 depth 12, rank 16, 197 tokens, synthetic weights of SURVEY 8(d), batch 4."""
     from oracle import cara_oracle as O
