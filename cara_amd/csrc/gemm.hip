@@ -974,7 +974,15 @@ bool cara_gemm8_policy(int M, int N, int K, int riders) {
   static const int mink = [] { const char* e = getenv("CARA_GEMM8_MINK"); return e ? atoi(e) : 2048; }();
   static const int maxn = [] { const char* e = getenv("CARA_GEMM8_MAXN"); return e ? atoi(e) : 1024; }();
   static const int maxk_ts = [] { const char* e = getenv("CARA_GEMM8_MAXK_TS"); return e ? atoi(e) : 2304; }();
-  return on == 160 && M >= 4096 && (M % 16) == 0 && (N % 16) == 0 && N <= maxn && K >= mink && (!riders || K <= maxk_ts);
+  // CARA_GEMM8_ALSO (A/B runs): more shape classes on the tile -- 1: N = 3 dim, K = dim without riders (qkv forward); 2: N = K = dim
+  // without riders (proj forward); 4: N = K = dim with riders (proj dX)
+  static const int also = [] { const char* e = getenv("CARA_GEMM8_ALSO"); return e ? atoi(e) : 0; }();
+  if (on != 160 || M < 4096 || (M % 16) || (N % 16)) return false;
+  if (N <= maxn && K >= mink && (!riders || K <= maxk_ts)) return true;
+  if ((also & 1) && !riders && N == 3 * K) return true;
+  if ((also & 2) && !riders && N == K && N <= maxn) return true;
+  if ((also & 4) && riders && N == K && N <= maxn) return true;
+  return false;
 }
 
 extern "C" int cara_gemm_bf16(const cara_gemm_args* a, void* stream) { return gemm_bf16_impl(a, stream, nullptr); }
