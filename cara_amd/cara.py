@@ -249,6 +249,10 @@ def cara(config: Dict[str, Any]) -> th.nn.Module:
         raise CaraError("cp_length must be 2, 3, 4 or 5")
     if cp_length == 2 and config.get("weight_dropout", "off") == "exact":
         raise CaraError("cp_length 2 (dense QKV deltas) runs with weight_dropout = 'off' only")
+    if cp_length == 2 and getattr(model, "embed_dim", 128) % 128:
+        raise CaraError("cp_length 2 (dense QKV deltas) needs embed_dim % 128 == 0 (its backward forms the dense x^T dY in 128 x 128 tiles)")
+    if config.get("precision", "bf16") == "bf16x3" and cp_length != 4:
+        raise CaraError("precision = 'bf16x3' (the split-operand parity instrument) evaluates the cp_length 4 tensorisation only")
     global global_model
     global_model = model
     set_cara(model, rank, scale, l_mu, l_std, cp_length=cp_length)

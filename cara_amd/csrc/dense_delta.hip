@@ -151,8 +151,10 @@ __global__ __launch_bounds__(256) void dd_sum_slabs_kernel(const float* __restri
   out[j] = s0 + s1;
 }
 
+// (dim % 128: the backward's dense dD = x^T dY comes from cara_gemm_tn_f32, whose output tiles are 128 x 128 -- refused here, at
+// set-up, not in the middle of a backward pass)
 bool dd_geom_ok(const cara_geom* g) {
-  return g && g->cp_length == 2 && g->depth > 0 && 3 * g->depth <= DD_MAXLK && g->dim > 0 && g->dim % 32 == 0 && g->rank > 0 && g->rank <= 64;
+  return g && g->cp_length == 2 && g->depth > 0 && 3 * g->depth <= DD_MAXLK && g->dim > 0 && g->dim % 128 == 0 && g->rank > 0 && g->rank <= 64;
 }
 
 }  // namespace

@@ -148,6 +148,7 @@ bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
   w->dd = w->ddt = w->dD = w->dd_slabs = w->dd_scratch = 0;
   if (g->cp_length == 2) {
     if (s->wd_exact) return false;   // (the dense-delta QKV form and the exact weight-dropout mode are not combined)
+    if (g->dim % 128) return false;  // (its backward's dense x^T dY: 128 x 128 output tiles, cara_gemm_tn_f32)
     w->dd = c.take((size_t)g->depth * 3 * D * D * 2);
     w->ddt = c.take((size_t)g->depth * 3 * D * D * 2);
     w->dD = c.take((size_t)g->depth * 3 * D * D * 4);
@@ -360,7 +361,7 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
   // with the dU products riding one launch later (CARA_DEFER_DU) nothing in a linear's own dX launch reads its G', so the GEMM
   // can compute it inside and the separate pass over dY goes (CARA_GEMM_G_INSIDE=0 keeps the pass)
   const bool g_inside = !inside && !have_G && want_dx && can_carry && defer_du() && pend && g_inside_enabled(L.slot) &&
-                        fuse_gemm_t(Mr, Rp, false) && a.epi == CARA_EPI_BF16;
+                        (Rp == 32 || Rp == 64) && Mr >= 1024 && a.epi == CARA_EPI_BF16;   // (its own switch: CARA_GEMM_G_INSIDE)
   if (!have_G && !inside && !g_inside) {
     SiteBracket b(CARA_SITE_SKINNY_BWD, cx);
     TRY(cara_skinny_xu_r(dY, lddy, L.Vst, G, Gt, ldt, Mr, L.out, Rp, cx.rank > 0 ? cx.rank : Rp, st));

@@ -44,8 +44,15 @@ class AdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        entries = []
-        step = None
+        # (re-checked at every step: param groups may have been added since the constructor ran)
+        if len(self.param_groups) > L.ADAMW_MAX_GROUPS:
+            raise CaraError(f"cara_amd.optim.AdamW takes at most {L.ADAMW_MAX_GROUPS} parameter groups")
+        b = self.param_groups[0]
+        if any(g["betas"] != b["betas"] or g["eps"] != b["eps"] for g in self.param_groups):
+            raise CaraError("cara_amd.optim.AdamW: betas and eps are shared by all parameter groups")
+        # parameters bucketed by their step count (torch keeps one per parameter: a parameter whose grad was None for a while, one
+        # added later or a loaded state with mixed steps simply has another count): the bias corrections are per launch
+        buckets = {}
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
                 if p.grad is None:
@@ -56,30 +63,26 @@ class AdamW(torch.optim.Optimizer):
                     raise CaraError("cara_amd.optim.AdamW needs contiguous parameters and gradients")
                 st = self._init_state(p)
                 st["step"] += 1
-                s = int(st["step"].item())
-                if step is None:
-                    step = s
-                elif s != step:
-                    raise CaraError("cara_amd.optim.AdamW: the parameters have been stepped a different number of times")
-                entries.append((p, st, gi))
-        if not entries:
+                buckets.setdefault(int(st["step"].item()), []).append((p, st, gi))
+        if not buckets:
             return loss
-        dev = entries[0][0].device
-        if any(e[0].device != dev for e in entries):
+        dev = next(iter(buckets.values()))[0][0].device
+        if any(e[0].device != dev for es in buckets.values() for e in es):
             raise CaraError("cara_amd.optim.AdamW: all parameters on one device")
         b1, b2 = self.param_groups[0]["betas"]
         with torch.cuda.device(dev):
-            for i in range(0, len(entries), L.ADAMW_MAX_TENSORS):
-                part = entries[i:i + L.ADAMW_MAX_TENSORS]
-                a = L.AdamWArgs()
-                for j, (p, st, gi) in enumerate(part):
-                    a.t[j] = L.AdamWTensor(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                                           p.numel(), gi)
-                a.ntensors, a.step = len(part), step
-                for gi, group in enumerate(self.param_groups):
-                    a.lr[gi], a.weight_decay[gi] = group["lr"], group["weight_decay"]
-                a.one_minus_beta1, a.beta2, a.one_minus_beta2, a.eps = 1.0 - b1, b2, 1.0 - b2, self.param_groups[0]["eps"]
-                a.bias_correction1 = 1.0 - b1 ** step
-                a.bias_correction2_sqrt = math.sqrt(1.0 - b2 ** step)
-                L.check(L.lib().cara_adamw_step(C.byref(a), L.stream(dev)), "cara_adamw_step")
+            for step, entries in sorted(buckets.items()):
+                for i in range(0, len(entries), L.ADAMW_MAX_TENSORS):
+                    part = entries[i:i + L.ADAMW_MAX_TENSORS]
+                    a = L.AdamWArgs()
+                    for j, (p, st, gi) in enumerate(part):
+                        a.t[j] = L.AdamWTensor(p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                               p.numel(), gi)
+                    a.ntensors, a.step = len(part), step
+                    for gi, group in enumerate(self.param_groups):
+                        a.lr[gi], a.weight_decay[gi] = group["lr"], group["weight_decay"]
+                    a.one_minus_beta1, a.beta2, a.one_minus_beta2, a.eps = 1.0 - b1, b2, 1.0 - b2, self.param_groups[0]["eps"]
+                    a.bias_correction1 = 1.0 - b1 ** step
+                    a.bias_correction2_sqrt = math.sqrt(1.0 - b2 ** step)
+                    L.check(L.lib().cara_adamw_step(C.byref(a), L.stream(dev)), "cara_adamw_step")
         return loss

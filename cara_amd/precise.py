@@ -80,6 +80,15 @@ def forward(model, images: torch.Tensor) -> torch.Tensor:
         raise CaraError("the bf16x3 parity instrument covers the default tensorisation (cp_length 4)")
     if not images.is_cuda:
         raise CaraError("cara_amd runs on the GPU only (no CPU fallback)")
+    if images.ndim != 4 or images.shape[2] != images.shape[3]:
+        raise CaraError("images must be [B, C, H, H]")
+    pk = model.patch_embed.proj.kernel_size[0]
+    if images.shape[2] % pk or (images.shape[2] // pk) ** 2 + 1 != model.pos_embed.shape[1]:
+        raise CaraError("the image size does not match the model's position embedding")
+    if images.shape[0] > 8:
+        # the attention core of this instrument is a Python loop over (image, head) pairs, three launches per product: use it on a
+        # few images (precision = "fp16" is the mode that meets 1e-3 at full speed and batch)
+        raise CaraError("precision = 'bf16x3' is a parity instrument for at most 8 images per call; use precision = 'fp16' for full batches")
     s = float(eng.scale)
     dev = images.device
     with torch.cuda.device(dev):
