@@ -982,6 +982,7 @@ bool cara_gemm8_policy(int M, int N, int K, int riders) {
   if ((also & 1) && !riders && N == 3 * K) return true;
   if ((also & 2) && !riders && N == K && N <= maxn) return true;
   if ((also & 4) && riders && N == K && N <= maxn) return true;
+  if ((also & 8) && !riders && N == 4 * K) return true;   // 8: N = 4 dim, K = dim without riders (fc1 forward)
   return false;
 }
 

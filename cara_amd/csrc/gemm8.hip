@@ -388,9 +388,18 @@ __device__ __forceinline__ void g8_tile(const cara_gemm_args& p, const int tiles
 #undef G8_TILE
 }
 
+// stagger > 0 (products of several rounds of tiles: N = 4 dim / 3 dim): the workgroups of the FIRST round start (blockIdx % 4) x
+// stagger x 64 clocks apart.  One tile per CU makes every CU end its tile at the same moment: all epilogues of a round hit HBM
+// together (155 MB per launch for fc1 forward: 31 us at 5 TB/s, four bursts with the chip's matrix pipes idle) and the next round
+// starts in lockstep again.  A quarter-period offset between neighbouring CUs, paid once, lets one group's stores run under the
+// other groups' K loops for the rest of the launch.
 template <class G, int EPI, int MODE>
-__global__ __launch_bounds__(512, 2) void gemm8_kernel(const cara_gemm_args p, const int tiles_n, const int nwg) {
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int stagger) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (stagger > 0 && blockIdx.x < 256) {
+    const int n = (int)((blockIdx.x >> 3) & 3) * stagger;   // (blocks b, b + 8 share an XCD: the offset varies inside an XCD)
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   constexpr bool TWO_CLASSES = (G::NPA0 % 8) != 0 || (G::NPA1 % 8) != 0;
   if constexpr (TWO_CLASSES) {
     if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) g8_tile<G, EPI, 0, MODE>(p, tiles_n, nwg, blockIdx.x, smem);
@@ -821,7 +830,8 @@ int g8_launch(const cara_gemm_args* a, hipStream_t st, const cara_g8_riders* ts,
         return CARA_E_LAUNCH;
       attr = true;
     }
-    hipLaunchKernelGGL((gemm8_kernel<G, EPI, MODE>), dim3(nwg), dim3(512), G::LDS, st, *a, tiles_n, nwg);
+    static const int stagger_env = [] { const char* e = getenv("CARA_GEMM8_STAGGER"); return e ? atoi(e) : 0; }();
+    hipLaunchKernelGGL((gemm8_kernel<G, EPI, MODE>), dim3(nwg), dim3(512), G::LDS, st, *a, tiles_n, nwg, nwg > 256 ? stagger_env : 0);
     CARA_CHECK_LAUNCH();
     return CARA_OK;
   }

@@ -21,14 +21,16 @@ MB = 1e6
 SITES = {
     "fc1_fwd": ("gemm32_kernel<2,", lambda r, w: w > 120 * MB),                 # two bf16 outputs of [12608, 3072]
     "qkv_fwd": ("gemm32_kernel<0,", lambda r, w: w > 50 * MB),
-    "fc2_fwd": ("gemm32ft_kernel<3", lambda r, w: r > 100 * MB),               # reads h (77 MB) + the fp32 residual
+    # (r04: fc2 forward and qkv dX run on the 160 x 256 x 64 tile of gemm8.hip; the gemm32ft patterns cover CARA_GEMM8=0 runs)
+    "fc2_fwd": [("gemm8_kernel<", lambda r, w: r > 100 * MB), ("gemm32ft_kernel<3", lambda r, w: r > 100 * MB)],   # reads h (77 MB) + the fp32 residual
     "proj_fwd": ("gemm32ft_kernel<3", lambda r, w: 30 * MB < r <= 100 * MB),
     "fc2_bwd": ("gemm32_ts_kernel<4, true", lambda r, w: w > 50 * MB),
     # (with G' inside -- the default since round 3 -- fc1 / qkv dX run gemm32ft_ts_kernel<BF16, NU = 1, COLSUM, ...>: COLSUM tells them apart)
     "fc1_bwd": [("gemm32ft_ts_kernel<0, 1, true", lambda r, w: w > 10 * MB),
                 ("gemm32_ts_kernel<0, true", lambda r, w: r > 150 * MB)],       # dH as GEMM operand and as the products' operand
     "proj_bwd": ("gemm32_ts_kernel<0, true", lambda r, w: 20 * MB < r <= 150 * MB),
-    "qkv_bwd": [("gemm32ft_ts_kernel<0, 1, false", lambda r, w: w > 10 * MB), ("gemm32_ts_kernel<0, false", lambda r, w: w > 10 * MB)],
+    "qkv_bwd": [("gemm8_ts_kernel<", lambda r, w: w > 10 * MB), ("gemm32ft_ts_kernel<0, 1, false", lambda r, w: w > 10 * MB),
+                ("gemm32_ts_kernel<0, false", lambda r, w: w > 10 * MB)],
     "attn_fwd": ("attn_fwd_persist_kernel", lambda r, w: True),
     "attn_bwd": ("attn_bwd_fused_kernel", lambda r, w: True),
     "ln_fwd": ("ln_fwd_kernelILi3ELb1", lambda r, w: w > 15 * MB),
