@@ -78,6 +78,32 @@ __device__ __forceinline__ float gelu_erf_grad(float u) {
   return __builtin_fmaf(u * 0.39894228040143268f, e, cdf);
 }
 
+// gelu(u) and gelu'(u) together (the epilogue that rebuilds h = gelu(u) next to dH = dY gelu'(u)): the two share e and P;
+// each result is bitwise what gelu_erf / gelu_erf_grad return
+__device__ __forceinline__ void gelu_erf_both(float u, float& g, float& gp) {
+#ifdef CARA_ABLATE_GELU
+  g = gp = u * 0.5f;
+  return;
+#endif
+  float e;
+  const float au = fabsf(u);
+  const float hp = gelu_half_poly(au, e, u * u);
+  g = __builtin_fmaf(-(au * hp), e, fmaxf(u, 0.f));
+  const float half_erf = __builtin_fmaf(-hp, e, 0.5f);
+  gp = __builtin_fmaf(u * 0.39894228040143268f, e, 0.5f + __builtin_copysignf(half_erf, u));
+}
+
+// D[16 x 16] += A[16 x 16] B[16 x 16] on four operand values per lane (lane l: A[l % 16][4 (l / 16) ..], B[4 (l / 16) ..][l % 16]):
+// the K = 16 MFMA, for products whose reduction index comes in runs of four (one transposing LDS read per fragment)
+__device__ __forceinline__ f32x4 mfma_16x16x16(bf16x4 a, bf16x4 b, f32x4 c) {
+#ifdef CARA_F16_OPERANDS
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+#else
+  typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a), __builtin_bit_cast(s16x4_t, b), c, 0, 0, 0);
+#endif
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -159,7 +159,8 @@ __device__ __forceinline__ void stage_ext32(const bf16* __restrict__ P, int Rp, 
 // one workgroup's tile; `block` = its index among the nwg tiles of the product, `zb` = product index of a batched launch
 // TWOB: every K step stages B AND B3 (cara_gemm_args::B3: same shape and ldb) next to the A tile and runs both products on
 // the same A fragments (24 KiB slots: three workgroups per CU; the first form ran the K loop twice and staged A twice)
-template <int EPI, int MI, int NW, bool TWOB = false>
+// ER: CARA_EPI_DGELU with epilogue riders (cara_gemm_args::er_*, gemm_epilogue.h)
+template <int EPI, int MI, int NW, bool TWOB = false, bool ER = false>
 __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int tiles_n, const int nwg, const int gm,
                                             const int block, const size_t zb_in, char* smem) {
   constexpr int TBM = MI * 16 * (NW / 2);
@@ -267,6 +268,70 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
   constexpr int WAVE_STG = HALF * 64 * 4 > EPI_FAST_WAVE_BYTES ? HALF * 64 * 4 : EPI_FAST_WAVE_BYTES;
   __syncthreads();
   STAMP(1);
+  if constexpr (ER) {
+    static_assert(EPI == CARA_EPI_DGELU && NW == 4 && !TWOB, "epilogue riders: the fc2 dX product");
+    static_assert(4 * (WAVE_STG + ER_WAVE_BYTES) <= 2 * SLOT, "the images fit beside the staging areas");
+    const int fr = lane & 15, fq = lane >> 4;
+    f32x4 rv[4], ru[4];
+    float cs[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rv[j] = ru[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cs[k] = 0.f;
+    float* stg = reinterpret_cast<float*>(smem + wave * WAVE_STG);
+    char* img = smem + 4 * WAVE_STG + wave * ER_WAVE_BYTES;
+    epilogue_dgelu_riders<MI>(p, acc, stg, img, m0 + wr * (MI * 16), n0 + wc * 64, lane, rv, ru, cs);
+    // column sums: add the eight row groups of the wave (lane bits 3 .. 5); lanes 0 .. 7 then hold columns 8 lane .. 8 lane + 7
+    if (p.er_colsum) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        cs[k] += __shfl_xor(cs[k], 8, 64);
+        cs[k] += __shfl_xor(cs[k], 16, 64);
+        cs[k] += __shfl_xor(cs[k], 32, 64);
+      }
+    }
+    // the two wave rows of a column: row 1 leaves its sums in its own staging area and image area, row 0 adds them and stores
+    f32x4* xv = reinterpret_cast<f32x4*>(stg);
+    f32x4* xu = reinterpret_cast<f32x4*>(img);
+    float* xc = reinterpret_cast<float*>(smem + wave * WAVE_STG + 4096);
+    if (wr == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xv[j * 64 + lane] = rv[j];
+        xu[j * 64 + lane] = ru[j];
+      }
+      if (lane < 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xc[lane * 8 + k] = cs[k];
+      }
+    }
+    __syncthreads();
+    if (wr == 0) {
+      const f32x4* pv = reinterpret_cast<const f32x4*>(smem + (wave + 2) * WAVE_STG);
+      const f32x4* pu = reinterpret_cast<const f32x4*>(smem + 4 * WAVE_STG + (wave + 2) * ER_WAVE_BYTES);
+      const float* pc = reinterpret_cast<const float*>(smem + (wave + 2) * WAVE_STG + 4096);
+      const int colblocks = p.N >> 6, tiles_m = nwg / tiles_n;
+      const size_t blk = (size_t)tm * colblocks + ((n0 >> 6) + wc);
+      float* sv = static_cast<float*>(p.er_slabs_v) + blk * (64 * 16);
+      float* su = static_cast<float*>(p.er_slabs_u) + blk * (64 * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 a = pv[j * 64 + lane], b = pu[j * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sv[(j * 16 + fq * 4 + r) * 16 + fr] = rv[j][r] + a[r];
+          su[(j * 16 + fq * 4 + r) * 16 + fr] = ru[j][r] + b[r];
+        }
+      }
+      if (p.er_colsum && lane < 8) {
+        float* cv = static_cast<float*>(p.er_slabs_v) + (size_t)tiles_m * colblocks * (64 * 32) + blk * 64 + lane * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cv[k] = cs[k] + pc[lane * 8 + k];
+      }
+    }
+    STAMP_END();
+    return;
+  }
   if constexpr ((EPI == CARA_EPI_BF16 || EPI == CARA_EPI_GELU) && (MI == 4 || MI == 8) && NW == 4) {
     const int mw = m0 + wr * (MI * 16), nw = n0 + wc * 64;
     if (mw + MI * 16 <= p.M && nw + 64 <= p.N && (p.ldc & 7) == 0) {   // wave-uniform
@@ -317,10 +382,10 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
 // 79 x 24 = 1896 tiles of 160 rows are 1.85, and a tile stages 10 % fewer bytes per flop; 36 KiB of LDS, still four per CU
 // (the 160-row tile with an epilogue that reads a second operand and no riding products -- not a product of the model -- would spill
 // a few registers at four workgroups per CU: it gets three)
-template <int EPI, bool TWOB = false, int MI = 4>
+template <int EPI, bool TWOB = false, int MI = 4, bool ER = false>
 __global__ __launch_bounds__(256, (TWOB || (MI == 5 && (EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU))) ? 3 : 4) void gemm32_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm32_body<EPI, MI, 4, TWOB>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
+  gemm32_body<EPI, MI, 4, TWOB, ER>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
 }
 
 // 8-wave workgroups (4 along M x 2 along N, 64-column wave tiles): MI = 3 -> 192 x 128 tiles, MI = 4 -> 256 x 128.  For the
@@ -343,8 +408,8 @@ __global__ __launch_bounds__(512, 4) void gemm32w8_kernel(const cara_gemm_args p
 // NT = Rp / 16 of the riding products: 2 (rank <= 32: four workgroups per CU) or 4 (rank <= 64: the products' 16 more
 // accumulator tiles take the kernel to 136 VGPRs, three workgroups per CU -- still far better than the products as a
 // launch of their own behind the GEMM, 55 us per pair at rank 64)
-template <int EPI, bool COLSUM, int MI = 4, int NT = 2>
-__global__ __launch_bounds__(256, NT <= 2 ? 4 : 3) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
+template <int EPI, bool COLSUM, int MI = 4, int NT = 2, bool ER = false>
+__global__ __launch_bounds__(256, (NT <= 2 && !ER) ? 4 : 3) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
                                                            const TsProblem t0, const TsProblem t1, const int ldg, const int Mts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // the products' blocks sit BEHIND the GEMM tiles: they fill the slots the GEMM's last, partly filled round leaves
@@ -356,7 +421,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 4 : 3) void gemm32_ts_kernel(const c
     STAMP(1);
     STAMP_END();
   } else {
-    gemm32_body<EPI, MI, 4>(p, tiles_n, nwg, gm, b, 0, smem);
+    gemm32_body<EPI, MI, 4, false, ER>(p, tiles_n, nwg, gm, b, 0, smem);
   }
 }
 
@@ -591,7 +656,7 @@ struct TsPair {
 };
 
 // one launch of the GEMM-with-riders kernel: COLSUM and NT (the products' Rp / 16) picked at run time
-template <int EPI, int MI>
+template <int EPI, int MI, bool ER = false>
 void launch_ts(const cara_gemm_args* a, hipStream_t st, const TsPair* ts, int tiles_n, int nwg, int gm, int gemm_lds) {
   const int nts = ts->a.nblk + ts->b.nblk;
   const dim3 grid(nwg + nts), block(256);
@@ -599,8 +664,12 @@ void launch_ts(const cara_gemm_args* a, hipStream_t st, const TsPair* ts, int ti
   do {                                                                                                                      \
     constexpr int RB = TsRing<NT, 1>::BLOCK_BYTES;                                                                          \
     const int lds = RB > gemm_lds ? RB : gemm_lds;                                                                          \
-    hipLaunchKernelGGL((gemm32_ts_kernel<EPI, CS, MI, NT>), grid, block, lds, st, *a, tiles_n, nwg, gm, ts->a, ts->b, ts->ldg, ts->M); \
+    hipLaunchKernelGGL((gemm32_ts_kernel<EPI, CS, MI, NT, ER>), grid, block, lds, st, *a, tiles_n, nwg, gm, ts->a, ts->b, ts->ldg, ts->M); \
   } while (0)
+  if constexpr (ER) {   // (epilogue riders: rank <= 16, so are the products that ride as workgroups)
+    if (ts->any_cs) TS_GO(true, 1); else TS_GO(false, 1);
+    return;
+  }
   if (ts->nt == 4) {
     if (ts->any_cs) TS_GO(true, 4); else TS_GO(false, 4);
   } else if (ts->nt == 1) {   // rank <= 16: the products compute 16 of their 32 columns (16-wide slabs)
@@ -652,6 +721,13 @@ int launch32ft(const cara_gemm_args* a, hipStream_t st, const TsPair* ts) {
   return CARA_OK;
 }
 
+// the 160-row tile takes the widest products (launch32)
+static bool tile160(const cara_gemm_args* a) {
+  static const int bm = [] { const char* e = getenv("CARA_GEMM_BM"); return e ? atoi(e) : 160; }();
+  static const int bm_minn = [] { const char* e = getenv("CARA_GEMM_BM_MINN"); return e ? atoi(e) : 3072; }();   // A/B: 2304 adds qkv forward
+  return bm == 160 && a->N >= bm_minn && a->M > 1024 && a->batch <= 1 && !a->B3;
+}
+
 template <int EPI>
 int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr) {
   const int tiles_n = (a->N + BN - 1) / BN;
@@ -662,11 +738,17 @@ int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr
   // The 160-row tile for the widest products (N >= 3072: fc1 forward, fc2 dX).  CARA_GEMM_BM=128 keeps the 128-row tile (A/B runs:
   // 9.22 -> 9.08 and 9.37 -> 9.28 ms per step on two boxes; for the N = 768 products, whose 594 / 474 tiles are a single
   // round either way, it made no difference in the step and stays off)
-  static const int bm = [] { const char* e = getenv("CARA_GEMM_BM"); return e ? atoi(e) : 160; }();
-  static const int bm_minn = [] { const char* e = getenv("CARA_GEMM_BM_MINN"); return e ? atoi(e) : 3072; }();   // A/B: 2304 adds qkv forward
-  if (bm == 160 && a->N >= bm_minn && a->M > 1024 && a->batch <= 1 && !a->B3) {
+  if (tile160(a)) {
     constexpr int LDS160 = 2 * (160 * BK32 * 2 + B32_BYTES);
     const int nwg5 = ((a->M + 159) / 160) * tiles_n;
+    if constexpr (EPI == CARA_EPI_DGELU) {
+      if (a->er_Tt) {   // epilogue riders (checked by the caller: cara_gemm_epi_rider_chunks)
+        if (ts) launch_ts<EPI, 5, true>(a, st, ts, tiles_n, nwg5, gm, LDS160);
+        else hipLaunchKernelGGL((gemm32_kernel<EPI, false, 5, true>), dim3(nwg5), dim3(256), LDS160, st, *a, tiles_n, nwg5, gm);
+        CARA_CHECK_LAUNCH();
+        return CARA_OK;
+      }
+    }
     if (ts) {
       launch_ts<EPI, 5>(a, st, ts, tiles_n, nwg5, gm, LDS160);
     } else {
@@ -1019,6 +1101,17 @@ extern "C" int cara_gemm_rider_slab_format(const cara_gemm_args* a, int Rp, int 
   return cara_gemm8_plan(a, g8, nt) == 2 ? 1 : 0;
 }
 
+extern "C" int cara_gemm_epi_rider_chunks(const cara_gemm_args* a) {
+  if (!a || a->epi != CARA_EPI_DGELU || !tile160(a) || a->Ut || (a->N & 127) || (a->ldc & 7) || (a->M & 3) || a->M <= 0) return 0;
+  if (g_gemm8_override > 0) return 0;
+  return (a->M + 159) / 160;
+}
+extern "C" size_t cara_gemm_epi_rider_scratch_bytes(int chunks, int N) {
+  if (chunks <= 0 || N <= 0 || (N & 63)) return 0;
+  const size_t nblk = (size_t)chunks * (N / 64);
+  return nblk * 64 * 32 * sizeof(float) + nblk * 64 * sizeof(float);   // (the column sums sit behind slabs of the full width 32, cara_tskinny_reduce*)
+}
+
 // ts != NULL: the launch also carries a pair of transposed skinny products; only the default 128 x 128 x 32 kernel can
 static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* ts) {
   if (!a || !a->A || !a->B || !a->C) return CARA_E_ARG;
@@ -1041,8 +1134,12 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
   if (a->epi == CARA_EPI_DGELU && !a->aux) return CARA_E_ARG;
   if (ts && (a->batch > 1 || a->M <= 128 || a->B3 || (a->Ut && a->epi != CARA_EPI_BF16))) return CARA_E_ARG;
   if (a->B3 && (a->Bp || a->Ut || a->batch > 1 || a->a_panels)) return CARA_E_ARG;
+  if (a->er_Tt) {   // epilogue riders: only where cara_gemm_epi_rider_chunks() says so
+    if (!cara_gemm_epi_rider_chunks(a) || !a->er_Gt || !a->er_slabs_v || !a->er_slabs_u || a->er_ldg < a->M || (a->er_ldg & 3)) return CARA_E_ARG;
+    if (ts && ts->nt != 1) return CARA_E_ARG;
+  }
   // The MT x 256 x 64 one-workgroup-per-CU tile (gemm8.hip) where the policy asks for it (cara_gemm8_policy) and the tile takes the product
-  const int g8 = g8_choice(a, ts != nullptr);
+  const int g8 = a->er_Tt ? 0 : g8_choice(a, ts != nullptr);
   if (g8) {
     cara_g8_riders rd;
     if (ts) {

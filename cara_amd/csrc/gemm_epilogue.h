@@ -344,3 +344,93 @@ __device__ __forceinline__ void epilogue_interior_aux(const cara_gemm_args& p, c
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// CARA_EPI_DGELU with EPILOGUE RIDERS (cara_gemm_args::er_*): the fc2 dX tile that turns its accumulators into
+// dH = acc * gelu'(u) also rebuilds h = gelu(u) from the u it has just read, and multiplies both -- transposed -- by its rows of
+// T^T (fc1's) and G'^T (fc2's): partial dVs_fc1 = dH^T T and dU_fc2 = h^T G' for its 64 columns.  The 77 MB of dH and the 77 MB of h
+// that those two products used to re-read per block (as workgroups riding in the fc1 dX launch) are never read again.
+// Per 16-row tile of the wave's NT: accumulators -> fp32 image -> 16-byte row pieces (as epilogue_interior_aux), dH / h values as
+// bf16 -> two 16 x 64 bf16 images (rows padded to 144 B) -> one transposing LDS read per 16-column tile and product = the A
+// operand of a K = 16 MFMA (lane fr: column fr, rows 4 fq .. 4 fq + 3), B operand = 8 bytes of T^T / G'^T row fr.  Everything is
+// wave-private (a wave's LDS operations complete in order; compiler fences between the differently typed accesses).
+// Handles edge tiles itself: rows >= M contribute zeros and are not stored (callers guarantee N % 64 == 0 for the wave tile,
+// ldc % 8 == 0, M % 4 == 0).  Results: rv[j] / ru[j] = the wave's partial [16 j + 4 fq + reg][fr] sums, cs[k] = this lane's share
+// of the column sums of dH (columns nbase + 8 (lane & 7) + k, rows of its lane group).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int ER_ROW_BYTES = 144;
+constexpr int ER_IMG_BYTES = 16 * ER_ROW_BYTES;
+constexpr int ER_WAVE_BYTES = 2 * ER_IMG_BYTES;   // 4608: the dH image and the h image
+
+template <int NT>
+__device__ __forceinline__ void epilogue_dgelu_riders(const cara_gemm_args& p, const f32x4 (&acc)[NT][4], float* stg, char* img, const int mbase,
+                                                      const int nbase, const int lane, f32x4 (&rv)[4], f32x4 (&ru)[4], float (&cs)[8]) {
+  typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int c8 = (lane & 7) * 8, rl = lane >> 3;
+  const int n = nbase + c8;
+  const bf16* __restrict__ Tt = static_cast<const bf16*>(p.er_Tt) + (size_t)fr * p.er_ldg;
+  const bf16* __restrict__ Gt = static_cast<const bf16*>(p.er_Gt) + (size_t)fr * p.er_ldg;
+  const bf16* __restrict__ up = static_cast<const bf16*>(p.aux) + n;
+  const bf16x4 z4 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+  bf16x8 u[2][2];
+  bf16x4 bt[2], bg[2];
+  auto request = [&](int i, int s) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int m = mbase + i * 16 + q * 8 + rl;
+      m = m < p.M ? m : p.M - 1;
+      u[s][q] = *reinterpret_cast<const bf16x8*>(up + (size_t)m * p.ldc);
+    }
+    const int m4 = mbase + i * 16 + 4 * fq;   // (M % 4 == 0: the four rows are valid together)
+    bt[s] = m4 < p.M ? *reinterpret_cast<const bf16x4*>(Tt + m4) : z4;
+    bg[s] = m4 < p.M ? *reinterpret_cast<const bf16x4*>(Gt + m4) : z4;
+  };
+  request(0, 0);
+  // the transposing reads of this lane: row 4 fq + (fr >> 2) of the image, 8 bytes at column 16 j + 4 (fr & 3)
+  const char* tbase = img + (4 * fq + (fr >> 2)) * ER_ROW_BYTES + (fr & 3) * 8;
+  char* wbase = img + rl * ER_ROW_BYTES + c8 * 2;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stg[(fq * 4 + r) * 64 + j * 16 + fr] = acc[i][j][r];
+    asm volatile("" ::: "memory");
+    if (i + 1 < NT) request(i + 1, (i + 1) & 1);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + (q * 8 + rl) * 64 + c8);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(stg + (q * 8 + rl) * 64 + c8 + 4);
+      const bf16x8 uv = u[i & 1][q];
+      const int m = mbase + i * 16 + q * 8 + rl;
+      const bool valid = m < p.M;
+      bf16x8 out, hv;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float g, gp;
+        gelu_erf_both((float)uv[k], g, gp);
+        const float a = k < 4 ? a0[k & 3] : a1[k & 3];
+        out[k] = valid ? (bf16)(a * gp) : (bf16)0.f;
+        hv[k] = valid ? (bf16)g : (bf16)0.f;
+        cs[k] += (float)out[k];
+      }
+      if (valid) {
+        bf16* dst = p.c_panels ? static_cast<bf16*>(p.C) + ((size_t)(n >> 5) * p.c_panels + m) * 32 + (n & 31)
+                               : static_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
+        *reinterpret_cast<bf16x8*>(dst) = out;
+      }
+      *reinterpret_cast<bf16x8*>(wbase + q * 8 * ER_ROW_BYTES) = out;
+      *reinterpret_cast<bf16x8*>(wbase + ER_IMG_BYTES + q * 8 * ER_ROW_BYTES) = hv;
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const s16x4_t d4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4_t*)(tbase + j * 32));
+      const s16x4_t h4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4_t*)(tbase + ER_IMG_BYTES + j * 32));
+      rv[j] = mfma_16x16x16(__builtin_bit_cast(bf16x4, d4), bt[i & 1], rv[j]);
+      ru[j] = mfma_16x16x16(__builtin_bit_cast(bf16x4, h4), bg[i & 1], ru[j]);
+    }
+    asm volatile("" ::: "memory");
+  }
+}

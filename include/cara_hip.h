@@ -93,8 +93,27 @@ typedef struct {
   /* With Ut: the adapter's rank, if the caller knows it (0 = not stated).  At Rp = 32 and 1 <= Ut_rank <= 16 the kernel computes  */
   /* columns 0 .. 15 of T only (rows >= rank of Ut are zero) and writes columns 16 .. 31 as zeros: same results, bit for bit.      */
   int Ut_rank;
+  /* Epilogue riders (CARA_EPI_DGELU only; er_Tt == NULL: none).  The tile that has just produced dH = acc * gelu'(u) from the pre-     */
+  /* activation u holds everything two transposed skinny products of the backward need: dVs = dH^T T of the linear whose dY this C is  */
+  /* (fc1), and dU = h^T G' of this linear (fc2) with h = gelu(u) rebuilt from the same u (4 more VALU per element) -- 154 MB of dH    */
+  /* and h per block that nothing has to read again.  Every workgroup multiplies its bf16 dH / h tile, transposed through LDS, by its  */
+  /* rows of er_Tt / er_Gt (bf16 [>= 16, er_ldg]: T^T and G'^T, rows = the first 16 adapter columns, er_ldg >= M) and writes 16-wide   */
+  /* fp32 partial sums for its 128 columns: slab `row tile` of column block n / 64, in the layout of cara_tskinny_partial2_r at rank   */
+  /* <= 16 with cara_gemm_epi_rider_chunks(a) slabs per column block (er_colsum: column sums of dH behind the er_slabs_v slabs, as     */
+  /* want_colsum leaves them).  Reduce with cara_ts_reduce::Rc = 16, ::wave_slabs = that chunk count.  Each slab region:               */
+  /* cara_gemm_epi_rider_scratch_bytes(chunks, N).  h is gelu of the bf16 u (the forward rounded gelu of the fp32 u).                  */
+  const void* er_Tt;
+  const void* er_Gt;
+  void* er_slabs_v;
+  void* er_slabs_u;
+  int er_ldg, er_colsum;
 } cara_gemm_args;
 int cara_gemm_bf16(const cara_gemm_args* a, void* stream);
+/* Slabs per column block a launch of `a` with epilogue riders writes (= its row tiles), 0: this product cannot carry them (then  */
+/* cara_gemm_bf16 / cara_gemm_with_tskinny* return CARA_E_ARG when er_Tt is set).  Needs CARA_EPI_DGELU, M > 1024, N >= 3072,     */
+/* N % 128 == 0, ldc % 8 == 0, no batch, M % 4 == 0.  Depends on the arguments only.                                              */
+int cara_gemm_epi_rider_chunks(const cara_gemm_args* a);
+size_t cara_gemm_epi_rider_scratch_bytes(int chunks, int N);
 /* B bf16 [N, K] (row stride ldb) -> out bf16 [K/32][N][32] (cara_gemm_args::Bp); K % 32 == 0 */
 int cara_pack_b_panels(const void* B, int ldb, int N, int K, void* out, void* stream);
 size_t cara_gemm_scratch_bytes(void);
@@ -170,7 +189,8 @@ typedef struct {
   int batch, M, K1, Rp;
   int Rc;   /* columns the slabs hold: 0 or Rp = all; 16 (at Rp = 32) = slabs written by the _r functions at rank <= 16 */
   int wave_slabs;   /* 1: the product wrote one slab per WAVE of its blocks (four per block): what cara_gemm_with_tskinny_r does  */
-                    /* where cara_gemm_rider_slab_format() says so; 0: one slab per block                                        */
+                    /* where cara_gemm_rider_slab_format() says so; 0: one slab per block; >= 2: that many slabs per column      */
+                    /* block (the epilogue riders of cara_gemm_args::er_*: cara_gemm_epi_rider_chunks)                            */
 } cara_ts_reduce;
 int cara_tskinny_reduce_many(const cara_ts_reduce* probs, int n, void* stream);
 
