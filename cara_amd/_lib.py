@@ -19,7 +19,7 @@ LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libcara_hip_f16.so")
 
 # every symbol include/cara_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "cara_abi_version", "cara_build_arch", "cara_operand_type", "cara_gemm_bf16", "cara_gemm_tn_f32", "cara_pack_b_panels", "cara_gemm_scratch_bytes", "cara_skinny_xu", "cara_skinny_xu_r", "cara_tskinny_partial2_r", "cara_gemm_with_tskinny_r", "cara_gemm_rider_slab_format", "cara_linear_fwd", "cara_linear_bwd",
+    "cara_abi_version", "cara_build_arch", "cara_operand_type", "cara_gemm_bf16", "cara_gemm_tn_f32", "cara_pack_b_panels", "cara_gemm_scratch_bytes", "cara_skinny_xu", "cara_skinny_xu_r", "cara_tskinny_partial2_r", "cara_gemm_with_tskinny_r", "cara_gemm_rider_slab_format", "cara_gemm_epi_rider_chunks", "cara_gemm_epi_rider_scratch_bytes", "cara_linear_fwd", "cara_linear_bwd",
     "cara_tskinny_scratch_bytes", "cara_tskinny_xtg", "cara_tskinny_partial", "cara_tskinny_partial2", "cara_tskinny_reduce", "cara_tskinny_reduce_many", "cara_gemm_with_tskinny", "cara_layernorm_fwd", "cara_layernorm_bwd", "cara_layernorm_fwd_xu", "cara_layernorm_bwd_xu", "cara_layernorm_fwd_ex", "cara_layernorm_bwd_ex",
     "cara_attention_fwd", "cara_attention_bwd", "cara_attention_cls_fwd", "cara_attention_cls_bwd", "cara_im2col_patches", "cara_assemble_tokens",
     "cara_cross_entropy", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_transpose_bf16_ld", "cara_pack_offsets",
@@ -28,7 +28,7 @@ SYMBOLS = (
     "cara_vit_backward", "cara_head_backward", "cara_sizeof_struct", "cara_sizeof_gemm_args", "cara_profile_sites", "cara_profile_site_read", "cara_debug_tr_probe", "cara_debug_tr_frag",
 )
 
-EPI_BF16, EPI_F32, EPI_GELU, EPI_RESID, EPI_DGELU = range(5)
+EPI_BF16, EPI_F32, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_GELU_DG, EPI_MULH = range(7)
 
 
 class GemmArgs(C.Structure):
@@ -40,7 +40,9 @@ class GemmArgs(C.Structure):
                 ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
                 ("batch", C.c_int), ("strideA", C.c_longlong), ("strideB", C.c_longlong), ("strideC", C.c_longlong),
                 ("Ut", C.c_void_p), ("T_out", C.c_void_p), ("Tt_out", C.c_void_p), ("ldt", C.c_int),
-                ("Bp", C.c_void_p), ("a_panels", C.c_int), ("c_panels", C.c_int), ("B3", C.c_void_p), ("Ut_rank", C.c_int)]
+                ("Bp", C.c_void_p), ("a_panels", C.c_int), ("c_panels", C.c_int), ("B3", C.c_void_p), ("Ut_rank", C.c_int),
+                ("er_Tt", C.c_void_p), ("er_Gt", C.c_void_p), ("er_h", C.c_void_p), ("er_slabs_v", C.c_void_p), ("er_slabs_u", C.c_void_p),
+                ("er_ldg", C.c_int), ("er_colsum", C.c_int), ("er_h_panels", C.c_int)]
 
 
 class Geom(C.Structure):
@@ -157,6 +159,7 @@ def lib(operands: str = "bf16") -> C.CDLL:
     if _lib.cara_operand_type() != operands.encode():
         raise CaraError(f"{path} was built for {_lib.cara_operand_type()!r} operands, not {operands!r}")
     _lib.cara_tskinny_scratch_bytes.restype = C.c_size_t
+    _lib.cara_gemm_epi_rider_scratch_bytes.restype = C.c_size_t
     _lib.cara_factor_grad_scratch_bytes.restype = C.c_size_t
     if hasattr(_lib, "cara_vit_workspace_bytes"):
         _lib.cara_vit_workspace_bytes.restype = C.c_size_t
@@ -202,7 +205,9 @@ def stream(device=None) -> C.c_void_p:
 
 def gemm(A, B, out, *, epi, bias=None, A2=None, B2=None, C2=None, aux=None, rowscale=None,
          rows_per_sample=0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, scratch=None, Ut=None, T_out=None,
-         Tt_out=None, Bp=None, a_panels=0, c_panels=0, B3=None, Ut_rank=0):
+         Tt_out=None, Bp=None, a_panels=0, c_panels=0, B3=None, Ut_rank=0, epi_riders=None):
+    """epi_riders = (Tt, Gt, h, want_colsum[, h_panels]) with CARA_EPI_MULH: the launch's epilogue also leaves the partial sums of
+    dVs = C^T T and dU = h^T G (cara_gemm_args::er_*); returns (out, slabs_v, slabs_u, chunks) then."""
     a = GemmArgs()
     a.Ut_rank = Ut_rank   # with Ut: the adapter's rank if known (<= 16 at Rp = 32: 16 of the 32 columns of T are computed)
     a.B3 = ptr(B3)   # optional second B operand: C = A B^T + A B3^T, accumulated in fp32
@@ -224,6 +229,19 @@ def gemm(A, B, out, *, epi, bias=None, A2=None, B2=None, C2=None, aux=None, rows
     a.C, a.ldc = ptr(out), ldc or out.shape[-1]
     a.C2, a.aux, a.rowscale = ptr(C2), ptr(aux), ptr(rowscale)
     a.rows_per_sample = rows_per_sample
+    if epi_riders is not None:
+        Tt, Gt, hh, want_cs = epi_riders[:4]
+        a.er_Tt, a.er_Gt, a.er_h, a.er_ldg, a.er_colsum = ptr(Tt), ptr(Gt), ptr(hh), Tt.shape[1], 1 if want_cs else 0
+        a.er_h_panels = epi_riders[4] if len(epi_riders) > 4 else 0
+        chunks = int(lib().cara_gemm_epi_rider_chunks(C.byref(a)))
+        if chunks <= 0:
+            raise ValueError("this product cannot carry epilogue riders (cara_gemm_epi_rider_chunks)")
+        nbytes = int(lib().cara_gemm_epi_rider_scratch_bytes(chunks, a.N))
+        slabs_v = torch.zeros(nbytes, dtype=torch.uint8, device=out.device)
+        slabs_u = torch.zeros(nbytes, dtype=torch.uint8, device=out.device)
+        a.er_slabs_v, a.er_slabs_u = ptr(slabs_v), ptr(slabs_u)
+        check(lib().cara_gemm_bf16(C.byref(a), stream()), "cara_gemm_bf16")
+        return out, slabs_v, slabs_u, chunks
     check(lib().cara_gemm_bf16(C.byref(a), stream()), "cara_gemm_bf16")
     return out
 

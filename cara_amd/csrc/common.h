@@ -26,6 +26,10 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 #define CARA_OPERAND_TYPE "bf16"
 #endif
+// IEEE half whatever the build's operand type: the saved gelu'(u) of CARA_EPI_GELU_DG / CARA_EPI_MULH
+typedef _Float16 h16;
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 

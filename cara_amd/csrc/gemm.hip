@@ -159,7 +159,7 @@ __device__ __forceinline__ void stage_ext32(const bf16* __restrict__ P, int Rp, 
 // one workgroup's tile; `block` = its index among the nwg tiles of the product, `zb` = product index of a batched launch
 // TWOB: every K step stages B AND B3 (cara_gemm_args::B3: same shape and ldb) next to the A tile and runs both products on
 // the same A fragments (24 KiB slots: three workgroups per CU; the first form ran the K loop twice and staged A twice)
-// ER: CARA_EPI_DGELU with epilogue riders (cara_gemm_args::er_*, gemm_epilogue.h)
+// ER: CARA_EPI_MULH with epilogue riders (cara_gemm_args::er_*, gemm_epilogue.h)
 template <int EPI, int MI, int NW, bool TWOB = false, bool ER = false>
 __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int tiles_n, const int nwg, const int gm,
                                             const int block, const size_t zb_in, char* smem) {
@@ -269,64 +269,83 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
   __syncthreads();
   STAMP(1);
   if constexpr (ER) {
-    static_assert(EPI == CARA_EPI_DGELU && NW == 4 && !TWOB, "epilogue riders: the fc2 dX product");
-    static_assert(4 * (WAVE_STG + ER_WAVE_BYTES) <= 2 * SLOT, "the images fit beside the staging areas");
+    static_assert(EPI == CARA_EPI_MULH && NW == 4 && !TWOB, "epilogue riders: the fc2 dX product");
+    // LDS of the riders' epilogue (the launch asks for ER_LDS_BYTES if that is more than the K loop's slots): per wave a 16 x 64 fp32
+    // staging image + 256 B for the column sums, and the two bf16 images
+    constexpr int ESTG = ER_STG_BYTES;
     const int fr = lane & 15, fq = lane >> 4;
     f32x4 rv[4], ru[4];
-    float cs[8];
+    float cs[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rv[j] = ru[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) cs[k] = 0.f;
-    float* stg = reinterpret_cast<float*>(smem + wave * WAVE_STG);
-    char* img = smem + 4 * WAVE_STG + wave * ER_WAVE_BYTES;
-    epilogue_dgelu_riders<MI>(p, acc, stg, img, m0 + wr * (MI * 16), n0 + wc * 64, lane, rv, ru, cs);
-    // column sums: add the eight row groups of the wave (lane bits 3 .. 5); lanes 0 .. 7 then hold columns 8 lane .. 8 lane + 7
+    for (int j = 0; j < 4; ++j) {
+      rv[j] = ru[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      cs[j] = 0.f;
+    }
+    float* stg = reinterpret_cast<float*>(smem + wave * ESTG);
+    char* img = smem + 4 * ESTG + wave * ER_WAVE_BYTES;
+    const int mw = m0 + wr * (MI * 16);
+    if (mw + MI * 16 <= p.M) epilogue_mulh_riders<MI, true>(p, acc, stg, img, mw, n0 + wc * 64, lane, rv, ru, cs);   // (wave-uniform)
+    else epilogue_mulh_riders<MI, false>(p, acc, stg, img, mw, n0 + wc * 64, lane, rv, ru, cs);
+    // column sums: add the four row groups of the wave (lane bits 4, 5); lanes 0 .. 15 then hold columns 16 j + lane
     if (p.er_colsum) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        cs[k] += __shfl_xor(cs[k], 8, 64);
-        cs[k] += __shfl_xor(cs[k], 16, 64);
-        cs[k] += __shfl_xor(cs[k], 32, 64);
+      for (int j = 0; j < 4; ++j) {
+        cs[j] += __shfl_xor(cs[j], 16, 64);
+        cs[j] += __shfl_xor(cs[j], 32, 64);
       }
     }
-    // the two wave rows of a column: row 1 leaves its sums in its own staging area and image area, row 0 adds them and stores
+    // the two wave rows of a column: row 1 leaves its sums in its own staging area and image area, row 0 adds them, lays the
+    // sums out as the slab (64 columns x 16 floats) in ITS areas and stores whole 1-KiB runs, 16 bytes per lane
     f32x4* xv = reinterpret_cast<f32x4*>(stg);
     f32x4* xu = reinterpret_cast<f32x4*>(img);
-    float* xc = reinterpret_cast<float*>(smem + wave * WAVE_STG + 4096);
+    float* xc = reinterpret_cast<float*>(smem + wave * ESTG + 4096);
     if (wr == 1) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         xv[j * 64 + lane] = rv[j];
         xu[j * 64 + lane] = ru[j];
       }
-      if (lane < 8) {
+      if (lane < 16) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) xc[lane * 8 + k] = cs[k];
+        for (int j = 0; j < 4; ++j) xc[j * 16 + lane] = cs[j];
       }
     }
     __syncthreads();
+#if defined(CARA_ER_ABLATE) && (CARA_ER_ABLATE & 2)   // timing diagnostic: without the slab stores
+    if (wr == 0 && p.M < 0) {
+#else
     if (wr == 0) {
-      const f32x4* pv = reinterpret_cast<const f32x4*>(smem + (wave + 2) * WAVE_STG);
-      const f32x4* pu = reinterpret_cast<const f32x4*>(smem + 4 * WAVE_STG + (wave + 2) * ER_WAVE_BYTES);
-      const float* pc = reinterpret_cast<const float*>(smem + (wave + 2) * WAVE_STG + 4096);
+#endif
+      const f32x4* pv = reinterpret_cast<const f32x4*>(smem + (wave + 2) * ESTG);
+      const f32x4* pu = reinterpret_cast<const f32x4*>(smem + 4 * ESTG + (wave + 2) * ER_WAVE_BYTES);
+      const float* pc = reinterpret_cast<const float*>(smem + (wave + 2) * ESTG + 4096);
       const int colblocks = p.N >> 6, tiles_m = nwg / tiles_n;
       const size_t blk = (size_t)tm * colblocks + ((n0 >> 6) + wc);
       float* sv = static_cast<float*>(p.er_slabs_v) + blk * (64 * 16);
       float* su = static_cast<float*>(p.er_slabs_u) + blk * (64 * 16);
+      float* lv = reinterpret_cast<float*>(stg);
+      float* lu = reinterpret_cast<float*>(img);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f32x4 a = pv[j * 64 + lane], b = pu[j * 64 + lane];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          sv[(j * 16 + fq * 4 + r) * 16 + fr] = rv[j][r] + a[r];
-          su[(j * 16 + fq * 4 + r) * 16 + fr] = ru[j][r] + b[r];
+          lv[(j * 16 + fq * 4 + r) * 16 + fr] = rv[j][r] + a[r];
+          lu[(j * 16 + fq * 4 + r) * 16 + fr] = ru[j][r] + b[r];
         }
       }
-      if (p.er_colsum && lane < 8) {
-        float* cv = static_cast<float*>(p.er_slabs_v) + (size_t)tiles_m * colblocks * (64 * 32) + blk * 64 + lane * 8;
+      asm volatile("" ::: "memory");
 #pragma unroll
-        for (int k = 0; k < 8; ++k) cv[k] = cs[k] + pc[lane * 8 + k];
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(lv + (t * 64 + lane) * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(lu + (t * 64 + lane) * 4);
+        *reinterpret_cast<f32x4*>(sv + (t * 64 + lane) * 4) = a;
+        *reinterpret_cast<f32x4*>(su + (t * 64 + lane) * 4) = b;
+      }
+      if (p.er_colsum && lane < 16) {
+        float* cv = static_cast<float*>(p.er_slabs_v) + (size_t)tiles_m * colblocks * (64 * 32) + blk * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cv[j * 16 + lane] = cs[j] + pc[j * 16 + lane];
       }
     }
     STAMP_END();
@@ -341,7 +360,7 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
       STAMP_END();
       return;
     }
-  } else if constexpr (EPI == CARA_EPI_BF16 || EPI == CARA_EPI_GELU) {
+  } else if constexpr (EPI == CARA_EPI_BF16 || EPI == CARA_EPI_GELU || EPI == CARA_EPI_GELU_DG) {
     const int mw = m0 + wr * (MI * 16), nw = n0 + wc * 64;
     if (mw + MI * 16 <= p.M && nw + 64 <= p.N && (p.ldc & 7) == 0) {   // wave-uniform
       epilogue_fast_bf16_rt<EPI, MI>(p, acc, smem + wave * WAVE_STG, mw, nw, lane, coff);
@@ -350,11 +369,11 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
     }
   }
   float* stg = reinterpret_cast<float*>(smem + wave * WAVE_STG);
-  if constexpr (EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU) {
+  if constexpr (EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU || EPI == CARA_EPI_MULH) {
     // interior wave tiles: the epilogue's input operand requested a pass group ahead (gemm_epilogue.h)
     const int mw = m0 + wr * (MI * 16), nw = n0 + wc * 64;
-    const bool ok = mw + MI * 16 <= p.M && nw + 64 <= p.N && (p.ldc & 7) == 0 && coff == 0 &&
-                    (EPI == CARA_EPI_DGELU || !p.rowscale || p.rows_per_sample >= MI * 16) && (!p.bias || (nw & 3) == 0);
+    const bool ok = mw + MI * 16 <= p.M && nw + 64 <= p.N && (p.ldc & 7) == 0 && coff == 0 && (EPI != CARA_EPI_MULH || !p.bias) &&
+                    (EPI != CARA_EPI_RESID || !p.rowscale || p.rows_per_sample >= MI * 16) && (!p.bias || (nw & 3) == 0);
     if (ok) {   // wave-uniform
       epilogue_interior_aux<EPI, MI, 1>(p, acc, stg, mw, nw, lane);
       STAMP_END();
@@ -383,7 +402,7 @@ __device__ __forceinline__ void gemm32_body(const cara_gemm_args& p, const int t
 // (the 160-row tile with an epilogue that reads a second operand and no riding products -- not a product of the model -- would spill
 // a few registers at four workgroups per CU: it gets three)
 template <int EPI, bool TWOB = false, int MI = 4, bool ER = false>
-__global__ __launch_bounds__(256, (TWOB || (MI == 5 && (EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU))) ? 3 : 4) void gemm32_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
+__global__ __launch_bounds__(256, (TWOB || ER || (MI == 5 && (EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU || EPI == CARA_EPI_MULH))) ? 3 : 4) void gemm32_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   gemm32_body<EPI, MI, 4, TWOB, ER>(p, tiles_n, nwg, gm, blockIdx.x, blockIdx.y, smem);
 }
@@ -409,7 +428,13 @@ __global__ __launch_bounds__(512, 4) void gemm32w8_kernel(const cara_gemm_args p
 // accumulator tiles take the kernel to 136 VGPRs, three workgroups per CU -- still far better than the products as a
 // launch of their own behind the GEMM, 55 us per pair at rank 64)
 template <int EPI, bool COLSUM, int MI = 4, int NT = 2, bool ER = false>
-__global__ __launch_bounds__(256, (NT <= 2 && !ER) ? 4 : 3) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
+#ifndef CARA_TS_WG   // (timing diagnostic: workgroups per CU of the riders-carrying kernels that default to four)
+#define CARA_TS_WG 4
+#endif
+#ifndef CARA_ER_WG
+#define CARA_ER_WG 3
+#endif
+__global__ __launch_bounds__(256, ER ? CARA_ER_WG : (NT <= 2 ? CARA_TS_WG : 3)) void gemm32_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int gm,
                                                            const TsProblem t0, const TsProblem t1, const int ldg, const int Mts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // the products' blocks sit BEHIND the GEMM tiles: they fill the slots the GEMM's last, partly filled round leaves
@@ -721,6 +746,12 @@ int launch32ft(const cara_gemm_args* a, hipStream_t st, const TsPair* ts) {
   return CARA_OK;
 }
 
+// rows of the tile that carries epilogue riders: CARA_ER_ROWS = 128 (default: 64 accumulator registers leave room for the riders' 32 +
+// the operand buffers inside the 168 of three workgroups per CU) or 160
+static int er_rows() {
+  static const int v = [] { const char* e = getenv("CARA_ER_ROWS"); return e ? atoi(e) : 128; }();
+  return v == 160 ? 160 : 128;
+}
 // the 160-row tile takes the widest products (launch32)
 static bool tile160(const cara_gemm_args* a) {
   static const int bm = [] { const char* e = getenv("CARA_GEMM_BM"); return e ? atoi(e) : 160; }();
@@ -738,19 +769,29 @@ int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr
   // The 160-row tile for the widest products (N >= 3072: fc1 forward, fc2 dX).  CARA_GEMM_BM=128 keeps the 128-row tile (A/B runs:
   // 9.22 -> 9.08 and 9.37 -> 9.28 ms per step on two boxes; for the N = 768 products, whose 594 / 474 tiles are a single
   // round either way, it made no difference in the step and stays off)
+  // launches that carry riding products: the dX GEMMs' epilogues only
+  constexpr bool TS_EPI = EPI == CARA_EPI_BF16 || EPI == CARA_EPI_DGELU || EPI == CARA_EPI_MULH;
   if (tile160(a)) {
     constexpr int LDS160 = 2 * (160 * BK32 * 2 + B32_BYTES);
     const int nwg5 = ((a->M + 159) / 160) * tiles_n;
-    if constexpr (EPI == CARA_EPI_DGELU) {
+    if constexpr (EPI == CARA_EPI_MULH) {
       if (a->er_Tt) {   // epilogue riders (checked by the caller: cara_gemm_epi_rider_chunks)
-        if (ts) launch_ts<EPI, 5, true>(a, st, ts, tiles_n, nwg5, gm, LDS160);
-        else hipLaunchKernelGGL((gemm32_kernel<EPI, false, 5, true>), dim3(nwg5), dim3(256), LDS160, st, *a, tiles_n, nwg5, gm);
+        if (er_rows() == 160) {
+          constexpr int L = LDS160 > ER_LDS_BYTES ? LDS160 : ER_LDS_BYTES;
+          if (ts) launch_ts<EPI, 5, true>(a, st, ts, tiles_n, nwg5, gm, L);
+          else hipLaunchKernelGGL((gemm32_kernel<EPI, false, 5, true>), dim3(nwg5), dim3(256), L, st, *a, tiles_n, nwg5, gm);
+        } else {
+          constexpr int L = GEMM_LDS > ER_LDS_BYTES ? GEMM_LDS : ER_LDS_BYTES;
+          if (ts) launch_ts<EPI, 4, true>(a, st, ts, tiles_n, nwg, gm, L);
+          else hipLaunchKernelGGL((gemm32_kernel<EPI, false, 4, true>), dim3(nwg), dim3(256), L, st, *a, tiles_n, nwg, gm);
+        }
         CARA_CHECK_LAUNCH();
         return CARA_OK;
       }
     }
     if (ts) {
-      launch_ts<EPI, 5>(a, st, ts, tiles_n, nwg5, gm, LDS160);
+      if constexpr (TS_EPI) launch_ts<EPI, 5>(a, st, ts, tiles_n, nwg5, gm, LDS160);
+      else return CARA_E_ARG;
     } else {
       hipLaunchKernelGGL((gemm32_kernel<EPI, false, 5>), dim3(nwg5), dim3(256), LDS160, st, *a, tiles_n, nwg5, gm);
     }
@@ -758,7 +799,8 @@ int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr
     return CARA_OK;
   }
   if (ts) {
-    launch_ts<EPI, 4>(a, st, ts, tiles_n, nwg, gm, GEMM_LDS);
+    if constexpr (TS_EPI) launch_ts<EPI, 4>(a, st, ts, tiles_n, nwg, gm, GEMM_LDS);
+    else return CARA_E_ARG;
     CARA_CHECK_LAUNCH();
     return CARA_OK;
   }
@@ -843,6 +885,13 @@ __global__ __launch_bounds__(256) void small_m_finish_kernel(const cara_gemm_arg
     } else if constexpr (EPI == CARA_EPI_GELU) {
       if (p.C2) static_cast<bf16*>(p.C2)[o + k] = (bf16)v[k];
       static_cast<bf16*>(p.C)[o + k] = (bf16)gelu_erf(v[k]);
+    } else if constexpr (EPI == CARA_EPI_GELU_DG) {
+      float g, gp;
+      gelu_erf_both(v[k], g, gp);
+      if (p.C2) static_cast<h16*>(p.C2)[o + k] = (h16)gp;
+      static_cast<bf16*>(p.C)[o + k] = (bf16)g;
+    } else if constexpr (EPI == CARA_EPI_MULH) {
+      static_cast<bf16*>(p.C)[o + k] = (bf16)(v[k] * (float)static_cast<const h16*>(p.aux)[o + k]);
     } else {
       static_cast<bf16*>(p.C)[o + k] = (bf16)(v[k] * gelu_erf_grad((float)static_cast<const bf16*>(p.aux)[o + k]));
     }
@@ -1102,9 +1151,9 @@ extern "C" int cara_gemm_rider_slab_format(const cara_gemm_args* a, int Rp, int 
 }
 
 extern "C" int cara_gemm_epi_rider_chunks(const cara_gemm_args* a) {
-  if (!a || a->epi != CARA_EPI_DGELU || !tile160(a) || a->Ut || (a->N & 127) || (a->ldc & 7) || (a->M & 3) || a->M <= 0) return 0;
+  if (!a || a->epi != CARA_EPI_MULH || !tile160(a) || a->Ut || (a->N & 127) || (a->ldc & 7) || (a->M & 3) || a->M <= 0) return 0;
   if (g_gemm8_override > 0) return 0;
-  return (a->M + 159) / 160;
+  return (a->M + er_rows() - 1) / er_rows();
 }
 extern "C" size_t cara_gemm_epi_rider_scratch_bytes(int chunks, int N) {
   if (chunks <= 0 || N <= 0 || (N & 63)) return 0;
@@ -1121,7 +1170,9 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
   if (panels) {   // K-panel-major activations: bf16 outputs
     if (a->a_panels < 0 || a->c_panels < 0 || (a->a_panels && a->a_panels < a->M) || (a->c_panels && a->c_panels < a->M))
       return CARA_E_ARG;
-    if (a->c_panels && ((a->N & 31) || !(a->epi == CARA_EPI_BF16 || a->epi == CARA_EPI_GELU || a->epi == CARA_EPI_DGELU))) return CARA_E_ARG;
+    if (a->c_panels && ((a->N & 31) || !(a->epi == CARA_EPI_BF16 || a->epi == CARA_EPI_GELU || a->epi == CARA_EPI_DGELU || a->epi == CARA_EPI_GELU_DG ||
+                                         a->epi == CARA_EPI_MULH)))
+      return CARA_E_ARG;
     if (a->batch > 1 || a->M <= 128) return CARA_E_ARG;
   }
   if (!(a->Rp == 0 || a->Rp == 32 || a->Rp == 64)) return CARA_E_ARG;
@@ -1131,11 +1182,19 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
   const bool small_ptrs = (unsigned long long)a->M * (a->a_panels ? 32 : a->lda) * 2 < (1ull << 32) && (unsigned long long)a->N * a->ldb * 2 < (1ull << 32);
   if (!small_ptrs) return CARA_E_ARG;
   if (a->epi == CARA_EPI_RESID && (!a->aux || (a->rowscale && a->rows_per_sample <= 0))) return CARA_E_ARG;
-  if (a->epi == CARA_EPI_DGELU && !a->aux) return CARA_E_ARG;
+  if ((a->epi == CARA_EPI_DGELU || a->epi == CARA_EPI_MULH) && !a->aux) return CARA_E_ARG;
+  if (a->epi == CARA_EPI_MULH && a->bias) return CARA_E_ARG;
   if (ts && (a->batch > 1 || a->M <= 128 || a->B3 || (a->Ut && a->epi != CARA_EPI_BF16))) return CARA_E_ARG;
   if (a->B3 && (a->Bp || a->Ut || a->batch > 1 || a->a_panels)) return CARA_E_ARG;
   if (a->er_Tt) {   // epilogue riders: only where cara_gemm_epi_rider_chunks() says so
-    if (!cara_gemm_epi_rider_chunks(a) || !a->er_Gt || !a->er_slabs_v || !a->er_slabs_u || a->er_ldg < a->M || (a->er_ldg & 3)) return CARA_E_ARG;
+    if (!cara_gemm_epi_rider_chunks(a) || !a->er_Gt || !a->er_h || !a->er_slabs_v || !a->er_slabs_u || a->er_ldg < a->M || (a->er_ldg & 3) ||
+        a->er_h_panels < 0 || (a->er_h_panels && a->er_h_panels < a->M))
+      return CARA_E_ARG;
+    // (the riders' epilogue addresses C, aux, h, T^T and G'^T with 32-bit byte offsets)
+    const unsigned long long pmax = a->c_panels > a->er_h_panels ? a->c_panels : a->er_h_panels;
+    if ((unsigned long long)a->M * a->ldc * 2 >= (1ull << 32) || (unsigned long long)(a->N / 32) * pmax * 64 >= (1ull << 32) ||
+        (unsigned long long)a->er_ldg * 32 >= (1ull << 32))
+      return CARA_E_ARG;
     if (ts && ts->nt != 1) return CARA_E_ARG;
   }
   // The MT x 256 x 64 one-workgroup-per-CU tile (gemm8.hip) where the policy asks for it (cara_gemm8_policy) and the tile takes the product
@@ -1171,6 +1230,8 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
       case CARA_EPI_GELU: return launch_small_m<CARA_EPI_GELU>(a, nslab, st);
       case CARA_EPI_RESID: return launch_small_m<CARA_EPI_RESID>(a, nslab, st);
       case CARA_EPI_DGELU: return launch_small_m<CARA_EPI_DGELU>(a, nslab, st);
+      case CARA_EPI_GELU_DG: return launch_small_m<CARA_EPI_GELU_DG>(a, nslab, st);
+      case CARA_EPI_MULH: return launch_small_m<CARA_EPI_MULH>(a, nslab, st);
       default: return CARA_E_ARG;
     }
   }
@@ -1180,6 +1241,8 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
     case CARA_EPI_GELU: return launch32<CARA_EPI_GELU>(a, st, ts);
     case CARA_EPI_RESID: return launch32<CARA_EPI_RESID>(a, st, ts);
     case CARA_EPI_DGELU: return launch32<CARA_EPI_DGELU>(a, st, ts);
+    case CARA_EPI_GELU_DG: return ts ? CARA_E_ARG : launch32<CARA_EPI_GELU_DG>(a, st);
+    case CARA_EPI_MULH: return launch32<CARA_EPI_MULH>(a, st, ts);
     default: return CARA_E_ARG;
   }
 }

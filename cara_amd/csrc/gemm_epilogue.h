@@ -62,7 +62,27 @@ __device__ __forceinline__ void epilogue_rows(const cara_gemm_args& p, const flo
                     a1[0] + bv[4], a1[1] + bv[5], a1[2] + bv[6], a1[3] + bv[7]};
       const size_t o = (size_t)m * p.ldc + n;
       bf16x8 out, out2;
-      if constexpr (EPI == CARA_EPI_BF16) {
+      h16x8 outh;
+      if constexpr (EPI == CARA_EPI_GELU_DG) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float g, gp;
+          gelu_erf_both(v[k], g, gp);
+          out[k] = (bf16)g;
+          outh[k] = (h16)gp;
+        }
+      } else if constexpr (EPI == CARA_EPI_MULH) {
+        const h16* gpp = static_cast<const h16*>(p.aux) + o;
+        h16x8 gv;
+        if (vec) {
+          gv = *reinterpret_cast<const h16x8*>(gpp);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) gv[k] = (n + k < p.N) ? gpp[k] : (h16)0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = (bf16)(v[k] * (float)gv[k]);
+      } else if constexpr (EPI == CARA_EPI_BF16) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) out[k] = (bf16)v[k];
       } else if constexpr (EPI == CARA_EPI_GELU) {
@@ -93,6 +113,9 @@ __device__ __forceinline__ void epilogue_rows(const cara_gemm_args& p, const flo
         if constexpr (EPI == CARA_EPI_GELU) {
           if (p.C2) *reinterpret_cast<bf16x8*>(static_cast<bf16*>(p.C2) + o) = out2;   // (NULL: inference, u is not kept)
         }
+        if constexpr (EPI == CARA_EPI_GELU_DG) {
+          if (p.C2) *reinterpret_cast<h16x8*>(static_cast<h16*>(p.C2) + o) = outh;
+        }
       } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
@@ -100,6 +123,9 @@ __device__ __forceinline__ void epilogue_rows(const cara_gemm_args& p, const flo
             dst[k] = out[k];
             if constexpr (EPI == CARA_EPI_GELU) {
               if (p.C2) (static_cast<bf16*>(p.C2) + o)[k] = out2[k];
+            }
+            if constexpr (EPI == CARA_EPI_GELU_DG) {
+              if (p.C2) (static_cast<h16*>(p.C2) + o)[k] = outh[k];
             }
           }
       }
@@ -187,7 +213,7 @@ __device__ __forceinline__ void epilogue_fast_bf16(const cara_gemm_args& p, cons
 template <int EPI, int NT>
 __device__ __forceinline__ void epilogue_fast_bf16_rt(const cara_gemm_args& p, const f32x4 (&acc)[NT][4], char* stg, const int mbase,
                                                       const int nbase, const int lane, const size_t coff) {
-  static_assert(EPI == CARA_EPI_BF16 || EPI == CARA_EPI_GELU, "bf16 outputs computed from the accumulator alone");
+  static_assert(EPI == CARA_EPI_BF16 || EPI == CARA_EPI_GELU || EPI == CARA_EPI_GELU_DG, "bf16 outputs computed from the accumulator alone");
   const int fr = lane & 15, fq = lane >> 4;
   float bv[4];
 #pragma unroll
@@ -195,6 +221,47 @@ __device__ __forceinline__ void epilogue_fast_bf16_rt(const cara_gemm_args& p, c
   char* wbase = stg + (4 * fq) * EPI_FAST_ROW_BYTES + fr * 2;
   const char* rbase = stg + (lane >> 3) * EPI_FAST_ROW_BYTES + (lane & 7) * 16;
   const int rrow = lane >> 3, rcol = (lane & 7) * 8;
+  if constexpr (EPI == CARA_EPI_GELU_DG) {
+    // h = gelu(u) and gelu'(u) from ONE evaluation of the shared terms, both 16-bit images written in the same pass (the two
+    // 16-row halves of the staging area); the derivative as IEEE half.  p.C2 == NULL (inference): h only
+    const bool keep = p.C2 != nullptr;   // (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float g[4], gp[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[i][j][r] + bv[j];
+          if (keep) gelu_erf_both(v, g[r], gp[r]);
+          else g[r] = gelu_erf(v);
+        }
+        char* w = wbase + j * 32;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<bf16*>(w + r * EPI_FAST_ROW_BYTES) = (bf16)g[r];
+        if (keep) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) *reinterpret_cast<h16*>(w + (16 + r) * EPI_FAST_ROW_BYTES) = (h16)gp[r];
+        }
+      }
+      asm volatile("" ::: "memory");
+      bf16x8 v8[2][2];
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) v8[o][pass] = *reinterpret_cast<const bf16x8*>(rbase + (o * 16 + pass * 8) * EPI_FAST_ROW_BYTES);
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int m = mbase + i * 16 + pass * 8 + rrow, n = nbase + rcol;
+        bf16* out = static_cast<bf16*>(p.C);
+        bf16* dst = p.c_panels ? out + ((size_t)(n >> 5) * p.c_panels + m) * 32 + (n & 31) : out + (size_t)m * p.ldc + n + coff;
+        *reinterpret_cast<bf16x8*>(dst) = v8[0][pass];
+        if (keep) *reinterpret_cast<bf16x8*>(static_cast<bf16*>(p.C2) + (size_t)m * p.ldc + n) = v8[1][pass];   // (16 bytes of halves)
+      }
+    }
+    return;
+  }
   constexpr int NOUT = EPI == CARA_EPI_GELU ? 2 : 1;
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
@@ -249,7 +316,7 @@ __device__ __forceinline__ void epilogue_fast_bf16_rt(const cara_gemm_args& p, c
 template <int EPI, int NT, int GROUP>
 __device__ __forceinline__ void epilogue_interior_aux(const cara_gemm_args& p, const f32x4 (&acc)[NT][4], float* stg, const int mbase,
                                                       const int nbase, const int lane) {
-  static_assert(EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU, "epilogues with an input operand");
+  static_assert(EPI == CARA_EPI_RESID || EPI == CARA_EPI_DGELU || EPI == CARA_EPI_MULH, "epilogues with an input operand");
   static_assert(NT % GROUP == 0, "whole pass groups");
   constexpr int ROWS = GROUP * 16, NG = NT / GROUP;
   const int fr = lane & 15, fq = lane >> 4;
@@ -330,10 +397,19 @@ __device__ __forceinline__ void epilogue_interior_aux(const cara_gemm_args& p, c
         const f32x4 a1 = *reinterpret_cast<const f32x4*>(stg + (q * 8 + rl) * 64 + c8 + 4);
         const bf16x8 uv = u[g & 1][q];
         bf16x8 out;
+        if constexpr (EPI == CARA_EPI_MULH) {   // (the saved derivative, IEEE half in the same 16 bytes)
+          const h16x8 gv = __builtin_bit_cast(h16x8, uv);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          out[k] = (bf16)(a0[k] * gelu_erf_grad((float)uv[k]));
-          out[4 + k] = (bf16)(a1[k] * gelu_erf_grad((float)uv[4 + k]));
+          for (int k = 0; k < 4; ++k) {
+            out[k] = (bf16)(a0[k] * (float)gv[k]);
+            out[4 + k] = (bf16)(a1[k] * (float)gv[4 + k]);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            out[k] = (bf16)(a0[k] * gelu_erf_grad((float)uv[k]));
+            out[4 + k] = (bf16)(a1[k] * gelu_erf_grad((float)uv[4 + k]));
+          }
         }
         const int m = mbase + g * ROWS + q * 8 + rl;
         bf16* dst = p.c_panels ? static_cast<bf16*>(p.C) + ((size_t)(n >> 5) * p.c_panels + m) * 32 + (n & 31)
@@ -346,50 +422,89 @@ __device__ __forceinline__ void epilogue_interior_aux(const cara_gemm_args& p, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// CARA_EPI_DGELU with EPILOGUE RIDERS (cara_gemm_args::er_*): the fc2 dX tile that turns its accumulators into
-// dH = acc * gelu'(u) also rebuilds h = gelu(u) from the u it has just read, and multiplies both -- transposed -- by its rows of
-// T^T (fc1's) and G'^T (fc2's): partial dVs_fc1 = dH^T T and dU_fc2 = h^T G' for its 64 columns.  The 77 MB of dH and the 77 MB of h
-// that those two products used to re-read per block (as workgroups riding in the fc1 dX launch) are never read again.
-// Per 16-row tile of the wave's NT: accumulators -> fp32 image -> 16-byte row pieces (as epilogue_interior_aux), dH / h values as
-// bf16 -> two 16 x 64 bf16 images (rows padded to 144 B) -> one transposing LDS read per 16-column tile and product = the A
-// operand of a K = 16 MFMA (lane fr: column fr, rows 4 fq .. 4 fq + 3), B operand = 8 bytes of T^T / G'^T row fr.  Everything is
-// wave-private (a wave's LDS operations complete in order; compiler fences between the differently typed accesses).
-// Handles edge tiles itself: rows >= M contribute zeros and are not stored (callers guarantee N % 64 == 0 for the wave tile,
-// ldc % 8 == 0, M % 4 == 0).  Results: rv[j] / ru[j] = the wave's partial [16 j + 4 fq + reg][fr] sums, cs[k] = this lane's share
-// of the column sums of dH (columns nbase + 8 (lane & 7) + k, rows of its lane group).
+// CARA_EPI_MULH with EPILOGUE RIDERS (cara_gemm_args::er_*): the fc2 dX tile that turns its accumulators into dH = acc * gelu'(u)
+// also reads the h = gelu(u) tile at the same coordinates and multiplies both -- transposed -- by its rows of T^T (fc1's) and G'^T
+// (fc2's): partial dVs_fc1 = dH^T T and dU_fc2 = h^T G' for its 64 columns.  The 77 MB of dH and the 77 MB of h that those two
+// products used to re-read per block (as workgroups riding in the fc1 dX launch, 4-KiB strided tiles) are read here once, as 16-byte
+// row pieces next to the saved derivative, and never again.
+// Per 16-row tile of the wave's NT: accumulators -> fp32 image -> 16-byte row pieces (as epilogue_interior_aux), dH / h as bf16 ->
+// two 16 x 64 bf16 images (rows padded to 144 B) -> one transposing LDS read per 16-column tile and product = the A operand of a
+// K = 16 MFMA (lane fr: column fr, rows 4 fq .. 4 fq + 3), B operand = 8 bytes of T^T / G'^T row fr.  The reads and MFMAs of a row
+// tile are issued one tile LATER, between the next tile's image writes and its arithmetic: the LDS round trip hides under VALU work.
+// Everything is wave-private (a wave's LDS operations complete in order; compiler fences between the differently typed accesses).
+// INTERIOR = false: rows >= M contribute zeros and are not stored.  Callers guarantee N % 64 == 0 for the wave tile, ldc % 8 == 0,
+// M % 4 == 0.  Results: rv[j] / ru[j] = the wave's partial [16 j + 4 fq + reg][fr] sums, cs[j] = this lane's share of the column sum
+// of the bf16 dH (column nbase + 16 j + fr, the rows 4 fq .. 4 fq + 3 of every row tile).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int ER_ROW_BYTES = 144;
 constexpr int ER_IMG_BYTES = 16 * ER_ROW_BYTES;
 constexpr int ER_WAVE_BYTES = 2 * ER_IMG_BYTES;   // 4608: the dH image and the h image
+constexpr int ER_STG_BYTES = 4096 + 256;          // per wave: the 16 x 64 fp32 staging image + the column sums of the wave-row exchange
+constexpr int ER_LDS_BYTES = 4 * (ER_STG_BYTES + ER_WAVE_BYTES);
 
-template <int NT>
-__device__ __forceinline__ void epilogue_dgelu_riders(const cara_gemm_args& p, const f32x4 (&acc)[NT][4], float* stg, char* img, const int mbase,
-                                                      const int nbase, const int lane, f32x4 (&rv)[4], f32x4 (&ru)[4], float (&cs)[8]) {
+template <int NT, bool INTERIOR>
+__device__ __forceinline__ void epilogue_mulh_riders(const cara_gemm_args& p, const f32x4 (&acc)[NT][4], float* stg, char* img, const int mbase,
+                                                     const int nbase, const int lane, f32x4 (&rv)[4], f32x4 (&ru)[4], float (&cs)[4]) {
   typedef __attribute__((ext_vector_type(4))) short s16x4_t;
   const int fr = lane & 15, fq = lane >> 4;
   const int c8 = (lane & 7) * 8, rl = lane >> 3;
   const int n = nbase + c8;
-  const bf16* __restrict__ Tt = static_cast<const bf16*>(p.er_Tt) + (size_t)fr * p.er_ldg;
-  const bf16* __restrict__ Gt = static_cast<const bf16*>(p.er_Gt) + (size_t)fr * p.er_ldg;
-  const bf16* __restrict__ up = static_cast<const bf16*>(p.aux) + n;
+  // Addresses: wave-uniform 64-bit bases (scalar registers) + ONE 32-bit byte offset per lane and layout.  Row-major [M, ldc] arrays
+  // (the saved derivative; h and C unless K-panel-major) share the offset of (row rl of the wave tile, column n); T^T and G'^T share
+  // (row fr, column 4 fq).  Every array spans < 4 GiB (callers check).
+  const unsigned ldc2 = (unsigned)p.ldc * 2u;
+  const unsigned off_rm = (unsigned)(mbase + rl) * ldc2 + (unsigned)n * 2u;
+  const unsigned off_hp = p.er_h_panels ? ((unsigned)(n >> 5) * (unsigned)p.er_h_panels + (unsigned)(mbase + rl)) * 64u + (unsigned)(n & 31) * 2u : off_rm;
+  const unsigned off_cp = p.c_panels ? ((unsigned)(n >> 5) * (unsigned)p.c_panels + (unsigned)(mbase + rl)) * 64u + (unsigned)(n & 31) * 2u : off_rm;
+  const unsigned hstep = p.er_h_panels ? 64u : ldc2, cstep = p.c_panels ? 64u : ldc2;   // bytes per row
+  const unsigned off_tg = (unsigned)fr * (unsigned)p.er_ldg * 2u + (unsigned)(mbase + 4 * fq) * 2u;
+  const char* __restrict__ gp_b = static_cast<const char*>(p.aux);
+  const char* __restrict__ h_b = static_cast<const char*>(p.er_h);
+  char* __restrict__ c_b = static_cast<char*>(p.C);
+  const char* __restrict__ tt_b = static_cast<const char*>(p.er_Tt);
+  const char* __restrict__ gt_b = static_cast<const char*>(p.er_Gt);
   const bf16x4 z4 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-  bf16x8 u[2][2];
-  bf16x4 bt[2], bg[2];
-  auto request = [&](int i, int s) {
+  h16x8 gv[2];
+  bf16x8 hv[2];
+  bf16x4 bt, bg;
+  // rows of an edge tile: the wave-uniform count of valid rows below mbase (INTERIOR: all)
+  const int rows_ok = p.M - mbase;
+  auto request = [&](int i) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      int m = mbase + i * 16 + q * 8 + rl;
-      m = m < p.M ? m : p.M - 1;
-      u[s][q] = *reinterpret_cast<const bf16x8*>(up + (size_t)m * p.ldc);
+      int r = i * 16 + q * 8;   // (row of the wave tile, without the lane's rl)
+      if (!INTERIOR) r = r + rl < rows_ok ? r : rows_ok - 1 - rl;   // clamp to the last valid row: a readable address, masked below
+      // (32-bit sums: a clamped row may lie ABOVE the wave tile's first row, r < 0, and the sum still lands inside the array)
+      gv[q] = *reinterpret_cast<const h16x8*>(gp_b + (size_t)(unsigned)((unsigned)r * ldc2 + off_rm));
+      hv[q] = *reinterpret_cast<const bf16x8*>(h_b + (size_t)(unsigned)((unsigned)r * hstep + off_hp));
     }
-    const int m4 = mbase + i * 16 + 4 * fq;   // (M % 4 == 0: the four rows are valid together)
-    bt[s] = m4 < p.M ? *reinterpret_cast<const bf16x4*>(Tt + m4) : z4;
-    bg[s] = m4 < p.M ? *reinterpret_cast<const bf16x4*>(Gt + m4) : z4;
   };
-  request(0, 0);
+  auto request_b = [&](int i) {
+    const bool ok = INTERIOR || i * 16 + 4 * fq < rows_ok;   // (M % 4 == 0: the four rows are valid together)
+    bt = ok ? *reinterpret_cast<const bf16x4*>(tt_b + (size_t)(unsigned)(i * 32 + off_tg)) : z4;
+    bg = ok ? *reinterpret_cast<const bf16x4*>(gt_b + (size_t)(unsigned)(i * 32 + off_tg)) : z4;
+  };
   // the transposing reads of this lane: row 4 fq + (fr >> 2) of the image, 8 bytes at column 16 j + 4 (fr & 3)
   const char* tbase = img + (4 * fq + (fr >> 2)) * ER_ROW_BYTES + (fr & 3) * 8;
   char* wbase = img + rl * ER_ROW_BYTES + c8 * 2;
+  auto products = [&]() {   // the images of the previous row tile x bt / bg; the column sums of dH from the same fragments
+#if !(defined(CARA_ER_ABLATE) && (CARA_ER_ABLATE & 1))   // timing diagnostic (tools/build_variant.sh): without the products
+    s16x4_t f4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f4[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4_t*)(tbase + j * 32));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16x4 d = __builtin_bit_cast(bf16x4, f4[j]);
+      rv[j] = mfma_16x16x16(d, bt, rv[j]);
+      cs[j] += ((float)d[0] + (float)d[1]) + ((float)d[2] + (float)d[3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f4[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4_t*)(tbase + ER_IMG_BYTES + j * 32));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ru[j] = mfma_16x16x16(__builtin_bit_cast(bf16x4, f4[j]), bg, ru[j]);
+#endif
+  };
+  request(0);
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
 #pragma unroll
@@ -397,40 +512,31 @@ __device__ __forceinline__ void epilogue_dgelu_riders(const cara_gemm_args& p, c
 #pragma unroll
       for (int r = 0; r < 4; ++r) stg[(fq * 4 + r) * 64 + j * 16 + fr] = acc[i][j][r];
     asm volatile("" ::: "memory");
-    if (i + 1 < NT) request(i + 1, (i + 1) & 1);
+    if (i > 0) products();
+    request_b(i);
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + (q * 8 + rl) * 64 + c8);
       const f32x4 a1 = *reinterpret_cast<const f32x4*>(stg + (q * 8 + rl) * 64 + c8 + 4);
-      const bf16x8 uv = u[i & 1][q];
-      const int m = mbase + i * 16 + q * 8 + rl;
-      const bool valid = m < p.M;
-      bf16x8 out, hv;
+      const int r = i * 16 + q * 8;
+      const bool valid = INTERIOR || r + rl < rows_ok;
+      bf16x8 out, hh = hv[q];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        float g, gp;
-        gelu_erf_both((float)uv[k], g, gp);
-        const float a = k < 4 ? a0[k & 3] : a1[k & 3];
-        out[k] = valid ? (bf16)(a * gp) : (bf16)0.f;
-        hv[k] = valid ? (bf16)g : (bf16)0.f;
-        cs[k] += (float)out[k];
+        float o = (k < 4 ? a0[k & 3] : a1[k & 3]) * (float)gv[q][k];
+        if (!INTERIOR) {
+          o = valid ? o : 0.f;
+          hh[k] = valid ? hh[k] : (bf16)0.f;
+        }
+        out[k] = (bf16)o;
       }
-      if (valid) {
-        bf16* dst = p.c_panels ? static_cast<bf16*>(p.C) + ((size_t)(n >> 5) * p.c_panels + m) * 32 + (n & 31)
-                               : static_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
-        *reinterpret_cast<bf16x8*>(dst) = out;
-      }
+      if (valid) *reinterpret_cast<bf16x8*>(c_b + (size_t)(unsigned)((unsigned)r * cstep + off_cp)) = out;
       *reinterpret_cast<bf16x8*>(wbase + q * 8 * ER_ROW_BYTES) = out;
-      *reinterpret_cast<bf16x8*>(wbase + ER_IMG_BYTES + q * 8 * ER_ROW_BYTES) = hv;
+      *reinterpret_cast<bf16x8*>(wbase + ER_IMG_BYTES + q * 8 * ER_ROW_BYTES) = hh;
     }
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const s16x4_t d4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4_t*)(tbase + j * 32));
-      const s16x4_t h4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4_t*)(tbase + ER_IMG_BYTES + j * 32));
-      rv[j] = mfma_16x16x16(__builtin_bit_cast(bf16x4, d4), bt[i & 1], rv[j]);
-      ru[j] = mfma_16x16x16(__builtin_bit_cast(bf16x4, h4), bg[i & 1], ru[j]);
-    }
+    if (i + 1 < NT) request(i + 1);
     asm volatile("" ::: "memory");
   }
+  products();
 }

@@ -279,8 +279,9 @@ extern "C" int cara_tskinny_reduce_many(const cara_ts_reduce* probs, int n, void
     if (!q.slabs || !q.D || q.batch <= 0 || q.M <= 0 || q.K1 <= 0 || (q.K1 % TS_COLS) || !(q.Rp == 32 || q.Rp == 64)) return CARA_E_ARG;
     if (!(q.Rc == 0 || q.Rc == q.Rp || (q.Rc == 16 && q.Rp == 32))) return CARA_E_ARG;
     t.p[i] = q;
-    if (q.wave_slabs && !(q.Rc == 16 && q.Rp == 32)) return CARA_E_ARG;   // (only the one-r-tile products are written per wave)
-    t.nchunks[i] = ts_chunks(q.M, q.K1) * (q.wave_slabs ? 4 : 1);   // slab (chunk * 4 + wave) of a column block
+    if (q.wave_slabs < 0 || (q.wave_slabs && !(q.Rc == 16 && q.Rp == 32))) return CARA_E_ARG;   // (only the one-r-tile products are written per wave / per row tile)
+    // slab (chunk * 4 + wave) of a column block; >= 2: the epilogue riders of a GEMM left that many slabs per column block
+    t.nchunks[i] = q.wave_slabs >= 2 ? q.wave_slabs : ts_chunks(q.M, q.K1) * (q.wave_slabs ? 4 : 1);
     const int blocks = (q.K1 * q.Rp + 255) / 256;
     maxblocks = blocks > maxblocks ? blocks : maxblocks;
     maxbatch = q.batch > maxbatch ? q.batch : maxbatch;

@@ -61,6 +61,8 @@ int dw_slabs(int out, int in, int M) {
   return n < 1 ? 1 : n;
 }
 
+bool epi_riders_geom(const cara_geom* g, int Mr, bool exact);
+bool save_gelu_grad(const cara_geom* g, const cara_vit_shape* s);
 bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
   if (!g || !s || g->depth <= 0 || g->depth > 64 || g->dim % g->heads || g->dim / g->heads != 64) return false;
   if (!(g->Rp == 32 || g->Rp == 64) || g->rank > g->Rp || s->B <= 0 || s->tokens <= 1 || s->tokens > 608) return false;
@@ -124,6 +126,10 @@ bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
     w->dc[i] = c.take((size_t)g->depth * outs[i] * 4);
     w->strideU[i] = (cara_tskinny_scratch_bytes((int)M, (int)ins[i], (int)Rp) + 255) & ~(size_t)255;
     w->strideV[i] = (cara_tskinny_scratch_bytes((int)M, (int)outs[i], (int)Rp) + 255) & ~(size_t)255;
+    // fc2's dU and fc1's dVs may come out of the fc2 dX epilogue, one slab per 160-row tile (cara_gemm_args::er_*)
+    const size_t er_bytes = (cara_gemm_epi_rider_scratch_bytes((int)((M + 127) / 128), (int)(4 * D)) + 255) & ~(size_t)255;   // (row tiles of 128 or 160)
+    if (i == 3 && epi_riders_geom(g, (int)M, s->wd_exact != 0) && er_bytes > w->strideU[i]) w->strideU[i] = er_bytes;
+    if (i == 2 && epi_riders_geom(g, (int)M, s->wd_exact != 0) && er_bytes > w->strideV[i]) w->strideV[i] = er_bytes;
     w->slabU[i] = c.take(w->strideU[i] * g->depth);
     w->slabV[i] = c.take(w->strideV[i] * g->depth);
   }
@@ -192,7 +198,15 @@ struct TsPending {
 // (cara_gemm_rider_slab_format: the launches of the 160 x 256 x 64 tile stream their riding products with helper waves).
 // The end-of-pass reduction groups the layers of a linear by it.
 struct SlabFormats {
-  unsigned char U[4][64] = {}, V[4][64] = {};
+  unsigned short U[4][64] = {}, V[4][64] = {};   // (>= 2: that many slabs per column block, cara_ts_reduce::wave_slabs)
+};
+
+// The products the fc2 dX launch computes in its epilogue (cara_gemm_args::er_*): fc1's dVs = dH^T T (+ dc) and fc2's own dU = h^T G'
+struct EpiRider {
+  const void* Tt;    // fc1's T^T
+  void* slabV;       // fc1's dVs slab region of this layer
+  size_t bytes;      // size of that region and of fc2's dU region
+  bool done = false; // set by the launch that computed them
 };
 
 // per-call context: what lin_fwd / lin_bwd need besides their operands (nothing here outlives the call)
@@ -343,7 +357,8 @@ int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char*
 // The two transposed skinny products ride in the launch of the dX GEMM when they can (cara_gemm_with_tskinny),
 // otherwise they are one launch of their own behind it, on the same stream.
 int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int Mr, int Rp, int ldt, char* ws, const Ws& W,
-            const LayerWs& lw, bool want_dx, cara_gemm_args a, bool want_dc, const Ctx& cx, bool have_G = false) {
+            const LayerWs& lw, bool want_dx, cara_gemm_args a, bool want_dc, const Ctx& cx, bool have_G = false, EpiRider* er = nullptr,
+            bool dvs_done = false) {
   void* st = cx.stream;
   const Ws::Bwd& R = W.bwd;
   bf16* G = reinterpret_cast<bf16*>(ws + R.G[L.slot]);
@@ -383,19 +398,43 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
     // of the PREVIOUS linear of the pass (a dU never shares an operand with its own dX GEMM, so it loses nothing by riding
     // elsewhere): fc2's dU, the 77-MB read of h, leaves the two-round fc2 dX launch for the single-round fc1 dX launch
     if (can_carry && defer_du() && pend && !inside) {
-      const bool take = pend->valid && pend->Rp == Rp && pend->M == Mr && pend->ldg == ldt;
-      if (pend->valid && !take) TRY(flush_pending(cx));
+      bool take = pend->valid && pend->Rp == Rp && pend->M == Mr && pend->ldg == ldt;
+      if (pend->valid && (!take || dvs_done)) {
+        TRY(flush_pending(cx));
+        take = false;
+      }
       if (g_inside) {   // G' = dY Vs computed by this GEMM on the tiles it streams (its own dVs does not read G'; its dU rides later)
         a.A2 = nullptr; a.Ut = L.Vst; a.T_out = G; a.Tt_out = Gt; a.ldt = ldt; a.Ut_rank = ts_rank(cx, Rp) <= 16 ? ts_rank(cx, Rp) : 0;
       }
+      if (dvs_done) {   // dVs and dc of this linear came out of the epilogue of the launch that produced its dY: a plain GEMM, its dU waits
+        TRY(cara_gemm_bf16(&a, st));
+        *pend = mine;
+        return CARA_OK;
+      }
+      int er_chunks = 0;
+      if (er) {   // this launch's epilogue computes the next linear's dVs (+ dc) and this linear's dU
+        a.er_Tt = er->Tt; a.er_Gt = Gt; a.er_slabs_v = er->slabV; a.er_slabs_u = slabU; a.er_ldg = ldt; a.er_colsum = 1;
+        a.er_h = X; a.er_h_panels = ldx < 0 ? -ldx : 0;   // (this linear's saved input: h)
+        er_chunks = cara_gemm_epi_rider_chunks(&a);
+        if (!er_chunks || er_chunks > 65535 || cara_gemm_epi_rider_scratch_bytes(er_chunks, L.in) > er->bytes) {
+          er_chunks = 0;
+          a.er_Tt = a.er_Gt = a.er_h = nullptr; a.er_slabs_v = a.er_slabs_u = nullptr;
+        }
+      }
       if (cx.fmt) {   // (depends on the arguments only: asked before the launch, valid for it)
-        const unsigned char f = (unsigned char)cara_gemm_rider_slab_format(&a, Rp, ts_rank(cx, Rp));
+        const unsigned short f = (unsigned short)cara_gemm_rider_slab_format(&a, Rp, ts_rank(cx, Rp));
         if (take) cx.fmt->U[pend->slot][pend->layer] = f;
         cx.fmt->V[L.slot][cx.layer] = f;
       }
       TRY(cara_gemm_with_tskinny_r(&a, take ? pend->Xa : nullptr, take ? pend->ldxa : 0, take ? pend->Gta : nullptr, take ? pend->slabs_a : nullptr,
                                    take ? pend->K1a : 0, mine.Xb, mine.ldxb, mine.Gtb, mine.slabs_b, mine.K1b, mine.want_cs, ldt, Mr, Rp,
                                    ts_rank(cx, Rp), st));
+      if (er_chunks) {   // (nothing of this linear waits: its dU is in the slabs the epilogue wrote)
+        pend->valid = false;
+        er->done = true;
+        if (cx.fmt) cx.fmt->U[L.slot][cx.layer] = (unsigned short)er_chunks;
+        return CARA_OK;
+      }
       *pend = mine;   // (its dU half waits for the next dX GEMM of the pass; flush_pending runs it alone otherwise)
       return CARA_OK;
     }
@@ -409,7 +448,7 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
     if (carry) { TRY(cara_gemm_bf16(&a, st)); return CARA_OK; }
 #endif
     if (carry && cx.fmt) {
-      const unsigned char f = (unsigned char)cara_gemm_rider_slab_format(&a, carry->Rp, ts_rank(cx, carry->Rp));
+      const unsigned short f = (unsigned short)cara_gemm_rider_slab_format(&a, carry->Rp, ts_rank(cx, carry->Rp));
       cx.fmt->U[carry->slot][carry->layer] = f;
       cx.fmt->V[carry->slot][carry->layer] = f;
     }
@@ -578,6 +617,35 @@ bool g_inside_enabled(int slot) {   // CARA_GEMM_G_INSIDE: bit 0 qkv, bit 1 fc1 
 bool defer_du() {
   static const int v = env_once("CARA_DEFER_DU", 1);
   return v != 0 && !defer_ts();
+}
+
+// CARA_SAVE_GELU_GRAD (default: on where CARA_EPI_RIDERS is): fc1 forward keeps gelu'(u) (IEEE half) instead of the pre-activation u, and
+// the fc2 dX epilogue is one multiply per element instead of the erf arithmetic (CARA_EPI_GELU_DG / CARA_EPI_MULH, include/cara_hip.h).
+// Where the LayerNorms compute T = X U (the forward's fc1 GEMM then never has the adapter inside, a form the new epilogue does not
+// take), factored mode.  Measured alone (r04, same box): a tie -- fc1 forward 77.3 -> 80.0 us, fc2 dX 76.9 -> 74.3: neither epilogue is
+// bound by its VALU count any more (docs/findings/r04.md section 6).
+static int epi_riders_env() {
+  static const int v = env_once("CARA_EPI_RIDERS", 0);
+  return v;
+}
+bool save_gelu_grad(const cara_geom* g, const cara_vit_shape* s) {
+  static const int v = env_once("CARA_SAVE_GELU_GRAD", -1);
+  return (v < 0 ? epi_riders_env() != 0 : v != 0) && fuse_xu(g) && !s->wd_exact;
+}
+
+// CARA_EPI_RIDERS (default 0): fc1's dVs = dH^T T (+ dc) and fc2's dU = h^T G' are computed by the epilogue of the fc2 dX GEMM, on the dH
+// tile it has just produced and the h tile at the same coordinates (cara_gemm_args::er_*), instead of as workgroups riding in the fc1 dX
+// launch that re-read dH and h (154 MB per block at the headline shape); the fc1 dX launch then carries nothing and runs on the
+// 160 x 256 x 64 tile.  Rank <= 16, full-size blocks; what the shape allows is asked of cara_gemm_epi_rider_chunks() at the launch.
+// Measured (r04, same box, profiles/r04_n_*): fc1 dX 86.4 -> 56.2 us, fc2 dX 74.3 -> 102.8 us, and the end-of-pass slab sums read
+// 99 slabs per product instead of 6 (+80 us per step): 8.005 -> 8.096 ms per step.  The riders' epilogue is a longer DEPENDENT chain
+// per wave (two operand streams, an LDS round trip more per row tile) in a launch that is bound by such chains, not by any unit
+// (MFMA-busy 0.25, LDS 24 %, +105 MB of reads at 3.5 TB/s): off.
+bool epi_riders_geom(const cara_geom* g, int Mr, bool exact) {
+  const int v = epi_riders_env();
+  cara_vit_shape sh = {};
+  sh.wd_exact = exact ? 1 : 0;
+  return v != 0 && !exact && save_gelu_grad(g, &sh) && g->Rp == 32 && g->rank > 0 && g->rank <= 16 && Mr > 1024 && (Mr & 3) == 0 && 4 * g->dim >= 3072 && ((4 * g->dim) & 127) == 0;
 }
 
 // tiny classifier-head backward (B x classes x D, fp32 VALU).  The three outputs are independent: blocks
@@ -756,8 +824,9 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
                                 fx ? lin[2].Ut : nullptr, g->rank, Rp, ws + lw.T[2], ws + lw.Tt[2], W.ldt, pa_n ? Mr : 0, stream));
     }
     e = {};
-    e.epi = CARA_EPI_GELU; e.C = ws + lw.h;
-    e.C2 = inference ? nullptr : ws + lw.u;   // the pre-activation is only read by the backward (gelu')
+    // what the backward's fc2 dX epilogue needs: gelu'(u) itself, kept as IEEE half (CARA_EPI_GELU_DG / _MULH), or the pre-activation u
+    e.epi = save_gelu_grad(g, s) ? CARA_EPI_GELU_DG : CARA_EPI_GELU; e.C = ws + lw.h;
+    e.C2 = inference ? nullptr : ws + lw.u;   // (only read by the backward)
     if (pa) { e.c_panels = Mr; e.ldc = 4 * D; }   // h (and dH in the backward) K-panel-major
     if (ex) TRY(lin_fwd_exact(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), D, Mr, Rp, ws, W, s, e, cx));
     else TRY(lin_fwd(lin[2], reinterpret_cast<bf16*>(ws + lw.xn2), pa_n ? -Mr : D, Mr, Rp, W.ldt, ws, lw, e, cx, fx));
@@ -830,24 +899,32 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     bf16* dQKV = reinterpret_cast<bf16*>(ws + R.dQKV);
     // ---- mlp branch: dY = drop_path scale * dx (already in dyb) ----
     cara_gemm_args e = {};
-    e.epi = CARA_EPI_DGELU; e.C = dH; e.aux = ws + lw.u;
+    e.epi = save_gelu_grad(g, s) ? CARA_EPI_MULH : CARA_EPI_DGELU; e.C = dH; e.aux = ws + lw.u;
     // K-panel-major activations, as the forward wrote them (xn1: pa_x; xn2, h: pa) and as the kernels here write
     // theirs: dH and dyp (pa), dyb of the block below (pa_x).  This block's own dyb came from the block above --
     // panels -- except in the last block, where the final norm's backward left it row-major on the cls rows.
     // (h as the forward wrote it: row-major where fc2 forward runs on the 160 x 256 x 64 tile; dH: row-major where fc1 dX does)
     const bool pa_x = panel_acts(M, s, 2) && !dense_qkv, pa = panel_acts(Mr, s, 1) && !cara_gemm8_policy(Mr, D, 4 * D, 0), pa_n = panel_acts(Mr, s, 2);
-    const bool pa_dh = panel_acts(Mr, s, 1) && !cara_gemm8_policy(Mr, D, 4 * D, 1);
+    // fc1's dVs / dc and fc2's dU out of the fc2 dX epilogue: the fc1 dX launch then carries nothing and runs on the 160 x 256 x 64 tile
+    const bool er_on = epi_riders_geom(g, Mr, ex) && ts_rank(cx, Rp) <= 16 && fuse_ts(Mr, Rp) && defer_du();
+    EpiRider er;
+    er.Tt = ws + lw.Tt[2];
+    er.slabV = ws + W.slabV[2] + (size_t)l * W.strideV[2];
+    er.bytes = W.strideV[2] < W.strideU[3] ? W.strideV[2] : W.strideU[3];
+    const bool pa_dh = panel_acts(Mr, s, 1) && !cara_gemm8_policy(Mr, D, 4 * D, er_on ? 0 : 1);
     const bool pa_dp = panel_acts(Mr, s, 4), pa_dx = panel_acts(M, s, 4);   // dyp here; dyb of the block below
     const bool pa_dyb = pa_dx && l < g->depth - 1;
     if (pa_dh) { e.c_panels = Mr; e.ldc = 4 * D; }
     if (ex) TRY(lin_bwd_exact(lin[3], dyb, reinterpret_cast<bf16*>(ws + lw.h), Mr, Rp, ws, W, s, true, e, true, cx));
     else TRY(lin_bwd(lin[3], dyb, pa_dyb ? -M : ldr, reinterpret_cast<bf16*>(ws + lw.h), pa ? -Mr : 4 * D, Mr, Rp, W.ldt, ws, W, lw, true, e, true, cx,
-                     have_G_fc2));
+                     have_G_fc2, er_on ? &er : nullptr));
+    if (er.done) formats.V[2][l] = formats.U[3][l];   // (fc1's dVs slabs: the same launch, the same count of row tiles)
     have_G_fc2 = false;
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
     if (ex) TRY(lin_bwd_exact(lin[2], dH, reinterpret_cast<bf16*>(ws + lw.xn2), Mr, Rp, ws, W, s, true, e, true, cx));
-    else TRY(lin_bwd(lin[2], dH, pa_dh ? -Mr : 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), pa_n ? -Mr : D, Mr, Rp, W.ldt, ws, W, lw, true, e, true, cx));
+    else TRY(lin_bwd(lin[2], dH, pa_dh ? -Mr : 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), pa_n ? -Mr : D, Mr, Rp, W.ldt, ws, W, lw, true, e, true, cx, false,
+                     nullptr, er.done));
     // dyp = dY of this block's proj: its G' = dY Vs comes out of the same kernel (CARA_LN2B_XU=0: out of proj's dX GEMM instead)
     static const int ln2b_xu = env_once("CARA_LN2B_XU", 1);
     const bool fxp = fx && (ln2b_xu != 0 || cls_only);

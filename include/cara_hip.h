@@ -48,6 +48,12 @@ enum {
   CARA_EPI_GELU = 2,   /* C2 bf16 = u = acc+bias ; C bf16 = gelu_erf(u)           (fc1 forward) */
   CARA_EPI_RESID = 3,  /* C fp32 = aux_f32 + rowscale[m / rows_per_sample] * (acc + bias)       */
   CARA_EPI_DGELU = 4,  /* C bf16 = acc * gelu_erf'(aux_bf16[m,n])                (fc2 backward) */
+  /* The same pair with the DERIVATIVE saved instead of the pre-activation: the forward has e = exp(-u^2/2) and the erf polynomial in  */
+  /* registers for gelu(u) anyway (4 more VALU per element give gelu'(u) of the UNROUNDED u), and the backward epilogue is one multiply */
+  /* instead of ~15 VALU per element of erf arithmetic in a launch whose epilogue is VALU-bound.  gelu' lies in [-0.13, 1.13]: it is kept */
+  /* as IEEE half (11 significand bits) in BOTH builds of the library -- bf16's 8 bits would cost more than rounding u did.              */
+  CARA_EPI_GELU_DG = 5, /* C bf16 = gelu_erf(u), u = acc+bias ; C2 fp16 = gelu_erf'(u) (NULL: not kept)         (fc1 forward) */
+  CARA_EPI_MULH = 6,    /* C bf16 = acc * aux_fp16[m,n]                                                          (fc2 backward) */
 };
 typedef struct {
   const void* A;  int lda;      /* bf16 [M,K]  */
@@ -57,8 +63,8 @@ typedef struct {
   const float* bias;            /* fp32 [N] or NULL */
   int epi;
   void* C;  int ldc;
-  void* C2;                     /* CARA_EPI_GELU only (same ldc); NULL = the pre-activation is not kept */
-  const void* aux;              /* CARA_EPI_RESID: fp32 [M,ldc]; CARA_EPI_DGELU: bf16 [M,ldc] */
+  void* C2;                     /* CARA_EPI_GELU / _GELU_DG only (same ldc); NULL = the pre-activation / derivative is not kept */
+  const void* aux;              /* CARA_EPI_RESID: fp32 [M,ldc]; CARA_EPI_DGELU: bf16 [M,ldc]; CARA_EPI_MULH: fp16 [M,ldc] */
   const float* rowscale;        /* CARA_EPI_RESID: fp32 [M / rows_per_sample] or NULL (=1) */
   int rows_per_sample;
   void* scratch;                /* optional: cara_gemm_scratch_bytes() of caller memory, used by ONE call  */
@@ -93,24 +99,26 @@ typedef struct {
   /* With Ut: the adapter's rank, if the caller knows it (0 = not stated).  At Rp = 32 and 1 <= Ut_rank <= 16 the kernel computes  */
   /* columns 0 .. 15 of T only (rows >= rank of Ut are zero) and writes columns 16 .. 31 as zeros: same results, bit for bit.      */
   int Ut_rank;
-  /* Epilogue riders (CARA_EPI_DGELU only; er_Tt == NULL: none).  The tile that has just produced dH = acc * gelu'(u) from the pre-     */
-  /* activation u holds everything two transposed skinny products of the backward need: dVs = dH^T T of the linear whose dY this C is  */
-  /* (fc1), and dU = h^T G' of this linear (fc2) with h = gelu(u) rebuilt from the same u (4 more VALU per element) -- 154 MB of dH    */
-  /* and h per block that nothing has to read again.  Every workgroup multiplies its bf16 dH / h tile, transposed through LDS, by its  */
-  /* rows of er_Tt / er_Gt (bf16 [>= 16, er_ldg]: T^T and G'^T, rows = the first 16 adapter columns, er_ldg >= M) and writes 16-wide   */
-  /* fp32 partial sums for its 128 columns: slab `row tile` of column block n / 64, in the layout of cara_tskinny_partial2_r at rank   */
-  /* <= 16 with cara_gemm_epi_rider_chunks(a) slabs per column block (er_colsum: column sums of dH behind the er_slabs_v slabs, as     */
-  /* want_colsum leaves them).  Reduce with cara_ts_reduce::Rc = 16, ::wave_slabs = that chunk count.  Each slab region:               */
-  /* cara_gemm_epi_rider_scratch_bytes(chunks, N).  h is gelu of the bf16 u (the forward rounded gelu of the fp32 u).                  */
+  /* Epilogue riders (CARA_EPI_MULH only; er_Tt == NULL: none).  The tile that has just produced dH = acc * gelu'(u) holds half of what  */
+  /* two transposed skinny products of the backward need: dVs = dH^T T of the linear whose dY this C is (fc1), and dU = h^T G' of this    */
+  /* linear (fc2) with the h = gelu(u) tile at the same coordinates (er_h: bf16, row-major with C's ldc, or K-panel-major                 */
+  /* [N/32][er_h_panels][32]) -- read here once, 16 bytes per lane, instead of 77 MB of dH and 77 MB of h re-read per block by products   */
+  /* that ride in the next launch.  Every workgroup multiplies its bf16 dH / h tile, transposed through LDS, by its rows of er_Tt / er_Gt */
+  /* (bf16 [>= 16, er_ldg]: T^T and G'^T, rows = the first 16 adapter columns, er_ldg >= M) and writes 16-wide fp32 partial sums for its   */
+  /* 128 columns: slab `row tile` of column block n / 64, in the layout of cara_tskinny_partial2_r at rank <= 16 with                     */
+  /* cara_gemm_epi_rider_chunks(a) slabs per column block (er_colsum: column sums of dH behind the er_slabs_v slabs, as want_colsum       */
+  /* leaves them).  Reduce with cara_ts_reduce::Rc = 16, ::wave_slabs = that chunk count.  Each slab region:                              */
+  /* cara_gemm_epi_rider_scratch_bytes(chunks, N).                                                                                         */
   const void* er_Tt;
   const void* er_Gt;
+  const void* er_h;
   void* er_slabs_v;
   void* er_slabs_u;
-  int er_ldg, er_colsum;
+  int er_ldg, er_colsum, er_h_panels;
 } cara_gemm_args;
 int cara_gemm_bf16(const cara_gemm_args* a, void* stream);
 /* Slabs per column block a launch of `a` with epilogue riders writes (= its row tiles), 0: this product cannot carry them (then  */
-/* cara_gemm_bf16 / cara_gemm_with_tskinny* return CARA_E_ARG when er_Tt is set).  Needs CARA_EPI_DGELU, M > 1024, N >= 3072,     */
+/* cara_gemm_bf16 / cara_gemm_with_tskinny* return CARA_E_ARG when er_Tt is set).  Needs CARA_EPI_MULH, M > 1024, N >= 3072,      */
 /* N % 128 == 0, ldc % 8 == 0, no batch, M % 4 == 0.  Depends on the arguments only.                                              */
 int cara_gemm_epi_rider_chunks(const cara_gemm_args* a);
 size_t cara_gemm_epi_rider_scratch_bytes(int chunks, int N);
@@ -160,7 +168,8 @@ int cara_tskinny_partial2(const void* Xa, int ldxa, const void* Gta, void* slabs
  * event between the kernels before and after).  M > 128, no batch; Rp in {32, 64} (64: three workgroups per CU); the
  * products need not be those of the GEMM's own linear (their M may differ from a->M); with a->Ut (the adapter inside
  * the GEMM) only CARA_EPI_BF16 and products of the same Rp.  CARA_E_ARG otherwise (callers then launch the two
- * separately).  Results are bitwise those of the two calls.                                                      */
+ * separately).  The GEMM's epilogue: CARA_EPI_BF16, CARA_EPI_DGELU or CARA_EPI_MULH (the dX products).  Results are bitwise
+ * those of the two calls.                                                                                          */
 int cara_gemm_with_tskinny(const cara_gemm_args* a, const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a,
                            const void* Xb, int ldxb, const void* Gtb, void* slabs_b, int K1b, int want_colsum_b,
                            int ldg, int M, int Rp, void* stream);

@@ -4,6 +4,7 @@ are accumulated in fp32 on the device and in fp64 here, so differences come only
 rounding (bf16: 2^-9 relative) and fp32 summation order."""
 import ctypes as C
 import math
+import os
 
 import pytest
 import torch
@@ -1115,3 +1116,83 @@ def test_one_adapted_linear_per_call(M, din, dout, rank, epi):
     close(dc, dY.double().sum(0), 1e-3, 1e-2 * math.sqrt(M / 1000), "dc")
     bad = L().Linear()
     assert lib.cara_linear_fwd(C.byref(bad), p(X), din, M, p(T), p(Tt), ldt, L().EPI_BF16, p(Y), 0, None, None, None, 0, st()) != 0
+
+
+def test_gelu_with_its_derivative_saved():
+    """CARA_EPI_GELU_DG / CARA_EPI_MULH: the forward keeps gelu'(u) as IEEE half instead of u, the backward multiplies by it.  h is
+    bitwise CARA_EPI_GELU's; the derivative against fp64 autograd at half precision; dH = acc * gelu' against fp64; the few-row and
+    edge-tile paths; inference (C2 = NULL) leaves only h."""
+    for (M, N, K) in ((12608, 3072, 768), (1500, 1024, 256), (64, 3072, 768), (333, 200, 128)):
+        A, W, bias = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3, dtype=torch.float32)
+        scratch = torch.zeros(L().gemm_scratch_bytes(), dtype=torch.uint8, device=DEV) if M <= 128 else None
+        h0, u0 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        h1 = torch.empty_like(h0)
+        gp = torch.empty(M, N, dtype=torch.float16, device=DEV)
+        L().gemm(A, W, h0, epi=L().EPI_GELU, bias=bias, C2=u0, scratch=scratch)
+        L().gemm(A, W, h1, epi=L().EPI_GELU_DG, bias=bias, C2=gp, scratch=scratch)
+        assert torch.equal(h0, h1)
+        ud = (A.double() @ W.double().t() + bias.double()).requires_grad_(True)
+        torch.nn.functional.gelu(ud).sum().backward()
+        close(gp, ud.grad, 2 ** -10, 2e-3 * math.sqrt(K / 64), f"gelu' saved as half ({M} x {N})")
+        h2 = torch.empty_like(h0)
+        L().gemm(A, W, h2, epi=L().EPI_GELU_DG, bias=bias, scratch=scratch)
+        assert torch.equal(h0, h2)
+        dY, Wt = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=0.05)
+        dH = torch.empty_like(h0)
+        L().gemm(dY, Wt, dH, epi=L().EPI_MULH, aux=gp, scratch=scratch)
+        close(dH, (dY.double() @ Wt.double().t()) * gp.double(), 2 ** -8, 3e-3 * math.sqrt(K / 64), f"acc * saved gelu' ({M} x {N})")
+
+
+@pytest.mark.parametrize("M,panels", [(12608, False), (2000, False), (1600, True)])
+def test_fc2_dx_epilogue_riders(M, panels):
+    """cara_gemm_args::er_*: the CARA_EPI_MULH launch also leaves, per row tile, the partial sums of dVs = dH^T T (+ column sums of
+    dH) and dU = h^T G' -- dH itself bitwise what the launch without riders writes; the reduced products against fp64 on the bf16
+    dH the kernel rounds to.  M = 2000: the last row tile is partial (at 160 rows its second wave row lies wholly outside)."""
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+    N, K, Rp, rank = 3072, 768, 32, 16
+    ldg = (M + 31) // 32 * 32
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    A2, B2 = rnd(M, Rp, seed=3, scale=0.3), rnd(N, Rp, seed=4, scale=0.3)
+    gp = (torch.rand(M, N, generator=torch.Generator().manual_seed(5)) * 1.26 - 0.13).to(torch.float16).to(DEV)
+    h = rnd(M, N, seed=8)
+    hp = h.reshape(M, N // 32, 32).permute(1, 0, 2).contiguous() if panels else h
+    Tt = torch.zeros(Rp, ldg, dtype=torch.bfloat16, device=DEV)
+    Gt = torch.zeros(Rp, ldg, dtype=torch.bfloat16, device=DEV)
+    Tt[:rank, :M] = rnd(rank, M, seed=6)
+    Gt[:rank, :M] = rnd(rank, M, seed=7)
+    Tt[:, M:] = float("nan")    # (columns >= M are never to be read into a sum)
+    Gt[:, M:] = float("nan")
+    kw = dict(c_panels=M, ldc=N) if panels else {}
+    shape = (N // 32, M, 32) if panels else (M, N)
+    ref = torch.zeros(shape, dtype=torch.bfloat16, device=DEV)
+    L().gemm(A, W, ref, epi=L().EPI_MULH, A2=A2, B2=B2, aux=gp, **kw)
+    out = torch.zeros(shape, dtype=torch.bfloat16, device=DEV)
+    out, sv, su, chunks = L().gemm(A, W, out, epi=L().EPI_MULH, A2=A2, B2=B2, aux=gp, epi_riders=(Tt, Gt, hp, True, M if panels else 0), **kw)
+    rows = 160 if os.environ.get("CARA_ER_ROWS") == "160" else 128
+    assert chunks == (M + rows - 1) // rows
+    assert torch.equal(out, ref)
+    Dv = torch.full((N, Rp), float("nan"), device=DEV)
+    Du = torch.full((N, Rp), float("nan"), device=DEV)
+    cs = torch.full((N,), float("nan"), device=DEV)
+    tab = (L().TsReduce * 2)(L().TsReduce(p(sv), 0, p(Dv), p(cs), 1, M, N, Rp, 16, chunks),
+                             L().TsReduce(p(su), 0, p(Du), None, 1, M, N, Rp, 16, chunks))
+    L().check(lib.cara_tskinny_reduce_many(tab, 2, st()), "reduce many")
+    torch.cuda.synchronize()
+    dH = out.permute(1, 0, 2).reshape(M, N) if panels else out
+    assert torch.count_nonzero(Dv[:, rank:]) == 0 and torch.count_nonzero(Du[:, rank:]) == 0
+    close(Dv[:, :rank], dH.double().t() @ Tt[:rank, :M].double().t(), 1e-3, 2e-2, "dVs from the epilogue")
+    close(cs, dH.double().sum(0), 1e-3, 2e-2, "dc from the epilogue")
+    close(Du[:, :rank], h.double().t() @ Gt[:rank, :M].double().t(), 1e-3, 2e-2, "dU from the epilogue")
+    # the same products by the kernels that re-read dH and h: equal to fp32 summation order
+    Dv2 = torch.empty(N, Rp, device=DEV)
+    cs2 = torch.empty(N, device=DEV)
+    Tz = Tt.clone()
+    Tz[:, M:] = 0
+    L().tskinny_xtg(dH.contiguous(), Tz, Dv2, cs2, M=M)
+    close(Dv[:, :rank], Dv2[:, :rank], 1e-5, 2e-3, "dVs: epilogue vs cara_tskinny_xtg")
+    close(cs, cs2, 1e-5, 2e-3, "dc: epilogue vs cara_tskinny_xtg")
+    # what cannot carry them says so
+    small = torch.zeros(M, 768, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(ValueError):
+        L().gemm(A, rnd(768, K, seed=8), small, epi=L().EPI_MULH, aux=gp[:, :768].contiguous(), epi_riders=(Tt, Gt, h[:, :768].contiguous(), True))

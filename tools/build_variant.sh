@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../cara_amd/csrc"
 mkdir -p build_$name
 OBJS=""
 pids=()
-for s in lib gemm skinny norm_misc attention factors dropout_exact dense_delta optim vit; do
+for s in lib gemm gemm8 skinny norm_misc attention factors dropout_exact dense_delta optim linear vit; do
   o=build_$name/$s.o
   OBJS="$OBJS $o"
   hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result "$@" -c $s.hip -o $o &
