@@ -291,6 +291,8 @@ def main():
     ap.add_argument("--weight-dropout", default="off", choices=["off", "exact"],
                     help="exact = the reference's train-mode Dropout(0.1) on the materialised adapters (merged weights + "
                          "dense dW gradients); informational, the reported metric uses the factored default")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"],
+                    help="fp16 = the IEEE-half operand build (the mode inside north_star's 1e-3); diagnostic, the reported metric is bf16")
     ap.add_argument("--model", default="vit_base_patch16_224_in21k",
                     help="vit_large_patch16_384 runs BASELINE.json configs[4] (use --batch 32); informational only")
     args = ap.parse_args()
@@ -330,6 +332,7 @@ def main():
     model, trainable = build_model(args.rank, scale, ncls, dev, seed=14, name=args.model)  # identical replicas on every rank
     eng = model._cara_engine
     eng.weight_dropout = args.weight_dropout
+    eng.precision = args.precision
     cdist.broadcast_parameters(trainable)   # replicas identical by construction; this makes it a fact (outside the timed region)
     eng.seed_rank_streams(2024, rank)       # per-rank DropPath / weight-dropout masks
     # vit_cp.py:185's AdamW as one HIP launch (cara_amd/optim.py; CARA_BENCH_TORCH_ADAMW=1: torch's fused one, for A/B runs)
@@ -487,7 +490,7 @@ def main():
                 info["fp16_ms_per_step"] = round(timed_steps(step), 3)
                 info["fp16_images_per_sec"] = round(args.batch / info["fp16_ms_per_step"] * 1e3, 1)
             finally:
-                eng.precision = "bf16"
+                eng.precision = args.precision
                 eng._ws.clear()
 
         leg("fp16", leg_fp16)
@@ -541,7 +544,7 @@ def main():
                        else "fine-tune images/sec ViT-B/16+CaRA r=16 @224, bs=64/GPU, 1/2/4/8 MI355X"),
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "ms_per_step_median": round(statistics.median(step_ms), 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": args.precision, "data": "synthetic",
             "config": {"workload": (f"ViT-L/16 + CaRA rank={args.rank}, synthetic 384x384, bs={args.batch}/GPU, bf16 "
                                     "(BASELINE.json configs[4], informational); fwd + CE + bwd + AdamW, drop-path 0.1, factored adapters"
                                     if large else

@@ -194,7 +194,7 @@ int cara_gemm_rider_slab_format(const cara_gemm_args* a, int Rp, int rank);
 /* Up to CARA_TS_REDUCE_MAX of those reductions in ONE launch (each entry = the arguments of cara_tskinny_reduce). */
 #define CARA_TS_REDUCE_MAX 24
 typedef struct {
-  const void* slabs; size_t slab_stride; float* D; float* colsum;   /* colsum may be NULL */
+  const void* slabs; size_t slab_stride; float* D; float* colsum;   /* colsum may be NULL; slabs, D, slab_stride: multiples of 16 bytes */
   int batch, M, K1, Rp;
   int Rc;   /* columns the slabs hold: 0 or Rp = all; 16 (at Rp = 32) = slabs written by the _r functions at rank <= 16 */
   int wave_slabs;   /* 1: the product wrote one slab per WAVE of its blocks (four per block): what cara_gemm_with_tskinny_r does  */
