@@ -25,3 +25,7 @@ int cara_gemm8_plan(const cara_gemm_args* a, int mt, int riders_nt);
 // the dispatcher's policy (gemm.hip): does a product of this shape go to the tile?  riders: the launch carries transposed skinny
 // products.  (Callers that choose activation layouts ask.)
 bool cara_gemm8_policy(int M, int N, int K, int riders);
+
+// skinny.hip: cara_tskinny_partial2_r at rank <= 16, Rp = 32 with a two-stage ring (40 KiB per block)
+int cara_tskinny_partial2_small(const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a, const void* Xb, int ldxb, const void* Gtb,
+                                void* slabs_b, int K1b, int want_colsum_b, int ldg, int M, int Rp, int rank, void* stream);

@@ -9,6 +9,7 @@
 // M*K*2 in, tiny out).  Both use MFMA so the VALU never bounds them.
 #include "common.h"
 #include "tskinny_body.h"
+#include "gemm8.h"
 
 namespace {
 
@@ -192,10 +193,10 @@ __global__ __launch_bounds__(256) void skinny_xu_kernel(const bf16* __restrict__
 // [64, Rp]; a second tiny kernel sums the slabs in a fixed order (bitwise reproducible, no
 // float atomics).
 // ------------------------------------------------------------------------------------------
-template <int NT, bool COLSUM>
+template <int NT, bool COLSUM, int NSTAGE = 3>
 __global__ __launch_bounds__(256) void tskinny_kernel(const TsProblem p0, const TsProblem p1, int ldg, int M) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  tskinny_body<NT, COLSUM, 3>(p0, p1, ldg, M, blockIdx.x, smem);
+  tskinny_body<NT, COLSUM, NSTAGE>(p0, p1, ldg, M, blockIdx.x, smem);
 }
 
 // sum of n values `stride` floats apart, in a FIXED order that keeps four loads in flight: four interleaved partial
@@ -363,7 +364,7 @@ extern "C" size_t cara_tskinny_scratch_bytes(int M, int K1, int Rp) {
 }
 
 namespace {
-int ts_launch(const TsProblem& a, const TsProblem& b, int ldg, int M, int Rp, bool any_cs, hipStream_t st, bool half = false) {
+int ts_launch(const TsProblem& a, const TsProblem& b, int ldg, int M, int Rp, bool any_cs, hipStream_t st, bool half = false, bool small = false) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tskinny_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TsRing<4>::WAVE_BYTES);
@@ -373,7 +374,11 @@ int ts_launch(const TsProblem& a, const TsProblem& b, int ldg, int M, int Rp, bo
     attr_set = true;
   }
   const dim3 grid(a.nblk + b.nblk), block(256);
-  if (Rp == 32 && half) {   // rank <= 16: one r-tile (16 of the 32 columns), 16-wide slabs
+  if (Rp == 32 && half && small) {   // the same with a two-stage ring per wave: 40 KiB of LDS, a block fits on a CU that holds a gemm8 tile
+    const size_t lds = TsRing<1, 2>::BLOCK_BYTES;
+    if (any_cs) hipLaunchKernelGGL((tskinny_kernel<1, true, 2>), grid, block, lds, st, a, b, ldg, M);
+    else hipLaunchKernelGGL((tskinny_kernel<1, false, 2>), grid, block, lds, st, a, b, ldg, M);
+  } else if (Rp == 32 && half) {   // rank <= 16: one r-tile (16 of the 32 columns), 16-wide slabs
     const size_t lds = TsRing<1>::BLOCK_BYTES;
     if (any_cs) hipLaunchKernelGGL((tskinny_kernel<1, true>), grid, block, lds, st, a, b, ldg, M);
     else hipLaunchKernelGGL((tskinny_kernel<1, false>), grid, block, lds, st, a, b, ldg, M);
@@ -419,6 +424,18 @@ extern "C" int cara_tskinny_partial2_r(const void* Xa, int ldxa, const void* Gta
   if (!Xa) a.nblk = 0;
   const TsProblem b = ts_problem(Xb, ldxb, Gtb, slabs_b, want_colsum_b, M, K1b, Rp);
   return ts_launch(a, b, ldg, M, Rp, want_colsum_b != 0, static_cast<hipStream_t>(stream), Rp == 32 && rank <= 16);
+}
+
+// library-internal (gemm8.h): cara_tskinny_partial2_r at rank <= 16 with the two-stage ring, for launches on a side stream UNDER a
+// GEMM of the 160 x 256 x 64 tile (one workgroup per CU leaves 56 KiB of LDS and a third of the registers)
+int cara_tskinny_partial2_small(const void* Xa, int ldxa, const void* Gta, void* slabs_a, int K1a, const void* Xb, int ldxb, const void* Gtb,
+                                void* slabs_b, int K1b, int want_colsum_b, int ldg, int M, int Rp, int rank, void* stream) {
+  if (rank <= 0 || rank > 16 || Rp != 32) return CARA_E_ARG;
+  if ((Xa && !ts_args_ok(Xa, ldxa, Gta, ldg, slabs_a, M, K1a, Rp)) || !ts_args_ok(Xb, ldxb, Gtb, ldg, slabs_b, M, K1b, Rp)) return CARA_E_ARG;
+  TsProblem a = ts_problem(Xa ? Xa : Xb, Xa ? ldxa : ldxb, Xa ? Gta : Gtb, Xa ? slabs_a : slabs_b, 0, M, Xa ? K1a : K1b, Rp);
+  if (!Xa) a.nblk = 0;
+  const TsProblem b = ts_problem(Xb, ldxb, Gtb, slabs_b, want_colsum_b, M, K1b, Rp);
+  return ts_launch(a, b, ldg, M, Rp, want_colsum_b != 0, static_cast<hipStream_t>(stream), true, true);
 }
 
 extern "C" int cara_tskinny_reduce(const void* slabs, size_t slab_stride, float* D, float* colsum, int batch, int M,

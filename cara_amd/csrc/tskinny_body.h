@@ -120,9 +120,21 @@ __device__ __forceinline__ void tskinny_body(const TsProblem& p0, const TsProble
     if (nmine > 0) ts_issue<NT>(X, ldx, Gt, ldg, i0, first * 32, M, ring, lane);
     if (nmine > 1) ts_issue<NT>(X, ldx, Gt, ldg, i0, (first + 4) * 32, M, ring + R::STAGE, lane);
   }
+  if constexpr (NSTAGE == 2) {
+    if (nmine > 0) ts_issue<NT>(X, ldx, Gt, ldg, i0, first * 32, M, ring, lane);
+  }
   for (int t = 0; t < nmine; ++t) {
     int slot = 0;
-    if constexpr (NSTAGE == 3) {
+    if constexpr (NSTAGE == 2) {   // one K step of prefetch (40 KiB per block: fits beside a 160 x 256 x 64 GEMM tile on its CU)
+      slot = t & 1;
+      if (t + 1 < nmine) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the other stage's LDS reads (step t - 1) are done
+        ts_issue<NT>(X, ldx, Gt, ldg, i0, (first + 4 * (t + 1)) * 32, M, ring + ((t + 1) & 1) * R::STAGE, lane);
+        wait_vmcnt<R::PIECES>();
+      } else {
+        wait_vmcnt<0>();
+      }
+    } else if constexpr (NSTAGE == 3) {
       slot = t % 3;
       if (t + 2 < nmine) {
         ts_issue<NT>(X, ldx, Gt, ldg, i0, (first + 4 * (t + 2)) * 32, M, ring + ((t + 2) % 3) * R::STAGE, lane);

@@ -209,6 +209,31 @@ struct EpiRider {
   bool done = false; // set by the launch that computed them
 };
 
+// CARA_FC1_SIDE=1 (default 0): the two heavy riders of the backward -- fc1's dVs = dH^T T (+ dc) and fc2's dU = h^T G', 154 MB -- as a
+// launch of their own on a SIDE stream under the fc1 dX GEMM, which then runs on the 160 x 256 x 64 tile (one workgroup per CU: the
+// products' blocks, 40 KiB of LDS and one wave per SIMD each, fit beside it).  One event record on the caller's stream per block
+// (the fork); the join is a wait on an event that completed long before.  The stream and the two events are created once per process.
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+SideStream* side_stream() {
+  static SideStream s;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    s.ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
+  }
+  return s.ok ? &s : nullptr;
+}
+struct SideRiders {   // per backward pass
+  SideStream* ss = nullptr;
+  bool pending_join = false;   // the side stream holds work the caller's stream has not waited for
+};
+
 // per-call context: what lin_fwd / lin_bwd need besides their operands (nothing here outlives the call)
 struct Ctx {
   void* stream;
@@ -358,7 +383,7 @@ int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char*
 // otherwise they are one launch of their own behind it, on the same stream.
 int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int Mr, int Rp, int ldt, char* ws, const Ws& W,
             const LayerWs& lw, bool want_dx, cara_gemm_args a, bool want_dc, const Ctx& cx, bool have_G = false, EpiRider* er = nullptr,
-            bool dvs_done = false) {
+            bool dvs_done = false, SideRiders* side = nullptr) {
   void* st = cx.stream;
   const Ws::Bwd& R = W.bwd;
   bf16* G = reinterpret_cast<bf16*>(ws + R.G[L.slot]);
@@ -405,6 +430,23 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
       }
       if (g_inside) {   // G' = dY Vs computed by this GEMM on the tiles it streams (its own dVs does not read G'; its dU rides later)
         a.A2 = nullptr; a.Ut = L.Vst; a.T_out = G; a.Tt_out = Gt; a.ldt = ldt; a.Ut_rank = ts_rank(cx, Rp) <= 16 ? ts_rank(cx, Rp) : 0;
+      }
+      if (side && side->ss && !dvs_done) {
+        // this linear's dVs (+ dc) and the waiting dU as a launch of their own on the side stream, under this GEMM
+        SideStream* ss = side->ss;
+        if (hipEventRecord(ss->fork, static_cast<hipStream_t>(st)) != hipSuccess || hipStreamWaitEvent(ss->stream, ss->fork, 0) != hipSuccess) return CARA_E_LAUNCH;
+        TRY(cara_tskinny_partial2_small(take ? pend->Xa : nullptr, take ? pend->ldxa : 0, take ? pend->Gta : nullptr, take ? pend->slabs_a : nullptr,
+                                        take ? pend->K1a : 0, mine.Xb, mine.ldxb, mine.Gtb, mine.slabs_b, mine.K1b, mine.want_cs, ldt, Mr, Rp,
+                                        ts_rank(cx, Rp), ss->stream));
+        if (hipEventRecord(ss->join, ss->stream) != hipSuccess) return CARA_E_LAUNCH;
+        side->pending_join = true;
+        if (cx.fmt) {
+          if (take) cx.fmt->U[pend->slot][pend->layer] = 0;
+          cx.fmt->V[L.slot][cx.layer] = 0;
+        }
+        TRY(cara_gemm_bf16(&a, st));
+        *pend = mine;   // (its dU half waits for the next dX GEMM of the pass)
+        return CARA_OK;
       }
       if (dvs_done) {   // dVs and dc of this linear came out of the epilogue of the launch that produced its dY: a plain GEMM, its dU waits
         TRY(cara_gemm_bf16(&a, st));
@@ -878,6 +920,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
   const bool fx = fuse_xu(g) && !ex;
   const bool dense_qkv = g->cp_length == 2;
   bool have_G_fc2 = false;   // G' of this block's fc2 was left by the LayerNorm backward of the block above
+  SideRiders side;
   for (int l = g->depth - 1; l >= 0; --l) {
     const LayerWs& lw = W.layer[l];
     Lin lin[4];
@@ -907,11 +950,15 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     const bool pa_x = panel_acts(M, s, 2) && !dense_qkv, pa = panel_acts(Mr, s, 1) && !cara_gemm8_policy(Mr, D, 4 * D, 0), pa_n = panel_acts(Mr, s, 2);
     // fc1's dVs / dc and fc2's dU out of the fc2 dX epilogue: the fc1 dX launch then carries nothing and runs on the 160 x 256 x 64 tile
     const bool er_on = epi_riders_geom(g, Mr, ex) && ts_rank(cx, Rp) <= 16 && fuse_ts(Mr, Rp) && defer_du();
+    static const int fc1_side = env_once("CARA_FC1_SIDE", 0);
+    const bool side_on = fc1_side != 0 && !er_on && !ex && Rp == 32 && ts_rank(cx, Rp) <= 16 && fuse_ts(Mr, Rp) && defer_du() && g_inside_enabled(2) &&
+                         cara_gemm8_policy(Mr, D, 4 * D, 0) && side_stream() != nullptr;
+    side.ss = side_on ? side_stream() : nullptr;
     EpiRider er;
     er.Tt = ws + lw.Tt[2];
     er.slabV = ws + W.slabV[2] + (size_t)l * W.strideV[2];
     er.bytes = W.strideV[2] < W.strideU[3] ? W.strideV[2] : W.strideU[3];
-    const bool pa_dh = panel_acts(Mr, s, 1) && !cara_gemm8_policy(Mr, D, 4 * D, er_on ? 0 : 1);
+    const bool pa_dh = panel_acts(Mr, s, 1) && !cara_gemm8_policy(Mr, D, 4 * D, (er_on || side_on) ? 0 : 1);
     const bool pa_dp = panel_acts(Mr, s, 4), pa_dx = panel_acts(M, s, 4);   // dyp here; dyb of the block below
     const bool pa_dyb = pa_dx && l < g->depth - 1;
     if (pa_dh) { e.c_panels = Mr; e.ldc = 4 * D; }
@@ -924,7 +971,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
     if (ex) TRY(lin_bwd_exact(lin[2], dH, reinterpret_cast<bf16*>(ws + lw.xn2), Mr, Rp, ws, W, s, true, e, true, cx));
     else TRY(lin_bwd(lin[2], dH, pa_dh ? -Mr : 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), pa_n ? -Mr : D, Mr, Rp, W.ldt, ws, W, lw, true, e, true, cx, false,
-                     nullptr, er.done));
+                     nullptr, er.done, side_on ? &side : nullptr));
     // dyp = dY of this block's proj: its G' = dY Vs comes out of the same kernel (CARA_LN2B_XU=0: out of proj's dX GEMM instead)
     static const int ln2b_xu = env_once("CARA_LN2B_XU", 1);
     const bool fxp = fx && (ln2b_xu != 0 || cls_only);
@@ -958,6 +1005,12 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
       TRY(lin_bwd_dense(lin[0], dQKV, reinterpret_cast<bf16*>(ws + lw.xn1), M, reinterpret_cast<bf16*>(ws + W.ddt) + (size_t)l * 3 * D * D,
                         reinterpret_cast<float*>(ws + W.dD) + (size_t)l * 3 * D * D, reinterpret_cast<float*>(ws + W.dd_slabs), l > 0, e, cx_all));
     else TRY(lin_bwd(lin[0], dQKV, 3 * D, reinterpret_cast<bf16*>(ws + lw.xn1), pa_x ? -M : D, M, Rp, W.ldt, ws, W, lw, l > 0, e, false, cx_all));
+    // the side stream's products read dH and G' of fc2, which the kernels below overwrite: the caller's stream waits for them (they
+    // were launched some 300 us ago)
+    if (side.pending_join) {
+      if (hipStreamWaitEvent(hs, side.ss ? side.ss->join : side_stream()->join, 0) != hipSuccess) return CARA_E_LAUNCH;
+      side.pending_join = false;
+    }
     if (l > 0) {
       // dyb = dY of fc2 of the block BELOW (all M rows there: only the last block runs on cls rows); this block's
       // fc2 is through with the buffer (stream order)
