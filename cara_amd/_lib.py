@@ -19,7 +19,7 @@ LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libcara_hip_f16.so")
 
 # every symbol include/cara_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "cara_abi_version", "cara_build_arch", "cara_operand_type", "cara_gemm_bf16", "cara_gemm_tn_f32", "cara_pack_b_panels", "cara_gemm_scratch_bytes", "cara_skinny_xu", "cara_skinny_xu_r", "cara_tskinny_partial2_r", "cara_gemm_with_tskinny_r", "cara_gemm_rider_slab_format", "cara_gemm_epi_rider_chunks", "cara_gemm_epi_rider_scratch_bytes", "cara_linear_fwd", "cara_linear_bwd",
+    "cara_abi_version", "cara_build_arch", "cara_operand_type", "cara_gemm_bf16", "cara_gemm_tn_f32", "cara_pack_b_panels", "cara_gemm_scratch_bytes", "cara_skinny_xu", "cara_skinny_xu_r", "cara_tskinny_partial2_r", "cara_gemm_with_tskinny_r", "cara_gemm_rider_slab_format", "cara_gemm_epi_rider_chunks", "cara_gemm_dv_chunks", "cara_gemm_epi_rider_scratch_bytes", "cara_linear_fwd", "cara_linear_bwd",
     "cara_tskinny_scratch_bytes", "cara_tskinny_xtg", "cara_tskinny_partial", "cara_tskinny_partial2", "cara_tskinny_reduce", "cara_tskinny_reduce_many", "cara_gemm_with_tskinny", "cara_layernorm_fwd", "cara_layernorm_bwd", "cara_layernorm_fwd_xu", "cara_layernorm_bwd_xu", "cara_layernorm_fwd_ex", "cara_layernorm_bwd_ex",
     "cara_attention_fwd", "cara_attention_bwd", "cara_attention_cls_fwd", "cara_attention_cls_bwd", "cara_im2col_patches", "cara_assemble_tokens",
     "cara_cross_entropy", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_transpose_bf16_ld", "cara_pack_offsets",
@@ -205,7 +205,7 @@ def stream(device=None) -> C.c_void_p:
 
 def gemm(A, B, out, *, epi, bias=None, A2=None, B2=None, C2=None, aux=None, rowscale=None,
          rows_per_sample=0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, scratch=None, Ut=None, T_out=None,
-         Tt_out=None, Bp=None, a_panels=0, c_panels=0, B3=None, Ut_rank=0, epi_riders=None):
+         Tt_out=None, Bp=None, a_panels=0, c_panels=0, B3=None, Ut_rank=0, epi_riders=None, dv=None):
     """epi_riders = (Tt, Gt, h, want_colsum[, h_panels]) with CARA_EPI_MULH: the launch's epilogue also leaves the partial sums of
     dVs = C^T T and dU = h^T G (cara_gemm_args::er_*); returns (out, slabs_v, slabs_u, chunks) then."""
     a = GemmArgs()
@@ -242,6 +242,17 @@ def gemm(A, B, out, *, epi, bias=None, A2=None, B2=None, C2=None, aux=None, rows
         a.er_slabs_v, a.er_slabs_u = ptr(slabs_v), ptr(slabs_u)
         check(lib().cara_gemm_bf16(C.byref(a), stream()), "cara_gemm_bf16")
         return out, slabs_v, slabs_u, chunks
+    if dv is not None:   # dv = (Tt, want_colsum) with CARA_EPI_BF16: dVs = A^T T (+ column sums of A) out of the launch's own A tiles
+        Tt, want_cs = dv
+        a.er_Tt, a.er_ldg, a.er_colsum = ptr(Tt), Tt.shape[1], 1 if want_cs else 0
+        a.er_slabs_v = C.c_void_p(16)   # (any non-NULL value for the query)
+        chunks = int(lib().cara_gemm_dv_chunks(C.byref(a), 0))
+        if chunks <= 0:
+            raise ValueError("this product cannot leave dVs from its A tiles (cara_gemm_dv_chunks)")
+        slabs = torch.full((int(lib().cara_gemm_epi_rider_scratch_bytes(chunks, a.K)) // 4,), float("nan"), dtype=torch.float32, device=out.device)
+        a.er_slabs_v = ptr(slabs)
+        check(lib().cara_gemm_bf16(C.byref(a), stream()), "cara_gemm_bf16")
+        return out, slabs, chunks
     check(lib().cara_gemm_bf16(C.byref(a), stream()), "cara_gemm_bf16")
     return out
 

@@ -1155,6 +1155,11 @@ extern "C" int cara_gemm_epi_rider_chunks(const cara_gemm_args* a) {
   if (g_gemm8_override > 0) return 0;
   return (a->M + er_rows() - 1) / er_rows();
 }
+extern "C" int cara_gemm_dv_chunks(const cara_gemm_args* a, int riders) {
+  static const int on = [] { const char* e = getenv("CARA_GEMM8"); return e ? atoi(e) : 160; }();
+  if (!a || !a->er_Tt || a->epi != CARA_EPI_BF16 || on != 160 || g_gemm8_override == 0) return 0;
+  return cara_gemm8_plan(a, 160, riders ? 1 : 0) == 1 ? (a->M + 159) / 160 : 0;
+}
 extern "C" size_t cara_gemm_epi_rider_scratch_bytes(int chunks, int N) {
   if (chunks <= 0 || N <= 0 || (N & 63)) return 0;
   const size_t nblk = (size_t)chunks * (N / 64);
@@ -1186,6 +1191,17 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
   if (a->epi == CARA_EPI_MULH && a->bias) return CARA_E_ARG;
   if (ts && (a->batch > 1 || a->M <= 128 || a->B3 || (a->Ut && a->epi != CARA_EPI_BF16))) return CARA_E_ARG;
   if (a->B3 && (a->Bp || a->Ut || a->batch > 1 || a->a_panels)) return CARA_E_ARG;
+  if (a->er_Tt && a->epi == CARA_EPI_BF16) {
+    // dVs (+ dc) of the GEMM's own linear out of the A sub-buffers of its K loop: the 160 x 256 x 64 tile only (cara_gemm_dv_chunks)
+    if (!cara_gemm_dv_chunks(a, ts ? 1 : 0)) return CARA_E_ARG;
+    cara_g8_riders rd;
+    if (ts) {
+      auto cp = [](const TsProblem& t) { return cara_g8_product{t.X, t.Gt, t.slabs, t.cs_slabs, t.ldx, t.K1, t.nchunks, t.nblk}; };
+      rd.a = cp(ts->a); rd.b = cp(ts->b); rd.ldg = ts->ldg; rd.M = ts->M; rd.any_cs = ts->any_cs ? 1 : 0; rd.nt = ts->nt;
+    }
+    const int rc = cara_gemm8_launch(a, static_cast<hipStream_t>(stream), 160, ts ? &rd : nullptr);
+    return rc < 0 ? CARA_E_ARG : rc;
+  }
   if (a->er_Tt) {   // epilogue riders: only where cara_gemm_epi_rider_chunks() says so
     if (!cara_gemm_epi_rider_chunks(a) || !a->er_Gt || !a->er_h || !a->er_slabs_v || !a->er_slabs_u || a->er_ldg < a->M || (a->er_ldg & 3) ||
         a->er_h_panels < 0 || (a->er_h_panels && a->er_h_panels < a->M))

@@ -43,6 +43,8 @@
 
 namespace {
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
 template <int N>
 __device__ __forceinline__ void g8_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -82,7 +84,16 @@ struct G8Cnt {
 
 // MODE: 0 plain product; 1 K-extension with T given (A2 / B2); 2 the adapter inside (Ut / B2: T computed here); 3 the adapter
 // inside with T computed by the workgroup's helper waves (gemm8h_kernel): the tile only waits for their image of T
-template <class G, int EPI, int CLS, int MODE>
+// DV: the launch also computes dVs = A^T T (+ the column sums of A) from the A sub-buffers of its own K loop (cara_gemm_args::er_Tt with
+// CARA_EPI_BF16: the dX GEMM of a linear stages that linear's dY as its A operand, whole rows in LDS).  The column tiles of a row panel
+// stage the same A: tile column tn takes the K steps t = tn (mod tiles_n), and in such a step the wave row (t / tiles_n) & 1; a wave's
+// share = the 16 columns (of the 64 of the K step) of its wave column over all MT rows: five 32-row chunks, each two transposing LDS
+// reads of the swizzled sub-buffer (in the phases in which the tile's own fragment reads happen: sub-tile 0 in phase 1, sub-tile 1 in
+// phase 3) and one MFMA against that chunk's rows of T^T, one more against (masked) ones for the column sums.  [16 r x 16 k] per wave
+// and active K step goes out as ONE 16-byte store per lane into slab (row tile, K step) of the products' slab layout; every wave issues
+// the same two store instructions at the end of EVERY K step (beyond num_records where it has nothing to store), so that the counted
+// waits stay constants: C::ALL + 2.
+template <class G, int EPI, int CLS, int MODE, bool DV = false>
 __device__ __forceinline__ void g8_tile(const cara_gemm_args& p, const int tiles_n, const int nwg, const int block, char* smem) {
   constexpr bool EXT = MODE != 0, UT = MODE == 2;
   using C = G8Cnt<G, CLS, UT>;
@@ -190,6 +201,51 @@ __device__ __forceinline__ void g8_tile(const cara_gemm_args& p, const int tiles
     ptb[kh] = G::A1_OFF + (wr * 16 * RT1 + ib * 16 + fr) * 128 + sw;
     pu[kh] = G::U_OFF + fr * 128 + sw;
   }
+  // ---- DV: this lane's rows of T^T per 32-row chunk (chunks 0 .. NC0 - 1 of sub-tile 0, the rest of sub-tile 1), the validity of
+  // those rows (the last row tile re-stages the operand's last rows beyond M: T reads as zero there, the ones as zero too), the
+  // transposing-read offsets inside a sub-buffer and the two store resources ----
+  constexpr int NC0 = G::A0_ROWS / 32, NC1 = G::A1_ROWS / 32, NC = NC0 + NC1;
+  static_assert(!DV || (G::A0_ROWS % 32 == 0 && G::A1_ROWS % 32 == 0 && (16 * RT0) % 8 == 0 && (16 * RT1) % 8 == 0), "DV: whole 32-row chunks of 8-row runs");
+  bf16x8 tfr[DV ? NC : 1];
+  unsigned dv_valid = 0;
+  unsigned dv_lo = 0, dv_hi = 0;
+  __amdgpu_buffer_rsrc_t rsDV = rsA;
+  int vDV = vD, vDC = vD, dv_cs_base = 0;
+  bool dv_act = false;
+  f32x4 accD = {0.f, 0.f, 0.f, 0.f};
+  float accC = 0.f;
+  s16x4 dvl[DV ? (NC0 > NC1 ? NC0 : NC1) : 1], dvh[DV ? (NC0 > NC1 ? NC0 : NC1) : 1];
+  const int tiles_m = nwg / tiles_n;
+  if constexpr (DV) {
+    const bf16* Tt = static_cast<const bf16*>(p.er_Tt) + (size_t)fr * p.er_ldg;
+    const bf16x8 z8 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int r0 = (c < NC0 ? 32 * c : 32 * (c - NC0)) + 8 * fq;   // local row of the sub-buffer
+      const int rows = c < NC0 ? 16 * RT0 : 16 * RT1;
+      const int w2 = r0 / rows, in = r0 - w2 * rows;
+      const int g = m0 + w2 * (16 * RT) + (c < NC0 ? 0 : 16 * RT0) + in;
+      const bool ok = g < p.M;   // (M % 16 == 0: the eight rows are valid together)
+      tfr[c] = ok ? *reinterpret_cast<const bf16x8*>(Tt + g) : z8;
+      dv_valid |= ok ? (1u << c) : 0u;
+    }
+    // rows 8 fq + (fr >> 2) (and + 4) of a chunk, the 8 bytes at column 16 wc + 4 (fr & 3) of the K step's 64: logical 16-byte chunk
+    // 2 wc + ((fr & 3) >> 1), XOR the row's swizzle key (row & 7)
+    const int rl = 8 * fq + (fr >> 2), ch = 2 * wc + ((fr & 3) >> 1);
+    dv_lo = (unsigned)(rl * 128 + ((ch ^ (rl & 7)) << 4) + (fr & 1) * 8);
+    dv_hi = (unsigned)((rl + 4) * 128 + ((ch ^ ((rl + 4) & 7)) << 4) + (fr & 1) * 8);
+    const int colblocks = p.K >> 6;
+    const size_t slab_floats = (size_t)tiles_m * colblocks * (64 * 16), cs_off = (size_t)tiles_m * colblocks * (64 * 32);
+    // ONE resource over the slabs and the column sums behind them (no column sums: its bound ends at the slabs, those stores are dropped)
+    rsDV = __builtin_amdgcn_make_buffer_rsrc(p.er_slabs_v, 0, (int)(p.er_colsum ? (cs_off + (size_t)tiles_m * colblocks * 64) * 4 : slab_floats * 4), 0x00020000);
+    dv_cs_base = (int)(cs_off * 4);
+    vDV = ((16 * wc + fr) * 16 + 4 * fq) * 4;
+    vDC = fq == 0 ? (16 * wc + fr) * 4 : vD;
+    // the loads above are complete before the loop (so that no wait of the compiler's for them lands inside it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(tfr[c]));
+  }
   bf16x8 ta[2], u[2];
   f32x4 accT[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   bf16x8 a[RT][2], b[4][2];
@@ -234,11 +290,43 @@ __device__ __forceinline__ void g8_tile(const cara_gemm_args& p, const int tiles
   } while (0)
   // one phase behind its reads and DMA issue: counted wait (one sub-buffer of each kind stays in flight), barrier, this
   // quadrant's MFMAs, barrier
-#define G8_SYNC_MMA(I0, I1, J0, J1, TW) \
+  constexpr int WAITN = C::ALL + (DV ? 2 : 0);
+  // DV: the transposing reads of sub-tile SUB of K step T in buffer BUFX (wave-uniform branch; inline asm: behind the builtin the compiler
+  // puts s_waitcnt vmcnt(0), it cannot tell the read from the LDS-DMA in flight), and their MFMAs (after the phase's lgkmcnt(0))
+#define G8_DV_RD(SUB, BUFX)                                                                                                         \
+  do {                                                                                                                             \
+    if (dv_act) {                                                                                                                  \
+      const unsigned lb_ = (unsigned)(uintptr_t)(LDS_AS const char*)(smem + (BUFX) * G::BUF + ((SUB) ? G::A1_OFF : G::A0_OFF));    \
+      _Pragma("unroll") for (int c_ = 0; c_ < ((SUB) ? NC1 : NC0); ++c_) {                                                         \
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dvl[c_]) : "v"(lb_ + dv_lo + c_ * 4096) : "memory");                       \
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dvh[c_]) : "v"(lb_ + dv_hi + c_ * 4096) : "memory");                       \
+      }                                                                                                                            \
+    }                                                                                                                              \
+  } while (0)
+#define G8_DV_MMA(SUB)                                                                                                              \
+  do {                                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                                             \
+    if (dv_act) {                                                                                                                  \
+      _Pragma("unroll") for (int c_ = 0; c_ < ((SUB) ? NC1 : NC0); ++c_) {                                                         \
+        /* K = 16 MFMAs on the two transposing reads as they are (rows 8 fq .. + 3 and + 4 .. + 7 of the chunk: the halves of tfr) */ \
+        const bf16x8 t_ = tfr[((SUB) ? NC0 : 0) + c_];                                                                             \
+        const bf16x4 tl_ = {t_[0], t_[1], t_[2], t_[3]}, th_ = {t_[4], t_[5], t_[6], t_[7]};                                       \
+        const bf16x4 l4_ = __builtin_bit_cast(bf16x4, dvl[c_]), h4_ = __builtin_bit_cast(bf16x4, dvh[c_]);                         \
+        accD = mfma_16x16x16(tl_, l4_, accD);                                                                                      \
+        accD = mfma_16x16x16(th_, h4_, accD);                                                                                      \
+        /* column sums: this lane's eight rows of column 16 wc + fr (rows >= M: not counted) */                                    \
+        const float cs_ = (((float)l4_[0] + (float)l4_[1]) + ((float)l4_[2] + (float)l4_[3])) +                                    \
+                          (((float)h4_[0] + (float)h4_[1]) + ((float)h4_[2] + (float)h4_[3]));                                    \
+        accC += ((dv_valid >> (((SUB) ? NC0 : 0) + c_)) & 1u) ? cs_ : 0.f;                                                         \
+      }                                                                                                                            \
+    }                                                                                                                              \
+  } while (0)
+#define G8_SYNC_MMA(I0, I1, J0, J1, TW, DVS) \
   do {                                  \
-    g8_vmcnt<C::ALL>();                 \
+    g8_vmcnt<WAITN>();                  \
     g8_barrier();                       \
     g8_lgkm0();                         \
+    if constexpr (DV && (DVS) >= 0) G8_DV_MMA(DVS); \
     G8_MMA(I0, I1, J0, J1, TW);         \
     g8_barrier();                       \
   } while (0)
@@ -247,29 +335,46 @@ __device__ __forceinline__ void g8_tile(const cara_gemm_args& p, const int tiles
   // fragments re-read in phase 1, multiplied in phase 2; T tile 1 of sub-tile 1: read in phase 3, multiplied in phase 4)
 #define G8_TILE(T, CUR)                                                                                  \
   do {                                                                                                   \
+    if constexpr (DV) {                                                                                  \
+      const int q_ = (T) / tiles_n;                                                                      \
+      dv_act = (T) - q_ * tiles_n == tn && (q_ & 1) == wr;                                               \
+    }                                                                                                    \
     G8_RD_A0(CUR) G8_RD_B0(CUR)                                                                          \
+    if constexpr (DV) G8_DV_RD(0, CUR);                                                                  \
     if constexpr (UT) {                                                                                  \
       ta[0] = *reinterpret_cast<const bf16x8*>(smem + (CUR) * G::BUF + pta[0]);                          \
       ta[1] = *reinterpret_cast<const bf16x8*>(smem + (CUR) * G::BUF + pta[1]);                          \
     }                                                                                                    \
     G8_ST_B1((T) + 1, (CUR) ^ 1);                                                                        \
-    G8_SYNC_MMA(0, RT0, 0, 2, -1);                                                                       \
+    G8_SYNC_MMA(0, RT0, 0, 2, -1, 0);                                                                    \
     G8_RD_B1(CUR)                                                                                        \
     if constexpr (UT) {                                                                                  \
       u[0] = *reinterpret_cast<const bf16x8*>(smem + (CUR) * 2048 + pu[0]);                              \
       u[1] = *reinterpret_cast<const bf16x8*>(smem + (CUR) * 2048 + pu[1]);                              \
     }                                                                                                    \
     G8_ST_A1((T) + 1, (CUR) ^ 1);                                                                        \
-    G8_SYNC_MMA(0, RT0, 2, 4, 0);                                                                        \
+    G8_SYNC_MMA(0, RT0, 2, 4, 0, -1);                                                                    \
     G8_RD_A1(CUR)                                                                                        \
+    if constexpr (DV) G8_DV_RD(1, CUR);                                                                  \
     if constexpr (UT) {                                                                                  \
       ta[0] = *reinterpret_cast<const bf16x8*>(smem + (CUR) * G::BUF + ptb[0]);                          \
       ta[1] = *reinterpret_cast<const bf16x8*>(smem + (CUR) * G::BUF + ptb[1]);                          \
     }                                                                                                    \
     G8_ST_A0((T) + 2, CUR);                                                                              \
-    G8_SYNC_MMA(RT0, RT, 2, 4, -1);                                                                      \
+    G8_SYNC_MMA(RT0, RT, 2, 4, -1, 1);                                                                   \
     G8_ST_B0((T) + 2, CUR);                                                                              \
-    G8_SYNC_MMA(RT0, RT, 0, 2, 1);                                                                       \
+    G8_SYNC_MMA(RT0, RT, 0, 2, 1, -1);                                                                   \
+    if constexpr (DV) {                                                                                  \
+      /* this K step's [16 r x 16 k] sums: row 4 fq + reg = r, column fr = k -> slab (row tile, K step), 16 bytes per lane */ \
+      const int so_ = (tm * (p.K >> 6) + (T)) * (64 * 16 * 4), sc_ = dv_cs_base + (tm * (p.K >> 6) + (T)) * (64 * 4);   \
+      float c_ = accC;                                                                                   \
+      c_ += __shfl_xor(c_, 16, 64);                                                                      \
+      c_ += __shfl_xor(c_, 32, 64);                                                                      \
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, accD), rsDV, dv_act ? vDV : vD, dv_act ? so_ : 0, 0); \
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c_), rsDV, dv_act ? vDC : vD, dv_act ? sc_ : 0, 0); \
+      accD = f32x4{0.f, 0.f, 0.f, 0.f};                                                                  \
+      accC = 0.f;                                                                                        \
+    }                                                                                                    \
   } while (0)
 
   const int nk = p.K >> 6;   // >= 2 (checked at dispatch)
@@ -280,7 +385,11 @@ __device__ __forceinline__ void g8_tile(const cara_gemm_args& p, const int tiles
   G8_ST_A1(0, 0);
   G8_ST_A0(1, 1);
   G8_ST_B0(1, 1);
-  g8_vmcnt<C::ALL>();
+  if constexpr (DV) {   // (the two store instructions "K step -1" would have issued here: the waits count them from the first phase on)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, accD), rsDV, vD, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(0u, rsDV, vD, 0, 0);
+  }
+  g8_vmcnt<WAITN>();
   g8_barrier();
   if (wr == 1) g8_barrier();   // the second wave row runs one barrier behind the first
   int t = 0;
@@ -385,6 +494,8 @@ __device__ __forceinline__ void g8_tile(const cara_gemm_args& p, const int tiles
 #undef G8_RD_B1
 #undef G8_MMA
 #undef G8_SYNC_MMA
+#undef G8_DV_RD
+#undef G8_DV_MMA
 #undef G8_TILE
 }
 
@@ -393,7 +504,7 @@ __device__ __forceinline__ void g8_tile(const cara_gemm_args& p, const int tiles
 // together (155 MB per launch for fc1 forward: 31 us at 5 TB/s, four bursts with the chip's matrix pipes idle) and the next round
 // starts in lockstep again.  A quarter-period offset between neighbouring CUs, paid once, lets one group's stores run under the
 // other groups' K loops for the rest of the launch.
-template <class G, int EPI, int MODE>
+template <class G, int EPI, int MODE, bool DV = false>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const int stagger) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (stagger > 0 && blockIdx.x < 256) {
@@ -402,17 +513,17 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(const cara_gemm_args p, c
   }
   constexpr bool TWO_CLASSES = (G::NPA0 % 8) != 0 || (G::NPA1 % 8) != 0;
   if constexpr (TWO_CLASSES) {
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) g8_tile<G, EPI, 0, MODE>(p, tiles_n, nwg, blockIdx.x, smem);
-    else g8_tile<G, EPI, 1, MODE>(p, tiles_n, nwg, blockIdx.x, smem);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) g8_tile<G, EPI, 0, MODE, DV>(p, tiles_n, nwg, blockIdx.x, smem);
+    else g8_tile<G, EPI, 1, MODE, DV>(p, tiles_n, nwg, blockIdx.x, smem);
   } else {
-    g8_tile<G, EPI, 0, MODE>(p, tiles_n, nwg, blockIdx.x, smem);
+    g8_tile<G, EPI, 0, MODE, DV>(p, tiles_n, nwg, blockIdx.x, smem);
   }
 }
 
 // The same grid with the blocks of a pair of transposed skinny products (rank <= 16: one r-tile) behind the tiles: a 512-thread
 // workgroup runs two of them side by side (the device code of tskinny_kernel with its three-deep ring per wave: 8 waves are all
 // a CU holds here).  They start on the CUs the tiles leave free and spread over the others as the tiles finish.
-template <class G, int EPI, int MODE, bool COLSUM>
+template <class G, int EPI, int MODE, bool COLSUM, bool DV = false>
 __global__ __launch_bounds__(512, 2) void gemm8_ts_kernel(const cara_gemm_args p, const int tiles_n, const int nwg, const TsProblem t0,
                                                           const TsProblem t1, const int ldg, const int Mts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -428,10 +539,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_ts_kernel(const cara_gemm_args p
   }
   constexpr bool TWO_CLASSES = (G::NPA0 % 8) != 0 || (G::NPA1 % 8) != 0;
   if constexpr (TWO_CLASSES) {
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) g8_tile<G, EPI, 0, MODE>(p, tiles_n, nwg, b, smem);
-    else g8_tile<G, EPI, 1, MODE>(p, tiles_n, nwg, b, smem);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) g8_tile<G, EPI, 0, MODE, DV>(p, tiles_n, nwg, b, smem);
+    else g8_tile<G, EPI, 1, MODE, DV>(p, tiles_n, nwg, b, smem);
   } else {
-    g8_tile<G, EPI, 0, MODE>(p, tiles_n, nwg, b, smem);
+    g8_tile<G, EPI, 0, MODE, DV>(p, tiles_n, nwg, b, smem);
   }
 }
 
@@ -782,7 +893,7 @@ int g8_launch(const cara_gemm_args* a, hipStream_t st, const cara_g8_riders* ts,
   const int nwg = tiles_m * tiles_n;
   if constexpr (G::MT == 160 && (MODE == 1 || MODE == 3)) {
     // helper waves: the riders' streams and, MODE 3, T = A Ut^T
-    if (helpers) {
+    if (helpers && !a->er_Tt) {
       if (ts && !(EPI == CARA_EPI_BF16 || EPI == CARA_EPI_DGELU)) return -1;
       TsProblem t0 = {}, t1 = {};
       if (ts) { t0 = g8_problem(ts->a); t1 = g8_problem(ts->b); }
@@ -800,6 +911,30 @@ int g8_launch(const cara_gemm_args* a, hipStream_t st, const cara_g8_riders* ts,
       return CARA_OK;
     }
   }
+  if constexpr (EPI == CARA_EPI_BF16 && (MODE == 1 || MODE == 2) && G::MT == 160) {
+    if (a->er_Tt) {   // dVs (+ dc) of the GEMM's own linear out of its A sub-buffers (g8_tile<.., DV>); riders: a pending dU at most
+      constexpr int TSB2 = 2 * TsRing<1, 3>::BLOCK_BYTES;
+      constexpr int LDS_TS = G::LDS > TSB2 ? G::LDS : TSB2;
+      static bool attr = false;
+      if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_kernel<G, EPI, MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_ts_kernel<G, EPI, MODE, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TS) != hipSuccess)
+          return CARA_E_LAUNCH;
+        attr = true;
+      }
+      if (ts) {
+        if (ts->any_cs) return -1;
+        const TsProblem t0 = g8_problem(ts->a), t1 = g8_problem(ts->b);
+        const int nts = (t0.nblk + t1.nblk + 1) / 2;
+        hipLaunchKernelGGL((gemm8_ts_kernel<G, EPI, MODE, false, true>), dim3(nwg + nts), dim3(512), LDS_TS, st, *a, tiles_n, nwg, t0, t1, ts->ldg, ts->M);
+      } else {
+        hipLaunchKernelGGL((gemm8_kernel<G, EPI, MODE, true>), dim3(nwg), dim3(512), G::LDS, st, *a, tiles_n, nwg, 0);
+      }
+      CARA_CHECK_LAUNCH();
+      return CARA_OK;
+    }
+  }
+  if (a->er_Tt) return -1;
   if (ts) {
     if constexpr ((EPI == CARA_EPI_BF16 || EPI == CARA_EPI_DGELU) && MODE != 3) {   // (the dX products; riders behind the tiles)
       constexpr int TSB2 = 2 * TsRing<1, 3>::BLOCK_BYTES;
@@ -877,6 +1012,12 @@ int cara_gemm8_plan(const cara_gemm_args* a, int mt, int riders_nt) {
   }
   const bool riders = riders_nt != 0;
   if (riders && (riders_nt != 1 || !(a->epi == CARA_EPI_BF16 || a->epi == CARA_EPI_DGELU))) return 0;
+  if (a->er_Tt) {   // dVs out of the A sub-buffers: CARA_EPI_BF16, the 160-row tile, a K-extension (given or inside), 32-bit slab offsets
+    if (a->epi != CARA_EPI_BF16 || mt != 160 || !mode || a->er_h || !a->er_slabs_v || a->er_ldg < a->M || (a->er_ldg & 7)) return 0;
+    const unsigned long long chunks = (a->M + 159) / 160;
+    if (chunks * (a->K / 64) * (64 * 16 * 4) >= 0x7fffff00ull) return 0;
+    return 1;
+  }
   if (mt == 256) return (mode || riders) ? 0 : 1;   // (the yardstick tile: plain products)
   if (mt != 160) return 0;
   if (g8_helpers() && (mode == 2 || (riders && mode == 1))) return 2;

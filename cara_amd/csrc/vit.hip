@@ -62,6 +62,7 @@ int dw_slabs(int out, int in, int M) {
 }
 
 bool epi_riders_geom(const cara_geom* g, int Mr, bool exact);
+int env_once(const char* name, int dflt);
 bool save_gelu_grad(const cara_geom* g, const cara_vit_shape* s);
 bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
   if (!g || !s || g->depth <= 0 || g->depth > 64 || g->dim % g->heads || g->dim / g->heads != 64) return false;
@@ -130,6 +131,9 @@ bool layout(const cara_geom* g, const cara_vit_shape* s, Ws* w) {
     const size_t er_bytes = (cara_gemm_epi_rider_scratch_bytes((int)((M + 127) / 128), (int)(4 * D)) + 255) & ~(size_t)255;   // (row tiles of 128 or 160)
     if (i == 3 && epi_riders_geom(g, (int)M, s->wd_exact != 0) && er_bytes > w->strideU[i]) w->strideU[i] = er_bytes;
     if (i == 2 && epi_riders_geom(g, (int)M, s->wd_exact != 0) && er_bytes > w->strideV[i]) w->strideV[i] = er_bytes;
+    // (CARA_DV: fc1's / qkv's dVs out of their dX tiles, one slab per 160-row tile and K step: K1 = the linear's out features)
+    const size_t dv_bytes = (cara_gemm_epi_rider_scratch_bytes((int)((M + 159) / 160), (int)outs[i]) + 255) & ~(size_t)255;
+    if ((i == 0 || i == 2) && env_once("CARA_DV", 0) != 0 && g->Rp == 32 && dv_bytes > w->strideV[i]) w->strideV[i] = dv_bytes;
     w->slabU[i] = c.take(w->strideU[i] * g->depth);
     w->slabV[i] = c.take(w->strideV[i] * g->depth);
   }
@@ -383,7 +387,9 @@ int lin_fwd(const Lin& L, const bf16* X, int ldx, int Mr, int Rp, int ldt, char*
 // otherwise they are one launch of their own behind it, on the same stream.
 int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int Mr, int Rp, int ldt, char* ws, const Ws& W,
             const LayerWs& lw, bool want_dx, cara_gemm_args a, bool want_dc, const Ctx& cx, bool have_G = false, EpiRider* er = nullptr,
-            bool dvs_done = false, SideRiders* side = nullptr) {
+            bool dvs_done = false, SideRiders* side = nullptr, int dv = 0) {
+  // dv: 1 = this linear's dVs (+ dc) out of its dX GEMM's own A tiles where the launch can (cara_gemm_dv_chunks); 2 = this linear carries
+  // BOTH its products in its own launch and leaves the waiting dU for the next one (the linear before a dv = 1 one: CARA_DV)
   void* st = cx.stream;
   const Ws::Bwd& R = W.bwd;
   bf16* G = reinterpret_cast<bf16*>(ws + R.G[L.slot]);
@@ -431,6 +437,33 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
       if (g_inside) {   // G' = dY Vs computed by this GEMM on the tiles it streams (its own dVs does not read G'; its dU rides later)
         a.A2 = nullptr; a.Ut = L.Vst; a.T_out = G; a.Tt_out = Gt; a.ldt = ldt; a.Ut_rank = ts_rank(cx, Rp) <= 16 ? ts_rank(cx, Rp) : 0;
       }
+      if (dv == 2 && !dvs_done && !er) {
+        if (cx.fmt) {
+          const unsigned short f = (unsigned short)cara_gemm_rider_slab_format(&a, Rp, ts_rank(cx, Rp));
+          cx.fmt->U[L.slot][cx.layer] = f;
+          cx.fmt->V[L.slot][cx.layer] = f;
+        }
+        TRY(cara_gemm_with_tskinny_r(&a, mine.Xa, mine.ldxa, mine.Gta, mine.slabs_a, mine.K1a, mine.Xb, mine.ldxb, mine.Gtb, mine.slabs_b, mine.K1b,
+                                     mine.want_cs, ldt, Mr, Rp, ts_rank(cx, Rp), st));
+        return CARA_OK;                // (the waiting dU, if any, stays for the next launch)
+      }
+      if (dv == 1 && !dvs_done && !er) {
+        cara_gemm_args d = a;
+        d.er_Tt = Tt; d.er_ldg = ldt; d.er_slabs_v = slabV; d.er_colsum = want_dc ? 1 : 0;
+        const int ch = cara_gemm_dv_chunks(&d, take ? 1 : 0);
+        if (ch > 0 && ch <= 65535 && cara_gemm_epi_rider_scratch_bytes(ch, L.out) <= W.strideV[L.slot]) {
+          if (take) {   // the waiting dU rides behind the tiles (the launch's only product: slot b, no column sums)
+            if (cx.fmt) cx.fmt->U[pend->slot][pend->layer] = 0;
+            TRY(cara_gemm_with_tskinny_r(&d, nullptr, 0, nullptr, nullptr, 0, pend->Xa, pend->ldxa, pend->Gta, pend->slabs_a, pend->K1a, 0, ldt, Mr, Rp,
+                                         ts_rank(cx, Rp), st));
+          } else {
+            TRY(cara_gemm_bf16(&d, st));
+          }
+          if (cx.fmt) cx.fmt->V[L.slot][cx.layer] = (unsigned short)ch;
+          *pend = mine;   // (its dU half waits for the next dX GEMM of the pass)
+          return CARA_OK;
+        }
+      }
       if (side && side->ss && !dvs_done) {
         // this linear's dVs (+ dc) and the waiting dU as a launch of their own on the side stream, under this GEMM
         SideStream* ss = side->ss;
@@ -468,6 +501,16 @@ int lin_bwd(const Lin& L, const bf16* dY, int lddy, const bf16* X, int ldx, int 
         if (take) cx.fmt->U[pend->slot][pend->layer] = f;
         cx.fmt->V[L.slot][cx.layer] = f;
       }
+#ifdef CARA_ABLATE_DVS   // timing experiment only (tools/build_variant.sh): fc1 / qkv dX WITHOUT their own dVs products (wrong gradients) --
+      // the bound on what computing dVs from the dX tile's own A sub-buffers could return
+      if ((L.slot == 0 || L.slot == 2) && g_inside) {
+        if (take) TRY(cara_gemm_with_tskinny_r(&a, nullptr, 0, nullptr, nullptr, 0, pend->Xa, pend->ldxa, pend->Gta, pend->slabs_a, pend->K1a, 0, ldt, Mr, Rp,
+                                               ts_rank(cx, Rp), st));
+        else TRY(cara_gemm_bf16(&a, st));
+        *pend = mine;
+        return CARA_OK;
+      }
+#endif
       TRY(cara_gemm_with_tskinny_r(&a, take ? pend->Xa : nullptr, take ? pend->ldxa : 0, take ? pend->Gta : nullptr, take ? pend->slabs_a : nullptr,
                                    take ? pend->K1a : 0, mine.Xb, mine.ldxb, mine.Gtb, mine.slabs_b, mine.K1b, mine.want_cs, ldt, Mr, Rp,
                                    ts_rank(cx, Rp), st));
@@ -673,6 +716,11 @@ static int epi_riders_env() {
 bool save_gelu_grad(const cara_geom* g, const cara_vit_shape* s) {
   static const int v = env_once("CARA_SAVE_GELU_GRAD", -1);
   return (v < 0 ? epi_riders_env() != 0 : v != 0) && fuse_xu(g) && !s->wd_exact;
+}
+
+static bool env_once_dv_off() {   // (the epilogue riders and CARA_DV are two placements of the same product)
+  static const int v = env_once("CARA_DV", 0);
+  return v == 0;
 }
 
 // CARA_EPI_RIDERS (default 0): fc1's dVs = dH^T T (+ dc) and fc2's dU = h^T G' are computed by the epilogue of the fc2 dX GEMM, on the dH
@@ -949,29 +997,36 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     // (h as the forward wrote it: row-major where fc2 forward runs on the 160 x 256 x 64 tile; dH: row-major where fc1 dX does)
     const bool pa_x = panel_acts(M, s, 2) && !dense_qkv, pa = panel_acts(Mr, s, 1) && !cara_gemm8_policy(Mr, D, 4 * D, 0), pa_n = panel_acts(Mr, s, 2);
     // fc1's dVs / dc and fc2's dU out of the fc2 dX epilogue: the fc1 dX launch then carries nothing and runs on the 160 x 256 x 64 tile
-    const bool er_on = epi_riders_geom(g, Mr, ex) && ts_rank(cx, Rp) <= 16 && fuse_ts(Mr, Rp) && defer_du();
+    const bool er_on = epi_riders_geom(g, Mr, ex) && ts_rank(cx, Rp) <= 16 && fuse_ts(Mr, Rp) && defer_du() && env_once_dv_off();
+    // CARA_DV (default 0; bit 0: fc1, bit 1: qkv): dVs (+ dc) of fc1 / qkv out of their dX GEMM's own A tiles on the 160 x 256 x 64 tile;
+    // CARA_DV_DU_HOME (default 1): fc2 then carries BOTH its products in its own launch, and the dU waiting from the block above rides
+    // behind fc1's tiles (19 MB instead of fc2's 77)
+    static const int dv_env = env_once("CARA_DV", 0), dv_home = env_once("CARA_DV_DU_HOME", 1);
+    const bool dv_ok = dv_env != 0 && !ex && Rp == 32 && ts_rank(cx, Rp) <= 16 && fuse_ts(Mr, Rp) && defer_du() && !cls_only;
+    const bool dv_fc1 = dv_ok && (dv_env & 1) && g_inside_enabled(2) && cara_gemm8_policy(Mr, D, 4 * D, 0);
+    const bool dv_qkv = dv_ok && (dv_env & 2) && g_inside_enabled(0) && cara_gemm8_policy(M, D, 3 * D, 0);
     static const int fc1_side = env_once("CARA_FC1_SIDE", 0);
     const bool side_on = fc1_side != 0 && !er_on && !ex && Rp == 32 && ts_rank(cx, Rp) <= 16 && fuse_ts(Mr, Rp) && defer_du() && g_inside_enabled(2) &&
-                         cara_gemm8_policy(Mr, D, 4 * D, 0) && side_stream() != nullptr;
+                         cara_gemm8_policy(Mr, D, 4 * D, 0) && !dv_fc1 && side_stream() != nullptr;
     side.ss = side_on ? side_stream() : nullptr;
     EpiRider er;
     er.Tt = ws + lw.Tt[2];
     er.slabV = ws + W.slabV[2] + (size_t)l * W.strideV[2];
     er.bytes = W.strideV[2] < W.strideU[3] ? W.strideV[2] : W.strideU[3];
-    const bool pa_dh = panel_acts(Mr, s, 1) && !cara_gemm8_policy(Mr, D, 4 * D, (er_on || side_on) ? 0 : 1);
+    const bool pa_dh = panel_acts(Mr, s, 1) && !cara_gemm8_policy(Mr, D, 4 * D, (er_on || side_on || dv_fc1) ? 0 : 1);
     const bool pa_dp = panel_acts(Mr, s, 4), pa_dx = panel_acts(M, s, 4);   // dyp here; dyb of the block below
     const bool pa_dyb = pa_dx && l < g->depth - 1;
     if (pa_dh) { e.c_panels = Mr; e.ldc = 4 * D; }
     if (ex) TRY(lin_bwd_exact(lin[3], dyb, reinterpret_cast<bf16*>(ws + lw.h), Mr, Rp, ws, W, s, true, e, true, cx));
     else TRY(lin_bwd(lin[3], dyb, pa_dyb ? -M : ldr, reinterpret_cast<bf16*>(ws + lw.h), pa ? -Mr : 4 * D, Mr, Rp, W.ldt, ws, W, lw, true, e, true, cx,
-                     have_G_fc2, er_on ? &er : nullptr));
+                     have_G_fc2, er_on ? &er : nullptr, false, nullptr, (dv_fc1 && dv_home) ? 2 : 0));
     if (er.done) formats.V[2][l] = formats.U[3][l];   // (fc1's dVs slabs: the same launch, the same count of row tiles)
     have_G_fc2 = false;
     e = {};
     e.epi = CARA_EPI_BF16; e.C = ws + W.dXn;
     if (ex) TRY(lin_bwd_exact(lin[2], dH, reinterpret_cast<bf16*>(ws + lw.xn2), Mr, Rp, ws, W, s, true, e, true, cx));
     else TRY(lin_bwd(lin[2], dH, pa_dh ? -Mr : 4 * D, reinterpret_cast<bf16*>(ws + lw.xn2), pa_n ? -Mr : D, Mr, Rp, W.ldt, ws, W, lw, true, e, true, cx, false,
-                     nullptr, er.done, side_on ? &side : nullptr));
+                     nullptr, er.done, side_on ? &side : nullptr, dv_fc1 ? 1 : 0));
     // dyp = dY of this block's proj: its G' = dY Vs comes out of the same kernel (CARA_LN2B_XU=0: out of proj's dX GEMM instead)
     static const int ln2b_xu = env_once("CARA_LN2B_XU", 1);
     const bool fxp = fx && (ln2b_xu != 0 || cls_only);
@@ -1004,7 +1059,8 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     else if (dense_qkv)
       TRY(lin_bwd_dense(lin[0], dQKV, reinterpret_cast<bf16*>(ws + lw.xn1), M, reinterpret_cast<bf16*>(ws + W.ddt) + (size_t)l * 3 * D * D,
                         reinterpret_cast<float*>(ws + W.dD) + (size_t)l * 3 * D * D, reinterpret_cast<float*>(ws + W.dd_slabs), l > 0, e, cx_all));
-    else TRY(lin_bwd(lin[0], dQKV, 3 * D, reinterpret_cast<bf16*>(ws + lw.xn1), pa_x ? -M : D, M, Rp, W.ldt, ws, W, lw, l > 0, e, false, cx_all));
+    else TRY(lin_bwd(lin[0], dQKV, 3 * D, reinterpret_cast<bf16*>(ws + lw.xn1), pa_x ? -M : D, M, Rp, W.ldt, ws, W, lw, l > 0, e, false, cx_all, false, nullptr,
+                     false, nullptr, dv_qkv ? 1 : 0));
     // the side stream's products read dH and G' of fc2, which the kernels below overwrite: the caller's stream waits for them (they
     // were launched some 300 us ago)
     if (side.pending_join) {

@@ -121,6 +121,12 @@ int cara_gemm_bf16(const cara_gemm_args* a, void* stream);
 /* cara_gemm_bf16 / cara_gemm_with_tskinny* return CARA_E_ARG when er_Tt is set).  Needs CARA_EPI_MULH, M > 1024, N >= 3072,      */
 /* N % 128 == 0, ldc % 8 == 0, no batch, M % 4 == 0.  Depends on the arguments only.                                              */
 int cara_gemm_epi_rider_chunks(const cara_gemm_args* a);
+/* The same fields with CARA_EPI_BF16 (er_h NULL, er_Gt / er_slabs_u unused): the dX GEMM of a linear stages that linear's dY as its A   */
+/* operand, so its K loop can leave dVs = A^T T (+ the column sums of A with er_colsum) on the way -- from the A tiles in LDS, nothing is */
+/* read again.  Slab (row tile of 160, K step of 64) of er_slabs_v, the layout above with K in the place of N; only on the 160 x 256 x 64 */
+/* tile: cara_gemm_dv_chunks(a, riders) = the slabs per column block such a launch writes (riders: it also carries a product through      */
+/* cara_gemm_with_tskinny_r), 0 = this product cannot (cara_gemm_bf16 then returns CARA_E_ARG).  A K-extension is required (A2 or Ut).    */
+int cara_gemm_dv_chunks(const cara_gemm_args* a, int riders);
 size_t cara_gemm_epi_rider_scratch_bytes(int chunks, int N);
 /* B bf16 [N, K] (row stride ldb) -> out bf16 [K/32][N][32] (cara_gemm_args::Bp); K % 32 == 0 */
 int cara_pack_b_panels(const void* B, int ldb, int N, int K, void* out, void* stream);

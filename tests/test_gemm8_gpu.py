@@ -203,3 +203,55 @@ def test_gemm8_carrying_transposed_skinny_products(M, N, K, epi, inside, Mts, fi
     close(cs, dYo.double().sum(0), 1e-3, 1e-2 * math.sqrt(Mts / 1000), "carried column sums")
     if first:
         close(new_red[2][:, :rank], Xo.double().t() @ Gt[:rank, :Mts].double().t(), 1e-3, 2e-2 * math.sqrt(Mts / 1000), "carried dU")
+
+
+@pytest.mark.parametrize("M,N,K,inside", [(12608, 768, 3072, True), (12608, 768, 2304, True), (2000, 768, 768, False), (12608, 768, 3072, False)])
+def test_dvs_out_of_the_dx_tiles_own_a_sub_buffers(M, N, K, inside):
+    """cara_gemm_args::er_Tt with CARA_EPI_BF16 (cara_gemm_dv_chunks): the dX launch on the 160 x 256 x 64 tile leaves dVs = A^T T and the
+    column sums of A from the A tiles of its own K loop.  C (and T with the adapter inside) bitwise the launch without it; the reduced
+    products against fp64 and against cara_tskinny_xtg on the same operands.  M = 2000: the last row tile holds 80 rows."""
+    Lm = L()
+    lib = Lm.lib()
+    p, st = Lm.ptr, Lm.stream
+    Rp, rank = 32, 16
+    ldg = (M + 31) // 32 * 32
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    B2 = rnd(N, Rp, seed=4, scale=0.3)
+    Tt = torch.zeros(Rp, ldg, dtype=torch.bfloat16, device=DEV)
+    Tt[:rank, :M] = rnd(rank, M, seed=6)
+    Tt[:, M:] = float("nan")
+    kw = {}
+    if inside:
+        Ut = torch.zeros(Rp, K, dtype=torch.bfloat16, device=DEV)
+        Ut[:rank] = rnd(rank, K, seed=3, scale=0.1)
+        kw = dict(Ut=Ut, B2=B2, Ut_rank=rank)
+        T0, Tt0 = torch.zeros(M, Rp, dtype=torch.bfloat16, device=DEV), torch.zeros(Rp, ldg, dtype=torch.bfloat16, device=DEV)
+        T1, Tt1 = torch.zeros_like(T0), torch.zeros_like(Tt0)
+    else:
+        kw = dict(A2=rnd(M, Rp, seed=3, scale=0.3), B2=B2)
+    ref = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    lib.cara_debug_set_gemm8(160)
+    try:
+        Lm.gemm(A, W, ref, epi=Lm.EPI_BF16, **(dict(kw, T_out=T0, Tt_out=Tt0) if inside else kw))
+        out = torch.zeros_like(ref)
+        out, slabs, chunks = Lm.gemm(A, W, out, epi=Lm.EPI_BF16, dv=(Tt, True), **(dict(kw, T_out=T1, Tt_out=Tt1) if inside else kw))
+    finally:
+        lib.cara_debug_set_gemm8(-1)
+    assert chunks == (M + 159) // 160
+    assert torch.equal(out, ref)
+    if inside:
+        assert torch.equal(T0, T1) and torch.equal(Tt0[:, :M], Tt1[:, :M])
+    D = torch.full((K, Rp), float("nan"), device=DEV)
+    cs = torch.full((K,), float("nan"), device=DEV)
+    tab = (Lm.TsReduce * 1)(Lm.TsReduce(p(slabs), 0, p(D), p(cs), 1, M, K, Rp, 16, chunks))
+    Lm.check(lib.cara_tskinny_reduce_many(tab, 1, st()), "reduce many")
+    torch.cuda.synchronize()
+    assert torch.count_nonzero(D[:, rank:]) == 0
+    close(D[:, :rank], A.double().t() @ Tt[:rank, :M].double().t(), 1e-3, 2e-2, "dVs from the A tiles")
+    close(cs, A.double().sum(0), 1e-3, 2e-2, "column sums from the A tiles")
+    D2, cs2 = torch.empty(K, Rp, device=DEV), torch.empty(K, device=DEV)
+    Tz = Tt.clone()
+    Tz[:, M:] = 0
+    Lm.tskinny_xtg(A, Tz, D2, cs2, M=M)
+    close(D[:, :rank], D2[:, :rank], 1e-5, 2e-3, "dVs: A tiles vs cara_tskinny_xtg")
+    close(cs, cs2, 1e-5, 2e-3, "column sums: A tiles vs cara_tskinny_xtg")

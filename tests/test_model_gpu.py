@@ -1242,16 +1242,16 @@ def test_forward_and_backward_capture_into_a_hip_graph():
     assert torch.equal(loss, eager) and not torch.equal(loss, want_loss)
 
 
-@pytest.mark.parametrize("switch", ["CARA_EPI_RIDERS", "CARA_FC1_SIDE"])
+@pytest.mark.parametrize("switch", ["CARA_EPI_RIDERS=1", "CARA_FC1_SIDE=1", "CARA_DV=3"])
 def test_rider_placement_switches_pass_the_whole_model_parity_tests(switch):
-    """Two measured-and-off placements of the backward's heavy riders (read once per process): CARA_EPI_RIDERS=1 -- fc1's dVs / dc and
+    """Three measured-and-off placements of the backward's heavy riders (read once per process): CARA_EPI_RIDERS=1 -- fc1's dVs / dc and
     fc2's dU out of the fc2 dX epilogue, gelu'(u) kept as IEEE half by fc1 forward; CARA_FC1_SIDE=1 -- the same products as a launch on a
-    side stream under the fc1 dX GEMM.  The batch-64 whole-model test, the train-step test and the fp16 headline test run again in a
-    process with the switch set."""
+    side stream under the fc1 dX GEMM; CARA_DV=3 -- fc1's and qkv's dVs / dc out of the A tiles of their own dX GEMM.  The batch-64
+    whole-model test, the train-step test and the fp16 headline test run again in a process with the switch set."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, **{switch: "1"})
+    env = dict(os.environ, **dict([switch.split("=")]))
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_model_gpu.py"), "-x", "-q", "-s", "-k",
                           "headline_batch_64_whole_model or train_step_against_oracle or fp16_precision_at_the_headline_size"],
                          cwd=root, env=env, capture_output=True, text=True, timeout=900)
