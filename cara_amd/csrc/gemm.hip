@@ -666,7 +666,9 @@ static int group_m(int tiles_n) {
   // measured with rocprofv3 FETCH_SIZE (x2 gfx950 correction), per launch, plain order -> groups of 8:
   // fc1 fwd (24 column tiles) 224 -> 133 MB, fc2 bwd 297 -> 207 MB, but the 6-column products
   // 82 -> 113 MB and qkv (18 columns) flat: group only when there are many column tiles
-  if (tiles_n >= 20) return 8;
+  static const int gm_wide = [] { const char* e = getenv("CARA_GEMM_GM"); return e ? atoi(e) : 8; }();       // (A/B: rows per supertile of the wide products)
+  static const int gm_minn = [] { const char* e = getenv("CARA_GEMM_GM_MINT"); return e ? atoi(e) : 20; }();   // (A/B: fewest column tiles that get supertiles)
+  if (tiles_n >= gm_minn) return gm_wide > 0 ? gm_wide : 1;
   // CARA_GEMM_CUSHARE=1: the narrow products (plain order) with the workgroups of a CU on consecutive tiles (xcd_remap_cu)
   static const int cushare = [] { const char* e = getenv("CARA_GEMM_CUSHARE"); return e ? atoi(e) : 0; }();
   return (cushare && tiles_n <= 8) ? -1 : 1;
