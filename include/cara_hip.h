@@ -229,7 +229,7 @@ int cara_linear_fwd(const cara_linear* L, const void* X, int ldx, int M, void* T
 /* Given dY bf16 [M, lddy], the saved input X and the forward's Tt: G [M, Rp] = dY Vs and Gt (scratch, written);
  * dX bf16 [M, lddx] = dY W + G U^T (skipped when NULL); dU fp32 [in, Rp] = X^T G, dVs fp32 [out, Rp] = dY^T T, dc fp32 [out] =
  * column sums of dY (NULL: not wanted) -- the gradients cara_factor_grad_reduce takes per layer.  slabs_u / slabs_v:
- * cara_tskinny_scratch_bytes(M, in, Rp) / (M, out, Rp) bytes of caller scratch.                                             */
+ * cara_tskinny_scratch_bytes(M, in, Rp) / (M, out, Rp) bytes of caller scratch; they, dU and dVs: 16-byte aligned.         */
 int cara_linear_bwd(const cara_linear* L, const void* dY, int lddy, const void* X, int ldx, const void* Tt, int M, void* G, void* Gt,
                     int ldt, void* dX, int lddx, void* slabs_u, void* slabs_v, float* dU, float* dVs, float* dc, void* stream);
 
