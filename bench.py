@@ -325,7 +325,7 @@ def main():
 
     from cara_amd import _lib
     from cara_amd import dist as cdist
-    lib = _lib.lib()
+    lib = _lib.lib("fp16" if args.precision == "fp16" else "bf16")   # (the site brackets live in the library that runs the step)
     scale, ncls = 0.1, 100
     large = args.model == "vit_large_patch16_384"
     gf, img, tokens, dim, heads = (GF_PER_IMG_L384, 384, 577, 1024, 16) if large else (GF_PER_IMG, 224, 197, 768, 12)

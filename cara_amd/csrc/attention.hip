@@ -585,6 +585,260 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_persist_kernel(cons
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 5: the persistent forward, SPECIALISED on the number of key tiles and written as an explicit schedule.
+// The kernel above serves any 128 < N <= 224 with one body: every tile is conditional (`kt < nkt`), so the compiler keeps the
+// accumulators' zero fill (112 v_mov per head and wave), selects every score against "is this the last tile" (112 v_cndmask), and
+// emits the three phases -- 28 MFMAs, then 112 maxima, then exponentials + 28 MFMAs -- one after the other: 779 vector
+// instructions per head and wave where ~470 are needed, the matrix pipe busy 13 % of the time (profiles/r04_pmc_attn.txt).
+// Here  * NKT is a template parameter: no per-tile conditions, the first MFMA of a chain takes a literal zero accumulator;
+//       * the padded keys of the last tile are masked through that tile's accumulator SEED (-1e30 in their rows: they are
+//         duplicates of key N - 1, finite, so their exponential is exactly 0): no select anywhere;
+//       * the row maximum of tile kt - 1 is taken between the MFMAs of tile kt, and in the P V loop the exponentials of tile
+//         kt + 1 are issued between the MFMAs of tile kt (an in-order wave that issues four MFMAs back to back waits 3 x 24
+//         cycles for the pipe; two such waves per SIMD wait for each other too).  Every "MFMA | vector chunk" boundary is a
+//         scheduling barrier: the order below is the order in the binary;
+//       * K fragments are requested two tiles ahead.
+// Same operand layouts, rounding points and LDS images as attn_fwd_persist_kernel (its results are bitwise equal where the
+// summation order of the row sum allows: four partial sums here).
+// ------------------------------------------------------------------------------------------
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
+template <int NKT>
+__global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_p2_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                                       float* __restrict__ lse, int N, int H, int BH, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NPAD = 224, IMG = NPAD * 128;       // one K or V image
+  char* Qs = smem + 4 * IMG;                         // wave-private Q images behind the two (K, V) pairs
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ld = 3 * H * HD;
+  const int ql = lane & 31, h = lane >> 5;
+  const int q0 = wave * 32;
+  const float c2 = scale * 1.4426950408889634f;
+  const RowOfs ro = row_ofs(lane);
+  const TrOfs to = tr_ofs(lane);
+  const int last_keys = N - (NKT - 1) * 32;
+  char* myQ = Qs + wave * 4096;
+  // accumulator seed of the LAST key tile: 0 in the rows of real keys, -1e30 in the padded ones
+  f32x16 seed_last;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) seed_last[r] = crow(r, h) < last_keys ? 0.f : -1.0e30f;
+
+  unsigned kvoff[8], kvdst[8], qoff[4];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int q = wave + t * PF_WAVES;              // 0..55: < 28 -> K, else V
+    const bool isv = q >= 28;
+    const int piece = isv ? q - 28 : q;
+    const int row = piece * 8 + (lane >> 3);
+    const int rr = row < N ? row : N - 1;
+    const int c = (lane & 7) ^ swzk(row);
+    kvoff[t] = (unsigned)rr * (unsigned)(ld * 2) + (unsigned)(c * 16) + (unsigned)((isv ? 2 : 1) * H * HD * 2);
+    kvdst[t] = (unsigned)((isv ? IMG : 0) + piece * 1024);   // wave-uniform
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = t * 8 + (lane >> 3);
+    int gr = q0 + row;
+    gr = gr < N ? gr : N - 1;
+    const int c = (lane & 7) ^ swzk(row);
+    qoff[t] = (unsigned)gr * (unsigned)(ld * 2) + (unsigned)(c * 16);
+  }
+  auto lds_of = [](const char* p) { return __builtin_amdgcn_readfirstlane((unsigned)(size_t)p); };   // LDS byte address
+  auto head_base = [&](int bh) {
+    const int b = bh / H, hd = bh - b * H;
+    return reinterpret_cast<const char*>(qkv + (size_t)b * N * ld + hd * HD);   // wave-uniform
+  };
+  auto stage_q = [&](int bh) {
+    const char* base = head_base(bh);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) glds16_hidden(base, qoff[t], lds_of(myQ) + t * 1024);
+  };
+
+  int bh = blockIdx.x;
+  if (bh >= BH) return;
+  {
+    const char* base = head_base(bh);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) glds16_hidden(base, kvoff[t], lds_of(smem) + __builtin_amdgcn_readfirstlane(kvdst[t]));
+  }
+  stage_q(bh);
+  int cur = 0;
+#ifdef CARA_ATTN_STAMPS
+  int slot = -1;
+#endif
+  for (; bh < BH; bh += gridDim.x) {
+    const int nxt = bh + gridDim.x;
+    const bool has_nxt = nxt < BH;
+#ifdef CARA_ATTN_STAMPS
+    ++slot;
+#endif
+    ATTN_STAMP(0);
+    // ONE barrier per head (see attn_fwd_persist_kernel): this head's K, V, Q have landed, the previous head is done with
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    SB();
+    ATTN_STAMP(1);
+    const char* Ks = smem + cur * 2 * IMG;
+    const char* Vs = Ks + IMG;
+    const int b = bh / H, head = bh - b * H;
+    const char* nbase = head_base(has_nxt ? nxt : bh);
+    const unsigned nimg = lds_of(smem + (cur ^ 1) * 2 * IMG);
+    // piece t (0..7) of the next head's K / V images.  UNCONDITIONAL: behind the last head the pieces re-read this head (the
+    // other image pair is free then, nobody reads it) -- a branch here splits the head's body into basic blocks, and the
+    // compiler then sinks the exponentials of a tile out from between the MFMAs into the block that uses them (seen in the
+    // first build of this kernel: every second tile's MFMAs came back to back).  The kernel drains its queue before it ends.
+    auto next_piece = [&](const int t) { glds16_hidden(nbase, kvoff[t], nimg + __builtin_amdgcn_readfirstlane(kvdst[t])); };
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(myQ + ro.o[ks]);
+    // ---------------- S^T = K Q^T, with the running maximum of the previous tile between the MFMAs ----------------
+    f32x16 s[NKT];
+    bf16x8 ka[3][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ka[0][ks] = *reinterpret_cast<const bf16x8*>(Ks + ro.o[ks]);
+    if (NKT > 1) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) ka[1][ks] = *reinterpret_cast<const bf16x8*>(Ks + 4096 + ro.o[ks]);
+    }
+    float m0 = -3.0e38f, m1 = -3.0e38f;   // two chains of v_max3
+    f32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt + 2 < NKT) {
+        const char* kb_ = Ks + (kt + 2) * 4096;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ka[(kt + 2) % 3][ks] = *reinterpret_cast<const bf16x8*>(kb_ + ro.o[ks]);
+      }
+      if ((kt & 1) == 0) next_piece(kt >> 1);   // pieces 0-3 behind the even tiles here, 4-7 in the P V loop
+      SB();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[kt % 3][ks], qf[ks], ks == 0 ? (kt == NKT - 1 ? seed_last : zero) : s[kt], 0, 0, 0);
+        SB();
+        if (kt > 0) {   // a quarter of the previous tile's maximum
+          m0 = fmaxf(fmaxf(m0, s[kt - 1][4 * ks]), s[kt - 1][4 * ks + 1]);
+          m1 = fmaxf(fmaxf(m1, s[kt - 1][4 * ks + 2]), s[kt - 1][4 * ks + 3]);
+          SB();
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r += 4) {
+      m0 = fmaxf(fmaxf(m0, s[NKT - 1][r]), s[NKT - 1][r + 1]);
+      m1 = fmaxf(fmaxf(m1, s[NKT - 1][r + 2]), s[NKT - 1][r + 3]);
+    }
+    ATTN_STAMP(2);
+    // the Q fragments are in registers: the wave's Q image may take the next head's rows
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SB();
+    stage_q(has_nxt ? nxt : bh);
+    float mx = fmaxf(m0, m1);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxc = mx * c2;
+    ATTN_STAMP(3);
+    // ---------------- P V, the exponentials of tile kt + 1 between the MFMAs of tile kt ----------------
+    float sum0 = 0.f, sum1 = 0.f, sum2 = 0.f, sum3 = 0.f;
+    auto exp4 = [&](f32x16& t, const int g) {   // registers 4g .. 4g+3 of a tile: p = exp2(s c2 - mx c2), into four partial sums
+      t[4 * g] = __builtin_amdgcn_exp2f(__builtin_fmaf(t[4 * g], c2, -mxc));
+      t[4 * g + 1] = __builtin_amdgcn_exp2f(__builtin_fmaf(t[4 * g + 1], c2, -mxc));
+      t[4 * g + 2] = __builtin_amdgcn_exp2f(__builtin_fmaf(t[4 * g + 2], c2, -mxc));
+      t[4 * g + 3] = __builtin_amdgcn_exp2f(__builtin_fmaf(t[4 * g + 3], c2, -mxc));
+      sum0 += t[4 * g];
+      sum1 += t[4 * g + 1];
+      sum2 += t[4 * g + 2];
+      sum3 += t[4 * g + 3];
+    };
+    f32x16 o[2];
+    bf16x8 pa[2], vf[2][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) exp4(s[0], g);
+    pa[0] = pack8(s[0], 0);
+    pa[1] = pack8(s[0], 1);
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) vf[st][dt] = tr_frag_at(Vs, to.lo[st][dt], to.hi[st][dt]);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if ((kt & 1) == 0) next_piece(4 + (kt >> 1));
+      SB();
+      // O^T = V^T P^T (d on the rows); the first tile's products start the chains from a literal zero
+      bf16x8 vn[2][2];
+      bf16x8 pn[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int st = i >> 1, dt = i & 1;
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[st][dt], pa[st], (kt == 0 && st == 0) ? zero : o[dt], 0, 0, 0);
+        SB();
+        if (kt + 1 < NKT) {
+          // next tile: its V fragment i is requested, a quarter of its exponentials computed
+          vn[st][dt] = tr_frag_at(Vs + (kt + 1) * 4096, to.lo[st][dt], to.hi[st][dt]);
+          exp4(s[kt + 1], i);
+          if (i == 1) pn[0] = pack8(s[kt + 1], 0);
+          if (i == 3) pn[1] = pack8(s[kt + 1], 1);
+          SB();
+        }
+      }
+      if (kt + 1 < NKT) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          pa[st] = pn[st];
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) vf[st][dt] = vn[st][dt];
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 4 + (NKT + 1) / 2; t < 8; ++t) next_piece(t);   // (the pieces of tiles this NKT does not have)
+    if (NKT < 7) {
+#pragma unroll
+      for (int t = (NKT + 1) / 2; t < 4; ++t) next_piece(t);
+    }
+    float sum = (sum0 + sum1) + (sum2 + sum3);
+    sum += __shfl_xor(sum, 32, 64);
+    ATTN_STAMP(4);
+    const float inv = 1.0f / sum;
+    // O^T layout and the store: as in attn_fwd_persist_kernel (lane halves swap runs of four d, 16-byte stores)
+    bf16* ob = out + (size_t)b * N * (H * HD) + head * HD;
+    if (q0 < N) {
+      bf16* orow = ob + (size_t)(q0 + ql < N ? q0 + ql : N - 1) * (H * HD);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        unsigned w[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x2 lo = {(bf16)(o[dt][4 * g] * inv), (bf16)(o[dt][4 * g + 1] * inv)};
+          const bf16x2 hi = {(bf16)(o[dt][4 * g + 2] * inv), (bf16)(o[dt][4 * g + 3] * inv)};
+          w[g][0] = __builtin_bit_cast(unsigned, lo);
+          w[g][1] = __builtin_bit_cast(unsigned, hi);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(w[g][k], w[g + 2][k], false, false);
+            w[g][k] = sw[0];
+            w[g + 2][k] = sw[1];
+          }
+        if (q0 + ql < N) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const uint4 v = {w[g][0], w[g][1], w[g + 2][0], w[g + 2][1]};
+            *reinterpret_cast<uint4*>(orow + dt * 32 + 8 * (g + 2 * h)) = v;
+          }
+        }
+      }
+      if (h == 0 && q0 + ql < N) lse[(size_t)bh * N + q0 + ql] = mx * scale + __logf(sum);
+    }
+    ATTN_STAMP(5);
+    cur ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the pieces issued behind the last head: no LDS-DMA may outlive the workgroup)
+}
+
+// ------------------------------------------------------------------------------------------
 // backward, kernel 1: dK, dV.  One workgroup of 7 waves per (batch, head); wave w owns keys
 // 32w..32w+31 and keeps dK^T, dV^T in accumulators while sweeping the query tiles.  Q and dO are
 // staged in LDS once, row-major: plain ds_read_b128 rows feed S = Q K^T and dP = dO V^T, and the
@@ -1202,6 +1456,374 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 5: the fused backward, SPECIALISED on the tile count and software-pipelined inside each wave.  Protocol, LDS images,
+// operand layouts, rounding points and barriers are those of attn_bwd_fused_kernel above; what changes is the order of issue:
+//   * NT is a template parameter (no `qt >= nt` exits, the accumulator chains start from literal zeros / the seeds);
+//   * phase B (dQ): the S^T / dP^T MFMAs of key tile kt + 1 are issued BETWEEN the exponentials, products and conversions of
+//     tile kt: a wave's matrix instructions are spaced by vector work of another tile instead of coming 8 + 4 back to back
+//     around a serial block of ~60 vector instructions.  Phase A keeps the per-tile order: its cross-tile pipeline needs two more
+//     accumulator tiles next to dK^T / dV^T / K / V rows and does not fit 256 registers at two waves per SIMD (built: 404 bytes
+//     of scratch); this wave's K / V rows of the next head are requested behind the sweep for the same reason; -delta rides in the dP accumulator seed (dS = p dP', one multiply);
+//   * the next head's DMA pieces are issued unconditionally (behind the last head they re-read this head into images nobody
+//     reads any more), so that a head's body is one basic block: see attn_fwd_p2_kernel.
+// ------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(448, 1) void attn_bwd_p2_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                             const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                             bf16* __restrict__ dqkv, int N, int H, int BH, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NPAD = 224, IMG = NPAD * 128;
+  char* Qs = smem;
+  char* dOs = smem + IMG;
+  char* Os = smem + 2 * IMG;
+  char* Ks = smem + 3 * IMG;
+  char* Vs = smem + 4 * IMG;
+  float* lse_s = reinterpret_cast<float*>(smem + 5 * IMG);
+  float* del_s = lse_s + 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ld = 3 * H * HD, ldo = H * HD;
+  const int l31 = lane & 31, h = lane >> 5;
+  const float c2 = scale * 1.4426950408889634f;
+  const float nrscale = -1.f / scale;
+  const RowOfs ro = row_ofs(lane);
+  const TrOfs to = tr_ofs(lane);
+  const int last = N - (NT - 1) * 32;           // valid rows of the last tile
+  const int t0 = wave * 32;                     // first key (phase A) / query (phase B) of this wave
+  const int trow = t0 + l31 < N ? t0 + l31 : N - 1;
+  const bool tvalid = t0 + l31 < N;
+
+  unsigned off_qkv[4], off_o[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = (wave + t * 7) * 8 + (lane >> 3);
+    const int rr = row < N ? row : N - 1;
+    const int c = (lane & 7) ^ swzk(row);
+    off_qkv[t] = (unsigned)rr * (unsigned)(ld * 2) + (unsigned)(c * 16);
+    off_o[t] = (unsigned)rr * (unsigned)(ldo * 2) + (unsigned)(c * 16);
+  }
+  auto lds_of = [](const char* p) { return __builtin_amdgcn_readfirstlane((unsigned)(size_t)p); };
+  auto dma_image = [&](const char* base, const unsigned (&off)[4], char* img) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) glds16_hidden(base, off[t], lds_of(img) + (unsigned)((wave + t * 7) * 1024));
+  };
+  auto qkv_base = [&](int bh) { const int b = bh / H, hd = bh - b * H; return reinterpret_cast<const char*>(qkv + (size_t)b * N * ld + hd * HD); };
+  auto o_base = [&](const bf16* p_, int bh) { const int b = bh / H, hd = bh - b * H; return reinterpret_cast<const char*>(p_ + (size_t)b * N * ldo + hd * HD); };
+
+  int bh = blockIdx.x;
+  if (bh >= BH) return;
+  bf16x8 kf[4], vf[4];
+  unsigned off_lse[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = t * 64 + lane;
+    off_lse[t] = (unsigned)((i < N ? i : N - 1) * 4);
+  }
+  auto dma_lse = [&](int bh_) {   // (every wave computes the base; wave 0 alone issues: the branch is wave-uniform and holds DMA only)
+    if (wave == 0) {
+      const char* base = reinterpret_cast<const char*>(lse + (size_t)bh_ * N);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t * 64 < NPAD) glds4_hidden(base, off_lse[t], lds_of(reinterpret_cast<const char*>(lse_s)) + (unsigned)(t * 256));
+    }
+  };
+  {
+    const char* qb = qkv_base(bh);
+    dma_image(qb, off_qkv, Qs);
+    dma_image(o_base(dout, bh), off_o, dOs);
+    dma_image(o_base(out, bh), off_o, Os);
+    const bf16* kb = reinterpret_cast<const bf16*>(qb) + H * HD;
+    const bf16* vb = kb + H * HD;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = *reinterpret_cast<const bf16x8*>(kb + (size_t)trow * ld + ks * 16 + h * 8);
+      vf[ks] = *reinterpret_cast<const bf16x8*>(vb + (size_t)trow * ld + ks * 16 + h * 8);
+    }
+    dma_lse(bh);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  f32x16 zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+#ifdef CARA_ATTN_STAMPS
+  int slot = -1;
+  if (g_attn_stamp_buf && tid == 0) {
+    g_attn_stamp_buf[((size_t)blockIdx.x * 4 + 3) * 8 + 0] = __builtin_amdgcn_s_memtime();
+    g_attn_stamp_buf[((size_t)blockIdx.x * 4 + 3) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+  for (; bh < BH; bh += gridDim.x) {
+    const int nxt = bh + gridDim.x;
+    const int b = bh / H, head = bh - b * H;
+#ifdef CARA_ATTN_STAMPS
+    ++slot;
+#endif
+    ATTN_STAMP(0);
+    // T0: every wave is through with phase B of the previous head and has seen its own pieces of this head's Q, dO, O images land
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    {
+      const int row = tid >> 1, half = tid & 1;
+      float dl = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int off = swz128(row, half * 4 + c);
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Os + off);
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(dOs + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += (float)a[j] * (float)g[j];
+      }
+      dl += __shfl_xor(dl, 1, 64);
+      if (half == 0) del_s[row] = -dl;
+      if (tid < NPAD) lse_s[tid] = tid < N ? lse_s[tid] * nrscale : -1e30f;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // T1
+    SB();
+    ATTN_STAMP(1);
+
+    // ================= phase A: dK, dV of keys t0 .. t0 + 31 =================
+    f32x16 dkt[2], dvt[2];
+    f32x16 sacc, pacc;
+    bf16x8 qa[4], da[4];
+    auto load_seeds = [&](const int qt, f32x16& s_, f32x16& p_) {   // register 4 g4 + k of lane half h is query row 32 qt + 8 g4 + 4 h + k
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 32 + 8 * g4 + 4 * h);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qt * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s_[4 * g4 + k] = l4[k]; p_[4 * g4 + k] = d4[k]; }
+      }
+    };
+    auto load_rows = [&](const char* img_a, const char* img_b, const int t, bf16x8 (&a_)[4], bf16x8 (&b_)[4]) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        a_[ks] = *reinterpret_cast<const bf16x8*>(img_a + t * 4096 + ro.o[ks]);
+        b_[ks] = *reinterpret_cast<const bf16x8*>(img_b + t * 4096 + ro.o[ks]);
+      }
+    };
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+      const char* qblk = Qs + qt * 4096;
+      const char* dblk = dOs + qt * 4096;
+      load_seeds(qt, sacc, pacc);
+      load_rows(Qs, dOs, qt, qa, da);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[ks], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vf[ks], pacc, 0, 0, 0);
+      }
+      if (qt == 0) {
+        // K, V of THIS head into their images (needed by phase B): issued behind the first use of kf / vf
+        SB();
+        const char* qb = qkv_base(bh);
+        dma_image(qb + H * HD * 2, off_qkv, Ks);
+        dma_image(qb + 2 * H * HD * 2, off_qkv, Vs);
+        SB();
+      }
+      bf16x8 pb[2], dsb[2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float e = __builtin_amdgcn_exp2f(sacc[8 * st + j] * c2);
+          pb[st][j] = (bf16)e;
+          dsb[st][j] = (bf16)(e * pacc[8 * st + j]);
+        }
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 doa = tr_frag_at(dblk, to.lo[st][dt], to.hi[st][dt]);
+          const bf16x8 qta = tr_frag_at(qblk, to.lo[st][dt], to.hi[st][dt]);
+          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa, pb[st], (qt == 0 && st == 0) ? zero : dvt[dt], 0, 0, 0);
+          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsb[st], (qt == 0 && st == 0) ? zero : dkt[dt], 0, 0, 0);
+        }
+    }
+    ATTN_STAMP(2);
+    // T2: this wave's pieces of K, V have landed (they are old by now); then every wave's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    SB();
+    ATTN_STAMP(3);
+    {
+      char* stg = Os + wave * 4096;
+      const int srow = lane >> 3, schunk = lane & 7;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {   // 0: dK (scaled), 1: dV
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x16& acc = m == 0 ? dkt[dt] : dvt[dt];
+            const float f = m == 0 ? scale : 1.f;
+            const bf16x4 a = {(bf16)(acc[4 * g] * f), (bf16)(acc[4 * g + 1] * f), (bf16)(acc[4 * g + 2] * f), (bf16)(acc[4 * g + 3] * f)};
+            *reinterpret_cast<bf16x4*>(stg + swz128(l31, dt * 4 + g) + h * 8) = a;     // d = dt 32 + 8 g + 4 h ..+3
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SB();
+        bf16* dst = dqkv + (size_t)(b * N + t0) * ld + (1 + m) * H * HD + head * HD + schunk * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint4 v = *reinterpret_cast<const uint4*>(stg + swz128(srow + 8 * i, schunk));
+          if (t0 + srow + 8 * i < N) *reinterpret_cast<uint4*>(dst + (size_t)(srow + 8 * i) * ld) = v;
+        }
+        asm volatile("" ::: "memory");
+      }
+    }
+
+    // ================= phase B: dQ of queries t0 .. t0 + 31 =================
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(Qs + wave * 4096 + ro.o[ks]);
+      dof[ks] = *reinterpret_cast<const bf16x8*>(dOs + wave * 4096 + ro.o[ks]);
+    }
+    const float lq = lse_s[t0 + l31] * c2, dlq = del_s[t0 + l31];   // (-lse in log2 units | -delta; a padded query: -inf-like)
+    ATTN_STAMP(4);
+    // T3: every wave holds its Q / dO rows and row constants: the Q, dO, O images may take the next head
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    SB();
+    ATTN_STAMP(5);
+    const bool has_nxt = nxt < BH;
+    const char* nqb = qkv_base(has_nxt ? nxt : bh);
+    const char* ndob = o_base(dout, has_nxt ? nxt : bh);
+    const char* nob = o_base(out, has_nxt ? nxt : bh);
+    const int nbh = has_nxt ? nxt : bh;
+    auto next_slice = [&](const int j) {   // j = 0 .. 5 (compile-time in the unrolled callers); unconditional, see the header
+      const int t = j & 3;
+      if (j < 4) {
+        glds16_hidden(nqb, off_qkv[t], lds_of(Qs) + (unsigned)((wave + t * 7) * 1024));
+        glds16_hidden(ndob, off_o[t], lds_of(dOs) + (unsigned)((wave + t * 7) * 1024));
+        glds16_hidden(nob, off_o[t], lds_of(Os) + (unsigned)((wave + t * 7) * 1024));
+      } else if (j == 4) {
+        dma_lse(nbh);
+      }
+    };
+    f32x16 dq[2];
+    f32x16 sT, dpT;
+    bf16x8 ka[4], va[4];
+    load_rows(Ks, Vs, 0, ka, va);
+    {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], ks == 0 ? zero : sT, 0, 0, 0);
+        dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ks], dof[ks], ks == 0 ? zero : dpT, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      const char* kblk = Ks + kt * 4096;
+      const char* knxt = Ks + (kt + 1) * 4096;
+      const char* vnxt = Vs + (kt + 1) * 4096;
+      f32x16 sn, pn;
+      bf16x8 kan[4], van[4];   // (requested one k step ahead of their MFMA: four fragments live, not eight)
+      if (kt + 1 < NT) {
+        kan[0] = *reinterpret_cast<const bf16x8*>(knxt + ro.o[0]);
+        van[0] = *reinterpret_cast<const bf16x8*>(vnxt + ro.o[0]);
+      }
+      bf16x8 kfr0[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) kfr0[dt] = tr_frag_at(kblk, to.lo[0][dt], to.hi[0][dt]);
+      if (kt < 5) next_slice(kt);
+      SB();
+      bf16x8 dsa[2];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (kt + 1 < NT) {
+          if (ks < 3) {
+            kan[ks + 1] = *reinterpret_cast<const bf16x8*>(knxt + ro.o[ks + 1]);
+            van[ks + 1] = *reinterpret_cast<const bf16x8*>(vnxt + ro.o[ks + 1]);
+          }
+          sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kan[ks], qf[ks], ks == 0 ? zero : sn, 0, 0, 0);
+          SB();
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = 4 * ks + k;
+          float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[r], c2, lq));
+          if (kt == NT - 1) e = crow(r, h) < last ? e : 0.f;   // the padded keys of the last tile (an accumulator seed for them costs 16 registers)
+          dsa[ks >> 1][4 * (ks & 1) + k] = (bf16)(e * (dpT[r] + dlq));
+        }
+        SB();
+        if (kt + 1 < NT) {
+          pn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(van[ks], dof[ks], ks == 0 ? zero : pn, 0, 0, 0);
+          SB();
+        }
+      }
+      // dQ^T += K^T dS^T
+      bf16x8 kfr1[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr0[dt], dsa[0], kt == 0 ? zero : dq[dt], 0, 0, 0);
+        SB();
+        kfr1[dt] = tr_frag_at(kblk, to.lo[1][dt], to.hi[1][dt]);
+        SB();
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr1[dt], dsa[1], dq[dt], 0, 0, 0);
+        SB();
+      }
+      if (kt + 1 < NT) {
+        sT = sn;
+        dpT = pn;
+      }
+    }
+#pragma unroll
+    for (int j = NT; j < 5; ++j) next_slice(j);   // (the slices of tiles this NT does not have)
+    ATTN_STAMP(6);
+    // the next head's images have landed (they are old by now): wait for them HERE, before this phase's stores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SB();
+    ATTN_STAMP(7);
+    {
+      // this wave's K / V rows of the next head, straight to registers: requested behind the sweep (live across it they cost 32
+      // registers: the sweep then spills) -- they have the dQ stores, two barriers and the delta step to land in
+      const bf16* kb = reinterpret_cast<const bf16*>(nqb) + H * HD;
+      const bf16* vb = kb + H * HD;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = *reinterpret_cast<const bf16x8*>(kb + (size_t)trow * ld + ks * 16 + h * 8);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(vb + (size_t)trow * ld + ks * 16 + h * 8);
+      }
+    }
+    bf16* qrow_out = dqkv + (size_t)(b * N + trow) * ld + head * HD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      unsigned w[4][2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const bf16x2 lo = {(bf16)(dq[dt][4 * g] * scale), (bf16)(dq[dt][4 * g + 1] * scale)};
+        const bf16x2 hi = {(bf16)(dq[dt][4 * g + 2] * scale), (bf16)(dq[dt][4 * g + 3] * scale)};
+        w[g][0] = __builtin_bit_cast(unsigned, lo);
+        w[g][1] = __builtin_bit_cast(unsigned, hi);
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(w[g][k], w[g + 2][k], false, false);
+          w[g][k] = sw[0];
+          w[g + 2][k] = sw[1];
+        }
+      if (tvalid) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const uint4 v = {w[g][0], w[g][1], w[g + 2][0], w[g + 2][1]};
+          *reinterpret_cast<uint4*>(qrow_out + dt * 32 + 8 * (g + 2 * h)) = v;
+        }
+      }
+    }
+  }
+#ifdef CARA_ATTN_STAMPS
+  if (g_attn_stamp_buf && tid == 0) {
+    g_attn_stamp_buf[((size_t)blockIdx.x * 4 + 3) * 8 + 2] = __builtin_amdgcn_s_memtime();
+    g_attn_stamp_buf[((size_t)blockIdx.x * 4 + 3) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no LDS-DMA may outlive the workgroup)
+}
+
+// ------------------------------------------------------------------------------------------
 // The LAST block: only the cls row of its attention output can reach the logits (the proj / MLP half of that block
 // already runs on the cls rows alone), i.e. ONE query per (batch, head) against all N keys.  The full kernels spend
 // 20 + 53 us on 197 queries there; this pair is two streaming passes over K and V: a workgroup of four waves per
@@ -1439,8 +2061,14 @@ static void attn_set_lds_limits() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<7>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_long_kernel<7>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_persist_kernel), at, MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_p2_kernel<5>), at, MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_p2_kernel<6>), at, MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_p2_kernel<7>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel), at, MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_p2_kernel<5>), at, MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_p2_kernel<6>), at, MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_p2_kernel<7>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<4>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<7>), at, MAX_LDS);
   done = true;
@@ -1465,8 +2093,18 @@ extern "C" int cara_attention_fwd(const void* qkv, void* out, float* lse, int B,
   if (use_persist && N > 128 && N <= NMAX) {
     // one workgroup per CU walks the (batch, head) pairs: K / V of the next pair stream in while this one computes
     const int BH = B * H, grid = BH < 256 ? BH : 256;
-    hipLaunchKernelGGL(attn_fwd_persist_kernel, dim3(grid), dim3(PF_WAVES * 64), 4 * 224 * 128 + PF_WAVES * 4096, st, (const bf16*)qkv,
-                       (bf16*)out, lse, N, H, BH, scale);
+    // CARA_ATTN_FWD_V=1: the round-3 body (any tile count in one kernel) for A/B runs; default: the specialised schedule
+    static const int fwd_v = [] { const char* e = getenv("CARA_ATTN_FWD_V"); return e ? atoi(e) : 2; }();
+    const size_t plds = 4 * 224 * 128 + PF_WAVES * 4096;
+    const int nkt = (N + 31) / 32;
+    if (fwd_v == 1)
+      hipLaunchKernelGGL(attn_fwd_persist_kernel, dim3(grid), dim3(PF_WAVES * 64), plds, st, (const bf16*)qkv, (bf16*)out, lse, N, H, BH, scale);
+    else if (nkt == 7)
+      hipLaunchKernelGGL(attn_fwd_p2_kernel<7>, dim3(grid), dim3(PF_WAVES * 64), plds, st, (const bf16*)qkv, (bf16*)out, lse, N, H, BH, scale);
+    else if (nkt == 6)
+      hipLaunchKernelGGL(attn_fwd_p2_kernel<6>, dim3(grid), dim3(PF_WAVES * 64), plds, st, (const bf16*)qkv, (bf16*)out, lse, N, H, BH, scale);
+    else
+      hipLaunchKernelGGL(attn_fwd_p2_kernel<5>, dim3(grid), dim3(PF_WAVES * 64), plds, st, (const bf16*)qkv, (bf16*)out, lse, N, H, BH, scale);
   } else if (N > NMAX || (use_long && N > 128))
     hipLaunchKernelGGL(attn_fwd_long_kernel<7>, dim3(B * H, (N + 223) / 224), dim3(448), lds, st, (const bf16*)qkv, (bf16*)out, lse, N,
                        H, scale, npad);
@@ -1489,8 +2127,16 @@ extern "C" int cara_attention_bwd(const void* qkv, const void* out, const void* 
   static const int use_fused = [] { const char* e = getenv("CARA_ATTN_PERSIST"); return e ? atoi(e) : 1; }();
   if (use_fused && N > 128 && N <= NMAX) {
     const int BH = B * H, grid = BH < 256 ? BH : 256;
-    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(grid), dim3(448), 5 * 224 * 128 + (256 + 224) * 4, st, (const bf16*)qkv, (const bf16*)out,
-                       (const bf16*)dout, lse, (bf16*)dqkv, N, H, BH, scale);
+    // CARA_ATTN_BWD_V=1: the round-3 body for A/B runs; default: the specialised, software-pipelined schedule
+    static const int bwd_v = [] { const char* e = getenv("CARA_ATTN_BWD_V"); return e ? atoi(e) : 2; }();
+    const size_t blds = 5 * 224 * 128 + (256 + 224) * 4;
+    const int nt = (N + 31) / 32;
+#define CARA_BWD_ARGS dim3(grid), dim3(448), blds, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, BH, scale
+    if (bwd_v == 1) hipLaunchKernelGGL(attn_bwd_fused_kernel, CARA_BWD_ARGS);
+    else if (nt == 7) hipLaunchKernelGGL(attn_bwd_p2_kernel<7>, CARA_BWD_ARGS);
+    else if (nt == 6) hipLaunchKernelGGL(attn_bwd_p2_kernel<6>, CARA_BWD_ARGS);
+    else hipLaunchKernelGGL(attn_bwd_p2_kernel<5>, CARA_BWD_ARGS);
+#undef CARA_BWD_ARGS
     CARA_CHECK_LAUNCH();
     return CARA_OK;
   }

@@ -33,6 +33,18 @@ typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// Two fp32 values to ONE packed pair of the build's 16-bit type (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32), returned as the dword.
+// The empty asm keeps the pair packed: where the two halves are then used separately (2-byte LDS stores of an epilogue) hipcc
+// otherwise converts IEEE halves one by one (v_cvt_f16_f32 x 2) -- the fp16 build's epilogues were 2-3 us per launch slower than
+// the bf16 build's for that alone (profiles/r05_a_fp16_vs_bf16_sites.txt).
+__device__ __forceinline__ unsigned cvt_pk_dword(float a, float b) {
+  const f32x2 v = {a, b};
+  unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  asm volatile("" : "+v"(u));
+  return u;
+}
+
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 

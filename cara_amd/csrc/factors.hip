@@ -11,7 +11,21 @@ struct PackDims {
   int depth, dim, heads, hd, rank, Rp;
   float s;
   int cpl;   // order of the QKV tensorisation: 2, 3, 4 or 5 (cara_geom::cp_length)
+  // loss scaling (cara_factor_grad_reduce_ex): every FINAL gradient is written through gout() -- times 1 / *loss_scale, and
+  // *found_inf raised when the value is not finite (all writers store the same 1.0f: a benign race)
+  const float* loss_scale;
+  float* found_inf;
 };
+struct GOut {
+  float gs;
+  float* found;
+  __device__ __forceinline__ float operator()(float v) const {
+    const float r = v * gs;
+    if (found && !(fabsf(r) <= 3.0e38f)) *found = 1.f;
+    return r;
+  }
+};
+__device__ __forceinline__ GOut gout_of(const PackDims& g) { return GOut{g.loss_scale ? 1.f / *g.loss_scale : 1.f, g.found_inf}; }
 
 // The QKV adapter of block l, projection k, in factored form for every supported order (cara_geom::cp_length):
 //   dW_k[e, o] = sum_r  R1[r] * qkv_coef(l, k, r) * qkv_in(e, r) * qkv_out(o, r)
@@ -150,6 +164,7 @@ __host__ __device__ inline GradScratch grad_scratch(float* sc, int L, int H, int
 __device__ __forceinline__ void grad_rowwise(const PackDims& g, const cara_cp& cp, const cara_layer_grads& lg, const cara_cp& out,
                                              const int e) {
   const int R = g.rank, Rp = g.Rp, dim = g.dim, L = g.depth;
+  const GOut W = gout_of(g);
   if (e < dim * R) {
     const int j = e / R, r = e - j * R;
     float a2 = 0.f, p3 = 0.f, p2 = 0.f, a3o = 0.f;
@@ -166,15 +181,15 @@ __device__ __forceinline__ void grad_rowwise(const PackDims& g, const cara_cp& c
         p2 += cp.P1[(9 * l + 5 + a) * R + r] * lg.dU_fc2[((size_t)l * 4 * dim + a * dim + j) * Rp + r];
       }
     }
-    if (g.cpl != 2) (g.cpl == 5 ? out.A3 : out.A2)[e] = a2;   // gradient of the in factor (order 2: cara_dense_delta_grad)
-    if (g.cpl == 3) out.A3[e] = g.s * cp.R1[r] * a3o;
-    out.P3[e] = p3;
-    out.P2[e] = p2;
+    if (g.cpl != 2) (g.cpl == 5 ? out.A3 : out.A2)[e] = W(a2);   // gradient of the in factor (order 2: cara_dense_delta_grad)
+    if (g.cpl == 3) out.A3[e] = W(g.s * cp.R1[r] * a3o);
+    out.P3[e] = W(p3);
+    out.P2[e] = W(p2);
   }
   if (e < 4 * dim) {
     float b = 0.f;
     for (int l = 0; l < L; ++l) b += lg.dc_fc1[(size_t)l * 4 * dim + e];
-    out.bias2[e] = g.s * b;
+    out.bias2[e] = W(g.s * b);
   }
   if (e < dim) {
     float b1 = 0.f, b3 = 0.f;
@@ -182,8 +197,8 @@ __device__ __forceinline__ void grad_rowwise(const PackDims& g, const cara_cp& c
       b1 += lg.dc_proj[(size_t)l * dim + e];
       b3 += lg.dc_fc2[(size_t)l * dim + e];
     }
-    out.bias1[e] = g.s * b1;
-    out.bias3[e] = g.s * b3;
+    out.bias1[e] = W(g.s * b1);
+    out.bias3[e] = W(g.s * b3);
   }
 }
 
@@ -290,6 +305,7 @@ __global__ __launch_bounds__(256) void grad_stage1_kernel(PackDims g, cara_cp cp
 __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp, float* __restrict__ scratch, cara_cp out, int nb_a) {
   const int R = g.rank, H = g.heads, hd = g.hd, L = g.depth;
   const GradScratch sc = grad_scratch(scratch, L, H, hd, R);
+  const GOut W = gout_of(g);
   if ((int)blockIdx.x < nb_a) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (g.cpl != 3 && g.cpl != 2 && e < (H + hd) * R) {
@@ -302,7 +318,7 @@ __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp
       for (int lk = 0; lk < 3 * L; ++lk) acc += p[(size_t)lk * per + e2];
       float* o3 = g.cpl == 5 ? out.A4 : out.A3;   // head factor
       float* o4 = g.cpl == 5 ? out.A5 : out.A4;   // head-dim factor
-      (is3 ? o3 : o4)[e2] = g.s * cp.R1[r] * acc;
+      (is3 ? o3 : o4)[e2] = W(g.s * cp.R1[r] * acc);
     }
     return;
   }
@@ -321,14 +337,14 @@ __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp
         if (g.cpl == 5 || g.cpl == 2) continue;   // order 5: A1 [depth, R] and A2 [3, R] mix the three projections, below; order 2: dense_delta.hip
         const int row = 3 * l + slot;
         d1 += cp.A1[row * R + r] * z;
-        out.A1[row * R + r] = cp.R1[r] * z;
+        out.A1[row * R + r] = W(cp.R1[r] * z);
       } else {
         const int row = 9 * l + (slot - 3);   // 3 -> 9l ; 4..7 -> 9l+1..4 ; 8..11 -> 9l+5..8
         if (slot < 8) {
           d2 += cp.P1[row * R + r] * z;
-          out.P1[row * R + r] = cp.R2[r] * z;
+          out.P1[row * R + r] = W(cp.R2[r] * z);
         } else {
-          out.P1[row * R + r] = z;
+          out.P1[row * R + r] = W(z);
         }
       }
     }
@@ -345,7 +361,7 @@ __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp
           a1 += cp.A2[k * R + r] * z;
           dk[k] += cp.A1[l * R + r] * z;
         }
-        out.A1[l * R + r] = cp.R1[r] * a1;
+        out.A1[l * R + r] = W(cp.R1[r] * a1);
         d1 += cp.A1[l * R + r] * a1;
       }
     }
@@ -361,12 +377,12 @@ __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp
   for (int k = 0; k < 3; ++k) red3[k][threadIdx.x] = dk[k];
   __syncthreads();
   if (qg == 0 && r < R) {
-    out.R1[r] = (red1[r] + red1[64 + r]) + (red1[128 + r] + red1[192 + r]);
-    out.R2[r] = (red2[r] + red2[64 + r]) + (red2[128 + r] + red2[192 + r]);
+    out.R1[r] = W((red1[r] + red1[64 + r]) + (red1[128 + r] + red1[192 + r]));
+    out.R2[r] = W((red2[r] + red2[64 + r]) + (red2[128 + r] + red2[192 + r]));
     if (g.cpl == 5) {
 #pragma unroll
       for (int k = 0; k < 3; ++k)
-        out.A2[k * R + r] = cp.R1[r] * ((red3[k][r] + red3[k][64 + r]) + (red3[k][128 + r] + red3[k][192 + r]));
+        out.A2[k * R + r] = W(cp.R1[r] * ((red3[k][r] + red3[k][64 + r]) + (red3[k][128 + r] + red3[k][192 + r])));
     }
   }
 }
@@ -376,6 +392,8 @@ PackDims dims_of(const cara_geom* g) {
   d.depth = g->depth; d.dim = g->dim; d.heads = g->heads; d.hd = g->dim / g->heads;
   d.rank = g->rank; d.Rp = g->Rp; d.s = g->scale;
   d.cpl = g->cp_length == 0 ? 4 : g->cp_length;
+  d.loss_scale = nullptr;
+  d.found_inf = nullptr;
   return d;
 }
 bool geom_ok(const cara_geom* g) {
@@ -429,12 +447,19 @@ extern "C" size_t cara_factor_grad_scratch_bytes(const cara_geom* g) {
 
 extern "C" int cara_factor_grad_reduce(const cara_geom* g, const cara_cp* cp, const cara_layer_grads* lg,
                                        const cara_cp* grads, void* scratch, void* stream) {
+  return cara_factor_grad_reduce_ex(g, cp, lg, grads, scratch, nullptr, nullptr, stream);
+}
+extern "C" int cara_factor_grad_reduce_ex(const cara_geom* g, const cara_cp* cp, const cara_layer_grads* lg,
+                                          const cara_cp* grads, void* scratch, const float* loss_scale, float* found_inf,
+                                          void* stream) {
   if (!geom_ok(g) || !cp_ok(g, cp) || !cp_ok(g, grads) || !lg || !scratch) return CARA_E_ARG;
   if (!lg->dU_qkv || !lg->dVs_qkv || !lg->dU_proj || !lg->dVs_proj || !lg->dU_fc1 || !lg->dVs_fc1 || !lg->dU_fc2 ||
       !lg->dVs_fc2 || !lg->dc_proj || !lg->dc_fc1 || !lg->dc_fc2)
     return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const PackDims d = dims_of(g);
+  PackDims d = dims_of(g);
+  d.loss_scale = loss_scale;
+  d.found_inf = found_inf;
   const int n1 = g->dim * g->rank > 4 * g->dim ? g->dim * g->rank : 4 * g->dim;
   const int nb_row = (n1 + 255) / 256, nb_col = g->depth * 13 * GS_SPLIT, nb_a34 = 3 * g->depth * 5;
   float* sc = static_cast<float*>(scratch);

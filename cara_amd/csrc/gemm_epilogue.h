@@ -186,11 +186,11 @@ __device__ __forceinline__ void epilogue_fast_bf16(const cara_gemm_args& p, cons
             if (EPI == CARA_EPI_GELU && o == 0) v[r] = gelu_erf(v[r]);
           }
           char* w = wbase + (i2 * 16) * EPI_FAST_ROW_BYTES + j * 32;
-          const bf16x2 p01 = {(bf16)v[0], (bf16)v[1]}, p23 = {(bf16)v[2], (bf16)v[3]};
-          *reinterpret_cast<bf16*>(w) = p01[0];
-          *reinterpret_cast<bf16*>(w + EPI_FAST_ROW_BYTES) = p01[1];
-          *reinterpret_cast<bf16*>(w + 2 * EPI_FAST_ROW_BYTES) = p23[0];
-          *reinterpret_cast<bf16*>(w + 3 * EPI_FAST_ROW_BYTES) = p23[1];
+          const unsigned p01 = cvt_pk_dword(v[0], v[1]), p23 = cvt_pk_dword(v[2], v[3]);
+          *reinterpret_cast<unsigned short*>(w) = (unsigned short)p01;
+          *reinterpret_cast<unsigned short*>(w + EPI_FAST_ROW_BYTES) = (unsigned short)(p01 >> 16);
+          *reinterpret_cast<unsigned short*>(w + 2 * EPI_FAST_ROW_BYTES) = (unsigned short)p23;
+          *reinterpret_cast<unsigned short*>(w + 3 * EPI_FAST_ROW_BYTES) = (unsigned short)(p23 >> 16);
         }
       // (wave-private image: the wave's own LDS operations complete in order, no barrier; the fences keep the COMPILER from
       // reordering the 2-byte stores and the 16-byte loads, different types to its alias analysis)
@@ -238,7 +238,11 @@ __device__ __forceinline__ void epilogue_fast_bf16_rt(const cara_gemm_args& p, c
         }
         char* w = wbase + j * 32;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) *reinterpret_cast<bf16*>(w + r * EPI_FAST_ROW_BYTES) = (bf16)g[r];
+        for (int r = 0; r < 4; r += 2) {
+          const unsigned pr = cvt_pk_dword(g[r], g[r + 1]);
+          *reinterpret_cast<unsigned short*>(w + r * EPI_FAST_ROW_BYTES) = (unsigned short)pr;
+          *reinterpret_cast<unsigned short*>(w + (r + 1) * EPI_FAST_ROW_BYTES) = (unsigned short)(pr >> 16);
+        }
         if (keep) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) *reinterpret_cast<h16*>(w + (16 + r) * EPI_FAST_ROW_BYTES) = (h16)gp[r];
@@ -278,11 +282,11 @@ __device__ __forceinline__ void epilogue_fast_bf16_rt(const cara_gemm_args& p, c
           if (EPI == CARA_EPI_GELU && o == 0) v[r] = gelu_erf(v[r]);
         }
         char* w = w0 + j * 32;
-        const bf16x2 p01 = {(bf16)v[0], (bf16)v[1]}, p23 = {(bf16)v[2], (bf16)v[3]};
-        *reinterpret_cast<bf16*>(w) = p01[0];
-        *reinterpret_cast<bf16*>(w + EPI_FAST_ROW_BYTES) = p01[1];
-        *reinterpret_cast<bf16*>(w + 2 * EPI_FAST_ROW_BYTES) = p23[0];
-        *reinterpret_cast<bf16*>(w + 3 * EPI_FAST_ROW_BYTES) = p23[1];
+        const unsigned p01 = cvt_pk_dword(v[0], v[1]), p23 = cvt_pk_dword(v[2], v[3]);
+        *reinterpret_cast<unsigned short*>(w) = (unsigned short)p01;
+        *reinterpret_cast<unsigned short*>(w + EPI_FAST_ROW_BYTES) = (unsigned short)(p01 >> 16);
+        *reinterpret_cast<unsigned short*>(w + 2 * EPI_FAST_ROW_BYTES) = (unsigned short)p23;
+        *reinterpret_cast<unsigned short*>(w + 3 * EPI_FAST_ROW_BYTES) = (unsigned short)(p23 >> 16);
       }
       // (compiler fences: the 2-byte stores and the 16-byte loads of the image are different types to the alias analysis)
       asm volatile("" ::: "memory");

@@ -1,7 +1,7 @@
 // Library identification for libcara_hip.so.
 #include "common.h"
 
-extern "C" int cara_abi_version(void) { return 13; }
+extern "C" int cara_abi_version(void) { return 14; }
 extern "C" const char* cara_build_arch(void) { return "gfx950"; }
 extern "C" const char* cara_operand_type(void) { return CARA_OPERAND_TYPE; }
 

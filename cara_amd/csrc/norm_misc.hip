@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__
 // one wave per sample; loss = mean_b (lse_b - logit_b[y_b]); dlogits = (softmax - onehot) / B
 __global__ __launch_bounds__(64) void xent_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                   float* __restrict__ loss_per, float* __restrict__ dlogits,
-                                                  int B, int C) {
+                                                  int B, int C, float dscale, const float* __restrict__ loss_scale) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const float* lr = logits + (size_t)b * C;
   float m = -3.0e38f;
@@ -345,16 +345,22 @@ __global__ __launch_bounds__(64) void xent_kernel(const float* __restrict__ logi
   const float lse = m + __logf(s);
   const int y = (int)labels[b];
   const float invB = 1.0f / B;
+  // (the gradient's scale: 1/B of the mean, times 1/world of a data-parallel job, times the loss scale of the IEEE-half build)
+  const float gsc = invB * dscale * (loss_scale ? *loss_scale : 1.f);
   if (dlogits)
     for (int c = lane; c < C; c += 64)
-      dlogits[(size_t)b * C + c] = (__expf(lr[c] - lse) - (c == y ? 1.f : 0.f)) * invB;
+      dlogits[(size_t)b * C + c] = (__expf(lr[c] - lse) - (c == y ? 1.f : 0.f)) * gsc;
   if (lane == 0) loss_per[b] = (lse - lr[y]) * invB;
 }
-__global__ __launch_bounds__(64) void xent_sum_kernel(const float* __restrict__ loss_per, float* __restrict__ loss, int B) {
+__global__ __launch_bounds__(64) void xent_sum_kernel(const float* __restrict__ loss_per, float* __restrict__ loss, int B,
+                                                      float* __restrict__ found_inf) {
   float s = 0.f;
   for (int b = threadIdx.x; b < B; b += 64) s += loss_per[b];
   s = wave_sum(s);
-  if (threadIdx.x == 0) *loss = s;
+  if (threadIdx.x == 0) {
+    *loss = s;
+    if (found_inf) *found_inf = 0.f;   // raised by the backward's final gradient writes (cara_vit_shape::found_inf)
+  }
 }
 
 __global__ __launch_bounds__(256) void cvt_kernel(const float* __restrict__ src, bf16* __restrict__ dst, size_t n) {
@@ -586,16 +592,20 @@ extern "C" int cara_assemble_tokens(const float* emb, const float* cls, const fl
   return CARA_OK;
 }
 
-extern "C" int cara_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits, int B,
-                                  int C, void* stream) {
+extern "C" int cara_cross_entropy_ex(const float* logits, const int64_t* labels, float* loss, float* dlogits, int B,
+                                     int C, float dscale, const float* loss_scale, float* found_inf, void* stream) {
   // loss doubles as scratch: needs room for 1 + B floats (loss[0] = mean loss, loss[1..B] per-sample terms)
-  if (!logits || !labels || !loss || B <= 0 || C <= 0) return CARA_E_ARG;
+  if (!logits || !labels || !loss || B <= 0 || C <= 0 || !(dscale > 0.f)) return CARA_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(xent_kernel, dim3(B), dim3(64), 0, st, logits, labels, loss + 1, dlogits, B, C);
+  hipLaunchKernelGGL(xent_kernel, dim3(B), dim3(64), 0, st, logits, labels, loss + 1, dlogits, B, C, dscale, loss_scale);
   CARA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(xent_sum_kernel, dim3(1), dim3(64), 0, st, loss + 1, loss, B);
+  hipLaunchKernelGGL(xent_sum_kernel, dim3(1), dim3(64), 0, st, loss + 1, loss, B, found_inf);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
+}
+extern "C" int cara_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits, int B,
+                                  int C, void* stream) {
+  return cara_cross_entropy_ex(logits, labels, loss, dlogits, B, C, 1.f, nullptr, nullptr, stream);
 }
 
 extern "C" int cara_f32_to_bf16(const float* src, void* dst, size_t n, void* stream) {

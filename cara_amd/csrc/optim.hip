@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const cara_adamw_args a) {
     first += nchunk;
   }
   if (t >= a.ntensors) return;
+  if (a.skip_flag && *a.skip_flag != 0.f) return;   // the step's gradients overflowed under the loss scale: nothing moves
   const cara_adamw_tensor& T = a.t[t];
   const float lr = a.lr[T.group], wd = a.weight_decay[T.group];
   const float decay = 1.f - lr * wd;
@@ -49,7 +50,35 @@ __global__ __launch_bounds__(256) void adamw_kernel(const cara_adamw_args a) {
   }
 }
 
+// GradScaler's update rule on the device: one thread (cara_hip.h, cara_amp_update)
+__global__ void amp_update_kernel(float* __restrict__ st, const float* __restrict__ found_inf, float growth, float backoff,
+                                  int interval, float max_scale) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (*found_inf != 0.f) {
+    st[0] = fmaxf(st[0] * backoff, 1.f);
+    st[1] = 0.f;
+    st[2] += 1.f;
+  } else {
+    const float n = st[1] + 1.f;
+    if (n >= (float)interval) {
+      st[0] = fminf(st[0] * growth, max_scale);
+      st[1] = 0.f;
+    } else {
+      st[1] = n;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int cara_amp_update(float* state, const float* found_inf, float growth, float backoff, int interval, float max_scale,
+                               void* stream) {
+  if (!state || !found_inf || !(growth >= 1.f) || !(backoff > 0.f && backoff <= 1.f) || interval <= 0 || !(max_scale >= 1.f)) return CARA_E_ARG;
+  hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), state, found_inf, growth, backoff,
+                     interval, max_scale);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
 
 extern "C" int cara_adamw_step(const cara_adamw_args* a, void* stream) {
   if (!a || a->ntensors <= 0 || a->ntensors > CARA_ADAMW_MAX_TENSORS || a->step <= 0) return CARA_E_ARG;

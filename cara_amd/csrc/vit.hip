@@ -743,21 +743,30 @@ bool epi_riders_geom(const cara_geom* g, int Mr, bool exact) {
 // every thread (58 -> ~25 us; it sits alone at the head of the backward pass)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl, const bf16* __restrict__ xn,
                                                        const float* __restrict__ W, float* __restrict__ dW,
-                                                       float* __restrict__ db, bf16* __restrict__ dxn, int B, int Cn, int D, int nbw) {
+                                                       float* __restrict__ db, bf16* __restrict__ dxn, int B, int Cn, int D, int nbw,
+                                                       const float* __restrict__ loss_scale, float* __restrict__ found_inf) {
   if ((int)blockIdx.x < nbw) {
+    // the two gradients this kernel FINISHES leave unscaled (cara_vit_shape::loss_scale); dxn stays in the scaled domain
+    const float gs = loss_scale ? 1.f / *loss_scale : 1.f;
     const int e = blockIdx.x * 256 + threadIdx.x;
+    bool bad = false;
     if (e < Cn * D) {
       const int c = e / D, d = e - c * D;
       float s = 0.f;
 #pragma unroll 8
       for (int b = 0; b < B; ++b) s += dl[b * Cn + c] * (float)xn[b * D + d];
+      s *= gs;
+      bad |= !(fabsf(s) <= 3.0e38f);
       dW[e] = s;
     }
     if (e < Cn) {
       float s = 0.f;
       for (int b = 0; b < B; ++b) s += dl[b * Cn + e];
+      s *= gs;
+      bad |= !(fabsf(s) <= 3.0e38f);
       db[e] = s;
     }
+    if (found_inf && bad) *found_inf = 1.f;
   } else {
     const int e = (blockIdx.x - nbw) * 256 + threadIdx.x;
     if (e < B * D) {
@@ -770,7 +779,74 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   }
 }
 
+// Final LayerNorm of one cls row + the classifier head in fp32 (cara_head_forward): workgroup (class chunk of HEAD_CHUNK, sample).
+// Every workgroup normalises its sample's row itself (D floats: cheaper than a launch boundary); chunk 0 also writes the
+// 16-bit xn row and mean / rstd for the backward.  The dot products run one class per wave and step over the row in float4
+// pieces (a wave instruction reads 1 KiB of a head_w row), two classes in flight per wave.
+constexpr int HEAD_CHUNK = 128;
+__global__ __launch_bounds__(256) void head_fwd_f32_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ Wh,
+                                                           const float* __restrict__ bh, bf16* __restrict__ xn16,
+                                                           float* __restrict__ mean, float* __restrict__ rstd,
+                                                           float* __restrict__ logits, int Cn, int D, float eps) {
+  __shared__ __attribute__((aligned(16))) float xs[1024];
+  __shared__ float red[8];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xr = x + (size_t)b * ldx;
+  float s = 0.f;
+  for (int d = tid; d < D; d += 256) { const float v = xr[d]; xs[d] = v; s += v; }
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float mu = ((red[0] + red[1]) + (red[2] + red[3])) / (float)D;
+  float q = 0.f;
+  for (int d = tid; d < D; d += 256) { const float a = xs[d] - mu; q += a * a; }
+  q = wave_sum(q);
+  if (lane == 0) red[4 + wave] = q;
+  __syncthreads();
+  const float rs = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)D + eps);
+  for (int d = tid; d < D; d += 256) {
+    const float v = (xs[d] - mu) * rs * gamma[d] + beta[d];
+    xs[d] = v;
+    if (blockIdx.x == 0) xn16[(size_t)b * D + d] = (bf16)v;
+  }
+  if (blockIdx.x == 0 && tid == 0) { mean[b] = mu; rstd[b] = rs; }
+  __syncthreads();
+  const int c0 = blockIdx.x * HEAD_CHUNK, c1 = c0 + HEAD_CHUNK < Cn ? c0 + HEAD_CHUNK : Cn;
+  const int nd4 = D >> 2;   // float4 pieces of a row (D % 4 == 0)
+  for (int c = c0 + wave * 2; c < c1; c += 8) {
+    const int ca = c, cb = c + 1 < c1 ? c + 1 : c;
+    const float4* wa = reinterpret_cast<const float4*>(Wh + (size_t)ca * D);
+    const float4* wb = reinterpret_cast<const float4*>(Wh + (size_t)cb * D);
+    float da = 0.f, db = 0.f;
+    for (int i = lane; i < nd4; i += 64) {
+      const float4 xv = *reinterpret_cast<const float4*>(xs + 4 * i);
+      const float4 a = wa[i], bq = wb[i];
+      da += (a.x * xv.x + a.y * xv.y) + (a.z * xv.z + a.w * xv.w);
+      db += (bq.x * xv.x + bq.y * xv.y) + (bq.z * xv.z + bq.w * xv.w);
+    }
+    da = wave_sum(da);
+    db = wave_sum(db);
+    if (lane == 0) {
+      logits[(size_t)b * Cn + ca] = da + bh[ca];
+      if (cb != ca) logits[(size_t)b * Cn + cb] = db + bh[cb];
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int cara_head_forward(const float* x, long ldx, const float* gamma, const float* beta, const float* head_w,
+                                 const float* head_b, void* xn_16, float* mean, float* rstd, float* logits, int B, int classes,
+                                 int D, float eps, void* stream) {
+  if (!x || !gamma || !beta || !head_w || !head_b || !xn_16 || !mean || !rstd || !logits || B <= 0 || classes <= 0 || D <= 0 ||
+      D > 1024 || (D & 3) || ldx < D)
+    return CARA_E_ARG;
+  hipLaunchKernelGGL(head_fwd_f32_kernel, dim3((classes + HEAD_CHUNK - 1) / HEAD_CHUNK, B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     x, ldx, gamma, beta, head_w, head_b, (bf16*)xn_16, mean, rstd, logits, classes, D, eps);
+  CARA_CHECK_LAUNCH();
+  return CARA_OK;
+}
 
 extern "C" int cara_profile_sites(unsigned long long mask, int every) {
   if (mask && !g_prof.made) {
@@ -813,14 +889,18 @@ extern "C" size_t cara_vit_workspace_bytes(const cara_geom* g, const cara_vit_sh
   return layout(g, s, &w) ? w.total : 0;
 }
 
-extern "C" int cara_head_backward(const float* dlogits, const void* xn, const float* head_w, float* dhead_w,
-                                  float* dhead_b, void* dxn, int B, int classes, int D, void* stream) {
+static int head_backward_scaled(const float* dlogits, const void* xn, const float* head_w, float* dhead_w, float* dhead_b, void* dxn,
+                                int B, int classes, int D, const float* loss_scale, float* found_inf, void* stream) {
   if (!dlogits || !xn || !head_w || !dhead_w || !dhead_b || !dxn || B <= 0 || classes <= 0 || D <= 0) return CARA_E_ARG;
   const int nbw = (classes * D + 255) / 256, nbx = (B * D + 255) / 256;
   hipLaunchKernelGGL(head_bwd_kernel, dim3(nbw + nbx), dim3(256), 0, static_cast<hipStream_t>(stream), dlogits,
-                     (const bf16*)xn, head_w, dhead_w, dhead_b, (bf16*)dxn, B, classes, D, nbw);
+                     (const bf16*)xn, head_w, dhead_w, dhead_b, (bf16*)dxn, B, classes, D, nbw, loss_scale, found_inf);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
+}
+extern "C" int cara_head_backward(const float* dlogits, const void* xn, const float* head_w, float* dhead_w,
+                                  float* dhead_b, void* dxn, int B, int classes, int D, void* stream) {
+  return head_backward_scaled(dlogits, xn, head_w, dhead_w, dhead_b, dxn, B, classes, D, nullptr, nullptr, stream);
 }
 
 extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, const cara_vit_weights* w,
@@ -836,7 +916,6 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
   TRY(cara_factor_prep(g, cp, w->proj_b, w->fc1_b, w->fc2_b, ws + W.pack, stream));
   const bool dense_qkv = g->cp_length == 2;   // order-2 tensorisation: the QKV linear in the dense-delta form
   if (dense_qkv) TRY(cara_dense_delta_materialize(g, cp, ws + W.dd, ws + W.ddt, stream));
-  TRY(cara_f32_to_bf16(head_w, ws + W.head_wb, (size_t)s->num_classes * D, stream));
   // patch embedding: Conv2d(k = s = patch) as a GEMM over im2col rows, then cls + pos_embed
   const int kp = s->chans * s->patch * s->patch;
   TRY(cara_im2col_patches(images, ws + W.patches, B, s->chans, s->img, s->img, s->patch, stream));
@@ -929,12 +1008,10 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
     else TRY(lin_fwd(lin[3], reinterpret_cast<bf16*>(ws + lw.h), pa ? -Mr : 4 * D, Mr, Rp, W.ldt, ws, lw, e, cx));
   }
   // norm -> cls token -> head  (LayerNorm is per token, so only the cls rows are normalised)
-  TRY(cara_layernorm_fwd(reinterpret_cast<float*>(ws + W.x_last), (long)N * D, w->norm_g, w->norm_b, ws + W.clsn,
-                         reinterpret_cast<float*>(ws + W.meanF), reinterpret_cast<float*>(ws + W.rstdF), B, D, s->eps, stream));
-  a = {};
-  a.A = ws + W.clsn; a.lda = D; a.B = ws + W.head_wb; a.ldb = D; a.M = B; a.N = s->num_classes; a.K = D;
-  a.bias = head_b; a.epi = CARA_EPI_F32; a.C = logits; a.ldc = s->num_classes;
-  return cara_gemm_bf16(&a, stream);
+  // ... all in fp32, one launch (cara_head_forward): the 16-bit xn and the row statistics are kept for the backward
+  return cara_head_forward(reinterpret_cast<float*>(ws + W.x_last), (long)N * D, w->norm_g, w->norm_b, head_w, head_b, ws + W.clsn,
+                           reinterpret_cast<float*>(ws + W.meanF), reinterpret_cast<float*>(ws + W.rstdF), logits, B, s->num_classes,
+                           D, s->eps, stream);
 }
 
 extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, const cara_vit_weights* w,
@@ -956,7 +1033,8 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
   float* dx = reinterpret_cast<float*>(ws + W.dx);
   const Ws::Bwd& R = W.bwd;
   bf16* dyb = reinterpret_cast<bf16*>(ws + R.dyb_fc2);   // dY of the last block's fc2
-  TRY(cara_head_backward(dlogits, ws + W.clsn, head_w, dhead_w, dhead_b, ws + W.dclsn, B, s->num_classes, D, stream));
+  TRY(head_backward_scaled(dlogits, ws + W.clsn, head_w, dhead_w, dhead_b, ws + W.dclsn, B, s->num_classes, D, s->loss_scale,
+                           s->found_inf, stream));
   // gradient enters the token stream only through the cls rows
   if (hipMemsetAsync(dx, 0, (size_t)M * D * 4, hs) != hipSuccess) return CARA_E_LAUNCH;
   if (hipMemsetAsync(dyb, 0, (size_t)M * D * 2, hs) != hipSuccess) return CARA_E_LAUNCH;
@@ -1133,7 +1211,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
   lg.dU_fc2 = reinterpret_cast<float*>(ws + W.dU[3]); lg.dVs_fc2 = reinterpret_cast<float*>(ws + W.dVs[3]);
   lg.dc_proj = reinterpret_cast<float*>(ws + W.dc[1]); lg.dc_fc1 = reinterpret_cast<float*>(ws + W.dc[2]);
   lg.dc_fc2 = reinterpret_cast<float*>(ws + W.dc[3]);
-  TRY(cara_factor_grad_reduce(g, cp, &lg, grads, ws + W.gscratch, stream));
+  TRY(cara_factor_grad_reduce_ex(g, cp, &lg, grads, ws + W.gscratch, s->loss_scale, s->found_inf, stream));
   if (dense_qkv)   // CP_A1 / CP_A2 / CP_R1 of the order-2 tensorisation, from the dense dD of every (layer, projection)
     TRY(cara_dense_delta_grad(g, cp, reinterpret_cast<const float*>(ws + W.dD), grads, ws + W.dd_scratch, stream));
   return CARA_OK;

@@ -43,6 +43,14 @@ def allreduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
     return flat
 
 
+def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place SUM over ranks: the collective of a train step whose dlogits was divided by the world size at its source
+    (cara_cross_entropy_ex), so that no scaling launch follows the all-reduce."""
+    if world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
 def epoch_shard(n_items: int, epoch: int, rank: int, world: int, per_rank_batch: int, seed: int = 0) -> List[torch.Tensor]:
     """Rank-strided slices of an epoch-seeded permutation, drop_last like vtab.py:84-88:
     every rank draws the same permutation, takes items rank, rank+world, ... and cuts them into

@@ -57,9 +57,7 @@ class CaraEngine:
         self.weight_dropout = "off"
         self.weight_dropout_p = 0.1
         self.weight_dropout_seed = None   # tests pin the mask seed; None = a fresh draw from torch's RNG per forward
-        # "bf16" (default): the fast path, bf16 MFMA operands.  "bf16x3": eval / no_grad forwards run every product as three
-        # split-bf16 MFMA products with fp32 activations (cara_amd/precise.py): a parity instrument that reaches north_star's
-        # 1e-3 on the logits at ~3x the GEMM work; training always runs the fast path.
+        # "bf16" (default): the fast path, bf16 MFMA operands.
         # "fp16": the SAME kernels compiled with IEEE-half MFMA operands (libcara_hip_f16.so: 11 significand bits at the bf16 MFMA
         # rate) for forward AND backward -- logits inside north_star's 1e-3 of the fp32 reference (measured: tests/test_model_gpu.py,
         # DESIGN.md section 2); the backward runs under a static loss scale (FP16_LOSS_SCALE: gradients need half's range, not its
@@ -74,6 +72,7 @@ class CaraEngine:
         self._need_backward = True
         self._flat_grad = None
         self._grad_views = None
+        self._slot = 0          # workspace slot of the call in flight (train_step_two_streams)
         # RNG streams of the stochastic parts (DropPath masks on the device, weight-dropout seeds on the host).
         # None = torch's global generators.  Under data parallelism every rank must draw DIFFERENT masks while the
         # parameters stay identical: seed_rank_streams(seed, rank) after the model is built.
@@ -84,7 +83,35 @@ class CaraEngine:
         from .modules import FactorPack
         self._factors = FactorPack(self)
 
+    # Loss scaling of precision = "fp16" (half's range, not its precision, is what gradients lack), entirely on the device:
+    # the scale lives in a device float (initially FP16_LOSS_SCALE), cara_cross_entropy_ex multiplies dlogits by it, the kernels
+    # that WRITE the final gradients divide it out and raise a found-inf word when a value is not finite; that word sits behind
+    # the last gradient in the flat buffer, so the step's one all-reduce carries it to every rank; cara_amp_update then halves the
+    # scale (or doubles it after AMP_GROWTH_INTERVAL clean steps: torch.amp.GradScaler's rule) and cara_amd.optim.AdamW skips the
+    # update of such a step -- no host synchronisation, no extra pass over the gradients.  A foreign optimiser is stepped behind a
+    # host-side check of the word instead (one synchronisation per step, fp16 only).
     FP16_LOSS_SCALE = 1024.0
+    AMP_GROWTH, AMP_BACKOFF, AMP_GROWTH_INTERVAL, AMP_MAX_SCALE = 2.0, 0.5, 2000, 65536.0
+
+    def _amp(self, dev):
+        """device float[4] = {loss scale, clean steps since the last change, steps skipped so far, unused} (fp16 only)"""
+        st = self.__dict__.get("_amp_state")
+        if st is None or st.device != dev:
+            st = torch.tensor([self.FP16_LOSS_SCALE, 0.0, 0.0, 0.0], device=dev)
+            self._amp_state = st
+        return st
+
+    @property
+    def loss_scale(self) -> float:
+        """current loss scale of precision = "fp16" (synchronises; diagnostics)"""
+        st = self.__dict__.get("_amp_state")
+        return float(st[0].item()) if st is not None else self.FP16_LOSS_SCALE
+
+    @property
+    def skipped_steps(self) -> int:
+        """steps whose gradients overflowed under the loss scale and were skipped (synchronises; diagnostics)"""
+        st = self.__dict__.get("_amp_state")
+        return int(st[2].item()) if st is not None else 0
 
     def _operands(self) -> str:
         return "fp16" if self.precision == "fp16" else "bf16"
@@ -162,7 +189,7 @@ class CaraEngine:
             raise CaraError(f"weight_dropout must be 'off' or 'exact', not {self.weight_dropout!r}")
         if exact and self.cp_length == 2:
             raise CaraError("cp_length 2 (dense QKV deltas) runs with weight_dropout = 'off' only")
-        key = (B, img, ncls, str(dev), exact, self._operands())
+        key = (B, img, ncls, str(dev), exact, self._operands(), self._slot)
         st = self._ws.get(key)
         if st is None:
             pe = model.patch_embed
@@ -177,7 +204,8 @@ class CaraEngine:
             if nbytes == 0:
                 raise CaraError(f"unsupported geometry for the HIP path: {geom.depth=} {geom.dim=} {geom.heads=} "
                                 f"{shape.tokens=} (needs head dim 64, tokens <= 608, dim % 256 == 0)")
-            self._ws.clear()  # one live workspace: activations of one step
+            if self._slot == 0:
+                self._ws.clear()  # one live workspace: activations of one step (slots > 0: the two-stream step's second half)
             ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
             st = {"geom": geom, "shape": shape, "ws": ws, "logits": torch.empty(B, ncls, device=dev)}
             self._ws[key] = st
@@ -227,32 +255,38 @@ class CaraEngine:
     def _grad_buffers(self, model, dev):
         names = [(n, getattr(model, "CP_" + n)) for n in self.cp_fields] + [("head_w", model.head.weight), ("head_b", model.head.bias)]
         sizes = [p.numel() for _, p in names]
-        if self._flat_grad is None or self._flat_grad.numel() != sum(sizes) or self._flat_grad.device != dev:
+        if self._flat_grad is None or self._flat_grad.numel() != sum(sizes) + 1 or self._flat_grad.device != dev:
             from .dist import flat_views
-            self._flat_grad, self._grad_views = flat_views([(n, p.shape) for n, p in names], dev)
+            # (one word behind the gradients: "a non-finite gradient was written" -- all-reduced with them, so every rank sees it)
+            self._flat_grad, self._grad_views = flat_views([(n, p.shape) for n, p in names] + [("_found_inf", (1,))], dev)
         return self._grad_views
 
-    def _run_backward(self, dlogits, droppath, head_w, cp):
+    def _run_backward(self, dlogits, droppath, head_w, cp, prescaled=False):
         model = self._model()
         st = self._ws[self._last_key]
         dev = dlogits.device
         with torch.cuda.device(dev):
-            return self._run_backward_on(model, st, dlogits, droppath, head_w, cp, dev)
+            return self._run_backward_on(model, st, dlogits, droppath, head_w, cp, dev, prescaled)
 
-    def _run_backward_on(self, model, st, dlogits, droppath, head_w, cp, dev):
+    def _run_backward_on(self, model, st, dlogits, droppath, head_w, cp, dev, prescaled=False):
         g = self._grad_buffers(model, dev)
         cps = self._cp_ptrs([t.detach().contiguous() for t in cp])
         gps = L.cp_ptrs(self.cp_fields, [g[n] for n in self.cp_fields])
         dl = dlogits.contiguous().float()
-        scaled = self.precision == "fp16"
-        if scaled:   # static loss scale: every 16-bit gradient of the pass is FP16_LOSS_SCALE times larger, the fp32 sums are scaled back
-            dl = dl * self.FP16_LOSS_SCALE
+        if self.precision == "fp16":
+            # every 16-bit gradient of the pass is loss-scale times larger; the kernels that write the final fp32 gradients divide
+            # the scale out again (cara_vit_shape::loss_scale) and raise found_inf on a non-finite value
+            amp = self._amp(dev)
+            if not prescaled:   # (train_step's cross-entropy has scaled dlogits and cleared the word already)
+                dl = dl * amp[0]
+                g["_found_inf"].zero_()
+            st["shape"].loss_scale, st["shape"].found_inf = ptr(amp), ptr(g["_found_inf"])
+        else:
+            st["shape"].loss_scale, st["shape"].found_inf = None, None
         check(self._lib().cara_vit_backward(C.byref(st["geom"]), C.byref(st["shape"]), C.byref(self._ingested[1]), C.byref(cps),
                                             ptr(head_w.detach().contiguous()), ptr(dl), ptr(droppath),
                                             ptr(st["ws"]), C.byref(gps), ptr(g["head_w"]), ptr(g["head_b"]), stream(dev)),
               "cara_vit_backward")
-        if scaled:
-            self._flat_grad.mul_(1.0 / self.FP16_LOSS_SCALE)
         self._bwd_ready = -1
         return g
 
@@ -318,13 +352,10 @@ class CaraEngine:
             raise CaraError("model parameters and images must be on the same device")
         params = [model.head.weight, model.head.bias, *cp]
         self._need_backward = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        if self.precision not in ("bf16", "bf16x3", "fp16"):
-            raise CaraError(f"precision must be 'bf16', 'fp16' or 'bf16x3', not {self.precision!r}")
+        if self.precision not in ("bf16", "fp16"):
+            raise CaraError(f"precision must be 'bf16' or 'fp16', not {self.precision!r}")
         if self.precision == "fp16" and (self.weight_dropout == "exact" or self.cp_length == 2):
             raise CaraError("precision = 'fp16' runs the factored adapters (weight_dropout = 'off', cp_length 3 / 4 / 5)")
-        if self.precision == "bf16x3" and not model.training and not self._need_backward:
-            from . import precise
-            return precise.forward(model, images)
         return _VitFn.apply(self, images, droppath, *params)
 
     # ------------------------------------------------------------------ fused train step
@@ -333,10 +364,11 @@ class CaraEngine:
         model = self._model()
         return [getattr(model, "CP_" + n) for n in self.cp_fields] + [model.head.weight, model.head.bias]
 
-    def _apply_gradients(self, optimizer=None, group=None):
+    def _apply_gradients(self, optimizer=None, group=None, prescaled=False):
         """Tail of a train step, shared by train_step and the CPU multi-process tests: bind ``p.grad`` of every
-        trainable parameter to its view of the flat buffer, ONE all-reduce (mean) of that buffer when the group
-        has more than one rank, ``optimizer.step()``."""
+        trainable parameter to its view of the flat buffer, ONE all-reduce of that buffer when the group has more than
+        one rank -- a plain SUM when the gradients were computed from a dlogits already divided by the world size
+        (``prescaled``: train_step), the mean otherwise -- and ``optimizer.step()``."""
         model = self._model()
         g = self._grad_views
         cp = [getattr(model, "CP_" + n) for n in self.cp_fields]
@@ -344,8 +376,22 @@ class CaraEngine:
             if p.grad is None or p.grad.data_ptr() != g[n].data_ptr():
                 p.grad = g[n]
         # the only data-path collective of a step: one RCCL all-reduce over xGMI of the flat buffer
-        from .dist import allreduce_mean_
-        allreduce_mean_(self._flat_grad, group)
+        from .dist import allreduce_mean_, allreduce_sum_
+        (allreduce_sum_ if prescaled else allreduce_mean_)(self._flat_grad, group)
+        if self.precision == "fp16" and self._flat_grad.is_cuda:
+            found = g["_found_inf"]
+            dev = found.device
+            with torch.cuda.device(dev):
+                check(self._lib().cara_amp_update(ptr(self._amp(dev)), ptr(found), C.c_float(self.AMP_GROWTH), C.c_float(self.AMP_BACKOFF),
+                                                  int(self.AMP_GROWTH_INTERVAL), C.c_float(self.AMP_MAX_SCALE), stream(dev)), "cara_amp_update")
+            if optimizer is not None:
+                from .optim import AdamW
+                if isinstance(optimizer, AdamW):
+                    optimizer.skip_flag = found          # the launch changes nothing when the word is set
+                    optimizer.step()
+                elif float(found.item()) == 0.0:         # a foreign optimiser: the host looks at the word (one sync per step)
+                    optimizer.step()
+            return
         if optimizer is not None:
             optimizer.step()
 
@@ -380,11 +426,77 @@ class CaraEngine:
                 self._dlogits = torch.empty(B, ncls, device=dev)
             if self._dlogits.shape != logits.shape:
                 self._dlogits = torch.empty(B, ncls, device=dev)
-            check(self._lib().cara_cross_entropy(ptr(logits), ptr(labels.contiguous()), ptr(self._loss_buf), ptr(self._dlogits),
-                                             B, ncls, stream(dev)), "cara_cross_entropy")
-            self._run_backward(self._dlogits, droppath, hw, cp)
-            self._apply_gradients(optimizer, group)
+            # dlogits leaves the cross-entropy already divided by the world size (the all-reduce is then a plain SUM) and, in the
+            # IEEE-half build, multiplied by the loss scale; the same launch clears the step's found-inf word
+            from .dist import world_size
+            fp16 = self.precision == "fp16"
+            gv = self._grad_buffers(model, dev)
+            check(self._lib().cara_cross_entropy_ex(ptr(logits), ptr(labels.contiguous()), ptr(self._loss_buf), ptr(self._dlogits),
+                                                    B, ncls, C.c_float(1.0 / world_size(group)), ptr(self._amp(dev)) if fp16 else None,
+                                                    ptr(gv["_found_inf"]) if fp16 else None, stream(dev)), "cara_cross_entropy_ex")
+            self._run_backward(self._dlogits, droppath, hw, cp, prescaled=True)
+            self._apply_gradients(optimizer, group, prescaled=True)
         return self._loss_buf[0]
+
+    def train_step_two_streams(self, images, labels, optimizer=None, group=None, lag_cycles: int = 0):
+        """EXPERIMENT (measured in profiles/r05_*two_streams*, not the default): the step as two half-batch
+        pipelines on two HIP streams, so that one half's LayerNorm / attention / epilogue tails can run under the other half's
+        K loops.  cara_vit_forward / cara_vit_backward are stateless and take a stream: each half has its own workspace and
+        its own flat gradient buffer; the mean over the batch is the average of the halves' means (dlogits scaled by 1/2 at the
+        cross-entropy), the second buffer is added to the first, then the usual all-reduce + optimiser.  bf16, factored adapters."""
+        model = self._model()
+        dev = images.device
+        B = images.shape[0]
+        if B % 2 or self.precision != "bf16" or self.weight_dropout != "off":
+            raise CaraError("train_step_two_streams: even batch, precision 'bf16', weight_dropout 'off'")
+        cp = [getattr(model, "CP_" + n) for n in self.cp_fields]
+        hw, hb = model.head.weight, model.head.bias
+        from .dist import flat_views, world_size
+        with torch.no_grad(), torch.cuda.device(dev):
+            main = torch.cuda.current_stream(dev)
+            if self.__dict__.get("_two") is None:
+                names = [(n, getattr(model, "CP_" + n).shape) for n in self.cp_fields] + [("head_w", hw.shape), ("head_b", hb.shape), ("_found_inf", (1,))]
+                self._two = {"streams": (torch.cuda.Stream(dev), torch.cuda.Stream(dev)), "flat2": flat_views(names, dev),
+                             "loss": [torch.empty(1 + B // 2, device=dev) for _ in range(2)],
+                             "dl": [torch.empty(B // 2, hw.shape[0], device=dev) for _ in range(2)]}
+            two = self._two
+            droppath = self.draw_droppath(model, B, dev)
+            gv0 = self._grad_buffers(model, dev)
+            flat1, gv1 = two["flat2"]
+            ev_in = torch.cuda.Event()
+            ev_in.record(main)
+            done = []
+            for h, (s_, gv) in enumerate(zip(two["streams"], (gv0, gv1))):
+                sl = slice(h * (B // 2), (h + 1) * (B // 2))
+                x_h, y_h = images[sl], labels[sl].contiguous()
+                dp_h = droppath[:, :, sl].contiguous() if droppath is not None else None
+                s_.wait_event(ev_in)
+                with torch.cuda.stream(s_):
+                    self._slot = h
+                    try:
+                        if h == 1 and lag_cycles > 0:   # phase shift of the second pipeline (a spin kernel of that many clocks)
+                            torch.cuda._sleep(int(lag_cycles))
+                        logits = self._run_forward(x_h, dp_h, hw, hb, cp)
+                        check(self._lib().cara_cross_entropy_ex(ptr(logits), ptr(y_h), ptr(two["loss"][h]), ptr(two["dl"][h]), B // 2, logits.shape[1],
+                                                                C.c_float(0.5 / world_size(group)), None, None, stream(dev)), "cara_cross_entropy_ex")
+                        st = self._ws[self._last_key]
+                        gps = L.cp_ptrs(self.cp_fields, [gv[n] for n in self.cp_fields])
+                        cps = self._cp_ptrs([t.detach().contiguous() for t in cp])
+                        st["shape"].loss_scale, st["shape"].found_inf = None, None
+                        check(self._lib().cara_vit_backward(C.byref(st["geom"]), C.byref(st["shape"]), C.byref(self._ingested[1]), C.byref(cps),
+                                                            ptr(hw.detach()), ptr(two["dl"][h]), ptr(dp_h), ptr(st["ws"]), C.byref(gps),
+                                                            ptr(gv["head_w"]), ptr(gv["head_b"]), stream(dev)), "cara_vit_backward")
+                    finally:
+                        self._slot = 0
+                    e = torch.cuda.Event()
+                    e.record(s_)
+                    done.append(e)
+            for e in done:
+                main.wait_event(e)
+            self._flat_grad.add_(flat1)
+            self._bwd_ready = -1
+            self._apply_gradients(optimizer, group, prescaled=True)
+            return two["loss"][0][0] + two["loss"][1][0]
 
     # module-level entries (cara.cp_attn / cara.cp_mlp): the reference's patched forwards
     def _weights(self, model, dev):

@@ -29,6 +29,10 @@ class AdamW(torch.optim.Optimizer):
         b = self.param_groups[0]
         if any(g["betas"] != b["betas"] or g["eps"] != b["eps"] for g in self.param_groups):
             raise CaraError("cara_amd.optim.AdamW: betas and eps are shared by all parameter groups")
+        # optional device float: when it is non-zero at the time the launch runs, the step changes nothing (CaraEngine sets it to
+        # the step's found-inf word under precision = "fp16").  The host-side step counts still advance: a skipped step moves the
+        # bias corrections on by one, which is what torch's fused AdamW does under GradScaler too.
+        self.skip_flag = None
 
     def _init_state(self, p):
         st = self.state[p]
@@ -84,5 +88,6 @@ class AdamW(torch.optim.Optimizer):
                     a.one_minus_beta1, a.beta2, a.one_minus_beta2, a.eps = 1.0 - b1, b2, 1.0 - b2, self.param_groups[0]["eps"]
                     a.bias_correction1 = 1.0 - b1 ** step
                     a.bias_correction2_sqrt = math.sqrt(1.0 - b2 ** step)
+                    a.skip_flag = self.skip_flag.data_ptr() if self.skip_flag is not None else None
                     L.check(L.lib().cara_adamw_step(C.byref(a), L.stream(dev)), "cara_adamw_step")
         return loss

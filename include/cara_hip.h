@@ -299,6 +299,14 @@ int cara_assemble_tokens(const float* emb, const float* cls, const float* pos, f
  * dlogits (optional) = (softmax - onehot)/B ; logits fp32 [B,C]   (vit_cp.py:47)              */
 int cara_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits,
                        int B, int C, void* stream);
+/* The same with the gradient pre-scaled, so that a train step needs no separate scaling launches:
+ *   dlogits = (softmax - onehot)/B * dscale * (loss_scale ? *loss_scale : 1)
+ * dscale (host) = 1/world_size of a data-parallel job (the all-reduce is then a plain SUM); loss_scale (device float,
+ * may be NULL) = the dynamic loss scale of the IEEE-half operand build (cara_amp_update).  found_inf (device float, may
+ * be NULL) is set to 0 here: the backward's final gradient writes raise it (cara_vit_shape::found_inf).  loss[0] is the
+ * UNSCALED mean loss.                                                                                                  */
+int cara_cross_entropy_ex(const float* logits, const int64_t* labels, float* loss, float* dlogits,
+                          int B, int C, float dscale, const float* loss_scale, float* found_inf, void* stream);
 /* bf16 <-> fp32 helpers (weight ingest)                                                        */
 int cara_f32_to_bf16(const float* src, void* dst, size_t n, void* stream);
 int cara_transpose_bf16(const void* src, void* dst, int rows, int cols, void* stream);
@@ -359,6 +367,11 @@ typedef struct {
 size_t cara_factor_grad_scratch_bytes(const cara_geom* g);
 int cara_factor_grad_reduce(const cara_geom* g, const cara_cp* cp, const cara_layer_grads* lg,
                             const cara_cp* grads, void* scratch, void* stream);
+/* The same under a loss scale: every gradient written is multiplied by 1 / *loss_scale (device float; NULL = 1), and
+ * *found_inf (device float; NULL = no check) is set to 1 when a written value is not finite.                          */
+int cara_factor_grad_reduce_ex(const cara_geom* g, const cara_cp* cp, const cara_layer_grads* lg,
+                               const cara_cp* grads, void* scratch, const float* loss_scale, float* found_inf,
+                               void* stream);
 
 /* ---- order-2 QKV tensorisation (image_classification/dim_experiment.py:203-207,293-297; cara_geom::cp_length == 2) ---- */
 /* Dm bf16 [depth][3 dim, dim] with Dm[l][k dim + o][e] = s * sum_r R1[r] A1[3l+k, r] A2[e dim + o, r] (the second B operand,
@@ -393,8 +406,18 @@ typedef struct {
   float lr[CARA_ADAMW_MAX_GROUPS], weight_decay[CARA_ADAMW_MAX_GROUPS];
   float one_minus_beta1, beta2, one_minus_beta2, eps;
   float bias_correction1, bias_correction2_sqrt;
+  /* device float or NULL: when *skip_flag != 0 the launch changes nothing (a step whose gradients overflowed under the
+   * loss scale of the IEEE-half build: cara_vit_shape::found_inf, all-reduced with the gradients)                     */
+  const float* skip_flag;
 } cara_adamw_args;
 int cara_adamw_step(const cara_adamw_args* a, void* stream);
+/* Dynamic loss scale of the IEEE-half operand build, entirely on the device (no host synchronisation anywhere in a step).
+ * state (device float[4]) = { scale, clean steps since the last change, steps skipped so far, unused }.  Once per step,
+ * AFTER the all-reduce and BEFORE the optimiser: *found_inf != 0 (some rank wrote a non-finite gradient) -> scale *= backoff,
+ * counter = 0, skipped += 1; otherwise counter += 1 and, at `interval` clean steps, scale *= growth (capped at max_scale),
+ * counter = 0.  torch.amp.GradScaler's rule.  found_inf is left as it is (cara_adamw_args::skip_flag reads it next).    */
+int cara_amp_update(float* state, const float* found_inf, float growth, float backoff, int interval, float max_scale,
+                    void* stream);
 
 /* ---- exact weight-space dropout mode (the reference's train-mode arithmetic, cara.py:35,57,81,92) ---- */
 /* keep(o,i) of linear `linear_id` = (cara_weight_dropout_hash(o*in + i, seed, linear_id) >> 8) >= p * 2^24
@@ -452,6 +475,12 @@ typedef struct {
    * reads -- the bf16 pre-activation of fc1 (77 MB per block at bs 64), T^T of the adapter products -- and
    * cara_vit_backward on that workspace is an error until a forward with inference = 0 has run.            */
   int inference;
+  /* Loss scaling (the IEEE-half operand build; both NULL otherwise).  cara_vit_backward is linear in dlogits: a caller that
+   * scaled dlogits by S = *loss_scale (device float) gets every gradient it writes multiplied by 1/S here, in the kernels
+   * that write them (no separate unscale launch), and *found_inf (device float, zeroed by the caller or by
+   * cara_cross_entropy_ex) is set to 1 when a written gradient is not finite.                                           */
+  const float* loss_scale;
+  float* found_inf;
 } cara_vit_shape;
 size_t cara_vit_workspace_bytes(const cara_geom* g, const cara_vit_shape* s);
 /* Both calls are stateless (everything lives in the caller's workspace and runs in order on the caller's stream):
@@ -471,6 +500,13 @@ int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, const cara_vi
  * dW[c,d] = sum_b dl[b,c] xn[b,d]; db[c] = sum_b dl[b,c]; dxn bf16 [B,D] = dl W               */
 int cara_head_backward(const float* dlogits, const void* xn_bf16, const float* head_w, float* dhead_w,
                        float* dhead_b, void* dxn_bf16, int B, int classes, int D, void* stream);
+/* final LayerNorm of the B cls rows (row stride ldx floats) + classifier head, in fp32 throughout:
+ * logits fp32 [B,classes] = LN(x) head_w^T + head_b; also writes LN(x) as 16-bit xn [B,D] and mean / rstd [B]
+ * (what cara_head_backward and the final LayerNorm's backward read).  The head is 0.1 % of the work; rounding its two
+ * operands to 16 bits was 2.8e-4 (fp16) / 2.4e-3 (bf16) of logit error for nothing (tools/fp16_sim_study.py).        */
+int cara_head_forward(const float* x, long ldx, const float* gamma, const float* beta, const float* head_w,
+                      const float* head_b, void* xn_16, float* mean, float* rstd, float* logits, int B, int classes,
+                      int D, float eps, void* stream);
 
 /* ---- ABI self-description ------------------------------------------------------------------- */
 /* sizeof() of the structs above as THIS library was compiled, so that a binding can assert that its own mirror of a

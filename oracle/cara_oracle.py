@@ -394,7 +394,8 @@ def vit_cara_forward(images, w: Dict[str, torch.Tensor], cp: Dict[str, torch.Ten
                      depth: int = 12, num_heads: int = 12, patch: int = 16, eps: float = 1e-6,
                      drop_path_keep: Optional[torch.Tensor] = None, factored: bool = False,
                      bf16_sim: bool = False, train: Optional[dict] = None,
-                     keep_masks=None, keep_p: float = 0.1, sim_dtype: Optional[torch.dtype] = None):
+                     keep_masks=None, keep_p: float = 0.1, sim_dtype: Optional[torch.dtype] = None,
+                     sim_only=None, sim_skip=None):
     """Whole adapted forward (timm VisionTransformer.forward with cp_attn/cp_mlp patched in),
     functional form over the state-dict ``w`` and CP tensors ``cp``.
 
@@ -425,7 +426,9 @@ def vit_cara_forward(images, w: Dict[str, torch.Tensor], cp: Dict[str, torch.Ten
     # rounding points would cost with fp16 MFMA operands -- 10 mantissa bits at the bf16 MFMA rate)
     if bf16_sim and sim_dtype is None:
         sim_dtype = torch.bfloat16
-    r = (lambda t: t.to(sim_dtype).to(t.dtype)) if sim_dtype is not None else (lambda t: t)
+    # ``sim_only`` / ``sim_skip``: sets of rounding CATEGORIES ("images", "weights", "xn", "T", "qkv", "P", "ao", "h", "head") to
+    # enable alone / to leave in fp32 -- the one-category-at-a-time error budget of DESIGN.md section 2 (tools/fp16_sim_study.py)
+    r = make_rounder(sim_dtype, sim_only, sim_skip)
     B = images.shape[0]
     dim = w["cls_token"].shape[-1]
     hd = dim // num_heads
@@ -434,14 +437,14 @@ def vit_cara_forward(images, w: Dict[str, torch.Tensor], cp: Dict[str, torch.Ten
     gh = images.shape[2] // patch
     cols = images.reshape(B, images.shape[1], gh, patch, gh, patch).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gh, -1)
     pw = w["patch_embed.proj.weight"].reshape(dim, -1)
-    x = r(cols) @ r(pw).t() + w["patch_embed.proj.bias"]
+    x = r(cols, "images") @ r(pw, "weights").t() + w["patch_embed.proj.bias"]
     x = torch.cat((w["cls_token"].expand(B, -1, -1), x), dim=1) + w["pos_embed"]
     idxs = block_indices(depth)
     fac = build_factored(cp, s, depth=depth, heads=num_heads) if factored else None
     for l in range(depth):
         p = f"blocks.{l}."
         a_idx, a_aidx, m_idx = idxs[l]
-        xn = r(F.layer_norm(x, (dim,), w[p + "norm1.weight"], w[p + "norm1.bias"], eps))
+        xn = r(F.layer_norm(x, (dim,), w[p + "norm1.weight"], w[p + "norm1.bias"], eps), "xn")
         if factored:
             y = _attn_factored(xn, w, p, fac[l], num_heads, scale, r)
         else:
@@ -454,7 +457,7 @@ def vit_cara_forward(images, w: Dict[str, torch.Tensor], cp: Dict[str, torch.Ten
         if drop_path_keep is not None:
             y = y * drop_path_keep[l, 0].reshape(B, 1, 1)
         x = x + y
-        xn = r(F.layer_norm(x, (dim,), w[p + "norm2.weight"], w[p + "norm2.bias"], eps))
+        xn = r(F.layer_norm(x, (dim,), w[p + "norm2.weight"], w[p + "norm2.bias"], eps), "xn")
         if factored:
             y = _mlp_factored(xn, w, p, fac[l], r)
         else:
@@ -466,7 +469,11 @@ def vit_cara_forward(images, w: Dict[str, torch.Tensor], cp: Dict[str, torch.Ten
             y = y * drop_path_keep[l, 1].reshape(B, 1, 1)
         x = x + y
     xc = F.layer_norm(x[:, 0], (dim,), w["norm.weight"], w["norm.bias"], eps)
-    return F.linear(r(xc), r(w["head.weight"]), w["head.bias"])
+    # (the device path runs the final LayerNorm + head in fp32 since round 5 -- cara_head_forward -- so the rounding model
+    # rounds nothing here; the "head" category remains for the error-budget study only: tools/fp16_sim_study.py)
+    if sim_only is not None and "head" in sim_only:
+        return F.linear(r(xc, "head"), r(w["head.weight"], "head"), w["head.bias"])
+    return F.linear(xc, w["head.weight"], w["head.bias"])
 
 
 # ----------------------------------------------------------------------------------------------
@@ -510,14 +517,29 @@ def build_factored(cp: Dict[str, torch.Tensor], s: float, depth: int = 12, heads
     return out
 
 
-def adapter_linear(x, wgt, bias, fac, r=lambda t: t):
+def make_rounder(sim_dtype, only=None, skip=None):
+    """r(t, category): t rounded to ``sim_dtype`` and back -- for every category, for the categories in ``only``, or for all
+    but those in ``skip``; the identity without a ``sim_dtype``."""
+    if sim_dtype is None:
+        return lambda t, cat=None: t
+    only = None if only is None else set(only)
+    skip = set(skip or ())
+
+    def r(t, cat=None):
+        if (only is not None and cat not in only) or cat in skip:
+            return t
+        return t.to(sim_dtype).to(t.dtype)
+    return r
+
+
+def adapter_linear(x, wgt, bias, fac, r=lambda t, cat=None: t, xcat=None):
     """y = x W^T + b + (x U) Vs^T + c_s with the rank-R term carried as a K-extension
-    ([x | T] [W | Vs]^T), T rounded like any other GEMM operand when ``r`` rounds."""
+    ([x | T] [W | Vs]^T), T rounded like any other GEMM operand when ``r`` rounds (``xcat``: the rounding category of x)."""
     U, Vs, cs = fac
     if isinstance(U, str):   # ("dense", Dm, None): two products on the same operand, accumulated in fp32 (the device's B3 form)
-        return r(x) @ r(wgt).t() + r(x) @ r(Vs).t() + bias
-    t = r(r(x) @ r(U))
-    y = r(x) @ r(wgt).t() + t @ r(Vs).t() + bias
+        return r(x, xcat) @ r(wgt, "weights").t() + r(x, xcat) @ r(Vs, "weights").t() + bias
+    t = r(r(x, xcat) @ r(U, "weights"), "T")
+    y = r(x, xcat) @ r(wgt, "weights").t() + t @ r(Vs, "weights").t() + bias
     if cs is not None:
         y = y + cs
     return y
@@ -526,7 +548,7 @@ def adapter_linear(x, wgt, bias, fac, r=lambda t: t):
 def _attn_factored(xn, w, p, fac, num_heads, scale, r):
     B, N, C = xn.shape
     hd = C // num_heads
-    qkv = r(adapter_linear(xn, w[p + "attn.qkv.weight"], w[p + "attn.qkv.bias"], fac["qkv"], r))
+    qkv = r(adapter_linear(xn, w[p + "attn.qkv.weight"], w[p + "attn.qkv.bias"], fac["qkv"], r, "xn"), "qkv")
     qkv = qkv.reshape(B, N, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     # softmax(S) V as the device evaluates it (cara_amd/csrc/attention.hip): P = exp(S - rowmax) is what gets rounded to
@@ -534,14 +556,14 @@ def _attn_factored(xn, w, p, fac, num_heads, scale, r):
     # this is softmax(S) V.
     sc = (q @ k.transpose(-2, -1)) * scale
     pe = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
-    y = r(((r(pe) @ v) / pe.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B, N, C))
-    return adapter_linear(y, w[p + "attn.proj.weight"], w[p + "attn.proj.bias"], fac["proj"], r)
+    y = r(((r(pe, "P") @ v) / pe.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B, N, C), "ao")
+    return adapter_linear(y, w[p + "attn.proj.weight"], w[p + "attn.proj.bias"], fac["proj"], r, "ao")
 
 
 def _mlp_factored(xn, w, p, fac, r):
-    up = adapter_linear(xn, w[p + "mlp.fc1.weight"], w[p + "mlp.fc1.bias"], fac["fc1"], r)
-    h = r(F.gelu(up))   # the device path takes GELU of the fp32 accumulator; its bf16 copy of `up` is for backward only
-    return adapter_linear(h, w[p + "mlp.fc2.weight"], w[p + "mlp.fc2.bias"], fac["fc2"], r)
+    up = adapter_linear(xn, w[p + "mlp.fc1.weight"], w[p + "mlp.fc1.bias"], fac["fc1"], r, "xn")
+    h = r(F.gelu(up), "h")   # the device path takes GELU of the fp32 accumulator; its bf16 copy of `up` is for backward only
+    return adapter_linear(h, w[p + "mlp.fc2.weight"], w[p + "mlp.fc2.bias"], fac["fc2"], r, "h")
 
 
 # ----------------------------------------------------------------------------------------------

@@ -168,7 +168,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.cara_abi_version() == 13 and lib.cara_build_arch() == b"gfx950"
+    assert lib.cara_abi_version() == 14 and lib.cara_build_arch() == b"gfx950"
 
 
 # ---- drop-in on a FOREIGN timm-shaped model (vit_cp.py:13-15,155 builds it with timm.models.create_model) --------

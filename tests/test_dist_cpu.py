@@ -4,6 +4,7 @@ partitions an epoch without overlap.  Per-rank gradients come from the CPU oracl
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -74,7 +75,7 @@ def test_epoch_shard_partitions():
 
 
 # ---- the engine's own flat buffer, p.grad views and optimizer step under gloo ---------------------------------
-def _engine_worker(rank, world, port, out):
+def _engine_worker(rank, world, port, out, prescaled=False):
     """Each rank: an adapted model (CPU construction), the ENGINE's flat gradient buffer and views
     (CaraEngine._grad_buffers), oracle gradients of this rank's shard written into the views, then the tail of
     CaraEngine.train_step -- p.grad binding, ONE all-reduce of the flat buffer, AdamW -- through _apply_gradients."""
@@ -103,20 +104,25 @@ def _engine_worker(rank, world, port, out):
     head = {"weight": sd["head.weight"], "bias": sd["head.bias"]}
     _, _, g = O.train_step_as_written(x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per], wb, cp, head, s=0.1, depth=1)
     views = eng._grad_buffers(m, torch.device("cpu"))
+    # prescaled: what train_step does -- dlogits leaves the cross-entropy divided by the world size (cara_cross_entropy_ex), so
+    # every rank's gradients are 1/world of its shard's and the collective is a plain SUM with no scaling launch behind it
+    f = 1.0 / world if prescaled else 1.0
     for n in eng.cp_fields:
-        views[n].copy_(g["CP_" + n])
-    views["head_w"].copy_(g["head.weight"])
-    views["head_b"].copy_(g["head.bias"])
+        views[n].copy_(g["CP_" + n] * f)
+    views["head_w"].copy_(g["head.weight"] * f)
+    views["head_b"].copy_(g["head.bias"] * f)
+    views["_found_inf"].fill_(float(rank))   # the word behind the gradients travels with them: raised on ONE rank, seen by all
     opt = torch.optim.AdamW(trainable, lr=1e-2, weight_decay=1e-4)
-    eng._apply_gradients(opt)
+    eng._apply_gradients(opt, prescaled=prescaled)
     assert all(p.grad.data_ptr() == views[n].data_ptr() for n, p in zip(list(eng.cp_fields) + ["head_w", "head_b"], trainable))
     torch.save({"params": [p.detach().clone() for p in trainable], "flat": eng._flat_grad.clone(), "sd0": sd}, out + f".{rank}")
     dist.destroy_process_group()
 
 
-def test_engine_flat_views_allreduce_and_step(tmp_path):
+@pytest.mark.parametrize("prescaled", [False, True])
+def test_engine_flat_views_allreduce_and_step(tmp_path, prescaled):
     out = str(tmp_path / "eng")
-    mp.spawn(_engine_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_engine_worker, args=(2, _free_port(), out, prescaled), nprocs=2, join=True)
     r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
     assert torch.equal(r0["flat"], r1["flat"])                                     # one buffer, the same mean on both ranks
     assert all(torch.equal(a, b) for a, b in zip(r0["params"], r1["params"]))      # identical replicas after the step
@@ -127,4 +133,5 @@ def test_engine_flat_views_allreduce_and_step(tmp_path):
     full = O.train_step_as_written(x, y, {k: v for k, v in sd.items() if not k.startswith("CP_")}, {k: sd[k] for k in O.CP_NAMES},
                                    {"weight": sd["head.weight"], "bias": sd["head.bias"]}, s=0.1, depth=1)[2]
     ref = torch.cat([full[n].reshape(-1) for n in list(O.CP_NAMES) + ["head.weight", "head.bias"]])
-    assert torch.allclose(r0["flat"], ref, rtol=1e-4, atol=1e-5 * ref.abs().max().item())
+    assert torch.allclose(r0["flat"][:-1], ref, rtol=1e-4, atol=1e-5 * ref.abs().max().item())
+    assert r0["flat"][-1].item() == (1.0 if prescaled else 0.5)                   # the found-inf word: SUM / mean of {0, 1}

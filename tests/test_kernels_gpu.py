@@ -1196,3 +1196,74 @@ def test_fc2_dx_epilogue_riders(M, panels):
     small = torch.zeros(M, 768, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(ValueError):
         L().gemm(A, rnd(768, K, seed=8), small, epi=L().EPI_MULH, aux=gp[:, :768].contiguous(), epi_riders=(Tt, Gt, h[:, :768].contiguous(), True))
+
+
+# ---- round 5: fp32 head, scaled cross-entropy, loss-scale state, AdamW skip word --------------------------------------------
+@pytest.mark.parametrize("B,classes,D,tokens", [(64, 100, 768, 197), (2, 21843, 768, 197), (3, 10, 1024, 5), (1, 257, 256, 1)])
+def test_head_forward_in_fp32(B, classes, D, tokens):
+    """cara_head_forward: final LayerNorm of the cls rows (row stride tokens * D) + classifier head, fp32 throughout, against fp64
+    torch; the 16-bit xn and the row statistics it leaves for the backward."""
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+    x = rnd(B, tokens, D, seed=1, scale=2.0, dtype=torch.float32) + 0.3
+    gamma, beta = rnd(D, seed=2, dtype=torch.float32) + 1.0, rnd(D, seed=3, scale=0.1, dtype=torch.float32)
+    W, b = rnd(classes, D, seed=4, scale=0.02, dtype=torch.float32), rnd(classes, seed=5, scale=0.1, dtype=torch.float32)
+    xn16 = torch.full((B, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(B, device=DEV), torch.empty(B, device=DEV)
+    logits = torch.full((B, classes), float("nan"), device=DEV)
+    L().check(lib.cara_head_forward(p(x), C.c_long(tokens * D), p(gamma), p(beta), p(W), p(b), p(xn16), p(mean), p(rstd), p(logits),
+                                    B, classes, D, C.c_float(1e-6), st()), "head fwd")
+    xd = x[:, 0].double()
+    mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    xn = (xd - mu) / torch.sqrt(var + 1e-6) * gamma.double() + beta.double()
+    close(logits, xn @ W.double().t() + b.double(), 2e-5, 2e-5, "head logits")
+    close(mean, mu[:, 0], 1e-5, 1e-6, "mean")
+    close(rstd, 1 / torch.sqrt(var[:, 0] + 1e-6), 1e-5, 1e-7, "rstd")
+    close(xn16, xn, 2 ** -8, 1e-6, "xn16")
+
+
+def test_cross_entropy_ex_amp_update_and_adamw_skip_word():
+    """The three pieces of the device-side loss scaling: cara_cross_entropy_ex scales dlogits by dscale * *loss_scale and clears the
+    found-inf word; cara_amp_update follows GradScaler's rule; an AdamW launch whose skip word is set changes nothing."""
+    lib = L().lib()
+    p, st = L().ptr, L().stream
+    Bc, Cn = 16, 100
+    logits = rnd(Bc, Cn, seed=5, scale=3.0, dtype=torch.float32)
+    labels = torch.randint(0, Cn, (Bc,), generator=torch.Generator().manual_seed(6)).to(DEV)
+    loss, dl = torch.empty(1 + Bc, device=DEV), torch.empty(Bc, Cn, device=DEV)
+    amp = torch.tensor([512.0, 0.0, 0.0, 0.0], device=DEV)
+    found = torch.ones(1, device=DEV)
+    L().check(lib.cara_cross_entropy_ex(p(logits), p(labels), p(loss), p(dl), Bc, Cn, C.c_float(0.25), p(amp), p(found), st()), "xent ex")
+    ld = logits.double().requires_grad_(True)
+    rl = torch.nn.functional.cross_entropy(ld, labels)
+    rl.backward()
+    close(loss[0], rl.detach(), 1e-5, 1e-6, "loss stays unscaled")
+    close(dl, ld.grad * 128.0, 1e-4, 1e-5, "dlogits x dscale x loss scale")
+    assert found.item() == 0.0
+    assert lib.cara_cross_entropy_ex(p(logits), p(labels), p(loss), p(dl), Bc, Cn, C.c_float(0.0), None, None, st()) != 0
+    # GradScaler's rule: clean steps count up, the interval doubles the scale (capped), an overflow halves it and counts a skip
+    args = (C.c_float(2.0), C.c_float(0.5), 3, C.c_float(2048.0))
+    for want in ([512, 1, 0], [512, 2, 0], [1024, 0, 0]):
+        L().check(lib.cara_amp_update(p(amp), p(found), *args, st()), "amp")
+        assert amp[:3].tolist() == [float(v) for v in want], amp
+    found.fill_(2.0)   # (the all-reduced word: a SUM over ranks)
+    L().check(lib.cara_amp_update(p(amp), p(found), *args, st()), "amp")
+    assert amp[:3].tolist() == [512.0, 0.0, 1.0]
+    found.zero_()
+    amp[0] = 2048.0
+    for _ in range(3):
+        L().check(lib.cara_amp_update(p(amp), p(found), *args, st()), "amp")
+    assert amp[0].item() == 2048.0      # capped
+    # AdamW: with the word set the launch leaves parameters and moments alone; cleared, it steps
+    from cara_amd.optim import AdamW
+    w = rnd(1500, seed=9, dtype=torch.float32).requires_grad_(True)
+    w.grad = rnd(1500, seed=10, dtype=torch.float32)
+    opt = AdamW([w], lr=1e-2)
+    before = w.detach().clone()
+    opt.skip_flag = found.fill_(1.0)
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(w.detach(), before) and not opt.state[w]["exp_avg"].any()
+    found.zero_()
+    opt.step()
+    assert not torch.equal(w.detach(), before)

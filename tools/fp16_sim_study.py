@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--depth", type=int, default=12)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--rank", type=int, default=16)
+    ap.add_argument("--categories", action="store_true", help="the error budget: one rounding category at a time, and all but one")
     args = ap.parse_args()
     torch.set_num_threads(8)
     w = O.synthetic_backbone(depth=args.depth)
@@ -37,6 +38,15 @@ def main():
     print(f"  factored fp32          {rel(fac, ref):.3e}")
     for name, o in out.items():
         print(f"  rounding model {name:5s}   {rel(o, ref):.3e}   argmax differs on {(o.argmax(1) != ref.argmax(1)).sum().item()} of {args.batch}")
+    if args.categories:
+        cats = ["images", "weights", "xn", "T", "qkv", "P", "ao", "h", "head"]
+        with torch.no_grad():
+            for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+                print(f"  {name}: one category alone | all but that category")
+                for c in cats:
+                    a = O.vit_cara_forward(x, w, cp, s=0.1, depth=args.depth, factored=True, sim_dtype=dt, sim_only={c})
+                    b = O.vit_cara_forward(x, w, cp, s=0.1, depth=args.depth, factored=True, sim_dtype=dt, sim_skip={c})
+                    print(f"    {c:8s} {rel(a, ref):.3e} | {rel(b, ref):.3e}", flush=True)
     print(f"  max |activation| seen by fp16 is bounded by its range 65504: check the fp16 run for inf/nan -> "
           f"{'finite' if torch.isfinite(out['fp16']).all() else 'NOT FINITE'}")
 
