@@ -287,6 +287,10 @@ def main():
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-info-legs", action="store_true", help="skip the informational exact-dropout / rank-64 legs behind the timed region")
+    ap.add_argument("--graph", action="store_true",
+                    help="N = 1: capture the whole step (forward, cross-entropy, backward, AdamW) once per synthetic batch into a hipGraph and "
+                         "replay it in the timed loop (cara_vit_forward / _backward only enqueue: DESIGN.md section 1); eager is the default")
+    ap.add_argument("--no-precision-matched", action="store_true", help="skip the second timed region (precision = 'fp16': the 1e-3 build)")
     ap.add_argument("--all-sites", action="store_true", help="diagnostic: roofline_top lists every bracketed MFMA site, not the top three")
     ap.add_argument("--weight-dropout", default="off", choices=["off", "exact"],
                     help="exact = the reference's train-mode Dropout(0.1) on the materialised adapters (merged weights + "
@@ -337,10 +341,13 @@ def main():
     eng.seed_rank_streams(2024, rank)       # per-rank DropPath / weight-dropout masks
     # vit_cp.py:185's AdamW as one HIP launch (cara_amd/optim.py; CARA_BENCH_TORCH_ADAMW=1: torch's fused one, for A/B runs)
     from cara_amd.optim import AdamW
+    use_graph = args.graph and world == 1 and args.weight_dropout == "off"
     if os.environ.get("CARA_BENCH_TORCH_ADAMW") == "1":
         opt = torch.optim.AdamW(trainable, lr=1e-3, weight_decay=1e-4, fused=True)
+        use_graph = False
     else:
-        opt = AdamW(trainable, lr=1e-3, weight_decay=1e-4)
+        # (capturable: step count and learning rates in device memory, so that a captured launch replays correctly)
+        opt = AdamW(trainable, lr=1e-3, weight_decay=1e-4, capturable=use_graph)
     gx = torch.Generator().manual_seed(1000 + rank)   # each rank its own shard of the global batch
     # four different synthetic batches, resident in HBM before the timed region, fed in turn (one fixed batch would be
     # memorised within a few steps: loss 0.13 after 25 steps)
@@ -357,10 +364,33 @@ def main():
         dist.all_reduce(one)
         ranks_seen = int(one.item())
 
+    graphs = []
+
     def step():
         i = fed[0] % NB
         fed[0] += 1
+        if use_graph:
+            opt.advance()
+            if graphs:                      # (captured below, after the warm-up: one graph per resident batch)
+                graphs[i][0].replay()
+                return graphs[i][1]
         return eng.train_step(xs[i], ys[i], opt)
+
+    def capture_graphs():
+        torch.cuda.synchronize()
+        for i in range(NB):
+            gr = torch.cuda.CUDAGraph()
+            gen = eng._device_generator(dev)
+            if gen is not None:             # this rank's DropPath stream: its state advances under replay like the default generator's
+                gr.register_generator_state(gen)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(gr, stream=side):
+                    lg = eng.train_step(xs[i], ys[i], opt)
+            torch.cuda.current_stream().wait_stream(side)
+            graphs.append((gr, lg))
+        torch.cuda.synchronize()
 
     M = args.batch * tokens
     work = site_work(M, dim, args.rank, args.batch, heads, tokens)
@@ -381,10 +411,15 @@ def main():
             dominant = max(mf, key=lambda n: mf[n]["avg_ms"] * mf[n]["brackets"])
     elif args.warmup > 0:
         step()
+    if use_graph:
+        lib.cara_profile_sites(C.c_ulonglong(0), 1)      # (no event brackets inside a captured step)
+        capture_graphs()
+        for _ in range(NB):
+            step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    _lib.check(lib.cara_profile_sites(C.c_ulonglong(1 << SITES.index(dominant)) if factored else C.c_ulonglong(0), PROFILE_EVERY),
+    _lib.check(lib.cara_profile_sites(C.c_ulonglong(1 << SITES.index(dominant)) if (factored and not use_graph) else C.c_ulonglong(0), PROFILE_EVERY),
                "cara_profile_sites")
     # one event per step boundary (a record between two kernels of a stream idles the chip ~3 us: 0.03 % of a step):
     # ms_per_step_median next to the mean that `value` is computed from
@@ -401,7 +436,9 @@ def main():
         dist.barrier()
     wall = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1)
-    dom = read_sites(lib, [dominant]).get(dominant) if factored else None
+    dom = read_sites(lib, [dominant]).get(dominant) if (factored and not use_graph) else None
+    graphs_live = list(graphs)
+    graphs.clear()           # everything behind the timed region runs eager (site brackets, the fp16 region, the informational legs)
     t = torch.tensor([wall], device="cpu" if (world > 1 and rehearsal) else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -417,6 +454,8 @@ def main():
                 step()
             torch.cuda.synchronize()
             post = read_sites(lib, SITES)
+            if use_graph:            # the dominant site's launch time: from these bracketed eager steps (a replayed graph carries no brackets)
+                dom = post.get(dominant)
     lib.cara_profile_sites(C.c_ulonglong(0), 1)
     if rank == 0:
         model.eval()
@@ -432,6 +471,46 @@ def main():
             torch.cuda.synchronize()
         fwd_ms = f0.elapsed_time(f1) / 10
         model.train()
+
+    # ---- the precision-matched object: the SAME step with precision = "fp16" (libcara_hip_f16.so: the same kernels with IEEE-half
+    # MFMA operands, the build whose logits sit inside north_star's 1e-3 of the fp32 reference on every configuration the parity
+    # tests run), timed under the same protocol as the headline region -- barrier + synchronize on both sides, max over ranks --
+    # with the dominant site bracketed in THAT library.  Every rank runs it (it contains the all-reduce).
+    pm = None
+    if factored and args.precision == "bf16" and not args.no_precision_matched:
+        try:
+            lib16 = _lib.lib("fp16")
+            eng.precision = "fp16"
+            for _ in range(3):
+                step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            _lib.check(lib16.cara_profile_sites(C.c_ulonglong(1 << SITES.index(dominant)), PROFILE_EVERY), "cara_profile_sites")
+            pevs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+            pt0 = time.perf_counter()
+            pevs[0].record()
+            for i in range(args.steps):
+                ploss = step()
+                pevs[i + 1].record()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            pwall = time.perf_counter() - pt0
+            pstep_ms = [pevs[i].elapsed_time(pevs[i + 1]) for i in range(args.steps)]
+            pdom = read_sites(lib16, [dominant]).get(dominant)
+            lib16.cara_profile_sites(C.c_ulonglong(0), 1)
+            tt = torch.tensor([pwall], device="cpu" if (world > 1 and rehearsal) else dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            pm = {"wall": tt.item(), "step_ms": pstep_ms, "dom": pdom, "loss": float(ploss), "skipped": eng.skipped_steps,
+                  "loss_scale": eng.loss_scale}
+        except Exception as exc:   # noqa: BLE001 -- behind the headline measurement: recorded, never fatal
+            pm = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        finally:
+            eng.precision = args.precision
+            eng._ws.clear()
+            torch.cuda.empty_cache()
 
     # informational legs (rank 0, N = 1, the headline configuration only; never the headline number): the reference's
     # train-mode arithmetic (exact weight-space dropout) and BASELINE.json configs[3] (rank 64), 2 warm-ups + 5 steps each
@@ -482,18 +561,6 @@ def main():
             o2 = AdamW(tr2, lr=1e-3, weight_decay=1e-4)
             info["order2_qkv_ms_per_step"] = round(timed_steps(lambda: e2.train_step(x, y, o2)), 3)
 
-        def leg_fp16():
-            # precision = "fp16": the same kernels with IEEE-half MFMA operands (same MFMA rate), forward and backward -- the mode
-            # whose logits sit inside north_star's 1e-3 of the fp32 reference (tests/test_model_gpu.py::test_fp16_precision_*)
-            try:
-                eng.precision = "fp16"
-                info["fp16_ms_per_step"] = round(timed_steps(step), 3)
-                info["fp16_images_per_sec"] = round(args.batch / info["fp16_ms_per_step"] * 1e3, 1)
-            finally:
-                eng.precision = args.precision
-                eng._ws.clear()
-
-        leg("fp16", leg_fp16)
         leg("exact_dropout", leg_exact)
         leg("rank64", leg_rank64)
         leg("order2_qkv", leg_order2)
@@ -554,6 +621,7 @@ def main():
                                        "EXACT weight-space dropout 0.1 (merged weights, dense dW; informational)")),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "batches": f"{NB} seeded synthetic batches per rank, resident in HBM before the timed region, fed in turn",
+                       "launch": ("hipGraph replay: the whole step captured once per resident batch" if use_graph else "eager"),
                        "ranks_in_allreduce": ranks_seen, "backend": ("gloo-rehearsal" if rehearsal else "rccl") if world > 1 else "none",
                        "step_algorithmic_gflop": round(gf["step"] * args.batch, 1),
                        "step_tflops_per_gpu": round(gf["step"] * args.batch / ms_step, 1),
@@ -578,6 +646,29 @@ def main():
             "roofline_top": top,
             "roofline_hbm": hbm,
         }
+        if pm is not None:
+            if "error" in pm:
+                out["precision_matched"] = {"dtype": "fp16", "error": pm["error"]}
+            else:
+                pms = pm["wall"] * 1e3 / args.steps
+                pfl = work[dominant][1]
+                pach = pfl / (pm["dom"]["avg_ms"] * 1e-3) / 1e12 if pm["dom"] else 0.0
+                out["precision_matched"] = {
+                    "what": ("the same step with precision = 'fp16': libcara_hip_f16.so, the same kernels with IEEE-half MFMA operands at the "
+                             "same MFMA rate, fp32 accumulation / residual stream, device-side dynamic loss scale -- the build whose logits are "
+                             "within north_star's 1e-3 (rel-L2) of the fp32 reference with every class index equal on every configuration of "
+                             "tests/test_model_gpu.py (PRECISIONS); same timing protocol as `value`"),
+                    "dtype": "fp16", "value": round(world * args.batch * args.steps / pm["wall"], 2), "unit": "images/sec",
+                    "ms_per_step": round(pms, 3), "ms_per_step_median": round(statistics.median(pm["step_ms"]), 3),
+                    "vs_bf16_step": round(pms / ms_step, 4), "loss": pm["loss"],
+                    "loss_scale": pm["loss_scale"], "steps_skipped_for_overflow": pm["skipped"],
+                    "step_frac_of_mfma_peak": round(gf["step"] * args.batch / pms / PEAK_BF16_TFLOPS, 4),
+                    "roofline": {"bound": "mfma", "achieved": round(pach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(pach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                                 "kernel": f"{SITE_KERNEL[dominant]}; site {dominant} (the bf16 region's dominant site) in the fp16 library; M={M}",
+                                 "algorithmic_gflop_per_launch": round(pfl / 1e9, 2),
+                                 "avg_launch_ms": round(pm["dom"]["avg_ms"], 4) if pm["dom"] else None,
+                                 "launches_timed": pm["dom"]["brackets"] if pm["dom"] else 0}}
         if info.get("exact_dropout_ms_per_step"):
             # the reference's own recipe keeps the model in eval mode after the first evaluation (vit_cp.py:60,75): weight-space
             # dropout and DropPath are live for 165 of its 1 500 steps, so a run of that recipe costs this per step on average
@@ -588,8 +679,7 @@ def main():
         if info:
             info["note"] = ("informational, 5 steps each after 2 warm-ups, same box and process: exact = the reference's train-mode "
                             "Dropout(0.1) on the materialised dW (cara.py:35,57,81,92); rank64 = BASELINE.json configs[3] (82.61 GF/image); order2_qkv = cp_length 2 of dim_experiment.py (dense dim x dim QKV deltas) at the headline rank and batch; "
-                            "blended = (165 exact + 1335 factored) / 1500, the reference's stuck-in-eval recipe (SURVEY 3.3); fp16 = precision 'fp16' "
-                            "(libcara_hip_f16.so: the same kernels with IEEE-half MFMA operands, logits within 1e-3 of the fp32 reference)")
+                            "blended = (165 exact + 1335 factored) / 1500, the reference's stuck-in-eval recipe (SURVEY 3.3)")
             out["informational"] = info
         if world == 1 and not args.no_cpu_baseline and not large:
             out["cpu_baseline"] = cpu_baseline(scale)

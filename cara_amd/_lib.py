@@ -127,7 +127,8 @@ class AdamWArgs(C.Structure):
     _fields_ = [("t", AdamWTensor * ADAMW_MAX_TENSORS), ("ntensors", C.c_int), ("step", C.c_int),
                 ("lr", C.c_float * ADAMW_MAX_GROUPS), ("weight_decay", C.c_float * ADAMW_MAX_GROUPS),
                 ("one_minus_beta1", C.c_float), ("beta2", C.c_float), ("one_minus_beta2", C.c_float), ("eps", C.c_float),
-                ("bias_correction1", C.c_float), ("bias_correction2_sqrt", C.c_float), ("skip_flag", C.c_void_p)]
+                ("bias_correction1", C.c_float), ("bias_correction2_sqrt", C.c_float), ("skip_flag", C.c_void_p),
+                ("dyn", C.c_void_p)]
 
 
 # CARA_STRUCT_* of include/cara_hip.h -> the mirror above (lib() asserts that every size agrees with the library's)
@@ -139,11 +140,37 @@ class CaraError(RuntimeError):
 
 
 _libs = {}
+_active = ["bf16"]   # the operand type the per-op wrappers below bind to (see `using`)
 
 
-def lib(operands: str = "bf16") -> C.CDLL:
+class using:
+    """``with using("fp16"):`` -- the per-op wrappers of this module (gemm, skinny_xu, tskinny_xtg ...) and ``lib()`` without an
+    argument bind to that operand build inside the block (the module-level Attention.forward / Mlp.forward path of an engine whose
+    precision is "fp16").  A process-wide switch: not for concurrent use from several threads."""
+
+    def __init__(self, operands: str):
+        self.operands = operands
+
+    def __enter__(self):
+        self.prev = _active[0]
+        _active[0] = self.operands
+        return self
+
+    def __exit__(self, *exc):
+        _active[0] = self.prev
+        return False
+
+
+def act_dtype(operands=None):
+    """torch dtype of the 16-bit activations / operands of a build"""
+    return torch.float16 if (operands or _active[0]) == "fp16" else torch.bfloat16
+
+
+def lib(operands: str = None) -> C.CDLL:
     """Load libcara_hip.so (operands = "bf16", the product) or libcara_hip_f16.so ("fp16": the same sources and ABI with IEEE-half
-    MFMA operands) or raise.  Never falls back to another implementation."""
+    MFMA operands) or raise.  Never falls back to another implementation.  No argument: the build `using` selected (default bf16)."""
+    if operands is None:
+        operands = _active[0]
     got = _libs.get(operands)
     if got is not None:
         return got

@@ -663,6 +663,45 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_p2_kernel(const bf1
   }
   stage_q(bh);
   int cur = 0;
+  // The epilogue of a head -- normalise, convert, swap halves, store -- is DEFERRED into the S^T loop of the next head, a quarter
+  // behind each of its first MFMA groups: that loop is bound by the matrix pipe (two waves x 28 MFMAs per SIMD) with the vector
+  // unit idle, while at the end of a head the same 60 instructions and five stores ran with nothing beside them (0.6 us per head,
+  // profiles/r05_c_attention_ab_and_stamps.txt).  Pending state: the output accumulators, 1 / sum, the log-sum-exp, two pointers.
+  f32x16 po[2];
+  float pinv = 0.f, plse = 0.f;
+  bf16* prow = out;
+  float* plsep = lse;
+  bool pvalid = false;   // (lane-wise: false before the first head and in the lanes of padded queries)
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) po[dt][r] = 0.f;
+  unsigned pw[4][2];
+  auto epi_convert = [&](const int dt) {   // run g = r >> 2 of this lane: d = 32 dt + 8 g + 4 h .. + 3, as two packed dwords
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      pw[g][0] = cvt_pk_dword(po[dt][4 * g] * pinv, po[dt][4 * g + 1] * pinv);
+      pw[g][1] = cvt_pk_dword(po[dt][4 * g + 2] * pinv, po[dt][4 * g + 3] * pinv);
+    }
+  };
+  auto epi_store = [&](const int dt) {     // lane halves swap runs: two runs of EIGHT consecutive d per lane, 16-byte stores
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(pw[g][k2], pw[g + 2][k2], false, false);
+        pw[g][k2] = sw[0];
+        pw[g + 2][k2] = sw[1];
+      }
+    if (pvalid) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const uint4 v = {pw[g][0], pw[g][1], pw[g + 2][0], pw[g + 2][1]};
+        *reinterpret_cast<uint4*>(prow + dt * 32 + 8 * (g + 2 * h)) = v;
+      }
+      if (dt == 1 && h == 0) *plsep = plse;
+    }
+  };
 #ifdef CARA_ATTN_STAMPS
   int slot = -1;
 #endif
@@ -687,6 +726,9 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_p2_kernel(const bf1
     // compiler then sinks the exponentials of a tile out from between the MFMAs into the block that uses them (seen in the
     // first build of this kernel: every second tile's MFMAs came back to back).  The kernel drains its queue before it ends.
     auto next_piece = [&](const int t) { glds16_hidden(nbase, kvoff[t], nimg + __builtin_amdgcn_readfirstlane(kvdst[t])); };
+    // piece t (0..3) of this wave's Q rows of the next head.  The wave's Q image is free as soon as its fragments are in registers:
+    // every caller sits behind an MFMA that consumed them (the compiler's wait for qf has passed by then)
+    auto next_q = [&](const int t) { glds16_hidden(nbase, qoff[t], lds_of(myQ) + t * 1024); };
 
     bf16x8 qf[4];
 #pragma unroll
@@ -711,7 +753,8 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_p2_kernel(const bf1
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) ka[(kt + 2) % 3][ks] = *reinterpret_cast<const bf16x8*>(kb_ + ro.o[ks]);
       }
-      if ((kt & 1) == 0) next_piece(kt >> 1);   // pieces 0-3 behind the even tiles here, 4-7 in the P V loop
+      if ((kt & 1) == 0) next_piece(kt >> 1);   // K / V pieces 0-3 behind the even tiles here, 4-7 in the P V loop
+      else if (kt < 6) next_q(kt >> 1);          // the wave's Q rows of the next head: pieces 0-2 here, 3 in the P V loop
       SB();
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -723,6 +766,12 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_p2_kernel(const bf1
           SB();
         }
       }
+      // the previous head's epilogue, one quarter per tile
+      if (kt == 0) epi_convert(0);
+      if (kt == 1) epi_store(0);
+      if (kt == 2) epi_convert(1);
+      if (kt == 3) epi_store(1);
+      if (kt < 4) SB();
     }
 #pragma unroll
     for (int r = 0; r < 16; r += 4) {
@@ -730,10 +779,6 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_p2_kernel(const bf1
       m1 = fmaxf(fmaxf(m1, s[NKT - 1][r + 2]), s[NKT - 1][r + 3]);
     }
     ATTN_STAMP(2);
-    // the Q fragments are in registers: the wave's Q image may take the next head's rows
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    SB();
-    stage_q(has_nxt ? nxt : bh);
     float mx = fmaxf(m0, m1);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mxc = mx * c2;
@@ -763,6 +808,7 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_p2_kernel(const bf1
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       if ((kt & 1) == 0) next_piece(4 + (kt >> 1));
+      else if (kt == 1) next_q(3);
       SB();
       // O^T = V^T P^T (d on the rows); the first tile's products start the chains from a literal zero
       bf16x8 vn[2][2];
@@ -790,6 +836,7 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_p2_kernel(const bf1
         }
       }
     }
+    if (NKT < 6) next_q(2);                                      // (NKT = 5 has no tile 5 in its S^T loop)
 #pragma unroll
     for (int t = 4 + (NKT + 1) / 2; t < 8; ++t) next_piece(t);   // (the pieces of tiles this NKT does not have)
     if (NKT < 7) {
@@ -799,42 +846,21 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_p2_kernel(const bf1
     float sum = (sum0 + sum1) + (sum2 + sum3);
     sum += __shfl_xor(sum, 32, 64);
     ATTN_STAMP(4);
-    const float inv = 1.0f / sum;
-    // O^T layout and the store: as in attn_fwd_persist_kernel (lane halves swap runs of four d, 16-byte stores)
-    bf16* ob = out + (size_t)b * N * (H * HD) + head * HD;
-    if (q0 < N) {
-      bf16* orow = ob + (size_t)(q0 + ql < N ? q0 + ql : N - 1) * (H * HD);
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        unsigned w[4][2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const bf16x2 lo = {(bf16)(o[dt][4 * g] * inv), (bf16)(o[dt][4 * g + 1] * inv)};
-          const bf16x2 hi = {(bf16)(o[dt][4 * g + 2] * inv), (bf16)(o[dt][4 * g + 3] * inv)};
-          w[g][0] = __builtin_bit_cast(unsigned, lo);
-          w[g][1] = __builtin_bit_cast(unsigned, hi);
-        }
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(w[g][k], w[g + 2][k], false, false);
-            w[g][k] = sw[0];
-            w[g + 2][k] = sw[1];
-          }
-        if (q0 + ql < N) {
-#pragma unroll
-          for (int g = 0; g < 2; ++g) {
-            const uint4 v = {w[g][0], w[g][1], w[g + 2][0], w[g + 2][1]};
-            *reinterpret_cast<uint4*>(orow + dt * 32 + 8 * (g + 2 * h)) = v;
-          }
-        }
-      }
-      if (h == 0 && q0 + ql < N) lse[(size_t)bh * N + q0 + ql] = mx * scale + __logf(sum);
-    }
+    // hand this head's epilogue to the next head's S^T loop (or to the tail behind the loop)
+    po[0] = o[0];
+    po[1] = o[1];
+    pinv = 1.0f / sum;
+    plse = mx * scale + __logf(sum);
+    pvalid = q0 + ql < N;
+    prow = out + (size_t)b * N * (H * HD) + head * HD + (size_t)(pvalid ? q0 + ql : N - 1) * (H * HD);
+    plsep = lse + (size_t)bh * N + (pvalid ? q0 + ql : 0);
     ATTN_STAMP(5);
     cur ^= 1;
   }
+  epi_convert(0);
+  epi_store(0);
+  epi_convert(1);
+  epi_store(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the pieces issued behind the last head: no LDS-DMA may outlive the workgroup)
 }
 
@@ -1456,373 +1482,13 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
 }
 
 // ------------------------------------------------------------------------------------------
-// Round 5: the fused backward, SPECIALISED on the tile count and software-pipelined inside each wave.  Protocol, LDS images,
-// operand layouts, rounding points and barriers are those of attn_bwd_fused_kernel above; what changes is the order of issue:
-//   * NT is a template parameter (no `qt >= nt` exits, the accumulator chains start from literal zeros / the seeds);
-//   * phase B (dQ): the S^T / dP^T MFMAs of key tile kt + 1 are issued BETWEEN the exponentials, products and conversions of
-//     tile kt: a wave's matrix instructions are spaced by vector work of another tile instead of coming 8 + 4 back to back
-//     around a serial block of ~60 vector instructions.  Phase A keeps the per-tile order: its cross-tile pipeline needs two more
-//     accumulator tiles next to dK^T / dV^T / K / V rows and does not fit 256 registers at two waves per SIMD (built: 404 bytes
-//     of scratch); this wave's K / V rows of the next head are requested behind the sweep for the same reason; -delta rides in the dP accumulator seed (dS = p dP', one multiply);
-//   * the next head's DMA pieces are issued unconditionally (behind the last head they re-read this head into images nobody
-//     reads any more), so that a head's body is one basic block: see attn_fwd_p2_kernel.
-// ------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(448, 1) void attn_bwd_p2_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
-                                                             const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                             bf16* __restrict__ dqkv, int N, int H, int BH, float scale) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NPAD = 224, IMG = NPAD * 128;
-  char* Qs = smem;
-  char* dOs = smem + IMG;
-  char* Os = smem + 2 * IMG;
-  char* Ks = smem + 3 * IMG;
-  char* Vs = smem + 4 * IMG;
-  float* lse_s = reinterpret_cast<float*>(smem + 5 * IMG);
-  float* del_s = lse_s + 256;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ld = 3 * H * HD, ldo = H * HD;
-  const int l31 = lane & 31, h = lane >> 5;
-  const float c2 = scale * 1.4426950408889634f;
-  const float nrscale = -1.f / scale;
-  const RowOfs ro = row_ofs(lane);
-  const TrOfs to = tr_ofs(lane);
-  const int last = N - (NT - 1) * 32;           // valid rows of the last tile
-  const int t0 = wave * 32;                     // first key (phase A) / query (phase B) of this wave
-  const int trow = t0 + l31 < N ? t0 + l31 : N - 1;
-  const bool tvalid = t0 + l31 < N;
-
-  unsigned off_qkv[4], off_o[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int row = (wave + t * 7) * 8 + (lane >> 3);
-    const int rr = row < N ? row : N - 1;
-    const int c = (lane & 7) ^ swzk(row);
-    off_qkv[t] = (unsigned)rr * (unsigned)(ld * 2) + (unsigned)(c * 16);
-    off_o[t] = (unsigned)rr * (unsigned)(ldo * 2) + (unsigned)(c * 16);
-  }
-  auto lds_of = [](const char* p) { return __builtin_amdgcn_readfirstlane((unsigned)(size_t)p); };
-  auto dma_image = [&](const char* base, const unsigned (&off)[4], char* img) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) glds16_hidden(base, off[t], lds_of(img) + (unsigned)((wave + t * 7) * 1024));
-  };
-  auto qkv_base = [&](int bh) { const int b = bh / H, hd = bh - b * H; return reinterpret_cast<const char*>(qkv + (size_t)b * N * ld + hd * HD); };
-  auto o_base = [&](const bf16* p_, int bh) { const int b = bh / H, hd = bh - b * H; return reinterpret_cast<const char*>(p_ + (size_t)b * N * ldo + hd * HD); };
-
-  int bh = blockIdx.x;
-  if (bh >= BH) return;
-  bf16x8 kf[4], vf[4];
-  unsigned off_lse[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int i = t * 64 + lane;
-    off_lse[t] = (unsigned)((i < N ? i : N - 1) * 4);
-  }
-  auto dma_lse = [&](int bh_) {   // (every wave computes the base; wave 0 alone issues: the branch is wave-uniform and holds DMA only)
-    if (wave == 0) {
-      const char* base = reinterpret_cast<const char*>(lse + (size_t)bh_ * N);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (t * 64 < NPAD) glds4_hidden(base, off_lse[t], lds_of(reinterpret_cast<const char*>(lse_s)) + (unsigned)(t * 256));
-    }
-  };
-  {
-    const char* qb = qkv_base(bh);
-    dma_image(qb, off_qkv, Qs);
-    dma_image(o_base(dout, bh), off_o, dOs);
-    dma_image(o_base(out, bh), off_o, Os);
-    const bf16* kb = reinterpret_cast<const bf16*>(qb) + H * HD;
-    const bf16* vb = kb + H * HD;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      kf[ks] = *reinterpret_cast<const bf16x8*>(kb + (size_t)trow * ld + ks * 16 + h * 8);
-      vf[ks] = *reinterpret_cast<const bf16x8*>(vb + (size_t)trow * ld + ks * 16 + h * 8);
-    }
-    dma_lse(bh);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  f32x16 zero;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-#ifdef CARA_ATTN_STAMPS
-  int slot = -1;
-  if (g_attn_stamp_buf && tid == 0) {
-    g_attn_stamp_buf[((size_t)blockIdx.x * 4 + 3) * 8 + 0] = __builtin_amdgcn_s_memtime();
-    g_attn_stamp_buf[((size_t)blockIdx.x * 4 + 3) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
-  }
-#endif
-  for (; bh < BH; bh += gridDim.x) {
-    const int nxt = bh + gridDim.x;
-    const int b = bh / H, head = bh - b * H;
-#ifdef CARA_ATTN_STAMPS
-    ++slot;
-#endif
-    ATTN_STAMP(0);
-    // T0: every wave is through with phase B of the previous head and has seen its own pieces of this head's Q, dO, O images land
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    {
-      const int row = tid >> 1, half = tid & 1;
-      float dl = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int off = swz128(row, half * 4 + c);
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Os + off);
-        const bf16x8 g = *reinterpret_cast<const bf16x8*>(dOs + off);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dl += (float)a[j] * (float)g[j];
-      }
-      dl += __shfl_xor(dl, 1, 64);
-      if (half == 0) del_s[row] = -dl;
-      if (tid < NPAD) lse_s[tid] = tid < N ? lse_s[tid] * nrscale : -1e30f;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // T1
-    SB();
-    ATTN_STAMP(1);
-
-    // ================= phase A: dK, dV of keys t0 .. t0 + 31 =================
-    f32x16 dkt[2], dvt[2];
-    f32x16 sacc, pacc;
-    bf16x8 qa[4], da[4];
-    auto load_seeds = [&](const int qt, f32x16& s_, f32x16& p_) {   // register 4 g4 + k of lane half h is query row 32 qt + 8 g4 + 4 h + k
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 32 + 8 * g4 + 4 * h);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qt * 32 + 8 * g4 + 4 * h);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { s_[4 * g4 + k] = l4[k]; p_[4 * g4 + k] = d4[k]; }
-      }
-    };
-    auto load_rows = [&](const char* img_a, const char* img_b, const int t, bf16x8 (&a_)[4], bf16x8 (&b_)[4]) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        a_[ks] = *reinterpret_cast<const bf16x8*>(img_a + t * 4096 + ro.o[ks]);
-        b_[ks] = *reinterpret_cast<const bf16x8*>(img_b + t * 4096 + ro.o[ks]);
-      }
-    };
-#pragma unroll
-    for (int qt = 0; qt < NT; ++qt) {
-      const char* qblk = Qs + qt * 4096;
-      const char* dblk = dOs + qt * 4096;
-      load_seeds(qt, sacc, pacc);
-      load_rows(Qs, dOs, qt, qa, da);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[ks], sacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vf[ks], pacc, 0, 0, 0);
-      }
-      if (qt == 0) {
-        // K, V of THIS head into their images (needed by phase B): issued behind the first use of kf / vf
-        SB();
-        const char* qb = qkv_base(bh);
-        dma_image(qb + H * HD * 2, off_qkv, Ks);
-        dma_image(qb + 2 * H * HD * 2, off_qkv, Vs);
-        SB();
-      }
-      bf16x8 pb[2], dsb[2];
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float e = __builtin_amdgcn_exp2f(sacc[8 * st + j] * c2);
-          pb[st][j] = (bf16)e;
-          dsb[st][j] = (bf16)(e * pacc[8 * st + j]);
-        }
-      }
-#pragma unroll
-      for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 doa = tr_frag_at(dblk, to.lo[st][dt], to.hi[st][dt]);
-          const bf16x8 qta = tr_frag_at(qblk, to.lo[st][dt], to.hi[st][dt]);
-          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa, pb[st], (qt == 0 && st == 0) ? zero : dvt[dt], 0, 0, 0);
-          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsb[st], (qt == 0 && st == 0) ? zero : dkt[dt], 0, 0, 0);
-        }
-    }
-    ATTN_STAMP(2);
-    // T2: this wave's pieces of K, V have landed (they are old by now); then every wave's
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    SB();
-    ATTN_STAMP(3);
-    {
-      char* stg = Os + wave * 4096;
-      const int srow = lane >> 3, schunk = lane & 7;
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {   // 0: dK (scaled), 1: dV
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x16& acc = m == 0 ? dkt[dt] : dvt[dt];
-            const float f = m == 0 ? scale : 1.f;
-            const bf16x4 a = {(bf16)(acc[4 * g] * f), (bf16)(acc[4 * g + 1] * f), (bf16)(acc[4 * g + 2] * f), (bf16)(acc[4 * g + 3] * f)};
-            *reinterpret_cast<bf16x4*>(stg + swz128(l31, dt * 4 + g) + h * 8) = a;     // d = dt 32 + 8 g + 4 h ..+3
-          }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SB();
-        bf16* dst = dqkv + (size_t)(b * N + t0) * ld + (1 + m) * H * HD + head * HD + schunk * 8;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint4 v = *reinterpret_cast<const uint4*>(stg + swz128(srow + 8 * i, schunk));
-          if (t0 + srow + 8 * i < N) *reinterpret_cast<uint4*>(dst + (size_t)(srow + 8 * i) * ld) = v;
-        }
-        asm volatile("" ::: "memory");
-      }
-    }
-
-    // ================= phase B: dQ of queries t0 .. t0 + 31 =================
-    bf16x8 qf[4], dof[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      qf[ks] = *reinterpret_cast<const bf16x8*>(Qs + wave * 4096 + ro.o[ks]);
-      dof[ks] = *reinterpret_cast<const bf16x8*>(dOs + wave * 4096 + ro.o[ks]);
-    }
-    const float lq = lse_s[t0 + l31] * c2, dlq = del_s[t0 + l31];   // (-lse in log2 units | -delta; a padded query: -inf-like)
-    ATTN_STAMP(4);
-    // T3: every wave holds its Q / dO rows and row constants: the Q, dO, O images may take the next head
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    SB();
-    ATTN_STAMP(5);
-    const bool has_nxt = nxt < BH;
-    const char* nqb = qkv_base(has_nxt ? nxt : bh);
-    const char* ndob = o_base(dout, has_nxt ? nxt : bh);
-    const char* nob = o_base(out, has_nxt ? nxt : bh);
-    const int nbh = has_nxt ? nxt : bh;
-    auto next_slice = [&](const int j) {   // j = 0 .. 5 (compile-time in the unrolled callers); unconditional, see the header
-      const int t = j & 3;
-      if (j < 4) {
-        glds16_hidden(nqb, off_qkv[t], lds_of(Qs) + (unsigned)((wave + t * 7) * 1024));
-        glds16_hidden(ndob, off_o[t], lds_of(dOs) + (unsigned)((wave + t * 7) * 1024));
-        glds16_hidden(nob, off_o[t], lds_of(Os) + (unsigned)((wave + t * 7) * 1024));
-      } else if (j == 4) {
-        dma_lse(nbh);
-      }
-    };
-    f32x16 dq[2];
-    f32x16 sT, dpT;
-    bf16x8 ka[4], va[4];
-    load_rows(Ks, Vs, 0, ka, va);
-    {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[ks], ks == 0 ? zero : sT, 0, 0, 0);
-        dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ks], dof[ks], ks == 0 ? zero : dpT, 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-      const char* kblk = Ks + kt * 4096;
-      const char* knxt = Ks + (kt + 1) * 4096;
-      const char* vnxt = Vs + (kt + 1) * 4096;
-      f32x16 sn, pn;
-      bf16x8 kan[4], van[4];   // (requested one k step ahead of their MFMA: four fragments live, not eight)
-      if (kt + 1 < NT) {
-        kan[0] = *reinterpret_cast<const bf16x8*>(knxt + ro.o[0]);
-        van[0] = *reinterpret_cast<const bf16x8*>(vnxt + ro.o[0]);
-      }
-      bf16x8 kfr0[2];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) kfr0[dt] = tr_frag_at(kblk, to.lo[0][dt], to.hi[0][dt]);
-      if (kt < 5) next_slice(kt);
-      SB();
-      bf16x8 dsa[2];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (kt + 1 < NT) {
-          if (ks < 3) {
-            kan[ks + 1] = *reinterpret_cast<const bf16x8*>(knxt + ro.o[ks + 1]);
-            van[ks + 1] = *reinterpret_cast<const bf16x8*>(vnxt + ro.o[ks + 1]);
-          }
-          sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kan[ks], qf[ks], ks == 0 ? zero : sn, 0, 0, 0);
-          SB();
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int r = 4 * ks + k;
-          float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[r], c2, lq));
-          if (kt == NT - 1) e = crow(r, h) < last ? e : 0.f;   // the padded keys of the last tile (an accumulator seed for them costs 16 registers)
-          dsa[ks >> 1][4 * (ks & 1) + k] = (bf16)(e * (dpT[r] + dlq));
-        }
-        SB();
-        if (kt + 1 < NT) {
-          pn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(van[ks], dof[ks], ks == 0 ? zero : pn, 0, 0, 0);
-          SB();
-        }
-      }
-      // dQ^T += K^T dS^T
-      bf16x8 kfr1[2];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr0[dt], dsa[0], kt == 0 ? zero : dq[dt], 0, 0, 0);
-        SB();
-        kfr1[dt] = tr_frag_at(kblk, to.lo[1][dt], to.hi[1][dt]);
-        SB();
-      }
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr1[dt], dsa[1], dq[dt], 0, 0, 0);
-        SB();
-      }
-      if (kt + 1 < NT) {
-        sT = sn;
-        dpT = pn;
-      }
-    }
-#pragma unroll
-    for (int j = NT; j < 5; ++j) next_slice(j);   // (the slices of tiles this NT does not have)
-    ATTN_STAMP(6);
-    // the next head's images have landed (they are old by now): wait for them HERE, before this phase's stores
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    SB();
-    ATTN_STAMP(7);
-    {
-      // this wave's K / V rows of the next head, straight to registers: requested behind the sweep (live across it they cost 32
-      // registers: the sweep then spills) -- they have the dQ stores, two barriers and the delta step to land in
-      const bf16* kb = reinterpret_cast<const bf16*>(nqb) + H * HD;
-      const bf16* vb = kb + H * HD;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        kf[ks] = *reinterpret_cast<const bf16x8*>(kb + (size_t)trow * ld + ks * 16 + h * 8);
-        vf[ks] = *reinterpret_cast<const bf16x8*>(vb + (size_t)trow * ld + ks * 16 + h * 8);
-      }
-    }
-    bf16* qrow_out = dqkv + (size_t)(b * N + trow) * ld + head * HD;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      unsigned w[4][2];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const bf16x2 lo = {(bf16)(dq[dt][4 * g] * scale), (bf16)(dq[dt][4 * g + 1] * scale)};
-        const bf16x2 hi = {(bf16)(dq[dt][4 * g + 2] * scale), (bf16)(dq[dt][4 * g + 3] * scale)};
-        w[g][0] = __builtin_bit_cast(unsigned, lo);
-        w[g][1] = __builtin_bit_cast(unsigned, hi);
-      }
-#pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(w[g][k], w[g + 2][k], false, false);
-          w[g][k] = sw[0];
-          w[g + 2][k] = sw[1];
-        }
-      if (tvalid) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const uint4 v = {w[g][0], w[g][1], w[g + 2][0], w[g + 2][1]};
-          *reinterpret_cast<uint4*>(qrow_out + dt * 32 + 8 * (g + 2 * h)) = v;
-        }
-      }
-    }
-  }
-#ifdef CARA_ATTN_STAMPS
-  if (g_attn_stamp_buf && tid == 0) {
-    g_attn_stamp_buf[((size_t)blockIdx.x * 4 + 3) * 8 + 2] = __builtin_amdgcn_s_memtime();
-    g_attn_stamp_buf[((size_t)blockIdx.x * 4 + 3) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-  }
-#endif
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no LDS-DMA may outlive the workgroup)
-}
-
+// (Round 5 built the same specialisation for this kernel -- NT as a template parameter, branch-free DMA issue, the S^T / dP^T
+// MFMAs of key tile kt + 1 between the vector work of tile kt in the dQ sweep -- and it LOST: 66.7-68.8 us per launch against
+// 62.9-63.5 for the body above, same box (profiles/r05_c_attention_ab_and_stamps.txt).  The cross-tile pipeline needs two more
+// accumulator tiles; next to dK^T / dV^T (64 registers), the K / V rows (32) and the fragments in flight that is more than the 256
+// registers of two waves per SIMD: the dK/dV sweep could not be pipelined at all (404 bytes of scratch), the dQ sweep only with
+// this wave's K / V rows of the next head requested behind it (0.4 -> 0.95 us exposed per head), and the compiler's order for the
+// unpipelined dK/dV sweep came out slower than the one it finds for the loop above (8.0 vs 5.7 us per head).  Removed.)
 // ------------------------------------------------------------------------------------------
 // The LAST block: only the cls row of its attention output can reach the logits (the proj / MLP half of that block
 // already runs on the cls rows alone), i.e. ONE query per (batch, head) against all N keys.  The full kernels spend
@@ -2066,9 +1732,6 @@ static void attn_set_lds_limits() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_p2_kernel<7>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel), at, MAX_LDS);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_p2_kernel<5>), at, MAX_LDS);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_p2_kernel<6>), at, MAX_LDS);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_p2_kernel<7>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<4>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<7>), at, MAX_LDS);
   done = true;
@@ -2127,16 +1790,8 @@ extern "C" int cara_attention_bwd(const void* qkv, const void* out, const void* 
   static const int use_fused = [] { const char* e = getenv("CARA_ATTN_PERSIST"); return e ? atoi(e) : 1; }();
   if (use_fused && N > 128 && N <= NMAX) {
     const int BH = B * H, grid = BH < 256 ? BH : 256;
-    // CARA_ATTN_BWD_V=1: the round-3 body for A/B runs; default: the specialised, software-pipelined schedule
-    static const int bwd_v = [] { const char* e = getenv("CARA_ATTN_BWD_V"); return e ? atoi(e) : 2; }();
-    const size_t blds = 5 * 224 * 128 + (256 + 224) * 4;
-    const int nt = (N + 31) / 32;
-#define CARA_BWD_ARGS dim3(grid), dim3(448), blds, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, BH, scale
-    if (bwd_v == 1) hipLaunchKernelGGL(attn_bwd_fused_kernel, CARA_BWD_ARGS);
-    else if (nt == 7) hipLaunchKernelGGL(attn_bwd_p2_kernel<7>, CARA_BWD_ARGS);
-    else if (nt == 6) hipLaunchKernelGGL(attn_bwd_p2_kernel<6>, CARA_BWD_ARGS);
-    else hipLaunchKernelGGL(attn_bwd_p2_kernel<5>, CARA_BWD_ARGS);
-#undef CARA_BWD_ARGS
+    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(grid), dim3(448), 5 * 224 * 128 + (256 + 224) * 4, st, (const bf16*)qkv, (const bf16*)out,
+                       (const bf16*)dout, lse, (bf16*)dqkv, N, H, BH, scale);
     CARA_CHECK_LAUNCH();
     return CARA_OK;
   }

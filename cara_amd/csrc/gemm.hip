@@ -1092,7 +1092,17 @@ static int gemm_bf16_impl(const cara_gemm_args* a, void* stream, const TsPair* t
 // measurement tools only (tools/gemm8_bench.py): pick the tile family per call sequence inside one process -- 160 / 256: that tile for
 // every product it takes; 0: never; -1: the policy below decides (the default)
 static int g_gemm8_override = -1;
-extern "C" int cara_debug_set_gemm8(int mt) { g_gemm8_override = mt; return CARA_OK; }
+// (test hooks, not in include/cara_hip.h: mutable process globals -- they do nothing unless the process opted in with
+// CARA_ALLOW_DEBUG_SETTERS=1, which tests/conftest.py sets)
+bool cara_debug_setters_allowed() {
+  static const bool ok = [] { const char* e = getenv("CARA_ALLOW_DEBUG_SETTERS"); return e && atoi(e) == 1; }();
+  return ok;
+}
+extern "C" int cara_debug_set_gemm8(int mt) {
+  if (!cara_debug_setters_allowed()) return CARA_E_ARG;
+  g_gemm8_override = mt;
+  return CARA_OK;
+}
 // Which products run on the 160 x 256 x 64 tile (same-box A/Bs of the step, profiles/r04_b_*): the long-K, narrow-N ones --
 //   * fc2 forward (K = 4 dim, N = dim, the adapter inside: 86 -> 74 us) and qkv dX (K = 3 dim, with its riding products as
 //     workgroups behind the tiles: 64.7 -> 60.3 us);

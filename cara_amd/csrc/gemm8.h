@@ -22,6 +22,9 @@ int cara_gemm8_launch(const cara_gemm_args* a, hipStream_t st, int mt, const car
 // one slab per WAVE (cara_ts_reduce::wave_slabs)
 int cara_gemm8_plan(const cara_gemm_args* a, int mt, int riders_nt);
 
+// helper waves on (CARA_GEMM8_HELPERS=1 or the debug setter; off by default): only then does a riding product write one slab per WAVE
+bool cara_gemm8_helpers_on();
+
 // the dispatcher's policy (gemm.hip): does a product of this shape go to the tile?  riders: the launch carries transposed skinny
 // products.  (Callers that choose activation layouts ask.)
 bool cara_gemm8_policy(int M, int N, int K, int riders);

@@ -991,11 +991,18 @@ int g8_launch_epi(const cara_gemm_args* a, hipStream_t st, const cara_g8_riders*
 // every barrier), and the streamed riders of fc1 dX end at 92 us against 87 for the 128 x 128 x 32 kernel (profiles/r04_b_*).
 // Without them the adapter inside is computed by the tile waves (MODE 2) and riding products run as workgroups behind the tiles.
 static int g_helpers_override = -1;
-extern "C" int cara_debug_set_gemm8_helpers(int on) { g_helpers_override = on; return CARA_OK; }
+bool cara_debug_setters_allowed();   // gemm.hip
+extern "C" int cara_debug_set_gemm8_helpers(int on) {
+  if (!cara_debug_setters_allowed()) return CARA_E_ARG;
+  g_helpers_override = on;
+  return CARA_OK;
+}
 static bool g8_helpers() {
   static const int env = [] { const char* e = getenv("CARA_GEMM8_HELPERS"); return e ? atoi(e) : 0; }();
   return (g_helpers_override >= 0 ? g_helpers_override : env) != 0;
 }
+
+bool cara_gemm8_helpers_on() { return g8_helpers(); }
 
 int cara_gemm8_plan(const cara_gemm_args* a, int mt, int riders_nt) {
   // what the tile takes: row-major A and B (whole 128-byte lines per K step of 64); the K-extension at Rp = 32 with T given (A2) or

@@ -26,9 +26,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(const cara_adamw_args a) {
   if (t >= a.ntensors) return;
   if (a.skip_flag && *a.skip_flag != 0.f) return;   // the step's gradients overflowed under the loss scale: nothing moves
   const cara_adamw_tensor& T = a.t[t];
-  const float lr = a.lr[T.group], wd = a.weight_decay[T.group];
+  float lr = a.lr[T.group], bc1 = a.bias_correction1, bc2s = a.bias_correction2_sqrt;
+  if (a.dyn) {   // the capturable form: step count and learning rates live in device memory (cara_adamw_args::dyn)
+    const float tt = a.dyn[0];
+    lr = a.dyn[1 + T.group];
+    bc1 = 1.f - powf(1.f - a.one_minus_beta1, tt);
+    bc2s = sqrtf(1.f - powf(a.beta2, tt));
+  }
+  const float wd = a.weight_decay[T.group];
   const float decay = 1.f - lr * wd;
-  const float step_size = lr / a.bias_correction1;
+  const float step_size = lr / bc1;
   float* __restrict__ p = T.p;
   const float* __restrict__ g = T.g;
   float* __restrict__ m = T.m;
@@ -42,7 +49,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const cara_adamw_args a) {
     float pi = p[i] * decay;
     const float mi = m[i] + a.one_minus_beta1 * (gi - m[i]);
     const float vi = a.beta2 * v[i] + a.one_minus_beta2 * gi * gi;
-    const float denom = sqrtf(vi) / a.bias_correction2_sqrt + a.eps;
+    const float denom = sqrtf(vi) / bc2s + a.eps;
     pi -= step_size * (mi / denom);
     p[i] = pi;
     m[i] = mi;
@@ -81,7 +88,7 @@ extern "C" int cara_amp_update(float* state, const float* found_inf, float growt
 }
 
 extern "C" int cara_adamw_step(const cara_adamw_args* a, void* stream) {
-  if (!a || a->ntensors <= 0 || a->ntensors > CARA_ADAMW_MAX_TENSORS || a->step <= 0) return CARA_E_ARG;
+  if (!a || a->ntensors <= 0 || a->ntensors > CARA_ADAMW_MAX_TENSORS || (a->step <= 0 && !a->dyn)) return CARA_E_ARG;
   size_t chunks = 0;
   for (int t = 0; t < a->ntensors; ++t) {
     const cara_adamw_tensor& T = a->t[t];

@@ -358,9 +358,15 @@ extern "C" int cara_skinny_xu_r(const void* X, int ldx, const void* Ut, void* T,
 
 extern "C" size_t cara_tskinny_scratch_bytes(int M, int K1, int Rp) {
   if (M <= 0 || K1 <= 0 || (K1 % TS_COLS) || !(Rp == 32 || Rp == 64)) return 0;
-  // (four times the blocks: a product that rides in a launch of the 160 x 256 x 64 tile writes one slab per wave, cara_ts_reduce::wave_slabs)
-  const size_t nblk = (size_t)4 * (K1 / TS_COLS) * ts_chunks(M, K1);
-  return nblk * TS_COLS * Rp * sizeof(float) + nblk * TS_COLS * sizeof(float);
+  // One slab per tskinny BLOCK.  With helper waves on (CARA_GEMM8_HELPERS=1, off by default) a product that rides in a launch of the
+  // 160 x 256 x 64 tile writes one slab per WAVE (cara_ts_reduce::wave_slabs): four times the blocks, the slabs spaced as 32-column
+  // ones (gemm8.hip: the column sums sit behind 4 nblk slabs of TS_COLS x 32) -- four times the bytes; that form exists at Rp = 32,
+  // rank <= 16 only.  Sizing every region 4x whatever the mode cost ~0.6 GB of workspace
+  // at ViT-B batch 64 and ~1.3 GB at ViT-L batch 32 for a path that is off.  The switch is read when the workspace is
+  // SIZED: flipping the debug setter between sizing and use is the caller's bug.
+  const size_t blocks = (size_t)(K1 / TS_COLS) * ts_chunks(M, K1);
+  const size_t one = blocks * TS_COLS * Rp * sizeof(float) + blocks * TS_COLS * sizeof(float);
+  return (cara_gemm8_helpers_on() && Rp == 32) ? 4 * one : one;
 }
 
 namespace {

@@ -7,6 +7,8 @@
 // sequence can be captured in a hipGraph (nothing here allocates or synchronises).
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 #include "gemm8.h"
 
@@ -223,10 +225,17 @@ struct SideStream {
   bool ok = false;
 };
 SideStream* side_stream() {
-  static SideStream s;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  // one stream + event pair per DEVICE, created under a lock on first use there (a process-wide pair made on
+  // whichever device was current at first use belongs to the wrong device in a multi-device or multi-threaded process)
+  static SideStream per_dev[16];
+  static bool tried[16] = {};
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  SideStream& s = per_dev[dev];
+  if (!tried[dev]) {
+    tried[dev] = true;
     s.ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
            hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
@@ -903,6 +912,14 @@ extern "C" int cara_head_backward(const float* dlogits, const void* xn, const fl
   return head_backward_scaled(dlogits, xn, head_w, dhead_w, dhead_b, dxn, B, classes, D, nullptr, nullptr, stream);
 }
 
+// Does the 160 x 256 x 64 tile really take this product of the model?  cara_gemm8_policy looks at the shape only; the tile's
+// adapter-inside path and its riders are built for one r-tile (cara_gemm8_plan: Rp = 32, rank <= 16).  The activation LAYOUT
+// (K-panel-major h / dH for the 128-tile family, row-major for the tile) must follow what will run: at rank 64 the shape-only
+// answer left fc2 forward on the 128-tile kernel reading row-major A (9.696 -> 9.75 ms on the rank-64 leg).
+static bool tile_policy(const cara_geom* g, int M, int N, int K, int riders) {
+  return g->Rp == 32 && g->rank > 0 && g->rank <= 16 && cara_gemm8_policy(M, N, K, riders);
+}
+
 extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, const cara_vit_weights* w,
                                 const cara_cp* cp, const float* head_w, const float* head_b, const float* images,
                                 const float* droppath, void* workspace, float* logits, void* stream) {
@@ -958,7 +975,7 @@ extern "C" int cara_vit_forward(const cara_geom* g, const cara_vit_shape* s, con
     // the proj / MLP half of the block (xn2, h)
     // (order 2: xn1 stays row-major -- the dense dD = xn1^T dY of the backward reads it with transposing LDS reads)
     // (h stays row-major where fc2 forward / fc1 dX run on the 160 x 256 x 64 tile, which stages whole 128-byte lines of row-major operands)
-    const bool pa_x = panel_acts(M, s, 2) && !dense_qkv, pa = panel_acts(Mr, s, 1) && !cara_gemm8_policy(Mr, D, 4 * D, 0), pa_n = panel_acts(Mr, s, 2);
+    const bool pa_x = panel_acts(M, s, 2) && !dense_qkv, pa = panel_acts(Mr, s, 1) && !tile_policy(g, Mr, D, 4 * D, 0), pa_n = panel_acts(Mr, s, 2);
     {
       SiteBracket sb(CARA_SITE_LN1_FWD, cx_all);
       TRY(cara_layernorm_fwd_ex(x_in, D, w->ln1_g + (size_t)l * D, w->ln1_b + (size_t)l * D, ws + lw.xn1,
@@ -1073,7 +1090,7 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     // theirs: dH and dyp (pa), dyb of the block below (pa_x).  This block's own dyb came from the block above --
     // panels -- except in the last block, where the final norm's backward left it row-major on the cls rows.
     // (h as the forward wrote it: row-major where fc2 forward runs on the 160 x 256 x 64 tile; dH: row-major where fc1 dX does)
-    const bool pa_x = panel_acts(M, s, 2) && !dense_qkv, pa = panel_acts(Mr, s, 1) && !cara_gemm8_policy(Mr, D, 4 * D, 0), pa_n = panel_acts(Mr, s, 2);
+    const bool pa_x = panel_acts(M, s, 2) && !dense_qkv, pa = panel_acts(Mr, s, 1) && !tile_policy(g, Mr, D, 4 * D, 0), pa_n = panel_acts(Mr, s, 2);
     // fc1's dVs / dc and fc2's dU out of the fc2 dX epilogue: the fc1 dX launch then carries nothing and runs on the 160 x 256 x 64 tile
     const bool er_on = epi_riders_geom(g, Mr, ex) && ts_rank(cx, Rp) <= 16 && fuse_ts(Mr, Rp) && defer_du() && env_once_dv_off();
     // CARA_DV (default 0; bit 0: fc1, bit 1: qkv): dVs (+ dc) of fc1 / qkv out of their dX GEMM's own A tiles on the 160 x 256 x 64 tile;
@@ -1081,17 +1098,17 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
     // behind fc1's tiles (19 MB instead of fc2's 77)
     static const int dv_env = env_once("CARA_DV", 0), dv_home = env_once("CARA_DV_DU_HOME", 1);
     const bool dv_ok = dv_env != 0 && !ex && Rp == 32 && ts_rank(cx, Rp) <= 16 && fuse_ts(Mr, Rp) && defer_du() && !cls_only;
-    const bool dv_fc1 = dv_ok && (dv_env & 1) && g_inside_enabled(2) && cara_gemm8_policy(Mr, D, 4 * D, 0);
-    const bool dv_qkv = dv_ok && (dv_env & 2) && g_inside_enabled(0) && cara_gemm8_policy(M, D, 3 * D, 0);
+    const bool dv_fc1 = dv_ok && (dv_env & 1) && g_inside_enabled(2) && tile_policy(g, Mr, D, 4 * D, 0);
+    const bool dv_qkv = dv_ok && (dv_env & 2) && g_inside_enabled(0) && tile_policy(g, M, D, 3 * D, 0);
     static const int fc1_side = env_once("CARA_FC1_SIDE", 0);
     const bool side_on = fc1_side != 0 && !er_on && !ex && Rp == 32 && ts_rank(cx, Rp) <= 16 && fuse_ts(Mr, Rp) && defer_du() && g_inside_enabled(2) &&
-                         cara_gemm8_policy(Mr, D, 4 * D, 0) && !dv_fc1 && side_stream() != nullptr;
+                         tile_policy(g, Mr, D, 4 * D, 0) && !dv_fc1 && side_stream() != nullptr;
     side.ss = side_on ? side_stream() : nullptr;
     EpiRider er;
     er.Tt = ws + lw.Tt[2];
     er.slabV = ws + W.slabV[2] + (size_t)l * W.strideV[2];
     er.bytes = W.strideV[2] < W.strideU[3] ? W.strideV[2] : W.strideU[3];
-    const bool pa_dh = panel_acts(Mr, s, 1) && !cara_gemm8_policy(Mr, D, 4 * D, (er_on || side_on || dv_fc1) ? 0 : 1);
+    const bool pa_dh = panel_acts(Mr, s, 1) && !tile_policy(g, Mr, D, 4 * D, (er_on || side_on || dv_fc1) ? 0 : 1);
     const bool pa_dp = panel_acts(Mr, s, 4), pa_dx = panel_acts(M, s, 4);   // dyp here; dyb of the block below
     const bool pa_dyb = pa_dx && l < g->depth - 1;
     if (pa_dh) { e.c_panels = Mr; e.ldc = 4 * D; }

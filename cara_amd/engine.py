@@ -72,7 +72,7 @@ class CaraEngine:
         self._need_backward = True
         self._flat_grad = None
         self._grad_views = None
-        self._slot = 0          # workspace slot of the call in flight (train_step_two_streams)
+        self._slot = 0          # workspace slot of the call in flight (0 in the product; tools/two_stream_step.py runs two at once)
         # RNG streams of the stochastic parts (DropPath masks on the device, weight-dropout seeds on the host).
         # None = torch's global generators.  Under data parallelism every rank must draw DIFFERENT masks while the
         # parameters stay identical: seed_rank_streams(seed, rank) after the model is built.
@@ -204,7 +204,7 @@ class CaraEngine:
             if nbytes == 0:
                 raise CaraError(f"unsupported geometry for the HIP path: {geom.depth=} {geom.dim=} {geom.heads=} "
                                 f"{shape.tokens=} (needs head dim 64, tokens <= 608, dim % 256 == 0)")
-            if self._slot == 0:
+            if self._slot == 0 and not self.__dict__.get("_keep_ws"):
                 self._ws.clear()  # one live workspace: activations of one step (slots > 0: the two-stream step's second half)
             ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
             st = {"geom": geom, "shape": shape, "ws": ws, "logits": torch.empty(B, ncls, device=dev)}
@@ -438,66 +438,6 @@ class CaraEngine:
             self._apply_gradients(optimizer, group, prescaled=True)
         return self._loss_buf[0]
 
-    def train_step_two_streams(self, images, labels, optimizer=None, group=None, lag_cycles: int = 0):
-        """EXPERIMENT (measured in profiles/r05_*two_streams*, not the default): the step as two half-batch
-        pipelines on two HIP streams, so that one half's LayerNorm / attention / epilogue tails can run under the other half's
-        K loops.  cara_vit_forward / cara_vit_backward are stateless and take a stream: each half has its own workspace and
-        its own flat gradient buffer; the mean over the batch is the average of the halves' means (dlogits scaled by 1/2 at the
-        cross-entropy), the second buffer is added to the first, then the usual all-reduce + optimiser.  bf16, factored adapters."""
-        model = self._model()
-        dev = images.device
-        B = images.shape[0]
-        if B % 2 or self.precision != "bf16" or self.weight_dropout != "off":
-            raise CaraError("train_step_two_streams: even batch, precision 'bf16', weight_dropout 'off'")
-        cp = [getattr(model, "CP_" + n) for n in self.cp_fields]
-        hw, hb = model.head.weight, model.head.bias
-        from .dist import flat_views, world_size
-        with torch.no_grad(), torch.cuda.device(dev):
-            main = torch.cuda.current_stream(dev)
-            if self.__dict__.get("_two") is None:
-                names = [(n, getattr(model, "CP_" + n).shape) for n in self.cp_fields] + [("head_w", hw.shape), ("head_b", hb.shape), ("_found_inf", (1,))]
-                self._two = {"streams": (torch.cuda.Stream(dev), torch.cuda.Stream(dev)), "flat2": flat_views(names, dev),
-                             "loss": [torch.empty(1 + B // 2, device=dev) for _ in range(2)],
-                             "dl": [torch.empty(B // 2, hw.shape[0], device=dev) for _ in range(2)]}
-            two = self._two
-            droppath = self.draw_droppath(model, B, dev)
-            gv0 = self._grad_buffers(model, dev)
-            flat1, gv1 = two["flat2"]
-            ev_in = torch.cuda.Event()
-            ev_in.record(main)
-            done = []
-            for h, (s_, gv) in enumerate(zip(two["streams"], (gv0, gv1))):
-                sl = slice(h * (B // 2), (h + 1) * (B // 2))
-                x_h, y_h = images[sl], labels[sl].contiguous()
-                dp_h = droppath[:, :, sl].contiguous() if droppath is not None else None
-                s_.wait_event(ev_in)
-                with torch.cuda.stream(s_):
-                    self._slot = h
-                    try:
-                        if h == 1 and lag_cycles > 0:   # phase shift of the second pipeline (a spin kernel of that many clocks)
-                            torch.cuda._sleep(int(lag_cycles))
-                        logits = self._run_forward(x_h, dp_h, hw, hb, cp)
-                        check(self._lib().cara_cross_entropy_ex(ptr(logits), ptr(y_h), ptr(two["loss"][h]), ptr(two["dl"][h]), B // 2, logits.shape[1],
-                                                                C.c_float(0.5 / world_size(group)), None, None, stream(dev)), "cara_cross_entropy_ex")
-                        st = self._ws[self._last_key]
-                        gps = L.cp_ptrs(self.cp_fields, [gv[n] for n in self.cp_fields])
-                        cps = self._cp_ptrs([t.detach().contiguous() for t in cp])
-                        st["shape"].loss_scale, st["shape"].found_inf = None, None
-                        check(self._lib().cara_vit_backward(C.byref(st["geom"]), C.byref(st["shape"]), C.byref(self._ingested[1]), C.byref(cps),
-                                                            ptr(hw.detach()), ptr(two["dl"][h]), ptr(dp_h), ptr(st["ws"]), C.byref(gps),
-                                                            ptr(gv["head_w"]), ptr(gv["head_b"]), stream(dev)), "cara_vit_backward")
-                    finally:
-                        self._slot = 0
-                    e = torch.cuda.Event()
-                    e.record(s_)
-                    done.append(e)
-            for e in done:
-                main.wait_event(e)
-            self._flat_grad.add_(flat1)
-            self._bwd_ready = -1
-            self._apply_gradients(optimizer, group, prescaled=True)
-            return two["loss"][0][0] + two["loss"][1][0]
-
     # module-level entries (cara.cp_attn / cara.cp_mlp): the reference's patched forwards
     def _weights(self, model, dev):
         if self._ingested is None or self._ingest_sig != self._signature(model) or self._ingested[0]["cls"].device != dev:
@@ -511,8 +451,6 @@ class CaraEngine:
             raise CaraError("cara_amd runs on the GPU only (no CPU fallback)")
         if x.ndim != 3 or x.shape[2] != model.embed_dim or x.shape[1] > 608:
             raise CaraError("module-level forward expects x of shape [B, N <= 608, embed_dim]")
-        if self.precision == "fp16":
-            raise CaraError("precision = 'fp16' is a whole-model mode: call model(x) / train_step, not a block's Attention.forward / Mlp.forward")
         if self.cp_length == 2:
             raise CaraError("with cp_length 2 (dense QKV deltas) call the whole model: the module-level Attention.forward / "
                             "Mlp.forward entries run the factored adapters only")

@@ -30,7 +30,7 @@ class FactorPack:
 
     def get(self, model, dev):
         cp = [getattr(model, "CP_" + n) for n in self.eng.cp_fields]
-        sig = tuple((p.data_ptr(), p._version) for p in cp) + (str(dev),)
+        sig = tuple((p.data_ptr(), p._version) for p in cp) + (str(dev), self.eng._operands())
         if sig != self.sig:
             eng = self.eng
             t, _ = eng._weights(model, dev)
@@ -46,9 +46,10 @@ class FactorPack:
             self.sig, self.lay, self.geom = sig, lay, geom
         return self
 
-    def op(self, layer, name, rows, cols, dtype=torch.bfloat16):
+    def op(self, layer, name, rows, cols, dtype=None):
+        dtype = dtype or L.act_dtype(self.eng._operands())   # (the pack is written by the library of the engine's precision)
         off = layer * self.lay.layer_stride + getattr(self.lay, name)
-        n = rows * cols * (2 if dtype == torch.bfloat16 else 4)
+        n = rows * cols * (4 if dtype == torch.float32 else 2)
         return self.pack[off:off + n].view(dtype).reshape(rows, cols)
 
 
@@ -56,8 +57,8 @@ def _lin_fwd(x, W, bias, Ut, Vs, out, epi, ldt, **kw):
     """T = x U ; out = [x | T] [W | Vs]^T + bias -> epilogue.  Returns T^T (kept for dVs)."""
     M = x.shape[0]
     Rp = Ut.shape[0]
-    T = torch.empty(M, Rp, dtype=torch.bfloat16, device=x.device)
-    Tt = torch.zeros(Rp, ldt, dtype=torch.bfloat16, device=x.device)
+    T = torch.empty(M, Rp, dtype=L.act_dtype(), device=x.device)
+    Tt = torch.zeros(Rp, ldt, dtype=L.act_dtype(), device=x.device)
     L.skinny_xu(x, Ut, T, Tt)
     L.gemm(x, W, out, epi=epi, bias=bias, A2=T, B2=Vs, **kw)
     return Tt
@@ -69,8 +70,8 @@ def _lin_bwd(dy, x_saved, Wt, Vst, U, Tt_saved, dx_out, epi, ldt, want_dc, **kw)
     in_f = x_saved.shape[1]
     Rp = Vst.shape[0]
     dev = dy.device
-    G = torch.empty(M, Rp, dtype=torch.bfloat16, device=dev)
-    Gt = torch.zeros(Rp, ldt, dtype=torch.bfloat16, device=dev)
+    G = torch.empty(M, Rp, dtype=L.act_dtype(), device=dev)
+    Gt = torch.zeros(Rp, ldt, dtype=L.act_dtype(), device=dev)
     L.skinny_xu(dy, Vst, G, Gt)
     L.gemm(dy, Wt, dx_out, epi=epi, A2=G, B2=U, **kw)
     dU = torch.empty(in_f, Rp, device=dev)
@@ -116,6 +117,16 @@ def _scatter(eng, model, dev, layer, pieces):
 class AttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, child, x, *cp):
+        with L.using(eng._operands()):
+            return AttnFn._forward(ctx, eng, child, x, *cp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        with L.using(ctx.eng._operands()):
+            return AttnFn._backward(ctx, dy)
+
+    @staticmethod
+    def _forward(ctx, eng, child, x, *cp):
         model = eng._model()
         dev = x.device
         t, _ = eng._weights(model, dev)
@@ -124,11 +135,11 @@ class AttnFn(torch.autograd.Function):
         B, N, Cd = x.shape
         M, H = B * N, child.num_heads
         ldt = (M + 31) // 32 * 32
-        xb = x.detach().reshape(M, Cd).to(torch.bfloat16).contiguous()
-        qkv = torch.empty(M, 3 * Cd, dtype=torch.bfloat16, device=dev)
+        xb = x.detach().reshape(M, Cd).to(L.act_dtype()).contiguous()
+        qkv = torch.empty(M, 3 * Cd, dtype=L.act_dtype(), device=dev)
         Tt1 = _lin_fwd(xb, t["qkv_w"][l], t["qkv_b"][l], fp.op(l, "Ut_qkv", fp.geom.Rp, Cd), fp.op(l, "Vs_qkv", 3 * Cd, fp.geom.Rp),
                        qkv, L.EPI_BF16, ldt)
-        ao = torch.empty(M, Cd, dtype=torch.bfloat16, device=dev)
+        ao = torch.empty(M, Cd, dtype=L.act_dtype(), device=dev)
         lse = torch.empty(B, H, N, device=dev)
         check(L.lib().cara_attention_fwd(ptr(qkv), ptr(ao), ptr(lse), B, N, H, C.c_float(child.scale), stream()), "cara_attention_fwd")
         y = torch.empty(M, Cd, device=dev)
@@ -139,7 +150,7 @@ class AttnFn(torch.autograd.Function):
         return y.reshape(B, N, Cd).to(x.dtype)
 
     @staticmethod
-    def backward(ctx, dy):
+    def _backward(ctx, dy):
         xb, qkv, lse, ao, Tt1, Tt2 = ctx.saved_tensors
         eng, child, l = ctx.eng, ctx.child, ctx.l
         B, N, Cd, H, ldt = ctx.shape
@@ -147,8 +158,8 @@ class AttnFn(torch.autograd.Function):
         t, _ = eng._weights(model, dev)
         fp = eng._factors.get(model, dev)
         Rp = fp.geom.Rp
-        dyb = dy.reshape(M, Cd).to(torch.bfloat16).contiguous()
-        dao = torch.empty(M, Cd, dtype=torch.bfloat16, device=dev)
+        dyb = dy.reshape(M, Cd).to(L.act_dtype()).contiguous()
+        dao = torch.empty(M, Cd, dtype=L.act_dtype(), device=dev)
         dU_p, dV_p, dc_p = _lin_bwd(dyb, ao, t["proj_wt"][l], fp.op(l, "Vst_proj", Rp, Cd), fp.op(l, "U_proj", Cd, Rp), Tt2, dao,
                                     L.EPI_BF16, ldt, True)
         dqkv = torch.empty_like(qkv)
@@ -164,6 +175,16 @@ class AttnFn(torch.autograd.Function):
 class MlpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, child, x, *cp):
+        with L.using(eng._operands()):
+            return MlpFn._forward(ctx, eng, child, x, *cp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        with L.using(ctx.eng._operands()):
+            return MlpFn._backward(ctx, dy)
+
+    @staticmethod
+    def _forward(ctx, eng, child, x, *cp):
         model = eng._model()
         dev = x.device
         t, _ = eng._weights(model, dev)
@@ -172,8 +193,8 @@ class MlpFn(torch.autograd.Function):
         B, N, Cd = x.shape
         M, Rp = B * N, fp.geom.Rp
         ldt = (M + 31) // 32 * 32
-        xb = x.detach().reshape(M, Cd).to(torch.bfloat16).contiguous()
-        h = torch.empty(M, 4 * Cd, dtype=torch.bfloat16, device=dev)
+        xb = x.detach().reshape(M, Cd).to(L.act_dtype()).contiguous()
+        h = torch.empty(M, 4 * Cd, dtype=L.act_dtype(), device=dev)
         u = torch.empty_like(h)
         Tt1 = _lin_fwd(xb, t["fc1_w"][l], fp.op(l, "bias_fc1", 1, 4 * Cd, torch.float32).reshape(-1),
                        fp.op(l, "Ut_fc1", Rp, Cd), fp.op(l, "Vs_fc1", 4 * Cd, Rp), h, L.EPI_GELU, ldt, C2=u)
@@ -185,7 +206,7 @@ class MlpFn(torch.autograd.Function):
         return y.reshape(B, N, Cd).to(x.dtype)
 
     @staticmethod
-    def backward(ctx, dy):
+    def _backward(ctx, dy):
         xb, u, h, Tt1, Tt2 = ctx.saved_tensors
         eng, l = ctx.eng, ctx.l
         B, N, Cd, ldt = ctx.shape
@@ -193,8 +214,8 @@ class MlpFn(torch.autograd.Function):
         t, _ = eng._weights(model, dev)
         fp = eng._factors.get(model, dev)
         Rp = fp.geom.Rp
-        dyb = dy.reshape(M, Cd).to(torch.bfloat16).contiguous()
-        dh = torch.empty(M, 4 * Cd, dtype=torch.bfloat16, device=dev)
+        dyb = dy.reshape(M, Cd).to(L.act_dtype()).contiguous()
+        dh = torch.empty(M, 4 * Cd, dtype=L.act_dtype(), device=dev)
         dU2, dV2, dc2 = _lin_bwd(dyb, h, t["fc2_wt"][l], fp.op(l, "Vst_fc2", Rp, Cd), fp.op(l, "U_fc2", 4 * Cd, Rp), Tt2, dh,
                                  L.EPI_DGELU, ldt, True, aux=u)
         dx = torch.empty(M, Cd, device=dev)

@@ -20,7 +20,8 @@ from ._lib import CaraError
 
 
 class AdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 capturable: bool = False):
         if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
             raise ValueError("AdamW: lr, eps, weight_decay >= 0 and betas in [0, 1)")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
@@ -33,6 +34,30 @@ class AdamW(torch.optim.Optimizer):
         # the step's found-inf word under precision = "fp16").  The host-side step counts still advance: a skipped step moves the
         # bias corrections on by one, which is what torch's fused AdamW does under GradScaler too.
         self.skip_flag = None
+        # capturable = True: the step count and the learning rates the kernel uses live in device memory (cara_adamw_args::dyn),
+        # so that a captured launch stays correct under hipGraph replay.  step() then only enqueues the launch; advance() -- call it
+        # once before every step / graph replay, outside the captured region -- moves the count on and uploads { t, lr per group }
+        # (one fill launch for the count, one per learning rate that changed).  All parameters share one step count in this mode.
+        self.capturable = bool(capturable)
+        self._dyn = None
+        self._dyn_step = 0
+
+    def advance(self):
+        """capturable mode: next step -- count + 1, current learning rates -> device (call before step() / graph.replay())"""
+        if not self.capturable:
+            raise CaraError("advance() belongs to AdamW(capturable=True)")
+        dev = next(p for g in self.param_groups for p in g["params"]).device
+        if self._dyn is None or self._dyn.device != dev:
+            self._dyn = torch.zeros(1 + L.ADAMW_MAX_GROUPS, device=dev)
+            self._dyn_lr = [None] * L.ADAMW_MAX_GROUPS
+        self._dyn_step += 1
+        # (fill_ launches carry the value in their arguments: stream-ordered and safe however far the host runs ahead of the device.
+        # An asynchronous copy from a temporary host tensor is neither -- the first build of this mode read freed host memory.)
+        self._dyn[0].fill_(float(self._dyn_step))
+        for gi, g in enumerate(self.param_groups):
+            if self._dyn_lr[gi] != float(g["lr"]):
+                self._dyn_lr[gi] = float(g["lr"])
+                self._dyn[1 + gi].fill_(self._dyn_lr[gi])
 
     def _init_state(self, p):
         st = self.state[p]
@@ -66,6 +91,12 @@ class AdamW(torch.optim.Optimizer):
                 if not p.is_contiguous() or not p.grad.is_contiguous():
                     raise CaraError("cara_amd.optim.AdamW needs contiguous parameters and gradients")
                 st = self._init_state(p)
+                if self.capturable:
+                    if self._dyn is None:
+                        raise CaraError("AdamW(capturable=True): call advance() before step()")
+                    st["step"] = torch.tensor(float(self._dyn_step))
+                    buckets.setdefault(max(self._dyn_step, 1), []).append((p, st, gi))
+                    continue
                 st["step"] += 1
                 buckets.setdefault(int(st["step"].item()), []).append((p, st, gi))
         if not buckets:
@@ -89,5 +120,6 @@ class AdamW(torch.optim.Optimizer):
                     a.bias_correction1 = 1.0 - b1 ** step
                     a.bias_correction2_sqrt = math.sqrt(1.0 - b2 ** step)
                     a.skip_flag = self.skip_flag.data_ptr() if self.skip_flag is not None else None
+                    a.dyn = self._dyn.data_ptr() if self.capturable else None
                     L.check(L.lib().cara_adamw_step(C.byref(a), L.stream(dev)), "cara_adamw_step")
         return loss

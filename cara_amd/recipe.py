@@ -17,6 +17,8 @@ from typing import Callable, Iterable, Optional
 
 import torch
 
+from ._lib import CaraError
+
 
 class CosineLRScheduler:
     def __init__(self, optimizer, t_initial: int, lr_min: float = 0.0, warmup_t: int = 0, warmup_lr_init: float = 0.0,
@@ -98,9 +100,57 @@ def evaluate_only(model, path: str, test_batches: Iterable) -> float:
     return evaluate(model, test_batches)
 
 
+class GraphedTrainStep:
+    """``CaraEngine.train_step`` captured into a hipGraph and replayed (``cara_vit_forward`` / ``cara_vit_backward`` only enqueue
+    work on the caller's stream, include/cara_hip.h; the optimiser must be ``cara_amd.optim.AdamW(capturable=True)``: its step count
+    and learning rates live in device memory).  One graph per (batch shape, train / eval mode): the first call with a new key runs
+    eagerly (weights ingested, workspaces sized), the second captures, later ones copy the batch into the graph's input buffers,
+    upload { step, lr } and replay.  What a capture cannot hold runs eagerly, every time: more than one rank (the all-reduce) and the
+    exact weight-dropout mode (a fresh host-side seed per step).  Same switch as ``bench.py --graph``."""
+
+    def __init__(self, engine, optimizer):
+        if not getattr(optimizer, "capturable", False):
+            raise CaraError("GraphedTrainStep needs cara_amd.optim.AdamW(capturable=True)")
+        self.eng, self.opt = engine, optimizer
+        self._graphs = {}
+
+    def __call__(self, x, y, group=None):
+        from . import dist as cdist
+        eng, model = self.eng, self.eng._model()
+        self.opt.advance()
+        if cdist.world_size(group) > 1 or (eng.weight_dropout == "exact" and model.training):
+            return eng.train_step(x, y, self.opt, group=group)
+        key = (tuple(x.shape), bool(model.training), eng.precision)
+        ent = self._graphs.get(key)
+        if ent is None:
+            self._graphs[key] = "warm"
+            return eng.train_step(x, y, self.opt, group=group)
+        if ent == "warm":
+            xs, ys = x.clone(), y.clone()
+            torch.cuda.synchronize(x.device)
+            gr = torch.cuda.CUDAGraph()
+            gen = eng._device_generator(x.device)
+            if gen is not None:
+                gr.register_generator_state(gen)
+            side = torch.cuda.Stream(x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(gr, stream=side):
+                    loss = eng.train_step(xs, ys, self.opt, group=group)
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            ent = self._graphs[key] = (gr, xs, ys, loss)
+            # (the capture itself ran nothing: fall through to the replay, which is this call's step)
+        gr, xs, ys, loss = ent
+        xs.copy_(x)
+        ys.copy_(y)
+        gr.replay()
+        return loss
+
+
 def fit(model, train_batches: Callable[[int], Iterable], test_batches: Optional[Callable[[], Iterable]] = None,
         epochs: int = 100, lr: float = 1e-3, weight_decay: float = 1e-4, group=None, reference_eval_quirk: bool = True,
-        on_eval: Optional[Callable[[int, float], None]] = None, save_best: Optional[dict] = None, seed: Optional[int] = None):
+        on_eval: Optional[Callable[[int, float], None]] = None, save_best: Optional[dict] = None, seed: Optional[int] = None,
+        graph: bool = False):
     """``train_batches(epoch)`` yields (images, labels) already on the device (per-rank shard under
     data parallelism).  Returns (best accuracy, optimizer).
 
@@ -112,7 +162,9 @@ def fit(model, train_batches: Callable[[int], Iterable], test_batches: Optional[
     seeded with (``seed``, rank); ``seed = None`` derives it from ``torch.initial_seed()`` (what the reference's
     ``torch.manual_seed(args.seed)`` set, vit_cp.py:139-144), so runs with different global seeds stay uncorrelated.
     Single process: the masks come from torch's global generators, exactly as in the reference, unless a ``seed`` is
-    passed explicitly."""
+    passed explicitly.
+    ``graph = True``: the step is replayed from a hipGraph (``GraphedTrainStep``; the host then issues one launch per step
+    instead of ~600: for boxes where several ranks share few cores).  Eager is the default: the step is GPU-bound."""
     from . import dist as cdist
     model.train()
     params = trainable_parameters(model)
@@ -125,13 +177,17 @@ def fit(model, train_batches: Callable[[int], Iterable], test_batches: Optional[
         seed = int(torch.initial_seed() % (1 << 31))   # (only names the checkpoint file below, like args.seed in vit_cp.py:65)
     # vit_cp.py:185's torch.optim.AdamW, as one HIP launch over the 14 trainable tensors (cara_amd/optim.py: same arithmetic)
     from .optim import AdamW
-    opt = AdamW(params, lr=lr, weight_decay=weight_decay)
+    opt = AdamW(params, lr=lr, weight_decay=weight_decay, capturable=graph)
     sched = CosineLRScheduler(opt, t_initial=100, warmup_t=10, lr_min=1e-5, warmup_lr_init=1e-6, decay_rate=0.1)
     eng = model._cara_engine
+    gstep = GraphedTrainStep(eng, opt) if graph else None
     best = 0.0
     for epoch in range(epochs):
         for x, y in train_batches(epoch):
-            eng.train_step(x, y, opt, group=group)
+            if gstep is not None:
+                gstep(x, y, group=group)
+            else:
+                eng.train_step(x, y, opt, group=group)
             if sched is not None:
                 sched.step(epoch)
         if epoch % 10 == 0 and epoch != 0:

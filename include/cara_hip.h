@@ -409,6 +409,11 @@ typedef struct {
   /* device float or NULL: when *skip_flag != 0 the launch changes nothing (a step whose gradients overflowed under the
    * loss scale of the IEEE-half build: cara_vit_shape::found_inf, all-reduced with the gradients)                     */
   const float* skip_flag;
+  /* device float[1 + CARA_ADAMW_MAX_GROUPS] or NULL: { step count t, lr of group 0, 1, ... }.  When given, the kernel takes the
+   * learning rates from it and computes both bias corrections from t itself (`step`, `lr`, `bias_correction*` above are ignored):
+   * nothing that changes from step to step travels in the launch arguments, so a launch captured into a hipGraph stays correct
+   * under replay -- the host rewrites the five floats (stream-ordered) before each replay.                                     */
+  const float* dyn;
 } cara_adamw_args;
 int cara_adamw_step(const cara_adamw_args* a, void* stream);
 /* Dynamic loss scale of the IEEE-half operand build, entirely on the device (no host synchronisation anywhere in a step).

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the library's test hooks (cara_debug_set_gemm8*: process-global switches) are inert unless the process opts in
+os.environ.setdefault("CARA_ALLOW_DEBUG_SETTERS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

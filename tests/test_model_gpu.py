@@ -484,17 +484,20 @@ def test_drop_path_masks_and_train_mode():
     assert all(torch.isfinite(getattr(m, n).grad).all() for n in O.CP_NAMES)
 
 
-def test_module_level_forwards_against_reference_vectors():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_module_level_forwards_against_reference_vectors(precision):
     """The reference's patched Attention.forward / Mlp.forward (cara.py:15-60, :63-95) called on
     their own: golden case 2 of make_golden.py (block 5 of a depth-12 model, rank 8, x [2,7,768]) --
     outputs recorded from the reference's own modules; gradients against fp64 autograd of the
-    oracle's as-written restatement."""
+    oracle's as-written restatement.  Both operand builds (fp16: the per-op entry points of libcara_hip_f16.so, no loss scale on
+    this path -- the gradient arriving from autograd is the caller's to scale, as with any fp16 module under torch.amp)."""
     from oracle import cara_oracle as O
     from tests.golden.inputs import oracle_case
     R, Lb, sb, sc, sx, sg = G["mod_cfg"].tolist()
     S = float(G["mod_scale"][0])
     w, cp = oracle_case(sg, sb, sc, R, 12, 32)
-    m = build(w, cp, R, S, 12, 32).eval()
+    m = build(w, cp, R, S, 12, 32, precision=precision).eval()
+    bar_y, bar_gx, bar_gp = (1.5e-3, 3e-3, 5e-3) if precision == "fp16" else (1e-2, 2e-2, 3e-2)
     x = torch.randn(2, 7, 768, generator=torch.Generator().manual_seed(sx))
     blk = m.blocks[Lb]
     a_idx, a_aidx, m_idx = O.block_indices(12)[Lb]
@@ -508,8 +511,8 @@ def test_module_level_forwards_against_reference_vectors():
         y = mod(xd)
         ref = torch.from_numpy(G[key])
         r = rel(y, ref)
-        print(f"module {kind}: rel-L2 vs reference output {r:.2e}")
-        assert r < 1e-2, (kind, r)
+        print(f"module {kind} [{precision}]: rel-L2 vs reference output {r:.2e}")
+        assert r < bar_y, (kind, r)
         gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7))
         y.backward(gy.to(DEV))
         cpv = {k: d(v).clone().requires_grad_(True) for k, v in cp.items()}
@@ -523,9 +526,9 @@ def test_module_level_forwards_against_reference_vectors():
                                   d(w[p + "mlp.fc2.bias"]), idx=m_idx, s=S)
             touched = ("CP_P1", "CP_P2", "CP_P3", "CP_R2", "CP_bias2", "CP_bias3")
         yr.backward(d(gy))
-        assert rel(xd.grad, xr.grad) < 2e-2, (kind, rel(xd.grad, xr.grad))
+        assert rel(xd.grad, xr.grad) < bar_gx, (kind, rel(xd.grad, xr.grad))
         for n in touched:
-            assert rel(getattr(m, n).grad, cpv[n].grad) < 3e-2, (kind, n, rel(getattr(m, n).grad, cpv[n].grad))
+            assert rel(getattr(m, n).grad, cpv[n].grad) < bar_gp, (kind, n, rel(getattr(m, n).grad, cpv[n].grad))
 
 
 def test_blockwise_path_equals_fused_path():
@@ -898,6 +901,8 @@ def test_bench_two_ranks_rehearsal(tmp_path):
         assert k in d, k
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
     assert d["value"] > 0 and "cpu_baseline" not in d          # the CPU baseline is a rank-0, N = 1 leg
+    pm = d["precision_matched"]                                  # the fp16 (1e-3) build, timed the same way on every rank
+    assert pm["dtype"] == "fp16" and pm["value"] > 0 and pm["roofline"]["bound"] == "mfma" and pm["steps_skipped_for_overflow"] == 0, pm
 
 
 def test_bench_two_gpus_over_rccl_when_the_box_has_them():
@@ -1195,8 +1200,7 @@ def test_fp16_precision_refuses_what_it_does_not_run():
     cp = O.synthetic_cp(rank=8, depth=1)
     m = build(w, cp, 8, 0.1, 1, 224).eval()
     m._cara_engine.precision = "fp16"
-    with pytest.raises(CaraError):
-        m.blocks[0].attn(torch.zeros(1, 197, 768, device=DEV))          # module-level entries: whole-model mode only
+    assert torch.isfinite(m.blocks[0].attn(torch.zeros(1, 197, 768, device=DEV))).all()   # (module-level entries run in fp16 since r05)
     m._cara_engine.weight_dropout = "exact"
     with pytest.raises(CaraError):
         m.train()(torch.zeros(1, 3, 224, 224, device=DEV))
@@ -1330,3 +1334,50 @@ def test_fp16_overflow_skips_the_step_and_backs_the_scale_off():
     _, _, gref = O.train_step_as_written(x, y, w, cps, head, s=0.1, depth=depth, drop_path_keep=keep.cpu())
     worst = max(rel(getattr(m, n).grad, gref[n]) for n in O.CP_NAMES)
     assert worst < 0.2 * T.CP_GRAD, worst
+
+
+def test_graphed_train_step_follows_the_eager_one():
+    """bench.py --graph / recipe.fit(graph=True): the whole step -- forward, cross-entropy, backward, AdamW with its step count and
+    learning rate in device memory -- replayed from a hipGraph.  Five steps with a learning rate that changes every step and batches
+    that alternate: (i) replayed vs the SAME capturable optimiser issued eagerly: bitwise (losses and every CP tensor) -- the capture
+    changes nothing; (ii) the capturable optimiser vs the ordinary one: its bias corrections are fp32 powf in the kernel instead of
+    the host's doubles, which moves parameters by one ulp per step -- and a bf16 pipeline answers a one-ulp change of every parameter
+    with ~1e-5 of the loss and ~1e-3 of the gradients (measured: tools, r05), so that comparison is held to 1e-3 / 3e-4.  In bf16
+    and -- with the loss-scale kernels in the graph -- in fp16; fit(graph=True) runs end to end."""
+    from oracle import cara_oracle as O
+    from cara_amd.optim import AdamW
+    from cara_amd.recipe import GraphedTrainStep, fit
+    depth, B = 2, 4
+    w = O.synthetic_backbone(depth=depth)
+    cp = O.synthetic_cp(rank=16, depth=depth)
+    xa, ya = O.synthetic_batch(batch=B)
+    xb, yb = O.synthetic_batch(batch=B, seed_x=5, seed_y=6)
+    batches = [(xa.to(DEV), ya.to(DEV)), (xb.to(DEV), yb.to(DEV))]
+    for precision in PRECISIONS:
+        out = {}
+        for mode in ("eager", "capturable", "graph"):
+            m = build(w, cp, 16, 0.1, depth, 224, drop_path_rate=0.0, precision=precision).train()
+            eng = m._cara_engine
+            opt = AdamW(eng.trainable_parameters(), lr=1e-3, weight_decay=1e-4, capturable=(mode != "eager"))
+            gstep = GraphedTrainStep(eng, opt) if mode == "graph" else None
+            losses = []
+            for it in range(5):
+                opt.param_groups[0]["lr"] = 1e-3 * (0.7 ** it)
+                x, y = batches[it % 2]
+                if mode == "graph":
+                    loss = gstep(x, y)
+                else:
+                    if mode == "capturable":
+                        opt.advance()
+                    loss = eng.train_step(x, y, opt)
+                losses.append(loss.item())
+            out[mode] = (losses, {n: getattr(m, n).detach().clone() for n in O.CP_NAMES})
+        assert out["graph"][0] == out["capturable"][0], (precision, out["graph"][0], out["capturable"][0])
+        assert all(torch.equal(out["graph"][1][n], out["capturable"][1][n]) for n in O.CP_NAMES), precision
+        assert np.allclose(out["eager"][0], out["graph"][0], rtol=1e-3), (precision, out["eager"][0], out["graph"][0])
+        for n in O.CP_NAMES:
+            assert rel(out["graph"][1][n], out["eager"][1][n]) < 3e-4, (precision, n)
+        assert out["eager"][0][-1] < out["eager"][0][0]
+    m = build(w, cp, 16, 0.1, depth, 224).train()
+    best, _ = fit(m, lambda epoch: batches, lambda: batches[:1], epochs=11, lr=1e-2, graph=True)
+    assert 0.0 <= best <= 1.0 and not m.training      # (evaluated at epoch 10; the eval mode sticks and the graph was re-captured for it)

@@ -8,7 +8,7 @@ run() { tag=$1; n=$2; shift 2
   timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" -d gpurun_out/pmc_er/${tag}_$n --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-info-legs > gpurun_out/pmc_er/${tag}_$n.log 2>&1 || echo "pass $tag $n failed"
 }
 for tag in on off; do
-  if [ $tag = off ]; then export CARA_EPI_RIDERS=0; else unset CARA_EPI_RIDERS; fi
+  if [ $tag = off ]; then export CARA_EPI_RIDERS=0; else export CARA_EPI_RIDERS=1; fi   # (the default is 0 since r04: the 'on' arm must say so)
   run $tag p1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES
   run $tag p2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS
   run $tag p3 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC
