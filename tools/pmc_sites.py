@@ -31,7 +31,7 @@ SITES = {
     "proj_bwd": ("gemm32_ts_kernel<0, true", lambda r, w: 20 * MB < r <= 150 * MB),
     "qkv_bwd": [("gemm8_ts_kernel<", lambda r, w: w > 10 * MB), ("gemm32ft_ts_kernel<0, 1, false", lambda r, w: w > 10 * MB),
                 ("gemm32_ts_kernel<0, false", lambda r, w: w > 10 * MB)],
-    "attn_fwd": ("attn_fwd_persist_kernel", lambda r, w: True),
+    "attn_fwd": [("attn_fwd_p2_kernel", lambda r, w: True), ("attn_fwd_persist_kernel", lambda r, w: True)],
     "attn_bwd": ("attn_bwd_fused_kernel", lambda r, w: True),
     "ln_fwd": ("ln_fwd_kernelILi3ELb1", lambda r, w: w > 15 * MB),
     "ln_bwd": ("ln_bwd_kernelILi3ELb1", lambda r, w: w > 40 * MB),
