@@ -248,18 +248,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_long_kernel(const bf16* _
   stage_rows_swz(vb, ld, N, Vs, tid, NW * 64, npad);
   __syncthreads();
 
-  const int q0 = (blockIdx.y * NW + wave) * 32;
-  if (q0 >= N) return;
   const int ql = lane & 31, h = lane >> 5;
-  const int qrow = (q0 + ql) < N ? (q0 + ql) : N - 1;
-  bf16x8 qf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qb + (size_t)qrow * ld + ks * 16 + h * 8);
   const int nkt = npad >> 5;
   const float c2 = scale * 1.4426950408889634f;
   const RowOfs ro = row_ofs(lane);
   const TrOfs to = tr_ofs(lane);
   const int last_keys = N - (nkt - 1) * 32;   // valid keys of the last tile (only that tile needs a mask)
+  // r05: the workgroup walks the query groups of its head (group = NW x 32 queries; gridDim.y = 1 since r05) instead of one group
+  // per workgroup: K / V are staged ONCE per head -- at 577 tokens three workgroups per head each staged all 148 KB, six rounds of
+  // workgroups on the chip, 56 % of the wave-cycles waiting (profiles/r05_pmc_attn.txt).  No barrier inside the loop.
+  for (int qg = blockIdx.y;; qg += gridDim.y) {
+  const int q0 = (qg * NW + wave) * 32;
+  if (q0 >= N) break;
+  const int qrow = (q0 + ql) < N ? (q0 + ql) : N - 1;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qb + (size_t)qrow * ld + ks * 16 + h * 8);
 
   auto score_tile = [&](int kt) {
     f32x16 t;
@@ -324,6 +328,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_long_kernel(const bf16* _
     }
   }
   if (h == 0 && q0 + ql < N) lse[(size_t)bh * N + q0 + ql] = mx * scale + __logf(sum);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -908,10 +913,12 @@ __global__ __launch_bounds__(448, 2) void attn_bwd_dkv_kernel(const bf16* __rest
   }
   __syncthreads();
 
-  const int key0 = (blockIdx.y * BWD_WAVES + wave) * 32;
-  if (key0 >= N) return;
   const int kl = lane & 31, h = lane >> 5;
   const float c2 = scale * 1.4426950408889634f;
+  // r05: the workgroup walks the key groups of its head (gridDim.y = 1): Q / dO / delta are staged once per head, not once per group
+  for (int kg = blockIdx.y;; kg += gridDim.y) {
+  const int key0 = (kg * BWD_WAVES + wave) * 32;
+  if (key0 >= N) break;
   const int key = key0 + kl;
   const int keyc = key < N ? key : N - 1;
   const bool kvalid = key < N;
@@ -991,6 +998,7 @@ __global__ __launch_bounds__(448, 2) void attn_bwd_dkv_kernel(const bf16* __rest
         *reinterpret_cast<bf16x4*>(dv + d) = c;
       }
   }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1020,9 +1028,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16* __r
   stage_rows_swz(vb, ld, N, Vs, tid, NW * 64, npad);
   __syncthreads();
 
-  const int q0 = (blockIdx.y * NW + wave) * 32;
-  if (q0 >= N) return;
   const int ql = lane & 31, h = lane >> 5;
+  // r05: the workgroup walks the query groups of its head (gridDim.y = 1): K / V are staged once per head
+  for (int qg = blockIdx.y;; qg += gridDim.y) {
+  const int q0 = (qg * NW + wave) * 32;
+  if (q0 >= N) break;
   const int qrow = (q0 + ql) < N ? (q0 + ql) : N - 1;
   bf16x8 qf[4], dof[4];
   float dl = 0.f;
@@ -1107,6 +1117,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16* __r
         *reinterpret_cast<uint4*>(qrow_out + dt * 32 + 8 * (g + 2 * h)) = v;
       }
     }
+  }
   }
 }
 
@@ -1769,8 +1780,8 @@ extern "C" int cara_attention_fwd(const void* qkv, void* out, float* lse, int B,
     else
       hipLaunchKernelGGL(attn_fwd_p2_kernel<5>, dim3(grid), dim3(PF_WAVES * 64), plds, st, (const bf16*)qkv, (bf16*)out, lse, N, H, BH, scale);
   } else if (N > NMAX || (use_long && N > 128))
-    hipLaunchKernelGGL(attn_fwd_long_kernel<7>, dim3(B * H, (N + 223) / 224), dim3(448), lds, st, (const bf16*)qkv, (bf16*)out, lse, N,
-                       H, scale, npad);
+    hipLaunchKernelGGL(attn_fwd_long_kernel<7>, dim3(B * H, 1), dim3(448), lds, st, (const bf16*)qkv, (bf16*)out, lse, N,
+                       H, scale, npad);   // (the workgroup walks its head's query groups: K / V staged once per head)
   else if (attn_waves(N) == 7)
     hipLaunchKernelGGL(attn_fwd_kernel<7>, dim3(B * H, (N + 223) / 224), dim3(448), lds, st, (const bf16*)qkv, (bf16*)out, lse, N, H,
                        scale, npad);
@@ -1795,11 +1806,11 @@ extern "C" int cara_attention_bwd(const void* qkv, const void* out, const void* 
     CARA_CHECK_LAUNCH();
     return CARA_OK;
   }
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H, (N + 223) / 224), dim3(448), dkv_lds_bytes(npad), st, (const bf16*)qkv,
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H, 1), dim3(448), dkv_lds_bytes(npad), st, (const bf16*)qkv,
                      (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale, npad);
   CARA_CHECK_LAUNCH();
   if (N > NMAX || attn_waves(N) == 7)
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<7>, dim3(B * H, (N + 223) / 224), dim3(448), lds, st, (const bf16*)qkv,
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<7>, dim3(B * H, 1), dim3(448), lds, st, (const bf16*)qkv,
                        (const bf16*)out, (const bf16*)dout, lse, (bf16*)dqkv, N, H, scale, npad);
   else
     hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, dim3(B * H, (N + 127) / 128), dim3(256), lds, st, (const bf16*)qkv,
