@@ -1140,6 +1140,7 @@ __device__ __forceinline__ void glds4_hidden(const char* base, unsigned voff, un
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory", "m0");
 }
 
+template <bool TWO_BARRIERS>
 __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                                 const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                                 bf16* __restrict__ dqkv, int N, int H, int BH, float scale) {
@@ -1196,8 +1197,13 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
     off_lse[t] = (unsigned)((i < N ? i : N - 1) * 4);
   }
   auto dma_lse = [&](int bh_) {
-    if (wave == 0) {
-      const char* base = reinterpret_cast<const char*>(lse + (size_t)bh_ * N);
+    const char* base = reinterpret_cast<const char*>(lse + (size_t)bh_ * N);
+    if constexpr (TWO_BARRIERS) {
+      // piece w by wave w (w < 4): the wave that scales entries 64 w .. 64 w + 63 in the delta step is the wave whose own wait covers them
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (wave == t && t * 64 < NPAD) glds4_hidden(base, off_lse[t], lds_of(reinterpret_cast<const char*>(lse_s)) + (unsigned)(t * 256));
+    } else if (wave == 0) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         if (t * 64 < NPAD) glds4_hidden(base, off_lse[t], lds_of(reinterpret_cast<const char*>(lse_s)) + (unsigned)(t * 256));
@@ -1236,10 +1242,16 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
     ATTN_STAMP(0);
     // T0: every wave is through with phase B of the previous head (K, V images free) and has seen its own pieces of this
     // head's Q, dO, O images land
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // TWO_BARRIERS (r05): no barrier here.  Each wave forms delta for the rows of ITS OWN DMA pieces (pieces w, w + 7, w + 14, w + 21 of
+    // the O / dO images: 32 rows, two lanes per row) and scales the 64 entries of its own LSE piece: everything it reads has landed
+    // behind its own wait at the end of the previous head's dQ sweep; nobody still reads lse_s / del_s of the previous head (their
+    // last reads sit in front of its T3).  T1 below then publishes delta / lse AND stands for "every wave's pieces have landed, every
+    // wave is through with the previous head".
+    if constexpr (TWO_BARRIERS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // delta[row] = sum_d dO[row][d] O[row][d] from the images, two threads per row (4 chunks of 8 each); lse in log2 units
     {
-      const int row = tid >> 1, half = tid & 1;
+      const int row = TWO_BARRIERS ? (wave + 7 * (lane >> 4)) * 8 + ((lane >> 1) & 7) : tid >> 1, half = tid & 1;
       float dl = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -1324,7 +1336,12 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
     ATTN_STAMP(2);
     // T2: this wave's pieces of K, V have landed (they are old by now); then every wave's
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // TWO_BARRIERS: no barrier here either -- the staging below is this wave's own 4 KiB of the O image (read by everybody in the
+    // delta step only, a barrier ago), the row reads behind it are of the Q / dO images; T3 then also stands for "every wave's K / V
+    // pieces have landed" (each wave passed the wait above first).  A wave that is through with its sweep stores while the others
+    // still sweep instead of waiting for them twice.
+    if constexpr (TWO_BARRIERS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     ATTN_STAMP(3);
     // dK, dV of this wave's 32 keys leave as WHOLE 128-byte rows: the accumulators hold them transposed (key on the lane, a
@@ -1742,7 +1759,8 @@ static void attn_set_lds_limits() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_p2_kernel<6>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_p2_kernel<7>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), at, MAX_LDS);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel), at, MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<false>), at, MAX_LDS);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<true>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<4>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<7>), at, MAX_LDS);
   done = true;
@@ -1801,8 +1819,14 @@ extern "C" int cara_attention_bwd(const void* qkv, const void* out, const void* 
   static const int use_fused = [] { const char* e = getenv("CARA_ATTN_PERSIST"); return e ? atoi(e) : 1; }();
   if (use_fused && N > 128 && N <= NMAX) {
     const int BH = B * H, grid = BH < 256 ? BH : 256;
-    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(grid), dim3(448), 5 * 224 * 128 + (256 + 224) * 4, st, (const bf16*)qkv, (const bf16*)out,
-                       (const bf16*)dout, lse, (bf16*)dqkv, N, H, BH, scale);
+    // CARA_ATTN_BWD_V=1: the four-barrier protocol of round 3 for A/B runs; default (r05): two barriers per head
+    static const int bwd_v = [] { const char* e = getenv("CARA_ATTN_BWD_V"); return e ? atoi(e) : 2; }();
+    if (bwd_v == 1)
+      hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, dim3(grid), dim3(448), 5 * 224 * 128 + (256 + 224) * 4, st, (const bf16*)qkv, (const bf16*)out,
+                         (const bf16*)dout, lse, (bf16*)dqkv, N, H, BH, scale);
+    else
+      hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, dim3(grid), dim3(448), 5 * 224 * 128 + (256 + 224) * 4, st, (const bf16*)qkv, (const bf16*)out,
+                         (const bf16*)dout, lse, (bf16*)dqkv, N, H, BH, scale);
     CARA_CHECK_LAUNCH();
     return CARA_OK;
   }

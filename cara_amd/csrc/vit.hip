@@ -791,8 +791,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 // Final LayerNorm of one cls row + the classifier head in fp32 (cara_head_forward): workgroup (class chunk of HEAD_CHUNK, sample).
 // Every workgroup normalises its sample's row itself (D floats: cheaper than a launch boundary); chunk 0 also writes the
 // 16-bit xn row and mean / rstd for the backward.  The dot products run one class per wave and step over the row in float4
-// pieces (a wave instruction reads 1 KiB of a head_w row), two classes in flight per wave.
-constexpr int HEAD_CHUNK = 128;
+// pieces (a wave instruction reads 1 KiB of a head_w row), two classes in flight per wave.  A chunk is 16 classes = two rounds of
+// the four waves: with 128 (64 workgroups for 64 x 100 logits, 13 dependent rounds each) the launch took 29 us (profiles/r05_g_*).
+constexpr int HEAD_CHUNK = 16;
 __global__ __launch_bounds__(256) void head_fwd_f32_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ Wh,
                                                            const float* __restrict__ bh, bf16* __restrict__ xn16,

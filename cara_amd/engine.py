@@ -92,6 +92,7 @@ class CaraEngine:
     # host-side check of the word instead (one synchronisation per step, fp16 only).
     FP16_LOSS_SCALE = 1024.0
     AMP_GROWTH, AMP_BACKOFF, AMP_GROWTH_INTERVAL, AMP_MAX_SCALE = 2.0, 0.5, 2000, 65536.0
+    DROPPATH_AHEAD = 32   # steps of DropPath masks per draw (draw_droppath)
 
     def _amp(self, dev):
         """device float[4] = {loss scale, clean steps since the last change, steps skipped so far, unused} (fp16 only)"""
@@ -295,6 +296,7 @@ class CaraEngine:
         Parameters are not touched (replicas stay identical); only the per-step masks differ between ranks."""
         self._gen_seed = int(seed) * (1 << 20) + int(rank)
         self._gen_dev = None
+        self._dp_buf = None      # (masks drawn ahead from the previous stream are dropped)
         self._gen_cpu = torch.Generator().manual_seed(self._gen_seed)
 
     @staticmethod
@@ -336,7 +338,21 @@ class CaraEngine:
             self._keep = 1.0 - torch.tensor(rates, device=dev).reshape(-1, 1, 1)
             self._keep_key = key
         keep = self._keep
-        return ((keep + torch.rand(len(rates), 2, B, device=dev, generator=self._device_generator(dev))).floor_() / keep).contiguous()
+        gen = self._device_generator(dev)
+        if dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            # (inside a hipGraph capture the draw must be a node of the graph; on the CPU there is nothing to amortise)
+            return ((keep + torch.rand(len(rates), 2, B, device=dev, generator=gen)).floor_() / keep).contiguous()
+        # DROPPATH_AHEAD steps' masks per draw: the four small torch launches of a draw (rand, add, floor, div: ~5 us each, serial
+        # between the optimiser and the next forward) are paid once per DROPPATH_AHEAD steps instead of every step (r05).  Same
+        # generator, same distribution; a step takes the next [depth, 2, B] slice (contiguous: no kernel).
+        bkey = (key, B, id(gen))
+        buf = self.__dict__.get("_dp_buf")
+        if buf is None or self._dp_key != bkey or self._dp_next >= buf.shape[0]:
+            buf = (keep + torch.rand(self.DROPPATH_AHEAD, len(rates), 2, B, device=dev, generator=gen)).floor_() / keep
+            self._dp_buf, self._dp_key, self._dp_next = buf, bkey, 0
+        out = buf[self._dp_next]
+        self._dp_next += 1
+        return out
 
     def forward(self, images, droppath: Optional[torch.Tensor] = None):
         model = self._model()
