@@ -53,6 +53,18 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
   return o;
 }
 
+// Two score elements per vector instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process a register PAIR at the rate of one
+// scalar-operand instruction; v_exp_f32 has no packed form).  Written out with two-element vectors on ALIGNED pairs (registers 2i,
+// 2i + 1 of an accumulator): left to itself hipcc paired the multiplies of the backward's dS one register off and then moved the
+// packed halves back into place with v_mov / v_alignbit / v_perm -- 90 vector instructions per 32 x 32 tile where 48 do (r05).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+__device__ __forceinline__ unsigned pk16(const f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+__device__ __forceinline__ f32x2 exp2_2(const f32x2 a) { return f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
+__device__ __forceinline__ bf16x8 dwords8(const unsigned (&w)[8], const int s) {   // = pack8 of the converted values: elements 8 s .. 8 s + 7
+  const u32x4_ v = {w[4 * s], w[4 * s + 1], w[4 * s + 2], w[4 * s + 3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 // B/A fragment whose k axis runs over image ROWS: element j of lane (c = lane & 31, h = lane >> 5) is
 // img[base + 8*(j>>2) + 4h + (j&3)][cbase + c] -- the k order in which the 32x32x16 accumulator of a
 // previous product is consumed as an operand (register 8s+j of lane half h = row 16s + 8(j>>2) + 4h
@@ -790,6 +802,8 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_p2_kernel(const bf1
     ATTN_STAMP(3);
     // ---------------- P V, the exponentials of tile kt + 1 between the MFMAs of tile kt ----------------
     float sum0 = 0.f, sum1 = 0.f, sum2 = 0.f, sum3 = 0.f;
+    // (scalar on purpose: the packed form -- v_pk_fma_f32 / v_pk_add_f32 on register pairs, 12 % fewer vector instructions -- measured
+    // SLOWER here, 20.4 -> 20.8 us alone and 16.9 -> 17.7 in the step: profiles/r05_n_packed_vector_math_in_attention.txt)
     auto exp4 = [&](f32x16& t, const int g) {   // registers 4g .. 4g+3 of a tile: p = exp2(s c2 - mx c2), into four partial sums
       t[4 * g] = __builtin_amdgcn_exp2f(__builtin_fmaf(t[4 * g], c2, -mxc));
       t[4 * g + 1] = __builtin_amdgcn_exp2f(__builtin_fmaf(t[4 * g + 1], c2, -mxc));
@@ -1259,7 +1273,7 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(Os + off);
         const bf16x8 g = *reinterpret_cast<const bf16x8*>(dOs + off);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dl += (float)a[j] * (float)g[j];
+        for (int j = 0; j < 8; j += 2) dl = dot2_acc(bf16x2{a[j], a[j + 1]}, bf16x2{g[j], g[j + 1]}, dl);   // (one instruction per pair, not six)
       }
       dl += __shfl_xor(dl, 1, 64);
       // Row constants in the form the S and dP accumulators are SEEDED with (phase A reads them straight into the
@@ -1314,16 +1328,19 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
       // (a lane whose key is padding -- t0 + l31 >= N, its K / V rows duplicates of row N - 1 -- carries finite values
       // that only ever reach its OWN columns of dK^T / dV^T, which are not stored; a padded QUERY row has p = 0 through its
       // seed: no select per element)
-      f32x16 p, ds;
+      unsigned pw[8], dw[8];   // p = exp2(c2 S'), dS = p dP', as packed pairs
+      {
+        const f32x2 c22 = {c2, c2};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(sacc[r] * c2);
-        p[r] = e;
-        ds[r] = e * pacc[r];
+        for (int i = 0; i < 8; ++i) {
+          const f32x2 e = exp2_2(f32x2{sacc[2 * i], sacc[2 * i + 1]} * c22);
+          pw[i] = pk16(e);
+          dw[i] = pk16(e * f32x2{pacc[2 * i], pacc[2 * i + 1]});
+        }
       }
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        const bf16x8 pb = pack8(p, st), dsb = pack8(ds, st);
+        const bf16x8 pb = dwords8(pw, st), dsb = dwords8(dw, st);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const bf16x8 doa = tr_frag_at(dblk, to.lo[st][dt], to.hi[st][dt]);
@@ -1434,15 +1451,18 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
         sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], sT, 0, 0, 0);
         dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dpT, 0, 0, 0);
       }
-      f32x16 ds;
+      unsigned dw[8];   // dS^T = exp2(c2 S^T + lq) (dP^T + dl), as packed pairs
+      {
+        const f32x2 c22 = {c2, c2}, lq2 = {lq, lq}, dl2 = {dl, dl};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(sT[r] * c2 + lq);
-        ds[r] = e * (dpT[r] + dl);
+        for (int i = 0; i < 8; ++i) {
+          const f32x2 e = exp2_2(__builtin_elementwise_fma(f32x2{sT[2 * i], sT[2 * i + 1]}, c22, lq2));
+          dw[i] = pk16(e * (f32x2{dpT[2 * i], dpT[2 * i + 1]} + dl2));
+        }
       }
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        const bf16x8 a = pack8(ds, st);
+        const bf16x8 a = dwords8(dw, st);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const bf16x8 kfr = tr_frag_at(kblk, to.lo[st][dt], to.hi[st][dt]);

@@ -45,6 +45,15 @@ __device__ __forceinline__ unsigned cvt_pk_dword(float a, float b) {
   return u;
 }
 
+// a[0] b[0] + a[1] b[1] + c in fp32, one instruction (v_dot2c_f32_bf16 / v_dot2_f32_f16): row dot products of 16-bit images
+__device__ __forceinline__ float dot2_acc(const bf16x2 a, const bf16x2 b, const float c) {
+#ifdef CARA_F16_OPERANDS
+  return __builtin_amdgcn_fdot2(a, b, c, false);
+#else
+  return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false);
+#endif
+}
+
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 

@@ -3,6 +3,8 @@
 // (/root/reference/src/cara/cara.py:26-34,51-56,76-80,88-91) collapses, in factored form, to
 // building per layer  U [in,Rp]  and  Vs = s * g (.) V [out,Rp]   and, in
 // backward, to scattering dU / dVs / dc back onto the 12 shared tensors (A.4).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void prep_bias_kernel(PackDims g, cara_cp cp, 
 // a fixed order (bitwise reproducible, no float atomics).  As five back-to-back launches of 36..144 blocks whose
 // threads walked 96..150 rows each, the same arithmetic took 210 us per step -- all of it latency.
 //   scratch: pa3 [3L][H][R], pa4 [3L][hd][R], zvp [L][GS_SPLIT][R], zp [12L][GS_SPLIT][R]
-constexpr int GS_SPLIT = 4;
+constexpr int GS_SPLIT = 8;   // (r05: 4 -> 8, six rows per thread of the column reductions instead of twelve)
 struct GradScratch {
   float *pa3, *pa4, *zvp, *zp;
 };
@@ -160,16 +162,25 @@ __host__ __device__ inline GradScratch grad_scratch(float* sc, int L, int H, int
   return g;
 }
 
-// (a) outputs indexed (j, r) that sum over layers: dA2, dP3, dP2, bias grads
+// (a) outputs indexed (j, r) that sum over layers: dA2, dP3, dP2, bias grads.  A block = 64 outputs x FOUR layer groups (a thread
+// walks depth / 4 layers: one batch of independent loads instead of a chain of twelve layers' -- the range was 15 us of the launch);
+// the four partial sums meet in LDS and are added in a fixed order.
+constexpr int ROW_E = 64;
 __device__ __forceinline__ void grad_rowwise(const PackDims& g, const cara_cp& cp, const cara_layer_grads& lg, const cara_cp& out,
-                                             const int e) {
+                                             const int blk, float (*red)[4][ROW_E]) {
   const int R = g.rank, Rp = g.Rp, dim = g.dim, L = g.depth;
   const GOut W = gout_of(g);
+  const int el = threadIdx.x % ROW_E, grp = threadIdx.x / ROW_E;     // grp 0 .. 3
+  const int e = blk * ROW_E + el;
+  const int l0 = L * grp / 4, l1 = L * (grp + 1) / 4;
+  float a2 = 0.f, p3 = 0.f, p2 = 0.f, a3o = 0.f;
+  int r = 0;
   if (e < dim * R) {
-    const int j = e / R, r = e - j * R;
-    float a2 = 0.f, p3 = 0.f, p2 = 0.f, a3o = 0.f;
+    const int j = e / R;
+    r = e - j * R;
     const float sr2 = g.s * cp.R2[r];
-    for (int l = 0; l < L; ++l) {
+#pragma unroll 3
+    for (int l = l0; l < l1; ++l) {
       if (g.cpl != 2) a2 += lg.dU_qkv[((size_t)l * dim + j) * Rp + r];
       if (g.cpl == 3)   // order 3: the out factor A3 [dim, R] is a plain row-wise sum over blocks and projections
         for (int k = 0; k < 3; ++k) a3o += cp.A1[(3 * l + k) * R + r] * lg.dVs_qkv[((size_t)l * 3 * dim + k * dim + j) * Rp + r];
@@ -181,24 +192,34 @@ __device__ __forceinline__ void grad_rowwise(const PackDims& g, const cara_cp& c
         p2 += cp.P1[(9 * l + 5 + a) * R + r] * lg.dU_fc2[((size_t)l * 4 * dim + a * dim + j) * Rp + r];
       }
     }
-    if (g.cpl != 2) (g.cpl == 5 ? out.A3 : out.A2)[e] = W(a2);   // gradient of the in factor (order 2: cara_dense_delta_grad)
-    if (g.cpl == 3) out.A3[e] = W(g.s * cp.R1[r] * a3o);
-    out.P3[e] = W(p3);
-    out.P2[e] = W(p2);
   }
-  if (e < 4 * dim) {
-    float b = 0.f;
-    for (int l = 0; l < L; ++l) b += lg.dc_fc1[(size_t)l * 4 * dim + e];
-    out.bias2[e] = W(g.s * b);
-  }
-  if (e < dim) {
-    float b1 = 0.f, b3 = 0.f;
-    for (int l = 0; l < L; ++l) {
+  float b2 = 0.f, b1 = 0.f, b3 = 0.f;
+  if (e < 4 * dim)
+    for (int l = l0; l < l1; ++l) b2 += lg.dc_fc1[(size_t)l * 4 * dim + e];
+  if (e < dim)
+    for (int l = l0; l < l1; ++l) {
       b1 += lg.dc_proj[(size_t)l * dim + e];
       b3 += lg.dc_fc2[(size_t)l * dim + e];
     }
-    out.bias1[e] = W(g.s * b1);
-    out.bias3[e] = W(g.s * b3);
+  auto total = [&](const float v, const int slot) {   // (block-uniform call sequence: every thread takes part in every barrier)
+    __syncthreads();
+    red[slot & 3][grp][el] = v;
+    __syncthreads();
+    return (red[slot & 3][0][el] + red[slot & 3][1][el]) + (red[slot & 3][2][el] + red[slot & 3][3][el]);
+  };
+  const float ta2 = total(a2, 0), tp3 = total(p3, 1), tp2 = total(p2, 2), ta3 = total(a3o, 3);
+  const float tb2 = total(b2, 0), tb1 = total(b1, 1), tb3 = total(b3, 2);
+  if (grp != 0) return;
+  if (e < dim * R) {
+    if (g.cpl != 2) (g.cpl == 5 ? out.A3 : out.A2)[e] = W(ta2);   // gradient of the in factor (order 2: cara_dense_delta_grad)
+    if (g.cpl == 3) out.A3[e] = W(g.s * cp.R1[r] * ta3);
+    out.P3[e] = W(tp3);
+    out.P2[e] = W(tp2);
+  }
+  if (e < 4 * dim) out.bias2[e] = W(g.s * tb2);
+  if (e < dim) {
+    out.bias1[e] = W(g.s * tb1);
+    out.bias3[e] = W(g.s * tb3);
   }
 }
 
@@ -208,13 +229,16 @@ __device__ __forceinline__ void grad_rowwise(const PackDims& g, const cara_cp& c
 __device__ __forceinline__ void grad_colred_part(const PackDims& g, const cara_cp& cp, const cara_layer_grads& lg, const GradScratch& sc,
                                                  const int l, const int slot, const int split, float* red) {
   const int R = g.rank, Rp = g.Rp, dim = g.dim;
-  const int r = threadIdx.x % 32, part = threadIdx.x / 32;  // 8 row partitions; R <= 64 -> loop over r groups
+  // Rr lanes of r (16 at rank <= 16: no idle half) x 256 / Rr row partitions; R <= 64 -> loop over r groups
+  const int Rr = R <= 16 ? 16 : 32, NP = 256 / Rr;
+  const int r = threadIdx.x % Rr, part = threadIdx.x / Rr;
   const int row0 = (int)((long)dim * split / GS_SPLIT), row1 = (int)((long)dim * (split + 1) / GS_SPLIT);
-  for (int rb = 0; rb < R; rb += 32) {
+  for (int rb = 0; rb < R; rb += Rr) {
     const int rr = rb + r;
     float z = 0.f;
     if (rr < R) {
-      for (int row = row0 + part; row < row1; row += 8) {
+#pragma unroll 6
+      for (int row = row0 + part; row < row1; row += NP) {
         float w, f;
         if (slot < 3) {
           if (g.cpl == 2) break;   // (no factored QKV adapter)
@@ -240,7 +264,7 @@ __device__ __forceinline__ void grad_colred_part(const PackDims& g, const cara_c
     __syncthreads();
     if (part == 0 && rr < R) {
       float s = 0.f;
-      for (int p = 0; p < 8; ++p) s += red[p * 32 + r];
+      for (int p = 0; p < NP; ++p) s += red[p * Rr + r];
       if (slot < 12) sc.zp[((size_t)(l * 12 + slot) * GS_SPLIT + split) * R + rr] = s;
       else sc.zvp[((size_t)l * GS_SPLIT + split) * R + rr] = s;
     }
@@ -263,6 +287,7 @@ __device__ __forceinline__ void grad_a34_part(const PackDims& g, const cara_cp& 
     for (int e = threadIdx.x; e < H * R; e += 256) {
       const int hh = e / R, r = e - hh * R;
       float in = 0.f;
+#pragma unroll 16
       for (int d = 0; d < hd; ++d) in += W[(size_t)(hh * hd + d) * Rp + r] * Fd[d * R + r];
       pa3[e] = qkv_coef(g, cp, l, k, r) * in;
     }
@@ -272,6 +297,7 @@ __device__ __forceinline__ void grad_a34_part(const PackDims& g, const cara_cp& 
     for (int e = e0 + threadIdx.x; e < e1; e += 256) {
       const int d = e / R, r = e - d * R;
       float in = 0.f;
+#pragma unroll 12
       for (int hh = 0; hh < H; ++hh) in += W[(size_t)(hh * hd + d) * Rp + r] * Fh[hh * R + r];
       pa4[e] = qkv_coef(g, cp, l, k, r) * in;
     }
@@ -280,12 +306,13 @@ __device__ __forceinline__ void grad_a34_part(const PackDims& g, const cara_cp& 
 
 // stage 1: block ranges [rowwise | colred + zv: L * 13 * GS_SPLIT | a34: 3L * 5]
 __global__ __launch_bounds__(256) void grad_stage1_kernel(PackDims g, cara_cp cp, cara_layer_grads lg, cara_cp out, float* __restrict__ scratch,
-                                                          int nb_row) {
-  __shared__ float red[256];
+                                                          int nb_row, int b0) {
+  __shared__ float red_all[4 * 4 * ROW_E];
+  float* red = red_all;
   const GradScratch sc = grad_scratch(scratch, g.depth, g.heads, g.hd, g.rank);
-  int b = blockIdx.x;
+  int b = blockIdx.x + b0;   // (b0: CARA_GRAD_STAGE1_SPLIT=1 launches the three block ranges one after the other, to time them)
   if (b < nb_row) {
-    grad_rowwise(g, cp, lg, out, b * 256 + threadIdx.x);
+    grad_rowwise(g, cp, lg, out, b, reinterpret_cast<float (*)[4][ROW_E]>(red_all));
     return;
   }
   b -= nb_row;
@@ -315,6 +342,7 @@ __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp
       const int per = is3 ? H * R : hd * R;
       const float* p = is3 ? sc.pa3 : sc.pa4;
       float acc = 0.f;
+#pragma unroll 12
       for (int lk = 0; lk < 3 * L; ++lk) acc += p[(size_t)lk * per + e2];
       float* o3 = g.cpl == 5 ? out.A4 : out.A3;   // head factor
       float* o4 = g.cpl == 5 ? out.A5 : out.A4;   // head-dim factor
@@ -323,11 +351,15 @@ __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp
     return;
   }
   __shared__ float red1[256], red2[256];
-  const int r = threadIdx.x % 64, qg = threadIdx.x / 64;   // R <= 64; four groups walk the 12L (layer, slot) pairs
+  // R <= 64: 256 / Rr groups of Rr lanes (Rr = R rounded up to 16 / 32 / 64) walk the 12L (layer, slot) pairs -- sixteen groups at
+  // rank <= 16, nine pairs each (four groups of 64 lanes, 16 of them active, walked 36 pairs each: 27 us of dependent latencies)
+  const int Rr = R <= 16 ? 16 : (R <= 32 ? 32 : 64), NG = 256 / Rr;
+  const int r = threadIdx.x % Rr, qg = threadIdx.x / Rr;
   __shared__ float red3[3][256];
   float d1 = 0.f, d2 = 0.f, dk[3] = {0.f, 0.f, 0.f};
   if (r < R) {
-    for (int q = qg; q < 12 * L; q += 4) {
+#pragma unroll 3
+    for (int q = qg; q < 12 * L; q += NG) {
       const float* zp = sc.zp + (size_t)q * GS_SPLIT * R + r;
       float z = 0.f;
 #pragma unroll
@@ -350,7 +382,7 @@ __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp
     }
     if (g.cpl == 5) {
       // dA1[l] = R1 sum_k A2[k] Z[l,k] ;  dA2[k] = R1 sum_l A1[l] Z[l,k] ;  dR1 = sum_{l,k} A1[l] A2[k] Z[l,k]
-      for (int l = qg; l < L; l += 4) {
+      for (int l = qg; l < L; l += NG) {
         float a1 = 0.f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -365,9 +397,9 @@ __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp
         d1 += cp.A1[l * R + r] * a1;
       }
     }
-    if (qg == 0) {
+    {
       float zv = 0.f;
-      for (int i = 0; i < L * GS_SPLIT; ++i) zv += sc.zvp[(size_t)i * R + r];
+      for (int i = qg; i < L * GS_SPLIT; i += NG) zv += sc.zvp[(size_t)i * R + r];
       d2 += g.s * zv;
     }
   }
@@ -376,13 +408,19 @@ __global__ __launch_bounds__(256) void grad_stage2_kernel(PackDims g, cara_cp cp
 #pragma unroll
   for (int k = 0; k < 3; ++k) red3[k][threadIdx.x] = dk[k];
   __syncthreads();
-  if (qg == 0 && r < R) {
-    out.R1[r] = W((red1[r] + red1[64 + r]) + (red1[128 + r] + red1[192 + r]));
-    out.R2[r] = W((red2[r] + red2[64 + r]) + (red2[128 + r] + red2[192 + r]));
+  if (qg == 0 && r < R) {   // the groups' sums in a fixed order
+    float s1 = 0.f, s2 = 0.f, s3[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < NG; ++k) {
+      s1 += red1[k * Rr + r];
+      s2 += red2[k * Rr + r];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) s3[j] += red3[j][k * Rr + r];
+    }
+    out.R1[r] = W(s1);
+    out.R2[r] = W(s2);
     if (g.cpl == 5) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
-        out.A2[k * R + r] = W(cp.R1[r] * ((red3[k][r] + red3[k][64 + r]) + (red3[k][128 + r] + red3[k][192 + r])));
+      for (int k = 0; k < 3; ++k) out.A2[k * R + r] = W(cp.R1[r] * s3[k]);
     }
   }
 }
@@ -461,9 +499,16 @@ extern "C" int cara_factor_grad_reduce_ex(const cara_geom* g, const cara_cp* cp,
   d.loss_scale = loss_scale;
   d.found_inf = found_inf;
   const int n1 = g->dim * g->rank > 4 * g->dim ? g->dim * g->rank : 4 * g->dim;
-  const int nb_row = (n1 + 255) / 256, nb_col = g->depth * 13 * GS_SPLIT, nb_a34 = 3 * g->depth * 5;
+  const int nb_row = (n1 + ROW_E - 1) / ROW_E, nb_col = g->depth * 13 * GS_SPLIT, nb_a34 = 3 * g->depth * 5;
   float* sc = static_cast<float*>(scratch);
-  hipLaunchKernelGGL(grad_stage1_kernel, dim3(nb_row + nb_col + nb_a34), dim3(256), 0, st, d, *cp, *lg, *grads, sc, nb_row);
+  static const int split = [] { const char* e = getenv("CARA_GRAD_STAGE1_SPLIT"); return e ? atoi(e) : 0; }();
+  if (split) {
+    hipLaunchKernelGGL(grad_stage1_kernel, dim3(nb_row), dim3(256), 0, st, d, *cp, *lg, *grads, sc, nb_row, 0);
+    hipLaunchKernelGGL(grad_stage1_kernel, dim3(nb_col), dim3(256), 0, st, d, *cp, *lg, *grads, sc, nb_row, nb_row);
+    hipLaunchKernelGGL(grad_stage1_kernel, dim3(nb_a34), dim3(256), 0, st, d, *cp, *lg, *grads, sc, nb_row, nb_row + nb_col);
+  } else {
+    hipLaunchKernelGGL(grad_stage1_kernel, dim3(nb_row + nb_col + nb_a34), dim3(256), 0, st, d, *cp, *lg, *grads, sc, nb_row, 0);
+  }
   CARA_CHECK_LAUNCH();
   const int nb_a = ((g->heads + g->dim / g->heads) * g->rank + 255) / 256;
   hipLaunchKernelGGL(grad_stage2_kernel, dim3(nb_a + 1), dim3(256), 0, st, d, *cp, sc, *grads, nb_a);

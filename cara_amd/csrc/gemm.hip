@@ -835,27 +835,9 @@ int launch32(const cara_gemm_args* a, hipStream_t st, const TsPair* ts = nullptr
 // partial products into scratch), and a small finishing kernel adds the slabs in fixed order, the rank-R term
 // T Vs^T, the bias, and applies the epilogue.
 // ---------------------------------------------------------------------------------------------
+// the tail of a few-row product for outputs (m, n .. n + 3), v = their A B^T sums: + the rank-R term T Vs^T, + bias, the epilogue
 template <int EPI>
-__global__ __launch_bounds__(256) void small_m_finish_kernel(const cara_gemm_args p, const float* __restrict__ slabs, const int nslab) {
-  const int n4 = (p.N + 3) / 4;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= p.M * n4) return;
-  const int m = idx / n4, n = (idx - m * n4) * 4;
-  const size_t slab_stride = (size_t)p.M * p.N;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool full = n + 4 <= p.N && (p.N & 3) == 0;
-  for (int s = 0; s < nslab; ++s) {
-    const float* src = slabs + s * slab_stride + (size_t)m * p.N + n;
-    if (full) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(src);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] += t[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (n + k < p.N) v[k] += src[k];
-    }
-  }
+__device__ __forceinline__ void small_m_finish4(const cara_gemm_args& p, const int m, const int n, float (&v)[4]) {
   if (p.Rp > 0) {   // the adapter term, straight from T [M,Rp] and Vs [N,Rp]
     const bf16* t = static_cast<const bf16*>(p.A2) + (size_t)m * p.Rp;
 #pragma unroll
@@ -900,6 +882,98 @@ __global__ __launch_bounds__(256) void small_m_finish_kernel(const cara_gemm_arg
   }
 }
 
+// The few-row product in ONE launch (the default; CARA_SMALL_M_DIRECT=0: the batched split-K launch + the finishing kernel below,
+// 8 + 9 us per product, seven of them per step).  A workgroup of 8 waves owns ONE 16 x 16 output tile; its waves split K (wave w: the
+// 32-wide K steps w, w + 8, ...), every MFMA operand fragment is one 16-byte global load per lane straight into registers (rows of
+// A / W are 64-byte runs: no LDS staging for a product whose operands are read once), six K steps of loads in flight; the eight
+// partial tiles meet in LDS, are added in a fixed order, and 64 threads finish four outputs of a row each (small_m_finish4).
+// One tile per workgroup, not a column of tiles: a workgroup that walks all of K reads all K columns of its A rows, and a CU takes
+// ~70 GB/s from the L2 -- with the four row tiles of M = 64 in one workgroup (393 KB of A at K = 3072) the launch lasted 23 us.
+// 192 (N = dim) .. 768 (N = 4 dim) workgroups at M = 64.
+// NW waves split K: 8 for the long products, 4 where K <= 1024 (three K steps per wave would be all launch and no work)
+template <int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void small_m_direct_kernel(const cara_gemm_args p) {
+  __shared__ float red[NW][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const int nb = n0 + fr < p.N ? n0 + fr : p.N - 1;
+  const int mb = m0 + fr < p.M ? m0 + fr : p.M - 1;
+  const bf16* pb = static_cast<const bf16*>(p.B) + (size_t)nb * p.ldb + fq * 8;
+  const bf16* pa = static_cast<const bf16*>(p.A) + (size_t)mb * p.lda + fq * 8;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = p.K / BK32;
+  constexpr int UN = 6;
+  int kt = wave;
+  for (; kt + NW * (UN - 1) < nk; kt += NW * UN) {
+    bf16x8 a[UN], b[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int k0 = (kt + NW * u) * BK32;
+      a[u] = *reinterpret_cast<const bf16x8*>(pa + k0);
+      b[u] = *reinterpret_cast<const bf16x8*>(pb + k0);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[u], acc, 0, 0, 0);
+  }
+  if (kt < nk) {   // the rest: up to UN - 1 steps, requested together (wave-uniform)
+    bf16x8 a[UN - 1], b[UN - 1];
+#pragma unroll
+    for (int u = 0; u < UN - 1; ++u) {
+      const int k = kt + NW * u;
+      const int k0 = (k < nk ? k : nk - 1) * BK32;
+      a[u] = *reinterpret_cast<const bf16x8*>(pa + k0);
+      b[u] = *reinterpret_cast<const bf16x8*>(pb + k0);
+    }
+#pragma unroll
+    for (int u = 0; u < UN - 1; ++u)
+      if (kt + NW * u < nk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[u], acc, 0, 0, 0);   // (wave-uniform)
+  }
+  // accumulator layout: acc[r] = C[m0 + 4 fq + r][n0 + fr]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][(fq * 4 + r) * 16 + fr] = acc[r];
+  __syncthreads();
+  if (tid < 64) {   // four consecutive columns of a row per thread
+    const int row = tid >> 2, c4 = (tid & 3) * 4;
+    const int m = m0 + row;
+    if (m < p.M) {
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w][row * 16 + c4 + k];
+        v[k] = t;
+      }
+      small_m_finish4<EPI>(p, m, n0 + c4, v);
+    }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void small_m_finish_kernel(const cara_gemm_args p, const float* __restrict__ slabs, const int nslab) {
+  const int n4 = (p.N + 3) / 4;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.M * n4) return;
+  const int m = idx / n4, n = (idx - m * n4) * 4;
+  const size_t slab_stride = (size_t)p.M * p.N;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool full = n + 4 <= p.N && (p.N & 3) == 0;
+  for (int s = 0; s < nslab; ++s) {
+    const float* src = slabs + s * slab_stride + (size_t)m * p.N + n;
+    if (full) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += t[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (n + k < p.N) v[k] += src[k];
+    }
+  }
+  small_m_finish4<EPI>(p, m, n, v);
+}
+
 // K slabs of at least 128 columns, at most 16 of them; 0 = not worth it
 static int small_m_slabs(const cara_gemm_args* a) {
   if (a->M > 128 || a->K < 512 || !a->scratch || a->Ut || a->batch > 1 || a->B3) return 0;
@@ -912,6 +986,14 @@ static int small_m_slabs(const cara_gemm_args* a) {
 
 template <int EPI>
 static int launch_small_m(const cara_gemm_args* a, int nslab, hipStream_t st) {
+  static const int direct = [] { const char* e = getenv("CARA_SMALL_M_DIRECT"); return e ? atoi(e) : 1; }();
+  if (direct) {   // (B: the row-major weights, also where a K-panel-major image exists)
+    const dim3 grid((a->N + 15) / 16, (a->M + 15) / 16);
+    if (a->K > 1024) hipLaunchKernelGGL((small_m_direct_kernel<EPI, 8>), grid, dim3(512), 0, st, *a);
+    else hipLaunchKernelGGL((small_m_direct_kernel<EPI, 4>), grid, dim3(256), 0, st, *a);
+    CARA_CHECK_LAUNCH();
+    return CARA_OK;
+  }
   cara_gemm_args d = {};
   d.A = a->A; d.lda = a->lda; d.B = a->B; d.ldb = a->ldb; d.M = a->M; d.N = a->N; d.K = a->K / nslab;
   d.epi = CARA_EPI_F32; d.C = a->scratch; d.ldc = a->N;

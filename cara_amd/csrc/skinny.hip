@@ -250,7 +250,7 @@ struct TsReduceTable {
 __device__ __forceinline__ f32x4 strided_sum4_v(const float* __restrict__ p, const size_t stride, const int n) {
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
   int c = 0;
-  for (; c + 4 <= n; c += 4) {
+  for (; c + 4 <= n; c += 4) {   // (unrolled twice -- eight loads in flight per thread -- the launch measured 38.7 us instead of 32.2: r05)
     s0 += *reinterpret_cast<const f32x4*>(p + (size_t)c * stride);
     s1 += *reinterpret_cast<const f32x4*>(p + (size_t)(c + 1) * stride);
     s2 += *reinterpret_cast<const f32x4*>(p + (size_t)(c + 2) * stride);

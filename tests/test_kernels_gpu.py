@@ -1267,3 +1267,4 @@ def test_cross_entropy_ex_amp_update_and_adamw_skip_word():
     found.zero_()
     opt.step()
     assert not torch.equal(w.detach(), before)
+
