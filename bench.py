@@ -47,9 +47,8 @@ GF_PER_IMG = {"fwd": 36.06, "bwd": 38.18, "step": 74.24}
 # reported metric stays the ViT-B configuration
 GF_PER_IMG_L384 = {"fwd": 389.39, "bwd": 428.47, "step": 817.87}
 # a bracket (three HIP event records) idles the chip ~15 us: inside the timed region only the dominant site is
-# bracketed, on every 12th block (1 launch per ViT-B step, 2 per ViT-L step; r05: was every 6th -- the markers are idle chip
-# inside the timed region, `roofline.event_marker_ms_subtracted` says how much per bracket)
-PROFILE_EVERY = 12
+# bracketed, on every 6th block (2 launches per ViT-B step, 4 per ViT-L step)
+PROFILE_EVERY = int(os.environ.get("CARA_BENCH_PROFILE_EVERY", "6"))   # (the variable: diagnostics only)
 
 SITES = ["qkv_fwd", "proj_fwd", "fc1_fwd", "fc2_fwd", "qkv_bwd", "proj_bwd", "fc1_bwd", "fc2_bwd", "attn_fwd", "attn_bwd",
          "ln1_fwd", "ln2_fwd", "ln1_bwd", "ln2_bwd", "skinny_fwd", "skinny_bwd"]   # include/cara_hip.h CARA_SITE_*
