@@ -47,8 +47,9 @@ GF_PER_IMG = {"fwd": 36.06, "bwd": 38.18, "step": 74.24}
 # reported metric stays the ViT-B configuration
 GF_PER_IMG_L384 = {"fwd": 389.39, "bwd": 428.47, "step": 817.87}
 # a bracket (three HIP event records) idles the chip ~15 us: inside the timed region only the dominant site is
-# bracketed, on every 6th block (2 launches per ViT-B step, 4 per ViT-L step)
-PROFILE_EVERY = int(os.environ.get("CARA_BENCH_PROFILE_EVERY", "6"))   # (the variable: diagnostics only)
+# bracketed, on every 12th block (1 launch per ViT-B step, 2 per ViT-L step; every 6th until r05: same-box 7.869 -> 7.831 ms,
+# profiles/r05_p_bracket_every_6_vs_12.txt)
+PROFILE_EVERY = int(os.environ.get("CARA_BENCH_PROFILE_EVERY", "12"))   # (the variable: diagnostics only)
 
 SITES = ["qkv_fwd", "proj_fwd", "fc1_fwd", "fc2_fwd", "qkv_bwd", "proj_bwd", "fc1_bwd", "fc2_bwd", "attn_fwd", "attn_bwd",
          "ln1_fwd", "ln2_fwd", "ln1_bwd", "ln2_bwd", "skinny_fwd", "skinny_bwd"]   # include/cara_hip.h CARA_SITE_*
@@ -61,7 +62,7 @@ SITE_KERNEL = {
     "proj_bwd": "gemm32_ts_kernel<BF16,true> (proj dX + its dVs / dc + fc1's dU riding in the launch)",
     "fc1_bwd": "gemm32ft_ts_kernel<BF16,true> (fc1 dX with G' = dY Vs inside + its dVs / dc + fc2's dU riding in the launch)",
     "fc2_bwd": "gemm32_ts_kernel<DGELU,true, MI=5> (fc2 dX, 160 x 128 tiles, gelu' epilogue + its dVs / dc + the dU of the qkv above)",
-    "attn_fwd": "attn_fwd_persist_kernel (3 heads per CU)", "attn_bwd": "attn_bwd_fused_kernel (dK/dV sweep then dQ sweep per head)",
+    "attn_fwd": "attn_fwd_p2_kernel<7> (persistent, 3 heads per CU)", "attn_bwd": "attn_bwd_fused_kernel<true> (dK/dV sweep then dQ sweep per head)",
     "ln1_fwd": "ln_fwd_kernel<XU> (LayerNorm 1 + T = LN(x) U of qkv)", "ln2_fwd": "ln_fwd_kernel<XU> (LayerNorm 2 + T of fc1)",
     "ln1_bwd": "ln_bwd_kernel<XU> (LayerNorm 1 backward + G' of the fc2 below)", "ln2_bwd": "ln_bwd_kernel<XU> (LayerNorm 2 backward + G' of proj)",
     "skinny_fwd": "skinny_xu_sliced_kernel (T = X U)", "skinny_bwd": "skinny_xu_sliced_kernel (G' = dY Vs where no dX GEMM computes it: block 0's qkv)",
@@ -89,6 +90,25 @@ def site_work(M, D, R, B, H, N):
         # skinny contractions read their [M, K] operand once (bf16): forward K = D or 4 D (unused by default); backward, with the
         # default switches, only block 0's qkv (K = 3 D) still runs the pass (the other G' come out of dX GEMMs / LayerNorms)
         "skinny_fwd": ("hbm", M * 2.5 * D * 2.0), "skinny_bwd": ("hbm", M * 3.0 * D * 2.0),
+    }
+
+
+def site_bytes(M, D):
+    """Algorithmic HBM bytes per launch of the matrix-core sites (every tensor a launch must read or write counted once, bf16
+    activations, fp32 residual stream; the skinny adapter operands are noise): with `site_work` they say which roof binds a site --
+    attention at 197 tokens and the N = K = dim products are HBM-bound kernels although they run on the matrix cores."""
+    md, dd = float(M) * D, float(D) * D
+    return {
+        "qkv_fwd": 8 * md + 6 * dd,        # xn1 in, qkv out
+        "proj_fwd": 10 * md + 2 * dd,      # ao in, fp32 residual stream read + written
+        "fc1_fwd": 18 * md + 8 * dd,       # xn2 in, u and gelu(u) out
+        "fc2_fwd": 16 * md + 8 * dd,       # h in, fp32 residual stream read + written
+        "qkv_bwd": 10 * md + 6 * dd,       # dQKV in, dXn out, ao for proj's dU
+        "proj_bwd": 6 * md + 2 * dd,       # dY in, dAO out, xn2 for fc1's dU
+        "fc1_bwd": 18 * md + 8 * dd,       # dH in, dX out, h for fc2's dU
+        "fc2_bwd": 20 * md + 8 * dd,       # dY and u in, dH out, xn1 for the qkv above's dU
+        "attn_fwd": 8 * md,                # qkv in, out
+        "attn_bwd": 16 * md,               # qkv, out, dout in; dqkv out
     }
 
 
@@ -394,6 +414,7 @@ def main():
 
     M = args.batch * tokens
     work = site_work(M, dim, args.rank, args.batch, heads, tokens)
+    sbytes = site_bytes(M, dim)
     all_mask = (1 << len(SITES)) - 1
     factored = args.weight_dropout == "off"
     for _ in range(max(args.warmup - 1, 0)):
@@ -577,6 +598,11 @@ def main():
             if kind == "mfma":
                 d.update(algorithmic_gflop=round(amount / 1e9, 2), achieved_tflops=round(amount / us / 1e6, 1),
                          frac_of_mfma_peak=round(amount / us / 1e6 / PEAK_BF16_TFLOPS, 4))
+                nb = sbytes.get(n)
+                if nb:   # the roof that binds this launch: its MFMA time at peak or its HBM time at peak, whichever is longer
+                    t_mfma, t_hbm = amount / (PEAK_BF16_TFLOPS * 1e6), nb / (PEAK_HBM_GBS * 1e3)   # us
+                    d.update(algorithmic_mb=round(nb / 1e6, 1), frac_of_hbm_peak=round(nb / us / 1e3 / PEAK_HBM_GBS, 4),
+                             binding_roof="hbm" if t_hbm > t_mfma else "mfma", frac_of_binding_roof=round(max(t_mfma, t_hbm) / us, 4))
             else:
                 d.update(algorithmic_mb=round(amount / 1e6, 1), achieved_gbs=round(amount / us / 1e3, 1),
                          frac_of_hbm_peak=round(amount / us / 1e3 / PEAK_HBM_GBS, 4))
