@@ -22,7 +22,7 @@ SYMBOLS = (
     "cara_abi_version", "cara_build_arch", "cara_operand_type", "cara_gemm_bf16", "cara_gemm_tn_f32", "cara_pack_b_panels", "cara_gemm_scratch_bytes", "cara_skinny_xu", "cara_skinny_xu_r", "cara_tskinny_partial2_r", "cara_gemm_with_tskinny_r", "cara_gemm_rider_slab_format", "cara_gemm_epi_rider_chunks", "cara_gemm_dv_chunks", "cara_gemm_epi_rider_scratch_bytes", "cara_linear_fwd", "cara_linear_bwd",
     "cara_tskinny_scratch_bytes", "cara_tskinny_xtg", "cara_tskinny_partial", "cara_tskinny_partial2", "cara_tskinny_reduce", "cara_tskinny_reduce_many", "cara_gemm_with_tskinny", "cara_layernorm_fwd", "cara_layernorm_bwd", "cara_layernorm_fwd_xu", "cara_layernorm_bwd_xu", "cara_layernorm_fwd_ex", "cara_layernorm_bwd_ex",
     "cara_attention_fwd", "cara_attention_bwd", "cara_attention_cls_fwd", "cara_attention_cls_bwd", "cara_im2col_patches", "cara_assemble_tokens",
-    "cara_cross_entropy", "cara_cross_entropy_ex", "cara_amp_update", "cara_head_forward", "cara_factor_grad_reduce_ex", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_transpose_bf16_ld", "cara_pack_offsets",
+    "cara_cross_entropy", "cara_cross_entropy_ex", "cara_amp_update", "cara_allreduce_flat", "cara_head_forward", "cara_factor_grad_reduce_ex", "cara_f32_to_bf16", "cara_transpose_bf16", "cara_transpose_bf16_ld", "cara_pack_offsets",
     "cara_dense_delta_materialize", "cara_dense_delta_grad_scratch_bytes", "cara_dense_delta_grad", "cara_sum_slabs_f32", "cara_adamw_step",
     "cara_weight_dropout_hash", "cara_materialize_merge", "cara_dropout_grad_scratch_bytes", "cara_dropout_grad_contract", "cara_colsum_scratch_bytes", "cara_colsum_bf16", "cara_factor_prep", "cara_factor_grad_scratch_bytes", "cara_factor_grad_reduce", "cara_vit_workspace_bytes", "cara_vit_forward",
     "cara_vit_backward", "cara_head_backward", "cara_sizeof_struct", "cara_sizeof_gemm_args", "cara_profile_sites", "cara_profile_site_read", "cara_debug_tr_probe", "cara_debug_tr_frag",

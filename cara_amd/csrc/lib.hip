@@ -1,4 +1,6 @@
 // Library identification for libcara_hip.so.
+#include <dlfcn.h>
+
 #include "common.h"
 
 extern "C" int cara_abi_version(void) { return 14; }
@@ -41,4 +43,21 @@ extern "C" int cara_debug_tr_probe(const int* byte_addr, short* out, void* strea
   hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), byte_addr, out);
   CARA_CHECK_LAUNCH();
   return CARA_OK;
+}
+
+// The optional RCCL wrapper of SURVEY.md 8(b): the step's ONE collective -- a SUM all-reduce of the flat fp32 gradient buffer
+// (487 696 bytes at the headline configuration: 121 923 gradients + the found-inf word) -- for a host that owns an ncclComm_t
+// (a C++ trainer; the Python side of this repository goes through torch.distributed, whose communicator is not exposed).
+// librccl is looked up at the first call (dlopen), so the library loads and runs on one GPU without it.
+extern "C" int cara_allreduce_flat(void* nccl_comm, float* buf, size_t count, void* stream) {
+  typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+  static const allreduce_fn fn = [] {
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    return h ? reinterpret_cast<allreduce_fn>(dlsym(h, "ncclAllReduce")) : nullptr;
+  }();
+  if (!nccl_comm || !buf || !count) return CARA_E_ARG;
+  if (!fn) return CARA_E_LAUNCH;   // no RCCL in this process's library path
+  constexpr int kNcclFloat32 = 7, kNcclSum = 0;   // (rccl.h: ncclDataType_t / ncclRedOp_t)
+  return fn(buf, buf, count, kNcclFloat32, kNcclSum, nccl_comm, static_cast<hipStream_t>(stream)) == 0 ? CARA_OK : CARA_E_LAUNCH;
 }

@@ -526,6 +526,15 @@ enum {
 size_t cara_sizeof_struct(int which);
 size_t cara_sizeof_gemm_args(void);      /* == cara_sizeof_struct(CARA_STRUCT_GEMM_ARGS) */
 
+/* ---- the step's one collective (optional) ------------------------------------------------------ */
+/* SUM all-reduce, in place, of `count` fp32 values on `stream` through RCCL: the flat gradient buffer of a data-parallel
+ * step (the reference: DistributedDataParallel's bucketed all-reduce, image_classification/vit_cp.py's launcher; here ONE
+ * call per step -- the buffer is 121 923 gradients + the found-inf word at the headline configuration, pre-scaled by
+ * 1 / world size at the cross-entropy, cara_cross_entropy_ex).  nccl_comm = the caller's ncclComm_t.  librccl is looked up at
+ * the first call: CARA_E_LAUNCH when the process has none.  The Python side of this repository uses torch.distributed
+ * (backend "nccl" = RCCL), whose communicator is not exposed; a C++ host that owns one calls this.                      */
+int cara_allreduce_flat(void* nccl_comm, float* buf, size_t count, void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 /* HIP-event brackets around the kernels of chosen call sites INSIDE cara_vit_forward / cara_vit_backward, recorded
  * on the compute stream, so that a benchmark can read per-kernel launch durations from within its timed region

@@ -1268,3 +1268,21 @@ def test_cross_entropy_ex_amp_update_and_adamw_skip_word():
     opt.step()
     assert not torch.equal(w.detach(), before)
 
+
+
+
+def test_allreduce_flat_through_a_one_rank_rccl_communicator():
+    """cara_allreduce_flat (SURVEY 8b's optional export): the step's one collective through RCCL for a host that owns an
+    ncclComm_t.  One GPU here: a communicator of ONE rank, made with ctypes on librccl itself -- the SUM over one rank leaves the
+    buffer as it was, on the caller's stream; NULL arguments are refused.  In a child process (tests/_rccl_one_rank.py): a
+    communicator is process-wide state this test run has no other use for."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(here, "_rccl_one_rank.py")], capture_output=True, text=True, timeout=300, env=env,
+                       cwd=os.path.dirname(here))
+    if r.returncode == 77:
+        pytest.skip(r.stdout.strip() or "no RCCL communicator in this environment")
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "allreduce ok" in r.stdout
