@@ -672,6 +672,15 @@ def main():
             "roofline_top": top,
             "roofline_hbm": hbm,
         }
+        if args.all_sites:   # every site was bracketed: the step's sites against the sum of their OWN binding roofs
+            rows = top + hbm
+            t_sites = sum(r["avg_launch_us"] * r["launches_per_step"] for r in rows)
+            t_roofs = sum(r["avg_launch_us"] * r["launches_per_step"] * r.get("frac_of_binding_roof", r.get("frac_of_hbm_peak", r.get("frac_of_mfma_peak", 0.0)))
+                          for r in rows)
+            out["sites_vs_their_roofs"] = {"sites_us_per_step": round(t_sites, 1), "roofs_us_per_step": round(t_roofs, 1),
+                                           "frac": round(t_roofs / t_sites, 4) if t_sites else None,
+                                           "note": "sum over the bracketed sites of launches x max(MFMA time at 2.5 PF/s, HBM time at 8 TB/s) "
+                                                   "of the site's algorithmic work, over the sum of the measured launch times"}
         if pm is not None:
             if "error" in pm:
                 out["precision_matched"] = {"dtype": "fp16", "error": pm["error"]}
