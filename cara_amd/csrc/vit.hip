@@ -285,7 +285,8 @@ struct SiteBracket {   // RAII: event 0 .. kernel(s) .. event 1, event 2 (an emp
   hipEvent_t* ev = nullptr;
   hipStream_t st;
   SiteBracket(int site, const Ctx& cx) : st(static_cast<hipStream_t>(cx.stream)) {
-    if (!(g_prof.mask >> site & 1ull) || !cx.full || cx.layer % g_prof.every) return;
+    // (block every / 2 of every run of `every` blocks: never block 0, whose qkv dX and LayerNorm-1 backward do not exist)
+    if (!(g_prof.mask >> site & 1ull) || !cx.full || cx.layer % g_prof.every != g_prof.every / 2) return;
     ev = g_prof.ev[site][g_prof.n[site]++ % CARA_SITE_RING];
     (void)hipEventRecord(ev[0], st);
   }

@@ -538,8 +538,8 @@ int cara_allreduce_flat(void* nccl_comm, float* buf, size_t count, void* stream)
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 /* HIP-event brackets around the kernels of chosen call sites INSIDE cara_vit_forward / cara_vit_backward, recorded
  * on the compute stream, so that a benchmark can read per-kernel launch durations from within its timed region
- * (bench.py: `roofline`).  mask = bit set of CARA_SITE_* (0 = off); only the full-size blocks l with l % every == 0
- * are bracketed.  Every bracket idles the chip for ~15 us (three event records), so a timed run brackets one site
+ * (bench.py: `roofline`).  mask = bit set of CARA_SITE_* (0 = off); only the full-size blocks l with l % every == every / 2
+ * are bracketed (every = 1: all of them; never block 0 otherwise -- its qkv dX and LayerNorm-1 backward do not exist).  Every bracket idles the chip for ~15 us (three event records), so a timed run brackets one site
  * on a few layers per step.  Read after synchronising: avg_ms = mean duration of the last (up to CARA_SITE_RING)
  * brackets of that site minus marker_ms, the mean of the EMPTY bracket recorded behind each (the markers' own
  * cost); launches = brackets recorded since cara_profile_sites() (0: the site never ran).  A GEMM site holds exactly the GEMM launch (with the
