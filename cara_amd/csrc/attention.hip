@@ -1328,15 +1328,14 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
       // (a lane whose key is padding -- t0 + l31 >= N, its K / V rows duplicates of row N - 1 -- carries finite values
       // that only ever reach its OWN columns of dK^T / dV^T, which are not stored; a padded QUERY row has p = 0 through its
       // seed: no select per element)
-      unsigned pw[8], dw[8];   // p = exp2(c2 S'), dS = p dP', as packed pairs
-      {
-        const f32x2 c22 = {c2, c2};
+      // (scalar on purpose, and the file is built with -fno-slp-vectorize: a packed fp32 instruction beside MFMAs costs ~22 cycles more
+      // than the two scalar ones it replaces -- MI355X_MICROARCH.md, price of one filler beside MFMAs; r05 measured both forms)
+      unsigned pw[8], dw[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const f32x2 e = exp2_2(f32x2{sacc[2 * i], sacc[2 * i + 1]} * c22);
-          pw[i] = pk16(e);
-          dw[i] = pk16(e * f32x2{pacc[2 * i], pacc[2 * i + 1]});
-        }
+      for (int i = 0; i < 8; ++i) {
+        const float e0 = __builtin_amdgcn_exp2f(sacc[2 * i] * c2), e1 = __builtin_amdgcn_exp2f(sacc[2 * i + 1] * c2);
+        pw[i] = pk16(f32x2{e0, e1});
+        dw[i] = pk16(f32x2{e0 * pacc[2 * i], e1 * pacc[2 * i + 1]});
       }
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
@@ -1451,14 +1450,11 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
         sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], sT, 0, 0, 0);
         dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dpT, 0, 0, 0);
       }
-      unsigned dw[8];   // dS^T = exp2(c2 S^T + lq) (dP^T + dl), as packed pairs
-      {
-        const f32x2 c22 = {c2, c2}, lq2 = {lq, lq}, dl2 = {dl, dl};
+      unsigned dw[8];   // dS^T = exp2(c2 S^T + lq) (dP^T + dl): scalar fp32, converted in pairs
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const f32x2 e = exp2_2(__builtin_elementwise_fma(f32x2{sT[2 * i], sT[2 * i + 1]}, c22, lq2));
-          dw[i] = pk16(e * (f32x2{dpT[2 * i], dpT[2 * i + 1]} + dl2));
-        }
+      for (int i = 0; i < 8; ++i) {
+        const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[2 * i], c2, lq)), e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[2 * i + 1], c2, lq));
+        dw[i] = pk16(f32x2{e0 * (dpT[2 * i] + dl), e1 * (dpT[2 * i + 1] + dl)});
       }
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
@@ -1615,9 +1611,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_w4_kernel(const bf16* __restr
     dma_lse(bh);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+#ifdef CARA_ATTN_STAMPS
+  int slot = -1;
+#endif
   for (; bh < BH; bh += gridDim.x) {
     const int nxt = bh + gridDim.x;
     const int b = bh / H, head = bh - b * H;
+#ifdef CARA_ATTN_STAMPS
+    ++slot;
+#endif
+    ATTN_STAMP(0);
     // T0: every wave is through with phase B of the previous head and has seen its own pieces of this head's Q, dO, O land
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // delta[row] = sum_d dO[row][d] O[row][d], two threads per row, two passes of 128 rows; lse in the seed form (see the 7-wave kernel)
@@ -1642,6 +1645,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_w4_kernel(const bf16* __restr
     lse_s[tid] = tid < N ? lse_s[tid] * nrscale : -1e30f;   // (256 threads, 256 entries: each touched by exactly one thread)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // T1
     __builtin_amdgcn_sched_barrier(0);
+    ATTN_STAMP(1);
 
     // ================= phase A: dK, dV of this wave's two key blocks =================
     f32x16 dkt[2][2], dvt[2][2];
@@ -1668,17 +1672,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_w4_kernel(const bf16* __restr
           sacc[1][4 * g4 + k] = l4[k]; pacc[1][4 * g4 + k] = d4[k];
         }
       }
+      // The order asked for (one wave per SIMD: nothing else fills the matrix pipe while this wave does vector work):
+      //   S0 dP0 | S1 dP1 with the vector work of block 0 between them | dV0 dK0 with the vector work of block 1 | dV1 dK1
+      // Every Q / dO row fragment and every transposed dO / Q fragment is read once and feeds both key blocks.
+      bf16x8 qa[4], da[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {   // every Q / dO row fragment feeds both key blocks
-        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qblk + ro.o[ks]);
-        const bf16x8 da = *reinterpret_cast<const bf16x8*>(dblk + ro.o[ks]);
-        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[0][ks], sacc[0], 0, 0, 0);
-        pacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[0][ks], pacc[0], 0, 0, 0);
-        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[1][ks], sacc[1], 0, 0, 0);
-        pacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[1][ks], pacc[1], 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) {
+        qa[ks] = *reinterpret_cast<const bf16x8*>(qblk + ro.o[ks]);
+        da[ks] = *reinterpret_cast<const bf16x8*>(dblk + ro.o[ks]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[0][ks], sacc[0], 0, 0, 0);
+        pacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vf[0][ks], pacc[0], 0, 0, 0);
       }
       if (qt == 0) {
-        // K, V of THIS head into their images (phase B reads them), behind the last first-use of kf / vf
+        // K, V of THIS head into their images (phase B reads them)
         __builtin_amdgcn_sched_barrier(0);
         const char* qb = qkv_base(bh);
 #pragma unroll
@@ -1686,38 +1695,61 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_w4_kernel(const bf16* __restr
           dma_piece(qb + H * HD * 2, off_qkv[t], Ks, t);
           dma_piece(qb + 2 * H * HD * 2, off_qkv[t], Vs, t);
         }
+      }
+      bf16x8 doa[2][2], qta[2][2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          doa[st][dt] = tr_frag_at(dblk, to.lo[st][dt], to.hi[st][dt]);
+          qta[st][dt] = tr_frag_at(qblk, to.lo[st][dt], to.hi[st][dt]);
+        }
+      unsigned pw[2][8], dw[2][8];
+      auto vec_pair = [&](const int j, const int i) {   // p = exp2(c2 S'), dS = p dP' of registers 2i, 2i + 1 of block j: six vector instructions
+        const float e0 = __builtin_amdgcn_exp2f(sacc[j][2 * i] * c2), e1 = __builtin_amdgcn_exp2f(sacc[j][2 * i + 1] * c2);
+        pw[j][i] = pk16(f32x2{e0, e1});
+        dw[j][i] = pk16(f32x2{e0 * pacc[j][2 * i], e1 * pacc[j][2 * i + 1]});
+      };
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- S1 dP1 (8 MFMAs), one pair of block 0's vector work behind each (a scheduling fence per MFMA keeps the order)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[1][ks], sacc[1], 0, 0, 0);
+        pacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vf[1][ks], pacc[1], 0, 0, 0);
+        vec_pair(0, 2 * ks);       // (two independent six-instruction chains per fence: one wave per SIMD has nobody else to
+        vec_pair(0, 2 * ks + 1);   // issue from while a transcendental's result is on its way)
         __builtin_amdgcn_sched_barrier(0);
       }
-      unsigned pw[2][8], dw[2][8];
-      {
-        const f32x2 c22 = {c2, c2};
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const f32x2 e = exp2_2(f32x2{sacc[j][2 * i], sacc[j][2 * i + 1]} * c22);
-            pw[j][i] = pk16(e);
-            dw[j][i] = pk16(e * f32x2{pacc[j][2 * i], pacc[j][2 * i + 1]});
-          }
-      }
+      // ---- dV0 dK0 (8 MFMAs), one pair of block 1's vector work behind each
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        const bf16x8 pb0 = dwords8(pw[0], st), dsb0 = dwords8(dw[0], st), pb1 = dwords8(pw[1], st), dsb1 = dwords8(dw[1], st);
+        const bf16x8 pb0 = dwords8(pw[0], st), dsb0 = dwords8(dw[0], st);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {   // every transposed dO / Q fragment feeds both key blocks
-          const bf16x8 doa = tr_frag_at(dblk, to.lo[st][dt], to.hi[st][dt]);
-          const bf16x8 qta = tr_frag_at(qblk, to.lo[st][dt], to.hi[st][dt]);
-          dvt[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa, pb0, dvt[0][dt], 0, 0, 0);
-          dkt[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsb0, dkt[0][dt], 0, 0, 0);
-          dvt[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa, pb1, dvt[1][dt], 0, 0, 0);
-          dkt[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsb1, dkt[1][dt], 0, 0, 0);
+        for (int dt = 0; dt < 2; ++dt) {
+          dvt[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa[st][dt], pb0, dvt[0][dt], 0, 0, 0);
+          dkt[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta[st][dt], dsb0, dkt[0][dt], 0, 0, 0);
+          vec_pair(1, 4 * st + 2 * dt);
+          vec_pair(1, 4 * st + 2 * dt + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // ---- dV1 dK1
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const bf16x8 pb1 = dwords8(pw[1], st), dsb1 = dwords8(dw[1], st);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dvt[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa[st][dt], pb1, dvt[1][dt], 0, 0, 0);
+          dkt[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta[st][dt], dsb1, dkt[1][dt], 0, 0, 0);
         }
       }
     }
     // T2: every wave's pieces of K, V have landed
+    ATTN_STAMP(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    ATTN_STAMP(3);
     // dK, dV of the valid blocks leave as whole 128-byte rows through the block's own 4 KiB of the O image (free between T1 and T3)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1765,9 +1797,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_w4_kernel(const bf16* __restr
     f32x16 seed_last;
 #pragma unroll
     for (int r = 0; r < 16; ++r) seed_last[r] = crow(r, h) < last ? 0.f : -1e30f;
+    ATTN_STAMP(4);
     // T3: every wave holds its Q / dO rows and row constants: the Q, dO, O images may take the next head
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    ATTN_STAMP(5);
     const bool has_nxt = nxt < BH;
     const char* nqb = qkv_base(has_nxt ? nxt : bh);
     const char* ndob = o_base(dout, has_nxt ? nxt : bh);
@@ -1809,37 +1843,53 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_w4_kernel(const bf16* __restr
       sT[1] = seed;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dpT[0][r] = 0.f; dpT[1][r] = 0.f; }
+      // sT0 dpT0 | sT1 dpT1 with the vector work of block 0 | dQ0 with the vector work of block 1 | dQ1
+      bf16x8 ka[4], va[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {   // every K / V row fragment feeds both query blocks
-        const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kblk + ro.o[ks]);
-        const bf16x8 va = *reinterpret_cast<const bf16x8*>(vblk + ro.o[ks]);
-        sT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[0][ks], sT[0], 0, 0, 0);
-        dpT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[0][ks], dpT[0], 0, 0, 0);
-        sT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[1][ks], sT[1], 0, 0, 0);
-        dpT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[1][ks], dpT[1], 0, 0, 0);
+        ka[ks] = *reinterpret_cast<const bf16x8*>(kblk + ro.o[ks]);
+        va[ks] = *reinterpret_cast<const bf16x8*>(vblk + ro.o[ks]);
       }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        sT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[0][ks], sT[0], 0, 0, 0);
+        dpT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ks], dof[0][ks], dpT[0], 0, 0, 0);
+      }
+      bf16x8 kfr[2][2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) kfr[st][dt] = tr_frag_at(kblk, to.lo[st][dt], to.hi[st][dt]);
       unsigned dw[2][8];
-      {
-        const f32x2 c22 = {c2, c2};
+      auto vec_pair = [&](const int j, const int i) {   // dS^T = exp2(c2 S^T + lq) (dP^T + dl) of registers 2i, 2i + 1 of block j
+        const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[j][2 * i], c2, lq[j])), e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[j][2 * i + 1], c2, lq[j]));
+        dw[j][i] = pk16(f32x2{e0 * (dpT[j][2 * i] + dl[j]), e1 * (dpT[j][2 * i + 1] + dl[j])});
+      };
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const f32x2 lq2 = {lq[j], lq[j]}, dl2 = {dl[j], dl[j]};
+      for (int ks = 0; ks < 4; ++ks) {
+        sT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[1][ks], sT[1], 0, 0, 0);
+        dpT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ks], dof[1][ks], dpT[1], 0, 0, 0);
+        vec_pair(0, 2 * ks);
+        vec_pair(0, 2 * ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const f32x2 e = exp2_2(__builtin_elementwise_fma(f32x2{sT[j][2 * i], sT[j][2 * i + 1]}, c22, lq2));
-            dw[j][i] = pk16(e * (f32x2{dpT[j][2 * i], dpT[j][2 * i + 1]} + dl2));
-          }
+      for (int st = 0; st < 2; ++st) {
+        const bf16x8 a0 = dwords8(dw[0], st);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dq[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[st][dt], a0, dq[0][dt], 0, 0, 0);   // dQ^T = K^T dS^T
+          vec_pair(1, 4 * st + 2 * dt);
+          vec_pair(1, 4 * st + 2 * dt + 1);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        const bf16x8 a0 = dwords8(dw[0], st), a1 = dwords8(dw[1], st);
+        const bf16x8 a1 = dwords8(dw[1], st);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {   // every transposed K fragment feeds both query blocks
-          const bf16x8 kfr = tr_frag_at(kblk, to.lo[st][dt], to.hi[st][dt]);
-          dq[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, a0, dq[0][dt], 0, 0, 0);   // dQ^T = K^T dS^T
-          dq[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, a1, dq[1][dt], 0, 0, 0);
-        }
+        for (int dt = 0; dt < 2; ++dt) dq[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[st][dt], a1, dq[1][dt], 0, 0, 0);
       }
     };
     {
@@ -1857,9 +1907,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_w4_kernel(const bf16* __restr
         if (s_ >= nt - 1) next_slice(s_);
       tile_b(nt - 1, seed_last);
     }
+    ATTN_STAMP(6);
     // the next head's images and row fragments have landed (they are old by now): wait for them HERE, before this phase's stores
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    ATTN_STAMP(7);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (!bval[j]) continue;   // (wave-uniform)

@@ -19,7 +19,7 @@ build_one() {   # $1 = object dir, $2 = output, $3.. = extra flags
       # (attn_bwd_w4_kernel; without the flag hipcc puts every accumulator in AGPRs and copies 1 100 registers per head back);
       # the flag changes no other kernel of the file (same ISA, checked r05)
       local extra=""
-      [ "$s" = attention.hip ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
+      [ "$s" = attention.hip ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize"   # (no packed fp32 arithmetic beside the MFMAs: an anti-lever, MI355X_MICROARCH.md)
       hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result $extra "$@" -c "$s" -o "$o" &
       pids+=($!)
     fi
