@@ -1526,426 +1526,13 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
 }
 
 // ------------------------------------------------------------------------------------------
-// The same backward as FOUR waves of 64 keys / queries (CARA_ATTN_BWD_V=3; r05 experiment): one wave per SIMD, two 32-row
-// blocks per wave.  Why: per head the 7-wave kernel spends ~6 us on LDS fragment reads (every wave reads all of Q / dO and then
-// all of K / V for its 32 keys / queries: 363 ds_read per head and wave) next to ~4.6 us of MFMA time and ~5-6 us of vector issue,
-// and the three add up.  With two blocks per wave every fragment read feeds TWO MFMAs (half the LDS bytes), and the vector work
-// of block 0 can sit between the MFMAs of block 1 in ONE instruction stream (the order below is the order asked for:
-// S0 dP0 | S1 dP1 + vector work 0 | dV0 dK0 + vector work 1 | dV1 dK1).  Same LDS images, same DMA protocol (four barriers),
-// same arithmetic per element as attn_bwd_fused_kernel.  Blocks 2 w, 2 w + 1 of wave w; a block beyond the sequence (block 7 at
-// 197 tokens) is computed on clamped rows and never stored.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void attn_bwd_w4_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
-                                                             const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                             bf16* __restrict__ dqkv, int N, int H, int BH, float scale) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NPAD = 224, IMG = NPAD * 128;
-  char* Qs = smem;
-  char* dOs = smem + IMG;
-  char* Os = smem + 2 * IMG;
-  char* Ks = smem + 3 * IMG;
-  char* Vs = smem + 4 * IMG;
-  float* lse_s = reinterpret_cast<float*>(smem + 5 * IMG);
-  float* del_s = lse_s + 256;   // (256 entries each: block 7's row constants exist, as padding)
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ld = 3 * H * HD, ldo = H * HD;
-  const int l31 = lane & 31, h = lane >> 5;
-  const float c2 = scale * 1.4426950408889634f;
-  const float nrscale = -1.f / scale;
-  const RowOfs ro = row_ofs(lane);
-  const TrOfs to = tr_ofs(lane);
-  const int nt = (N + 31) >> 5;                 // query / key tiles (<= 7)
-  const int last = N - (nt - 1) * 32;           // valid rows of the last tile
-  int blk[2], bt[2], trow[2];
-  bool bval[2], tvalid[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    blk[j] = 2 * wave + j;
-    bval[j] = blk[j] < nt;                      // (wave-uniform)
-    bt[j] = bval[j] ? blk[j] : nt - 1;          // the image tile read for this block
-    trow[j] = blk[j] * 32 + l31 < N ? blk[j] * 32 + l31 : N - 1;
-    tvalid[j] = blk[j] * 32 + l31 < N;
-  }
-
-  // DMA pieces: an image = 28 pieces of 8 rows; wave w takes pieces w, w + 4, ..., w + 24
-  unsigned off_qkv[7], off_o[7];
-#pragma unroll
-  for (int t = 0; t < 7; ++t) {
-    const int row = (wave + t * 4) * 8 + (lane >> 3);
-    const int rr = row < N ? row : N - 1;
-    const int c = (lane & 7) ^ swzk(row);
-    off_qkv[t] = (unsigned)rr * (unsigned)(ld * 2) + (unsigned)(c * 16);
-    off_o[t] = (unsigned)rr * (unsigned)(ldo * 2) + (unsigned)(c * 16);
-  }
-  auto lds_of = [](const char* p) { return __builtin_amdgcn_readfirstlane((unsigned)(size_t)p); };
-  auto dma_piece = [&](const char* base, const unsigned off, char* img, const int t) {
-    glds16_hidden(base, off, lds_of(img) + (unsigned)((wave + t * 4) * 1024));
-  };
-  auto qkv_base = [&](int bh) { const int b = bh / H, hd = bh - b * H; return reinterpret_cast<const char*>(qkv + (size_t)b * N * ld + hd * HD); };
-  auto o_base = [&](const bf16* p_, int bh) { const int b = bh / H, hd = bh - b * H; return reinterpret_cast<const char*>(p_ + (size_t)b * N * ldo + hd * HD); };
-  const unsigned off_lse = (unsigned)(((wave * 64 + lane) < N ? (wave * 64 + lane) : N - 1) * 4);
-  auto dma_lse = [&](int bh_) {   // piece w (64 floats) by wave w
-    glds4_hidden(reinterpret_cast<const char*>(lse + (size_t)bh_ * N), off_lse, lds_of(reinterpret_cast<const char*>(lse_s)) + (unsigned)(wave * 256));
-  };
-
-  int bh = blockIdx.x;
-  if (bh >= BH) return;
-  bf16x8 kf[2][4], vf[2][4];
-  {
-    const char* qb = qkv_base(bh);
-#pragma unroll
-    for (int t = 0; t < 7; ++t) {
-      dma_piece(qb, off_qkv[t], Qs, t);
-      dma_piece(o_base(dout, bh), off_o[t], dOs, t);
-      dma_piece(o_base(out, bh), off_o[t], Os, t);
-    }
-    const bf16* kb = reinterpret_cast<const bf16*>(qb) + H * HD;
-    const bf16* vb = kb + H * HD;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        kf[j][ks] = *reinterpret_cast<const bf16x8*>(kb + (size_t)trow[j] * ld + ks * 16 + h * 8);
-        vf[j][ks] = *reinterpret_cast<const bf16x8*>(vb + (size_t)trow[j] * ld + ks * 16 + h * 8);
-      }
-    dma_lse(bh);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-#ifdef CARA_ATTN_STAMPS
-  int slot = -1;
-#endif
-  for (; bh < BH; bh += gridDim.x) {
-    const int nxt = bh + gridDim.x;
-    const int b = bh / H, head = bh - b * H;
-#ifdef CARA_ATTN_STAMPS
-    ++slot;
-#endif
-    ATTN_STAMP(0);
-    // T0: every wave is through with phase B of the previous head and has seen its own pieces of this head's Q, dO, O land
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    // delta[row] = sum_d dO[row][d] O[row][d], two threads per row, two passes of 128 rows; lse in the seed form (see the 7-wave kernel)
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int row = pass * 128 + (tid >> 1), half = tid & 1;
-      if (row < NPAD) {
-        float dl = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int off = swz128(row, half * 4 + c);
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(Os + off);
-          const bf16x8 g = *reinterpret_cast<const bf16x8*>(dOs + off);
-#pragma unroll
-          for (int jj = 0; jj < 8; jj += 2) dl = dot2_acc(bf16x2{a[jj], a[jj + 1]}, bf16x2{g[jj], g[jj + 1]}, dl);
-        }
-        dl += __shfl_xor(dl, 1, 64);
-        if (half == 0) del_s[row] = -dl;
-      }
-    }
-    if (tid >= NPAD) del_s[tid] = 0.f;
-    lse_s[tid] = tid < N ? lse_s[tid] * nrscale : -1e30f;   // (256 threads, 256 entries: each touched by exactly one thread)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // T1
-    __builtin_amdgcn_sched_barrier(0);
-    ATTN_STAMP(1);
-
-    // ================= phase A: dK, dV of this wave's two key blocks =================
-    f32x16 dkt[2][2], dvt[2][2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dkt[j][dt][r] = 0.f; dvt[j][dt][r] = 0.f; }
-#pragma unroll
-    for (int qt = 0; qt < 7; ++qt) {
-      if (qt >= nt) break;
-      const int q0 = qt * 32;
-      const char* qblk = Qs + qt * 4096;
-      const char* dblk = dOs + qt * 4096;
-      f32x16 sacc[2], pacc[2];
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + q0 + 8 * g4 + 4 * h);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + q0 + 8 * g4 + 4 * h);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          sacc[0][4 * g4 + k] = l4[k]; pacc[0][4 * g4 + k] = d4[k];
-          sacc[1][4 * g4 + k] = l4[k]; pacc[1][4 * g4 + k] = d4[k];
-        }
-      }
-      // The order asked for (one wave per SIMD: nothing else fills the matrix pipe while this wave does vector work):
-      //   S0 dP0 | S1 dP1 with the vector work of block 0 between them | dV0 dK0 with the vector work of block 1 | dV1 dK1
-      // Every Q / dO row fragment and every transposed dO / Q fragment is read once and feeds both key blocks.
-      bf16x8 qa[4], da[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        qa[ks] = *reinterpret_cast<const bf16x8*>(qblk + ro.o[ks]);
-        da[ks] = *reinterpret_cast<const bf16x8*>(dblk + ro.o[ks]);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[0][ks], sacc[0], 0, 0, 0);
-        pacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vf[0][ks], pacc[0], 0, 0, 0);
-      }
-      if (qt == 0) {
-        // K, V of THIS head into their images (phase B reads them)
-        __builtin_amdgcn_sched_barrier(0);
-        const char* qb = qkv_base(bh);
-#pragma unroll
-        for (int t = 0; t < 7; ++t) {
-          dma_piece(qb + H * HD * 2, off_qkv[t], Ks, t);
-          dma_piece(qb + 2 * H * HD * 2, off_qkv[t], Vs, t);
-        }
-      }
-      bf16x8 doa[2][2], qta[2][2];
-#pragma unroll
-      for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          doa[st][dt] = tr_frag_at(dblk, to.lo[st][dt], to.hi[st][dt]);
-          qta[st][dt] = tr_frag_at(qblk, to.lo[st][dt], to.hi[st][dt]);
-        }
-      unsigned pw[2][8], dw[2][8];
-      auto vec_pair = [&](const int j, const int i) {   // p = exp2(c2 S'), dS = p dP' of registers 2i, 2i + 1 of block j: six vector instructions
-        const float e0 = __builtin_amdgcn_exp2f(sacc[j][2 * i] * c2), e1 = __builtin_amdgcn_exp2f(sacc[j][2 * i + 1] * c2);
-        pw[j][i] = pk16(f32x2{e0, e1});
-        dw[j][i] = pk16(f32x2{e0 * pacc[j][2 * i], e1 * pacc[j][2 * i + 1]});
-      };
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- S1 dP1 (8 MFMAs), one pair of block 0's vector work behind each (a scheduling fence per MFMA keeps the order)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[1][ks], sacc[1], 0, 0, 0);
-        pacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vf[1][ks], pacc[1], 0, 0, 0);
-        vec_pair(0, 2 * ks);       // (two independent six-instruction chains per fence: one wave per SIMD has nobody else to
-        vec_pair(0, 2 * ks + 1);   // issue from while a transcendental's result is on its way)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // ---- dV0 dK0 (8 MFMAs), one pair of block 1's vector work behind each
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        const bf16x8 pb0 = dwords8(pw[0], st), dsb0 = dwords8(dw[0], st);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          dvt[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa[st][dt], pb0, dvt[0][dt], 0, 0, 0);
-          dkt[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta[st][dt], dsb0, dkt[0][dt], 0, 0, 0);
-          vec_pair(1, 4 * st + 2 * dt);
-          vec_pair(1, 4 * st + 2 * dt + 1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      // ---- dV1 dK1
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        const bf16x8 pb1 = dwords8(pw[1], st), dsb1 = dwords8(dw[1], st);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          dvt[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doa[st][dt], pb1, dvt[1][dt], 0, 0, 0);
-          dkt[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta[st][dt], dsb1, dkt[1][dt], 0, 0, 0);
-        }
-      }
-    }
-    // T2: every wave's pieces of K, V have landed
-    ATTN_STAMP(2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    ATTN_STAMP(3);
-    // dK, dV of the valid blocks leave as whole 128-byte rows through the block's own 4 KiB of the O image (free between T1 and T3)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (!bval[j]) continue;   // (wave-uniform)
-      char* stg = Os + blk[j] * 4096;
-      const int srow = lane >> 3, schunk = lane & 7;
-      const int t0 = blk[j] * 32;
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {   // 0: dK (scaled), 1: dV
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x16& acc = m == 0 ? dkt[j][dt] : dvt[j][dt];
-            const float f = m == 0 ? scale : 1.f;
-            const bf16x4 a = {(bf16)(acc[4 * g] * f), (bf16)(acc[4 * g + 1] * f), (bf16)(acc[4 * g + 2] * f), (bf16)(acc[4 * g + 3] * f)};
-            *reinterpret_cast<bf16x4*>(stg + swz128(l31, dt * 4 + g) + h * 8) = a;
-          }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        bf16* dst = dqkv + (size_t)(b * N + t0) * ld + (1 + m) * H * HD + head * HD + schunk * 8;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint4 v = *reinterpret_cast<const uint4*>(stg + swz128(srow + 8 * i, schunk));
-          if (t0 + srow + 8 * i < N) *reinterpret_cast<uint4*>(dst + (size_t)(srow + 8 * i) * ld) = v;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the staging image is rewritten by the next matrix / the next head's DMA)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-
-    // ================= phase B: dQ of this wave's two query blocks =================
-    bf16x8 qf[2][4], dof[2][4];
-    float lq[2], dl[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        qf[j][ks] = *reinterpret_cast<const bf16x8*>(Qs + bt[j] * 4096 + ro.o[ks]);
-        dof[j][ks] = *reinterpret_cast<const bf16x8*>(dOs + bt[j] * 4096 + ro.o[ks]);
-      }
-      lq[j] = lse_s[blk[j] * 32 + l31] * c2;   // (-lse in log2 units; a padded query: -inf-like)
-      dl[j] = del_s[blk[j] * 32 + l31];        // (-delta)
-    }
-    f32x16 seed_last;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) seed_last[r] = crow(r, h) < last ? 0.f : -1e30f;
-    ATTN_STAMP(4);
-    // T3: every wave holds its Q / dO rows and row constants: the Q, dO, O images may take the next head
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    ATTN_STAMP(5);
-    const bool has_nxt = nxt < BH;
-    const char* nqb = qkv_base(has_nxt ? nxt : bh);
-    const char* ndob = o_base(dout, has_nxt ? nxt : bh);
-    const char* nob = o_base(out, has_nxt ? nxt : bh);
-    auto next_slice = [&](const int s_) {   // s_ = 0 .. 5: the next head's 21 DMA pieces + 16 row loads + the LSE piece, spread over the key tiles
-      if (!has_nxt) return;
-      if (s_ < 4) {
-#pragma unroll
-        for (int t = s_; t < 7; t += 4) {
-          dma_piece(nqb, off_qkv[t], Qs, t);
-          dma_piece(ndob, off_o[t], dOs, t);
-          dma_piece(nob, off_o[t], Os, t);
-        }
-        const bf16* kb = reinterpret_cast<const bf16*>(nqb) + H * HD;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) kf[j][s_] = *reinterpret_cast<const bf16x8*>(kb + (size_t)trow[j] * ld + s_ * 16 + h * 8);
-      } else if (s_ == 4) {
-        const bf16* vb = reinterpret_cast<const bf16*>(nqb) + 2 * H * HD;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) vf[j][ks] = *reinterpret_cast<const bf16x8*>(vb + (size_t)trow[j] * ld + ks * 16 + h * 8);
-      } else {
-        dma_lse(nxt);
-      }
-    };
-    f32x16 dq[2][2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[j][dt][r] = 0.f;
-    auto tile_b = [&](const int kt, const f32x16& seed) {
-      const char* kblk = Ks + kt * 4096;
-      const char* vblk = Vs + kt * 4096;
-      f32x16 sT[2], dpT[2];
-      sT[0] = seed;
-      sT[1] = seed;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { dpT[0][r] = 0.f; dpT[1][r] = 0.f; }
-      // sT0 dpT0 | sT1 dpT1 with the vector work of block 0 | dQ0 with the vector work of block 1 | dQ1
-      bf16x8 ka[4], va[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {   // every K / V row fragment feeds both query blocks
-        ka[ks] = *reinterpret_cast<const bf16x8*>(kblk + ro.o[ks]);
-        va[ks] = *reinterpret_cast<const bf16x8*>(vblk + ro.o[ks]);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        sT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[0][ks], sT[0], 0, 0, 0);
-        dpT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ks], dof[0][ks], dpT[0], 0, 0, 0);
-      }
-      bf16x8 kfr[2][2];
-#pragma unroll
-      for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) kfr[st][dt] = tr_frag_at(kblk, to.lo[st][dt], to.hi[st][dt]);
-      unsigned dw[2][8];
-      auto vec_pair = [&](const int j, const int i) {   // dS^T = exp2(c2 S^T + lq) (dP^T + dl) of registers 2i, 2i + 1 of block j
-        const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[j][2 * i], c2, lq[j])), e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sT[j][2 * i + 1], c2, lq[j]));
-        dw[j][i] = pk16(f32x2{e0 * (dpT[j][2 * i] + dl[j]), e1 * (dpT[j][2 * i + 1] + dl[j])});
-      };
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        sT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks], qf[1][ks], sT[1], 0, 0, 0);
-        dpT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ks], dof[1][ks], dpT[1], 0, 0, 0);
-        vec_pair(0, 2 * ks);
-        vec_pair(0, 2 * ks + 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        const bf16x8 a0 = dwords8(dw[0], st);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          dq[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[st][dt], a0, dq[0][dt], 0, 0, 0);   // dQ^T = K^T dS^T
-          vec_pair(1, 4 * st + 2 * dt);
-          vec_pair(1, 4 * st + 2 * dt + 1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        const bf16x8 a1 = dwords8(dw[1], st);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) dq[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[st][dt], a1, dq[1][dt], 0, 0, 0);
-      }
-    };
-    {
-      f32x16 zero;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 6; ++kt) {
-        if (kt >= nt - 1) break;
-        next_slice(kt);
-        tile_b(kt, zero);
-      }
-#pragma unroll
-      for (int s_ = 0; s_ < 6; ++s_)   // (the slices of tiles this N does not have)
-        if (s_ >= nt - 1) next_slice(s_);
-      tile_b(nt - 1, seed_last);
-    }
-    ATTN_STAMP(6);
-    // the next head's images and row fragments have landed (they are old by now): wait for them HERE, before this phase's stores
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    ATTN_STAMP(7);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (!bval[j]) continue;   // (wave-uniform)
-      bf16* qrow_out = dqkv + (size_t)(b * N + trow[j]) * ld + head * HD;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        unsigned w[4][2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const bf16x2 lo = {(bf16)(dq[j][dt][4 * g] * scale), (bf16)(dq[j][dt][4 * g + 1] * scale)};
-          const bf16x2 hi = {(bf16)(dq[j][dt][4 * g + 2] * scale), (bf16)(dq[j][dt][4 * g + 3] * scale)};
-          w[g][0] = __builtin_bit_cast(unsigned, lo);
-          w[g][1] = __builtin_bit_cast(unsigned, hi);
-        }
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(w[g][k], w[g + 2][k], false, false);
-            w[g][k] = sw[0];
-            w[g + 2][k] = sw[1];
-          }
-        if (tvalid[j]) {
-#pragma unroll
-          for (int g = 0; g < 2; ++g) {
-            const uint4 v = {w[g][0], w[g][1], w[g + 2][0], w[g + 2][1]};
-            *reinterpret_cast<uint4*>(qrow_out + dt * 32 + 8 * (g + 2 * h)) = v;
-          }
-        }
-      }
-    }
-  }
-}
-
+// (Round 5 also built this backward as FOUR waves of 64 keys / queries -- one wave per SIMD, two 32-row blocks per wave, every
+// LDS fragment read feeding two MFMAs (-39 % LDS reads), the vector work of block 0 fenced between the MFMAs of block 1 -- and it
+// LOST: 67-69 us per launch against 60-65, 55-58 against 48-52 in the step, three builds (profiles/
+// r05_u_attention_bwd_four_waves_rejected.txt, with time stamps: dK/dV sweep 6.9 vs 6.2 us per head, dQ sweep 5.7-8.5 vs 4.7-7.0).
+// Correct at the first run; 256 architectural VGPRs + 184 AGPRs with ~300 v_accvgpr moves per head.  A lone wave pays every LDS and
+// transcendental latency itself, and 6 vector instructions with two v_exp per MFMA gap are twice what hides in a gap
+// (MI355X_MICROARCH.md, one wave per SIMD: <= 5 fillers, one of them 8-cycle).  Removed; commit 22344d3 has the kernel.)
 // ------------------------------------------------------------------------------------------
 // (Round 5 built the same specialisation for this kernel -- NT as a template parameter, branch-free DMA issue, the S^T / dP^T
 // MFMAs of key tile kt + 1 between the vector work of tile kt in the dQ sweep -- and it LOST: 66.7-68.8 us per launch against
@@ -2198,7 +1785,6 @@ static void attn_set_lds_limits() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<false>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<true>), at, MAX_LDS);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_w4_kernel), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<4>), at, MAX_LDS);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<7>), at, MAX_LDS);
   done = true;
@@ -2259,10 +1845,7 @@ extern "C" int cara_attention_bwd(const void* qkv, const void* out, const void* 
     const int BH = B * H, grid = BH < 256 ? BH : 256;
     // CARA_ATTN_BWD_V=1: the four-barrier protocol of round 3 for A/B runs; default (r05): two barriers per head
     static const int bwd_v = [] { const char* e = getenv("CARA_ATTN_BWD_V"); return e ? atoi(e) : 2; }();
-    if (bwd_v == 3)   // r05 experiment: four waves of 64 keys / queries
-      hipLaunchKernelGGL(attn_bwd_w4_kernel, dim3(grid), dim3(256), 5 * 224 * 128 + 512 * 4, st, (const bf16*)qkv, (const bf16*)out,
-                         (const bf16*)dout, lse, (bf16*)dqkv, N, H, BH, scale);
-    else if (bwd_v == 1)
+    if (bwd_v == 1)
       hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, dim3(grid), dim3(448), 5 * 224 * 128 + (256 + 224) * 4, st, (const bf16*)qkv, (const bf16*)out,
                          (const bf16*)dout, lse, (bf16*)dqkv, N, H, BH, scale);
     else

@@ -10,7 +10,8 @@ pids=()
 for s in lib gemm gemm8 skinny norm_misc attention factors dropout_exact dense_delta optim linear vit; do
   o=build_$name/$s.o
   OBJS="$OBJS $o"
-  hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result "$@" -c $s.hip -o $o &
+  extra=""; [ $s = attention ] && extra="-fno-slp-vectorize"   # (as cara_amd/csrc/build.sh)
+  hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result $extra "$@" -c $s.hip -o $o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
