@@ -722,6 +722,9 @@ __global__ __launch_bounds__(PF_WAVES * 64, 1) void attn_fwd_p2_kernel(const bf1
 #ifdef CARA_ATTN_STAMPS
   int slot = -1;
 #endif
+#ifdef CARA_ATTN_PRIO   // (A/B build: static priority for the second-dispatched waves)
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   for (; bh < BH; bh += gridDim.x) {
     const int nxt = bh + gridDim.x;
     const bool has_nxt = nxt < BH;
@@ -1246,6 +1249,9 @@ __global__ __launch_bounds__(448, 1) void attn_bwd_fused_kernel(const bf16* __re
     g_attn_stamp_buf[((size_t)blockIdx.x * 4 + 3) * 8 + 0] = __builtin_amdgcn_s_memtime();
     g_attn_stamp_buf[((size_t)blockIdx.x * 4 + 3) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
   }
+#endif
+#ifdef CARA_ATTN_PRIO   // (A/B build: static priority for the second-dispatched waves, cdna_hip_programming.md T5 static form)
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
   for (; bh < BH; bh += gridDim.x) {
     const int nxt = bh + gridDim.x;
