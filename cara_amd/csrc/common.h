@@ -54,6 +54,13 @@ __device__ __forceinline__ float dot2_acc(const bf16x2 a, const bf16x2 b, const 
 #endif
 }
 
+// cara_layernorm_bwd_ex with the running gradient dx_in read on every dx_in_every-th row only (0: every row).  Library-internal
+// (norm_misc.hip -> vit.hip's last block), not part of include/cara_hip.h.
+int cara_layernorm_bwd_rows_in(const void* dy, const float* x, long ldx, const float* gamma, const float* mean, const float* rstd,
+                               const float* dx_in, float* dx_out, void* dyb, const float* rowscale, int rows_per_sample, int M, int C,
+                               const void* Vst, int rank, int Rp, void* G, void* Gt, int ldt, int dyb_panels, int dx_in_every,
+                               void* stream);
+
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 

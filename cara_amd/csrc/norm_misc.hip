@@ -205,7 +205,9 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_bwd_kernel(const 
                                                      const float* __restrict__ rowscale,
                                                      int rows_per_sample, int M,
                                                      const bf16* __restrict__ Vst, int rank, int Rp, bf16* __restrict__ G,
-                                                     bf16* __restrict__ Gt, int ldt, const int yp) {
+                                                     bf16* __restrict__ Gt, int ldt, const int yp, const int dx_in_every) {
+  // dx_in_every > 0: the running gradient dx_in is nonzero on rows that are multiples of it only (the last block of a ViT whose head
+  // reads the cls token: gradient has reached nothing but the cls rows yet) -- the other rows are neither read nor expected zeroed
   constexpr int C = V4 * 256;
   constexpr int RPW = XU ? XU_ROWS : 1;
   const int lane = threadIdx.x & 63;
@@ -230,10 +232,12 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_bwd_kernel(const 
     mu_[rr] = mean[row];
     rs_[rr] = rstd[row];
   }
-  if (dx_in) {
+  bool has_in[RPW];
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int row = row0 + rr < M ? row0 + rr : M - 1;
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int row = row0 + rr < M ? row0 + rr : M - 1;
+    has_in[rr] = dx_in && (dx_in_every <= 0 || row % dx_in_every == 0);   // (wave-uniform: a wave owns whole rows)
+    if (has_in[rr]) {
 #pragma unroll
       for (int i = 0; i < V4; ++i) pv[rr][i] = *reinterpret_cast<const float4*>(dx_in + (size_t)row * ldx + i * 256 + lane * 4);
     }
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(XU ? XU_WAVES * 64 : 256) void ln_bwd_kernel(const 
     const int c0 = i * 256 + lane * 4;
     float4 o = make_float4(rs * (g[i].x - c1 - xh[i].x * c2), rs * (g[i].y - c1 - xh[i].y * c2),
                            rs * (g[i].z - c1 - xh[i].z * c2), rs * (g[i].w - c1 - xh[i].w * c2));
-    if (dx_in) {
+    if (has_in[rr]) {
       const float4 pq = pv[rr][i];
       o.x += pq.x; o.y += pq.y; o.z += pq.z; o.w += pq.w;
     }
@@ -490,7 +494,7 @@ int ln_fwd_launch(const float* x, long ldx, const float* gamma, const float* bet
 
 int ln_bwd_launch(const void* dy, const float* x, long ldx, const float* gamma, const float* mean, const float* rstd,
                   const float* dx_in, float* dx_out, void* dyb, const float* rowscale, int rows_per_sample, int M, int C,
-                  const XuArgs& a, void* stream, int yp = 0) {
+                  const XuArgs& a, void* stream, int yp = 0, int dx_in_every = 0) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx_out || M <= 0 || ldx < C || (ldx & 3) || !xu_ok(a, M, C)) return CARA_E_ARG;
   if (yp && (yp < M || !dyb)) return CARA_E_ARG;
   if (rowscale && rows_per_sample <= 0) return CARA_E_ARG;
@@ -499,11 +503,11 @@ int ln_bwd_launch(const void* dy, const float* x, long ldx, const float* gamma, 
   const int rows_per_block = a.Ut ? 16 : 4;
   const dim3 grid((M + rows_per_block - 1) / rows_per_block), block(a.Ut ? XU_WAVES * 64 : 256);
 #define LNB(V, X) hipLaunchKernelGGL((ln_bwd_kernel<V, X>), grid, block, 0, st, (const bf16*)dy, x, ldx, gamma, mean, rstd, \
-                                     dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M, a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp)
+                                     dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M, a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp, dx_in_every)
 #define LNB4(V) hipLaunchKernelGGL((ln_bwd_kernel<V, true, 4>), grid, block, 0, st, (const bf16*)dy, x, ldx, gamma, mean, rstd, \
-                                   dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M, a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp)
+                                   dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M, a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp, dx_in_every)
 #define LNB1(V) hipLaunchKernelGGL((ln_bwd_kernel<V, true, 1>), grid, block, 0, st, (const bf16*)dy, x, ldx, gamma, mean, rstd, \
-                                   dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M, a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp)
+                                   dx_in, dx_out, (bf16*)dyb, rowscale, rows_per_sample, M, a.Ut, a.rank, a.Rp, a.T, a.Tt, a.ldt, yp, dx_in_every)
   if (a.Ut && a.Rp == 64) {
     if (C == 768) LNB4(3);
     else if (C == 1024) LNB4(4);
@@ -571,6 +575,17 @@ extern "C" int cara_layernorm_bwd_ex(const void* dy, const float* x, long ldx, c
   const XuArgs a = Vst ? XuArgs{static_cast<const bf16*>(Vst), rank, Rp, static_cast<bf16*>(G), static_cast<bf16*>(Gt), ldt}
                        : XuArgs{nullptr, 0, 0, nullptr, nullptr, 0};
   return ln_bwd_launch(dy, x, ldx, gamma, mean, rstd, dx_in, dx_out, dyb, rowscale, rows_per_sample, M, C, a, stream, dyb_panels);
+}
+
+// cara_layernorm_bwd_ex with dx_in read on every dx_in_every-th row only (not in include/cara_hip.h: vit.hip's last block)
+int cara_layernorm_bwd_rows_in(const void* dy, const float* x, long ldx, const float* gamma, const float* mean, const float* rstd,
+                               const float* dx_in, float* dx_out, void* dyb, const float* rowscale, int rows_per_sample, int M, int C,
+                               const void* Vst, int rank, int Rp, void* G, void* Gt, int ldt, int dyb_panels, int dx_in_every,
+                               void* stream) {
+  if (dyb_panels < 0 || dx_in_every < 0) return CARA_E_ARG;
+  const XuArgs a = Vst ? XuArgs{static_cast<const bf16*>(Vst), rank, Rp, static_cast<bf16*>(G), static_cast<bf16*>(Gt), ldt}
+                       : XuArgs{nullptr, 0, 0, nullptr, nullptr, 0};
+  return ln_bwd_launch(dy, x, ldx, gamma, mean, rstd, dx_in, dx_out, dyb, rowscale, rows_per_sample, M, C, a, stream, dyb_panels, dx_in_every);
 }
 
 extern "C" int cara_im2col_patches(const float* img, void* patches, int B, int C, int Hi, int Wi, int p, void* stream) {

@@ -1054,9 +1054,16 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
   bf16* dyb = reinterpret_cast<bf16*>(ws + R.dyb_fc2);   // dY of the last block's fc2
   TRY(head_backward_scaled(dlogits, ws + W.clsn, head_w, dhead_w, dhead_b, ws + W.dclsn, B, s->num_classes, D, s->loss_scale,
                            s->found_inf, stream));
-  // gradient enters the token stream only through the cls rows
-  if (hipMemsetAsync(dx, 0, (size_t)M * D * 4, hs) != hipSuccess) return CARA_E_LAUNCH;
-  if (hipMemsetAsync(dyb, 0, (size_t)M * D * 2, hs) != hipSuccess) return CARA_E_LAUNCH;
+  // Gradient enters the token stream only through the cls rows.  With the last block on its cls rows (the default) every kernel of that
+  // block reads dx / dyb on those rows only, and its LayerNorm-1 backward -- the first launch that touches every row of dx -- is told
+  // so (cara_layernorm_bwd_rows_in: dx_in on every N-th row): the two buffers need no zeroing (58 MB of memset + 39 MB of zeros read
+  // back, ~18 us per step, r05).  Otherwise (CARA_CLS_SHORTCUT=0, exact weight dropout) the last block runs on all rows: zeros.
+  static const int force_zero = env_once("CARA_BWD_MEMSETS", 0);   // (1: the memsets and the all-rows read back, for A/B runs)
+  const bool last_on_cls = cls_shortcut_enabled() && !s->wd_exact && !force_zero;
+  if (!last_on_cls) {
+    if (hipMemsetAsync(dx, 0, (size_t)M * D * 4, hs) != hipSuccess) return CARA_E_LAUNCH;
+    if (hipMemsetAsync(dyb, 0, (size_t)M * D * 2, hs) != hipSuccess) return CARA_E_LAUNCH;
+  }
   const float* dp_last = droppath ? droppath + (size_t)(2 * (g->depth - 1) + 1) * B : nullptr;
   TRY(cara_layernorm_bwd(ws + W.dclsn, reinterpret_cast<float*>(ws + W.x_last), (long)N * D, w->norm_g,
                          reinterpret_cast<float*>(ws + W.meanF), reinterpret_cast<float*>(ws + W.rstdF), nullptr, dx, dyb,
@@ -1170,10 +1177,10 @@ extern "C" int cara_vit_backward(const cara_geom* g, const cara_vit_shape* s, co
       Lin below[4];
       make_lins(g, w, ws + W.pack, pl, l - 1, below);
       SiteBracket sb(CARA_SITE_LN1_BWD, cx_all);
-      TRY(cara_layernorm_bwd_ex(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_in), D, w->ln1_g + (size_t)l * D,
-                                reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), dx, dx, dyb,
-                                dp_prev, N, M, D, fx ? below[3].Vst : nullptr, g->rank, Rp, ws + R.G[3], ws + R.Gt[3], W.ldt,
-                                pa_dx ? M : 0, stream));
+      TRY(cara_layernorm_bwd_rows_in(ws + W.dXn, reinterpret_cast<float*>(ws + lw.x_in), D, w->ln1_g + (size_t)l * D,
+                                     reinterpret_cast<float*>(ws + lw.mean1), reinterpret_cast<float*>(ws + lw.rstd1), dx, dx, dyb,
+                                     dp_prev, N, M, D, fx ? below[3].Vst : nullptr, g->rank, Rp, ws + R.G[3], ws + R.Gt[3], W.ldt,
+                                     pa_dx ? M : 0, (cls_only && last_on_cls) ? N : 0, stream));   // (last block: dx holds the cls rows only so far)
       have_G_fc2 = fx;
     }
   }
